@@ -1,0 +1,461 @@
+"""TEST INFRASTRUCTURE — CPU (torch fp32) restatement of PSI's generation-and-fitting hot path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module.  The product (``psi-release_amd/``) never does, and fails loudly when its HIP library is
+missing instead of falling back to anything here.
+
+Every function cites the reference lines (relative to /root/reference) whose arithmetic it follows.
+Pinning status:
+
+* pinned against the *imported reference modules* by ``oracle/make_golden.py`` -> ``tests/golden/*.npz``:
+  rotation-representation glue (source/cvae.py), VPoser.decode (human_body_prior/train/vposer_smpl.py),
+  ``lbs`` (human_body_prior/body_model/lbs.py), ``FittingOP.cal_loss``/``fitting`` (source/fitting_proxe.py),
+  the CVAE forward passes (source/cvae.py, source/net_layers.py);
+* **parity unpinned** at three third-party boundaries whose sources are not under /root/reference and
+  for which the reference holds no tests: ``smplx==0.1.13`` (SMPLX.forward: hand PCA, pose_mean),
+  ``torchgeometry==0.1.2`` (angle-axis <-> rotation matrix) and ``torchvision==0.4.0`` (resnet18) —
+  restated from their published behaviour, requirements.txt:95,102-104;
+* the Chamfer CUDA kernels (chamfer_pytorch/chamfer.cu) cannot be built or run here; they are restated
+  in ``oracle/chamfer_oracle.c`` and pinned by the reference's own known-answer check
+  (chamfer_pytorch/test_chamfer.py:35-54).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, '_build')
+_LIB = None
+
+
+# --------------------------------------------------------------------------------------------
+# C oracle (Chamfer NN + scalar trilinear) build/load
+# --------------------------------------------------------------------------------------------
+def build_c_oracle(force: bool = False) -> str:
+    """gcc -O3 -ffp-contract=off -fopenmp: IEEE fp32, no FMA contraction."""
+    os.makedirs(_BUILD, exist_ok=True)
+    src = os.path.join(_HERE, 'chamfer_oracle.c')
+    out = os.path.join(_BUILD, 'libpsi_oracle.so')
+    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        cmd = ['gcc', '-O3', '-march=native', '-ffp-contract=off', '-fno-fast-math', '-fopenmp', '-shared', '-fPIC',
+               src, '-o', out]
+        try:
+            subprocess.run(cmd, check=True, capture_output=True)
+        except subprocess.CalledProcessError as e:  # pragma: no cover
+            raise RuntimeError('oracle build failed: ' + e.stderr.decode())
+    return out
+
+
+def c_oracle():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build_c_oracle())
+    return _LIB
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def chamfer_nn_np(xyz1: np.ndarray, xyz2: np.ndarray, both: bool = True, chunked: bool = False):
+    """chamfer.cu:12-154.  Returns dist1[B,n], idx1[B,n] (int32), dist2[B,m], idx2[B,m]."""
+    lib = c_oracle()
+    xyz1 = np.ascontiguousarray(xyz1, np.float32)
+    xyz2 = np.ascontiguousarray(xyz2, np.float32)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d1 = np.zeros((B, n), np.float32)
+    i1 = np.zeros((B, n), np.int32)
+    d2 = np.zeros((B, m), np.float32)
+    i2 = np.zeros((B, m), np.int32)
+    fn = lib.psi_oracle_nm_distance_chunked if chunked else lib.psi_oracle_nm_distance
+    fn(B, n, _fp(xyz1), m, _fp(xyz2), _fp(d1), _fp(i1))
+    if both:
+        fn(B, m, _fp(xyz2), n, _fp(xyz1), _fp(d2), _fp(i2))
+    return d1, i1, d2, i2
+
+
+def chamfer_grad_np(xyz1, xyz2, g1, g2, i1, i2):
+    """chamfer.cu:155-196 on zero-initialised grads (dist_chamfer.py:40-45)."""
+    lib = c_oracle()
+    xyz1 = np.ascontiguousarray(xyz1, np.float32)
+    xyz2 = np.ascontiguousarray(xyz2, np.float32)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    gx1 = np.zeros_like(xyz1)
+    gx2 = np.zeros_like(xyz2)
+    g1 = np.ascontiguousarray(g1, np.float32)
+    i1 = np.ascontiguousarray(i1, np.int32)
+    if g2 is not None:
+        g2 = np.ascontiguousarray(g2, np.float32)
+        i2 = np.ascontiguousarray(i2, np.int32)
+    lib.psi_oracle_chamfer_backward(_fp(xyz1), _fp(xyz2), _fp(gx1), _fp(gx2), _fp(g1),
+                                    _fp(g2) if g2 is not None else None, _fp(i1),
+                                    _fp(i2) if g2 is not None else None, B, n, m)
+    return gx1, gx2
+
+
+class ChamferOracleFn(torch.autograd.Function):
+    """chamferFunction (dist_chamfer.py:13-46) over the C restatement."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        d1, i1, d2, i2 = chamfer_nn_np(xyz1.detach().numpy(), xyz2.detach().numpy())
+        ctx.save_for_backward(xyz1, xyz2)
+        ctx.idx = (i1, i2)
+        return torch.from_numpy(d1), torch.from_numpy(d2)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        xyz1, xyz2 = ctx.saved_tensors
+        gx1, gx2 = chamfer_grad_np(xyz1.detach().numpy(), xyz2.detach().numpy(),
+                                   g1.contiguous().numpy(), g2.contiguous().numpy(), *ctx.idx)
+        return torch.from_numpy(gx1), torch.from_numpy(gx2)
+
+
+def chamfer_dist(xyz1, xyz2):
+    return ChamferOracleFn.apply(xyz1, xyz2)
+
+
+def sdf_sample_c(sdf, scene_id, gmin, gmax, verts, align_corners=True):
+    """Scalar C statement of SURVEY Appendix C trilinear + analytic gradient."""
+    lib = c_oracle()
+    sdf = np.ascontiguousarray(sdf, np.float32)
+    verts = np.ascontiguousarray(verts, np.float32)
+    S, D = sdf.shape[0], sdf.shape[1]
+    B, V, _ = verts.shape
+    sid = np.ascontiguousarray(scene_id, np.int32)
+    gmin = np.ascontiguousarray(gmin, np.float32).reshape(S, 3)
+    gmax = np.ascontiguousarray(gmax, np.float32).reshape(S, 3)
+    out = np.zeros((B, V), np.float32)
+    grad = np.zeros((B, V, 3), np.float32)
+    lib.psi_oracle_sdf_sample(_fp(sdf), _fp(sid), _fp(gmin), _fp(gmax), _fp(verts), B, V, D,
+                              int(bool(align_corners)), _fp(out), _fp(grad))
+    return out, grad
+
+
+# --------------------------------------------------------------------------------------------
+# torchgeometry==0.1.2 (third party, parity unpinned)
+# --------------------------------------------------------------------------------------------
+def tgm_angle_axis_to_rotation_matrix(aa: torch.Tensor) -> torch.Tensor:
+    """tgm.angle_axis_to_rotation_matrix: [N,3] -> [N,4,4]; call sites cvae.py:88, vposer_smpl.py:170."""
+    th2 = (aa * aa).sum(1, keepdim=True)
+    th = torch.sqrt(th2)
+    w = aa / (th + 1e-6)
+    wx, wy, wz = w[:, 0:1], w[:, 1:2], w[:, 2:3]
+    c, s = torch.cos(th), torch.sin(th)
+    one = 1.0
+    rows = [c + wx * wx * (one - c), wx * wy * (one - c) - wz * s, wy * s + wx * wz * (one - c),
+            wz * s + wx * wy * (one - c), c + wy * wy * (one - c), -wx * s + wy * wz * (one - c),
+            -wy * s + wx * wz * (one - c), wx * s + wy * wz * (one - c), c + wz * wz * (one - c)]
+    Rn = torch.cat(rows, 1).view(-1, 3, 3)
+    rx, ry, rz = aa[:, 0:1], aa[:, 1:2], aa[:, 2:3]
+    o = torch.ones_like(rx)
+    Rt = torch.cat([o, -rz, ry, rz, o, -rx, -ry, rx, o], 1).view(-1, 3, 3)
+    pos = (th2 > 1e-6).view(-1, 1, 1).type_as(th2)
+    out = torch.eye(4, dtype=aa.dtype).view(1, 4, 4).repeat(aa.shape[0], 1, 1)
+    out[:, :3, :3] = pos * Rn + (1.0 - pos) * Rt
+    return out
+
+
+def tgm_rotation_matrix_to_quaternion(R34: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    r = R34.transpose(1, 2)
+    d2 = r[:, 2, 2] < eps
+    d01 = r[:, 0, 0] > r[:, 1, 1]
+    d0n1 = r[:, 0, 0] < -r[:, 1, 1]
+    t0 = 1 + r[:, 0, 0] - r[:, 1, 1] - r[:, 2, 2]
+    q0 = torch.stack([r[:, 1, 2] - r[:, 2, 1], t0, r[:, 0, 1] + r[:, 1, 0], r[:, 2, 0] + r[:, 0, 2]], -1)
+    t1 = 1 - r[:, 0, 0] + r[:, 1, 1] - r[:, 2, 2]
+    q1 = torch.stack([r[:, 2, 0] - r[:, 0, 2], r[:, 0, 1] + r[:, 1, 0], t1, r[:, 1, 2] + r[:, 2, 1]], -1)
+    t2 = 1 - r[:, 0, 0] - r[:, 1, 1] + r[:, 2, 2]
+    q2 = torch.stack([r[:, 0, 1] - r[:, 1, 0], r[:, 2, 0] + r[:, 0, 2], r[:, 1, 2] + r[:, 2, 1], t2], -1)
+    t3 = 1 + r[:, 0, 0] + r[:, 1, 1] + r[:, 2, 2]
+    q3 = torch.stack([t3, r[:, 1, 2] - r[:, 2, 1], r[:, 2, 0] - r[:, 0, 2], r[:, 0, 1] - r[:, 1, 0]], -1)
+    c0 = (d2 & d01).view(-1, 1).type_as(q0)
+    c1 = (d2 & ~d01).view(-1, 1).type_as(q0)
+    c2 = (~d2 & d0n1).view(-1, 1).type_as(q0)
+    c3 = (~d2 & ~d0n1).view(-1, 1).type_as(q0)
+    q = q0 * c0 + q1 * c1 + q2 * c2 + q3 * c3
+    q = q / torch.sqrt(t0.unsqueeze(1) * c0 + t1.unsqueeze(1) * c1 + t2.unsqueeze(1) * c2 + t3.unsqueeze(1) * c3)
+    return q * 0.5
+
+
+def tgm_quaternion_to_angle_axis(q: torch.Tensor) -> torch.Tensor:
+    q1, q2, q3 = q[..., 1], q[..., 2], q[..., 3]
+    s2 = q1 * q1 + q2 * q2 + q3 * q3
+    s = torch.sqrt(s2)
+    c = q[..., 0]
+    two_theta = 2.0 * torch.where(c < 0.0, torch.atan2(-s, -c), torch.atan2(s, c))
+    k = torch.where(s2 > 0.0, two_theta / s, 2.0 * torch.ones_like(s))
+    return torch.stack([q1 * k, q2 * k, q3 * k], -1)
+
+
+def tgm_rotation_matrix_to_angle_axis(R34: torch.Tensor) -> torch.Tensor:
+    """tgm.rotation_matrix_to_angle_axis: [N,3,4] -> [N,3]; call sites cvae.py:79, vposer_smpl.py:160."""
+    return tgm_quaternion_to_angle_axis(tgm_rotation_matrix_to_quaternion(R34))
+
+
+# --------------------------------------------------------------------------------------------
+# source/cvae.py glue (a1-a7)
+# --------------------------------------------------------------------------------------------
+def rot6d_decode(x6: torch.Tensor) -> torch.Tensor:
+    """ContinousRotReprDecoder.decode, cvae.py:58-68 (same as vposer_smpl.py:53-62): [N,6] -> [N,3,3]."""
+    a = x6.view(-1, 3, 2)
+    b1 = F.normalize(a[:, :, 0], dim=1)
+    dot = torch.sum(b1 * a[:, :, 1], dim=1, keepdim=True)
+    b2 = F.normalize(a[:, :, 1] - dot * b1, dim=-1)
+    b3 = torch.cross(b1, b2, dim=1)
+    return torch.stack([b1, b2, b3], dim=-1)
+
+
+def matrot2aa(R: torch.Tensor) -> torch.Tensor:
+    """cvae.py:71-80 / vposer_smpl.py:152-161: pad a zero column, tgm conversion. [N,3,3] -> [N,3]."""
+    return tgm_rotation_matrix_to_angle_axis(F.pad(R.reshape(-1, 3, 3), [0, 1])).view(-1, 3).contiguous()
+
+
+def aa2matrot(aa: torch.Tensor) -> torch.Tensor:
+    """cvae.py:82-89: [N,3] -> [N,3,3]."""
+    return tgm_angle_axis_to_rotation_matrix(aa.reshape(-1, 3))[:, :3, :3].contiguous()
+
+
+def convert_to_6d_rot(x: torch.Tensor) -> torch.Tensor:
+    """GeometryTransformer.convert_to_6D_rot, cvae.py:117-126: [B,72] -> [B,75]."""
+    R = aa2matrot(x[:, 3:6])
+    return torch.cat([x[:, :3], R[:, :, :-1].reshape(-1, 6), x[:, 6:]], -1)
+
+
+def convert_to_3d_rot(x: torch.Tensor) -> torch.Tensor:
+    """GeometryTransformer.convert_to_3D_rot, cvae.py:128-137: [B,75] -> [B,72]."""
+    return torch.cat([x[:, :3], matrot2aa(rot6d_decode(x[:, 3:9])), x[:, 9:]], -1)
+
+
+def verts_transform(verts: torch.Tensor, cam_ext: torch.Tensor) -> torch.Tensor:
+    """GeometryTransformer.verts_transform, cvae.py:141-149."""
+    vh = F.pad(verts, (0, 1), mode='constant', value=1)
+    return torch.matmul(vh, cam_ext.permute(0, 2, 1))[:, :, :-1]
+
+
+def normalize_global_T(x, cam_int, max_d):
+    """cvae.py:175-199."""
+    t, r = x[:, :3], x[:, 3:]
+    fx, fy, px, py = cam_int[:, 0, 0], cam_int[:, 1, 1], cam_int[:, 0, 2], cam_int[:, 1, 2]
+    s_ = 1.0 / torch.max(px, py)
+    xx = s_ * t[:, 0] * fx / (t[:, 2] + 1e-6)
+    yy = s_ * t[:, 1] * fy / (t[:, 2] + 1e-6)
+    zz = 2.0 * t[:, 2] / max_d - 1.0
+    return torch.cat([torch.stack([xx, yy, zz], -1), r], -1)
+
+
+def recover_global_T(x, cam_int, max_d):
+    """cvae.py:152-172."""
+    t, r = x[:, :3], x[:, 3:]
+    fx, fy, px, py = cam_int[:, 0, 0], cam_int[:, 1, 1], cam_int[:, 0, 2], cam_int[:, 1, 2]
+    s_ = 1.0 / torch.max(px, py)
+    z = (t[:, 2] + 1.0) / 2.0 * max_d
+    xx = t[:, 0] * z / s_ / fx
+    yy = t[:, 1] * z / s_ / fy
+    return torch.cat([torch.stack([xx, yy, z], -1), r], -1)
+
+
+def split_body_vector(x72: torch.Tensor) -> dict:
+    """BodyParamParser.body_params_encapsulate_batch, cvae.py:238-249."""
+    return {'transl': x72[:, :3], 'global_orient': x72[:, 3:6], 'betas': x72[:, 6:16],
+            'body_pose_vp': x72[:, 16:48], 'left_hand_pose': x72[:, 48:60], 'right_hand_pose': x72[:, 60:]}
+
+
+# --------------------------------------------------------------------------------------------
+# VPoser.decode (a8)
+# --------------------------------------------------------------------------------------------
+def vposer_decode_aa(sd: dict, z: torch.Tensor) -> torch.Tensor:
+    """VPoser.decode(z, 'aa'), vposer_smpl.py:107-121 in eval mode (dropout off, model_loader.py:70): [B,32] -> [B,63]."""
+    h = F.leaky_relu(F.linear(z, sd['bodyprior_dec_fc1.weight'], sd['bodyprior_dec_fc1.bias']), negative_slope=.2)
+    h = F.leaky_relu(F.linear(h, sd['bodyprior_dec_fc2.weight'], sd['bodyprior_dec_fc2.bias']), negative_slope=.2)
+    h = F.linear(h, sd['bodyprior_dec_out.weight'], sd['bodyprior_dec_out.bias'])
+    R = rot6d_decode(h).view(-1, 1, 21, 9)
+    return matrot2aa(R).view(z.shape[0], -1)
+
+
+# --------------------------------------------------------------------------------------------
+# LBS (a10) and SMPL-X forward (a9)
+# --------------------------------------------------------------------------------------------
+def batch_rodrigues(aa: torch.Tensor) -> torch.Tensor:
+    """lbs.py:165-192: angle = ||aa + 1e-8||, R = I + sin K + (1-cos) K K."""
+    n = aa.shape[0]
+    angle = torch.norm(aa + 1e-8, dim=1, keepdim=True)
+    d = aa / angle
+    cos = torch.cos(angle).unsqueeze(1)
+    sin = torch.sin(angle).unsqueeze(1)
+    rx, ry, rz = torch.split(d, 1, dim=1)
+    z = torch.zeros((n, 1), dtype=aa.dtype)
+    K = torch.cat([z, -rz, ry, rz, z, -rx, -ry, rx, z], dim=1).view(n, 3, 3)
+    return torch.eye(3, dtype=aa.dtype).unsqueeze(0) + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+def batch_rigid_transform(R, joints, parents):
+    """lbs.py:207-262."""
+    B, J = joints.shape[:2]
+    joints = joints.unsqueeze(-1)
+    rel = joints.clone()
+    rel[:, 1:] -= joints[:, parents[1:]]
+    T = torch.cat([F.pad(R.reshape(-1, 3, 3), [0, 0, 0, 1]), F.pad(rel.reshape(-1, 3, 1), [0, 0, 0, 1], value=1)],
+                  dim=2).view(B, J, 4, 4)
+    chain = [T[:, 0]]
+    for i in range(1, J):
+        chain.append(torch.matmul(chain[int(parents[i])], T[:, i]))
+    G = torch.stack(chain, dim=1)
+    posed = G[:, :, :3, 3]
+    jh = torch.cat([joints, torch.zeros(B, J, 1, 1, dtype=R.dtype)], dim=2)
+    init = F.pad(torch.matmul(G, jh), [3, 0, 0, 0, 0, 0, 0, 0])
+    return posed, G - init
+
+
+def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights):
+    """lbs.py:34-118.  betas [B,NB], pose [B,J*3] axis-angle, posedirs [P,3V]; returns verts [B,V,3], joints [B,J,3]."""
+    B = betas.shape[0]
+    J = J_regressor.shape[0]
+    v_shaped = v_template + torch.einsum('bl,mkl->bmk', betas, shapedirs)          # lbs.py:81,161
+    Jloc = torch.einsum('bik,ji->bjk', v_shaped, J_regressor).contiguous()          # lbs.py:85,138
+    R = batch_rodrigues(pose.reshape(-1, 3)).view(B, -1, 3, 3)                      # lbs.py:89
+    pose_feature = (R[:, 1:] - torch.eye(3, dtype=betas.dtype)).view(B, -1)         # lbs.py:94-95
+    v_posed = torch.matmul(pose_feature, posedirs).view(B, -1, 3) + v_shaped        # lbs.py:98-99
+    J_tr, A = batch_rigid_transform(R, Jloc, parents)                               # lbs.py:104
+    W = lbs_weights.unsqueeze(0).expand(B, -1, -1)                                  # lbs.py:108 (.repeat there)
+    T = torch.matmul(W, A.view(B, J, 16)).view(B, -1, 4, 4)                         # lbs.py:110
+    vh = torch.cat([v_posed, torch.ones(B, v_posed.shape[1], 1, dtype=betas.dtype)], dim=2)
+    verts = torch.matmul(T, vh.unsqueeze(-1))[:, :, :3, 0]                          # lbs.py:112-116
+    return verts, J_tr
+
+
+class SMPLXOracle:
+    """smplx==0.1.13 ``SMPLX.forward`` as PSI calls it (fitting_proxe.py:55-69,125-128): THIRD PARTY, parity unpinned.
+
+    num_pca_comps=12, flat_hand_mean=False; jaw/eye poses and expression default to zeros.
+    Restated per SURVEY Appendix D on top of the in-tree lbs (human_body_prior/body_model/lbs.py).
+    """
+
+    def __init__(self, data, num_pca_comps: int = 12, num_betas: int = 10, num_expr: int = 10):
+        t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+        self.v_template = t(data.v_template)
+        sd = np.asarray(data.shapedirs)
+        expr0 = 300 if sd.shape[-1] > 300 else 10                                   # body_model.py:105-106
+        self.shapedirs = t(np.concatenate([sd[:, :, :num_betas], sd[:, :, expr0:expr0 + num_expr]], -1))
+        pd = np.asarray(data.posedirs)
+        self.posedirs = t(pd.reshape(-1, pd.shape[-1]).T.copy())                    # [486, 3V] body_model.py:123-125
+        self.J_regressor = t(data.J_regressor)
+        self.lbs_weights = t(data.weights)
+        par = np.asarray(data.kintree_table)[0].astype(np.int64).copy()
+        par[0] = -1
+        self.parents = torch.tensor(par)
+        self.lh_comp = t(np.asarray(data.hands_componentsl)[:num_pca_comps])
+        self.rh_comp = t(np.asarray(data.hands_componentsr)[:num_pca_comps])
+        J = self.J_regressor.shape[0]
+        pm = np.zeros(J * 3, np.float32)
+        pm[(J - 30) * 3:(J - 15) * 3] = np.asarray(data.hands_meanl)
+        pm[(J - 15) * 3:] = np.asarray(data.hands_meanr)
+        self.pose_mean = t(pm)
+        self.num_expr = num_expr
+
+    def __call__(self, body_pose, transl, global_orient, betas, left_hand_pose, right_hand_pose, expression=None,
+                 return_verts=True, **kw):
+        B = betas.shape[0]
+        z3 = torch.zeros(B, 3)
+        lh = torch.einsum('bi,ij->bj', left_hand_pose, self.lh_comp)
+        rh = torch.einsum('bi,ij->bj', right_hand_pose, self.rh_comp)
+        full = torch.cat([global_orient, body_pose, z3, z3, z3, lh, rh], 1) + self.pose_mean
+        expr = torch.zeros(B, self.num_expr) if expression is None else expression
+        shape = torch.cat([betas, expr], -1)
+        v, j = lbs(shape, full, self.v_template, self.shapedirs, self.posedirs, self.J_regressor, self.parents,
+                   self.lbs_weights)
+        return SimpleNamespace(vertices=v + transl.unsqueeze(1), joints=j + transl.unsqueeze(1))
+
+
+# --------------------------------------------------------------------------------------------
+# Scene losses (a11-a17) and the fitting loop (a18)
+# --------------------------------------------------------------------------------------------
+def sdf_sample(sdf_vol, grid_min, grid_max, verts, align_corners=True):
+    """fitting_proxe.py:144-151.  sdf_vol [B,D,D,D]; grid_min/max [B,3]; verts [B,V,3] -> [B,1,V,1,1].
+
+    ``align_corners`` is explicit: the pinned torch 1.2.0 had no such argument and behaved as True."""
+    gmin, gmax = grid_min.unsqueeze(1), grid_max.unsqueeze(1)
+    norm = (verts - gmin) / (gmax - gmin) * 2 - 1
+    nv = norm.shape[1]
+    return F.grid_sample(sdf_vol.unsqueeze(1), norm[:, :, [2, 1, 0]].view(-1, nv, 1, 1, 3),
+                         padding_mode='border', align_corners=align_corners)
+
+
+def penetration_loss(body_sdf):
+    """fitting_proxe.py:155-158: mean |sdf| over the penetrating entries of the WHOLE batch, 0 if none."""
+    if body_sdf.lt(0).sum().item() < 1:
+        return torch.tensor(0.0, dtype=torch.float32)
+    return body_sdf[body_sdf < 0].abs().mean()
+
+
+def contact_loss(contact_dist, const):
+    """fitting_proxe.py:139 (const 0.01) / fitting_habitat.py:141, train_s1.py:175-177 (const 1.0)."""
+    s = torch.sqrt(contact_dist + 1e-4)
+    return torch.mean(s / (s + const))
+
+
+class FittingOracle:
+    """FittingOP (fitting_proxe.py:40-195) with explicit inputs instead of files."""
+
+    def __init__(self, smplx_model: SMPLXOracle, vposer_sd: dict, scene_verts, sdf, grid_min, grid_max,
+                 contact_ids, batch_size, weights=None, lr=0.1, contact_const=0.01, align_corners=True):
+        self.bm = smplx_model
+        self.vp = {k: torch.tensor(np.asarray(v)) for k, v in vposer_sd.items() if 'dec' in k}
+        self.B = batch_size
+        self.s_verts = torch.tensor(scene_verts, dtype=torch.float32).unsqueeze(0).repeat(batch_size, 1, 1)
+        self.sdf = torch.tensor(sdf, dtype=torch.float32).unsqueeze(0)
+        self.gmin = torch.tensor(grid_min, dtype=torch.float32).unsqueeze(0)
+        self.gmax = torch.tensor(grid_max, dtype=torch.float32).unsqueeze(0)
+        self.vid = torch.tensor(np.asarray(contact_ids), dtype=torch.long)
+        w = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1, 'weight_collision': 0.5}
+        w.update(weights or {})
+        self.w = w
+        self.contact_const = contact_const
+        self.align_corners = align_corners
+        self.xhr_rec = torch.zeros(batch_size, 75, requires_grad=True)
+        self.optimizer = torch.optim.Adam([self.xhr_rec], lr=lr)                   # fitting_proxe.py:73-74
+
+    def body_verts(self, xh_rec, cam_ext):
+        p = split_body_vector(xh_rec)
+        aa = vposer_decode_aa(self.vp, p['body_pose_vp']).view(self.B, -1)
+        out = self.bm(body_pose=aa, transl=p['transl'], global_orient=p['global_orient'], betas=p['betas'],
+                      left_hand_pose=p['left_hand_pose'], right_hand_pose=p['right_hand_pose'])
+        return verts_transform(out.vertices, cam_ext)
+
+    def cal_loss(self, xhr, cam_ext):
+        """fitting_proxe.py:101-162."""
+        loss_rec = self.w['weight_loss_rec'] * F.l1_loss(xhr, self.xhr_rec)
+        xh_rec = convert_to_3d_rot(self.xhr_rec)
+        loss_vposer = self.w['weight_loss_vposer'] * torch.mean(xh_rec[:, 16:48] ** 2)
+        verts = self.body_verts(xh_rec, cam_ext)
+        contact = verts[:, self.vid, :]
+        d1, _ = chamfer_dist(contact.contiguous(), self.s_verts.contiguous())
+        loss_contact = self.w['weight_contact'] * contact_loss(d1, self.contact_const)
+        # the reference replicates the volume per sample (fitting_proxe.py:90); expand() is arithmetic-neutral
+        body_sdf = sdf_sample(self.sdf.expand(self.B, -1, -1, -1), self.gmin, self.gmax, verts, self.align_corners)
+        loss_coll = self.w['weight_collision'] * penetration_loss(body_sdf)
+        self.last = SimpleNamespace(verts=verts, dist=d1, sdf=body_sdf)
+        return loss_rec, loss_vposer, loss_contact, loss_coll
+
+    def fitting(self, xh72, cam_ext, num_iter, record=None):
+        """fitting_proxe.py:167-195 (Adam state persists across calls, :74,:175)."""
+        xhr = convert_to_6d_rot(torch.as_tensor(xh72, dtype=torch.float32))
+        cam_ext = torch.as_tensor(cam_ext, dtype=torch.float32)
+        self.xhr_rec.data = xhr.clone()
+        for _ in range(num_iter):
+            self.optimizer.zero_grad()
+            losses = self.cal_loss(xhr, cam_ext)
+            if record is not None:
+                record.append([float(l) for l in losses])
+            sum(losses).backward()
+            self.optimizer.step()
+        return convert_to_3d_rot(self.xhr_rec)
