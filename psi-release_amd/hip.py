@@ -1,0 +1,78 @@
+"""ctypes binding of libpsi_hip.so (include/psi_hip.h).  PyTorch supplies device memory and streams only.
+
+The library is REQUIRED: importing an op that needs it raises if it is missing — there is no
+CPU or eager fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'lib', 'libpsi_hip.so')
+_lib = None
+
+c_void_p, c_int, c_long, c_size_t, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_float
+
+# name -> (restype, argtypes); every symbol declared in include/psi_hip.h must appear here
+SIGNATURES = {
+    'psi_last_error': (ctypes.c_char_p, []),
+    'psi_version': (c_int, []),
+    'psi_device_info': (c_int, [c_void_p] * 4),
+    'psi_chamfer_workspace_bytes': (c_size_t, [c_int] * 3),
+    'psi_chamfer_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    'psi_chamfer_backward': (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    'psi_sdf_sample_forward': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p] * 3),
+    'psi_sdf_sample_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'psi_sdf_penetration_stats': (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
+}
+
+
+class PsiHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises PsiHipError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PsiHipError('libpsi_hip.so not found at %s — run `python -m psi_release_amd.build` '
+                              '(there is no CPU fallback)' % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise PsiHipError('%s failed (code %d): %s' % (what, rc, lib().psi_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be a contiguous CUDA(HIP) tensor."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PsiHipError('expected a GPU tensor (the HIP kernels are the only implementation)')
+    if not t.is_contiguous():
+        raise PsiHipError('expected a contiguous tensor')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def device_info():
+    cu, ws, clk, is950 = c_int(), c_int(), c_int(), c_int()
+    check(lib().psi_device_info(ctypes.byref(cu), ctypes.byref(ws), ctypes.byref(clk), ctypes.byref(is950)),
+          'psi_device_info')
+    return {'cu_count': cu.value, 'wave_size': ws.value, 'clock_khz': clk.value, 'gfx950': bool(is950.value)}

@@ -1,0 +1,164 @@
+"""Autograd operators over the C ABI (include/psi_hip.h).  Same call signatures as the reference's ops.
+
+* ``chamferFunction`` / ``chamferDist``   <- chamfer_pytorch/dist_chamfer.py:13-53 (+ idx variant, dist_chamfer_idx.py)
+* ``sdf_sample``                          <- F.grid_sample call of fitting_proxe.py:144-151
+* ``penetration_loss``                    <- fitting_proxe.py:155-158 (no host sync)
+
+Inputs must live on the GPU; there is no CPU path (hip.ptr raises).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from . import hip
+
+
+# ------------------------------------------------------------------------------------------
+# Chamfer
+# ------------------------------------------------------------------------------------------
+def chamfer_forward_raw(xyz1, xyz2, both=True):
+    """chamfer.forward (chamfer_cuda.cpp:17-19): returns dist1, idx1, dist2, idx2 (None, None when both=False)."""
+    xyz1 = xyz1.contiguous().float()
+    xyz2 = xyz2.contiguous().float()
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    if xyz2.shape[0] != B or xyz1.shape[2] != 3 or xyz2.shape[2] != 3:
+        raise ValueError('expected xyz1 [B,n,3] and xyz2 [B,m,3]')
+    dev = xyz1.device
+    dist1 = torch.zeros(B, n, device=dev)
+    idx1 = torch.zeros(B, n, dtype=torch.int32, device=dev)
+    dist2 = torch.zeros(B, m, device=dev) if both else None
+    idx2 = torch.zeros(B, m, dtype=torch.int32, device=dev) if both else None
+    L = hip.lib()
+    nbytes = L.psi_chamfer_workspace_bytes(B, n, m)
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
+    hip.check(L.psi_chamfer_forward(hip.ptr(xyz1), hip.ptr(xyz2), B, n, m, hip.ptr(dist1), hip.ptr(idx1),
+                                    hip.ptr(dist2), hip.ptr(idx2), hip.ptr(ws), hip.stream()), 'psi_chamfer_forward')
+    return dist1, idx1, dist2, idx2
+
+
+class chamferFunction(Function):
+    """dist_chamfer.py:13-46.  ``return_idx`` selects the dist_chamfer_idx.py:28 output tuple."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, return_idx=False, both=True):
+        xyz1 = xyz1.contiguous()
+        xyz2 = xyz2.contiguous()
+        dist1, idx1, dist2, idx2 = chamfer_forward_raw(xyz1, xyz2, both)
+        ctx.both = both
+        if both:
+            ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        else:
+            ctx.save_for_backward(xyz1, xyz2, idx1)
+            dist2 = torch.zeros(xyz2.shape[0], xyz2.shape[1], device=xyz1.device)
+            idx2 = torch.zeros(xyz2.shape[0], xyz2.shape[1], dtype=torch.int32, device=xyz1.device)
+        ctx.mark_non_differentiable(idx1, idx2)
+        if return_idx:
+            return dist1, dist2, idx1, idx2
+        return dist1, dist2
+
+    @staticmethod
+    def backward(ctx, graddist1, graddist2, *unused):
+        if ctx.both:
+            xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        else:
+            xyz1, xyz2, idx1 = ctx.saved_tensors
+            idx2 = None
+        B, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        graddist1 = graddist1.contiguous()
+        need2 = ctx.needs_input_grad[1]
+        use_dir2 = ctx.both and graddist2 is not None
+        gradxyz1 = torch.zeros_like(xyz1)
+        gradxyz2 = torch.zeros_like(xyz2) if (need2 or use_dir2) else None
+        g2 = graddist2.contiguous() if use_dir2 else None
+        hip.check(hip.lib().psi_chamfer_backward(hip.ptr(xyz1), hip.ptr(xyz2), hip.ptr(gradxyz1), hip.ptr(gradxyz2),
+                                                 hip.ptr(graddist1), hip.ptr(g2), hip.ptr(idx1),
+                                                 hip.ptr(idx2) if use_dir2 else None, B, n, m, hip.stream()),
+                  'psi_chamfer_backward')
+        return gradxyz1, (gradxyz2 if need2 else None), None, None
+
+
+class chamferDist(nn.Module):
+    """dist_chamfer.py:48-53: ``chamferDist()(xyz1, xyz2) -> (dist1, dist2)``.
+
+    ``one_sided=True`` skips the scene->body direction that PSI discards (fitting_proxe.py:136);
+    ``dist2`` is then returned as zeros."""
+
+    def __init__(self, return_idx: bool = False, one_sided: bool = False):
+        super().__init__()
+        self.return_idx = return_idx
+        self.one_sided = one_sided
+
+    def forward(self, input1, input2):
+        return chamferFunction.apply(input1, input2, self.return_idx, not self.one_sided)
+
+
+# ------------------------------------------------------------------------------------------
+# SDF lookup
+# ------------------------------------------------------------------------------------------
+class _SdfSample(Function):
+    @staticmethod
+    def forward(ctx, verts, sdf, scene_id, gmin, gmax, align_corners):
+        verts = verts.contiguous().float()
+        B, V, _ = verts.shape
+        S, D = sdf.shape[0], sdf.shape[1]
+        out = torch.empty(B, V, device=verts.device)
+        og = torch.empty(B, V, 3, device=verts.device)
+        hip.check(hip.lib().psi_sdf_sample_forward(hip.ptr(sdf), hip.ptr(scene_id), hip.ptr(gmin), hip.ptr(gmax),
+                                                   hip.ptr(verts), B, V, D, S, int(bool(align_corners)), hip.ptr(out),
+                                                   hip.ptr(og), hip.stream()), 'psi_sdf_sample_forward')
+        ctx.save_for_backward(og)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (og,) = ctx.saved_tensors
+        B, V, _ = og.shape
+        gv = torch.zeros_like(og)
+        hip.check(hip.lib().psi_sdf_sample_backward(hip.ptr(gout.contiguous()), hip.ptr(og), B, V, hip.ptr(gv),
+                                                    hip.stream()), 'psi_sdf_sample_backward')
+        return gv, None, None, None, None, None
+
+
+def sdf_sample(verts, sdf, grid_min, grid_max, scene_id=None, align_corners=True):
+    """Trilinear SDF values [B,V] of world-space ``verts`` [B,V,3].
+
+    sdf [S,D,D,D] (or [D,D,D]) holds ONE volume per scene, ``scene_id`` [B] int32 picks it (None = scene 0);
+    grid_min / grid_max [S,3] (or [3]).  Equivalent to fitting_proxe.py:144-151 with the volume not replicated."""
+    if sdf.dim() == 3:
+        sdf = sdf.unsqueeze(0)
+    sdf = sdf.contiguous().float()
+    S = sdf.shape[0]
+    gmin = grid_min.reshape(-1, 3).contiguous().float()
+    gmax = grid_max.reshape(-1, 3).contiguous().float()
+    if gmin.shape[0] != S or gmax.shape[0] != S:
+        raise ValueError('grid_min/grid_max must have one row per scene volume')
+    if scene_id is not None:
+        scene_id = scene_id.to(device=verts.device, dtype=torch.int32).contiguous()
+    return _SdfSample.apply(verts, sdf, scene_id, gmin, gmax, align_corners)
+
+
+class _PenLoss(Function):
+    """mean |sdf| over the negative entries of the whole batch, 0 when there are none (fitting_proxe.py:155-158)."""
+
+    @staticmethod
+    def forward(ctx, vals):
+        vals = vals.contiguous()
+        stats = torch.zeros(2, device=vals.device)
+        hip.check(hip.lib().psi_sdf_penetration_stats(hip.ptr(vals), vals.numel(), hip.ptr(stats), hip.stream()),
+                  'psi_sdf_penetration_stats')
+        ctx.save_for_backward(vals, stats)
+        return torch.where(stats[1] > 0, stats[0] / stats[1].clamp(min=1.0), torch.zeros((), device=vals.device))
+
+    @staticmethod
+    def backward(ctx, g):
+        vals, stats = ctx.saved_tensors
+        scale = torch.where(stats[1] > 0, -g / stats[1].clamp(min=1.0), torch.zeros((), device=vals.device))
+        return (vals < 0).to(vals.dtype) * scale
+
+
+def penetration_loss(body_sdf):
+    return _PenLoss.apply(body_sdf)
