@@ -77,6 +77,35 @@ int psi_sdf_sample_backward(const float *grad_sdf, const float *out_grad, int B,
  * stats must be zeroed by the caller (it is accumulated with atomics). */
 int psi_sdf_penetration_stats(const float *sdf_vals, long n, float *stats, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * SMPL-X linear blend skinning — replaces the body-model call
+ *   smplx.create(path, model_type='smplx', ..., batch_size=B)(return_verts=True, body_pose=..., ...)
+ *                                                       fitting_proxe.py:55-69,125-128; train_s1.py:66-81,150-153
+ * whose arithmetic is lbs() (human_body_prior/body_model/lbs.py:34-118 == smplx 0.1.13 lbs), plus
+ * `vertices + transl` and, when cam_ext is given, GeometryTransformer.verts_transform (cvae.py:141-149).
+ * psi_lbs_create takes HOST arrays laid out as the SMPL-X loader leaves them:
+ *   v_template [V,3]; shapedirs [V,3,NB] (betas | expression); posedirs [P,3V], P=(J-1)*9
+ *   (i.e. reshape(posedirs,[-1,P]).T); J_regressor [J,V]; weights [V,J]; parents [J] (-1 for the root).
+ * Forward inputs (device): betas [B,NB] (shape | expression), pose [B,J*3] axis-angle of ALL joints
+ * (after hand PCA and pose_mean), transl [B,3] or NULL, cam_ext [B,4,4] row-major or NULL.
+ * Outputs: verts [B,V,3]; joints [B,J,3] or NULL (posed joints + transl, no camera transform).
+ * ws: psi_lbs_workspace_floats(model,B) floats of device scratch; forward saves what backward needs
+ * there, so the same ws must be passed to the matching psi_lbs_backward.
+ * Backward: grad_verts [B,V,3] -> grad_betas [B,NB], grad_pose [B,J*3], grad_transl [B,3] (each
+ * nullable, each OVERWRITTEN).  Joints are not differentiated (PSI reads .vertices only).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct psi_lbs_model psi_lbs_model;
+int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, const float *h_shapedirs,
+                   const float *h_posedirs, const float *h_J_regressor, const float *h_weights,
+                   const int32_t *h_parents, int V, int J, int NB);
+void psi_lbs_destroy(psi_lbs_model *model);
+size_t psi_lbs_workspace_floats(const psi_lbs_model *model, int B);
+int psi_lbs_forward(const psi_lbs_model *model, const float *betas, const float *pose, const float *transl,
+                    const float *cam_ext, int B, float *verts, float *joints, float *ws, void *stream);
+int psi_lbs_backward(const psi_lbs_model *model, const float *grad_verts, const float *betas, const float *pose,
+                     const float *cam_ext, int B, float *ws, float *grad_betas, float *grad_pose,
+                     float *grad_transl, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

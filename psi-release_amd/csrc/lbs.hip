@@ -1,0 +1,767 @@
+// SMPL-X linear blend skinning (forward + hand-derived backward) for gfx950.
+// Replaces the body-model call of the reference,
+//   smplx.create(...)(return_verts=True, body_pose, transl, global_orient, betas, hands)   fitting_proxe.py:55-69,125-128
+// whose arithmetic is `lbs` (human_body_prior/body_model/lbs.py:34-118 == smplx 0.1.13 lbs), followed by
+// `+ transl` and PSI's verts_transform (cvae.py:141-149).
+//
+// Data layout in HBM (built once by psi_lbs_create, fp32):
+//   dirs  [Kpad][Npad]   rows 0..NB-1 = shapedirs^T, rows NB..NB+P-1 = posedirs, zero padded; N = 3V.
+//                        Shape and pose blendshapes are ONE contraction: v_posed = v_template + feat @ dirs,
+//                        feat[b] = [betas | (R_1..R_{J-1} - I)]  (lbs.py:81 and :94-99 fused; 64 MB streamed once).
+//   WT    [64][Vpad]     skinning weights transposed (coalesced per-vertex reads), zero padded.
+//   J_t [J][3], J_s [J][3][NB]   joint regressor pre-contracted with v_template / shapedirs (fp64 on the host):
+//                        J = J_t + J_s @ betas, algebraically lbs.py:85 without the V-long reduction per call.
+// Kernels:
+//   pose_fwd   (1 wave per body)   Rodrigues (lbs.py:165-192), joints, level-parallel kinematic chain (lbs.py:207-262)
+//   blend_fwd  (MFMA f32 16x16x4)  v_posed = v_template + feat @ dirs       — HBM-bound on dirs (64 MB)
+//   skin_fwd                       verts = cam_ext * (sum_j W_j A_j [v_posed;1] + transl)  (lbs.py:108-116, cvae.py:141-149)
+//   skin_bwd_v                     g_local = R_c^T g_verts;  g_vposed = T_R^T g_local;  partial g_transl
+//   skin_bwd_A (MFMA)              gA[b][j] = sum_v W[v][j] * g_local (x) [v_posed;1]   (contraction over V)
+//   blend_bwd  (MFMA)              g_feat = g_vposed @ dirs^T                (contraction over N, dirs streamed again)
+//   pose_bwd   (1 wave per body)   chain reverse sweep, Rodrigues derivative, joint/shape gradients
+// The f32 MFMA (v_mfma_f32_16x16x4_f32) is bit-identical to an fmaf chain, so these are exact-f32 GEMMs.
+#include "psi_common.h"
+#include <math.h>
+#include <vector>
+#include <string.h>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int JP = 64;          // padded joint count (one wave)
+constexpr int SKIN_BT = 4;      // bodies per skinning workgroup
+constexpr int SKIN_BLK = 256;
+
+struct LbsDev {
+    int V, J, NB, P, K, Kpad, N, Npad, Vpad, maxlevel;
+    const float *dirs, *v_template, *WT, *J_t, *J_s;
+    const int *parents, *level, *child_ptr, *child_idx;
+};
+
+}  // namespace
+
+struct psi_lbs_model {
+    LbsDev d;
+    void *blob;   // single device allocation holding everything above
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout (floats)
+// ------------------------------------------------------------------------------------------------
+struct WsLayout {
+    size_t feat, R, Jl, G, A, v_posed, gl, g_vp, gA_part, gfeat_part, gt_part, gA, total;
+    int nsv, nsn, nvb;
+};
+
+WsLayout ws_layout(const LbsDev &m, int B)
+{
+    WsLayout w;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+    w.nsv = m.Vpad / 256;                 // v-slices of 256 vertices for skin_bwd_A
+    w.nsn = psi_cdiv(m.Npad / 16, 48);    // n-slices of 48 MFMA steps (768 columns) for blend_bwd
+    w.nvb = m.Vpad / SKIN_BLK;
+    w.feat = take((size_t)B * m.Kpad);
+    w.R = take((size_t)B * m.J * 9);
+    w.Jl = take((size_t)B * m.J * 3);
+    w.G = take((size_t)B * m.J * 12);
+    w.A = take((size_t)B * m.J * 12);
+    w.v_posed = take((size_t)B * m.Npad);
+    w.gl = take((size_t)B * m.Npad);
+    w.g_vp = take((size_t)B * m.Npad);
+    w.gA_part = take((size_t)w.nsv * B * JP * 16);
+    w.gfeat_part = take((size_t)w.nsn * B * m.Kpad);
+    w.gt_part = take((size_t)w.nvb * B * 4);
+    w.gA = take((size_t)B * JP * 16);
+    w.total = o;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pose forward: one wave per body
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rodrigues(const float *aa, float *R)
+{
+    // lbs.py:177-191: angle = ||aa + 1e-8||, dir = aa / angle, R = I + sin K + (1 - cos) K K
+    float x = aa[0] + 1e-8f, y = aa[1] + 1e-8f, z = aa[2] + 1e-8f;
+    float angle = sqrtf(x * x + y * y + z * z);
+    float rx = aa[0] / angle, ry = aa[1] / angle, rz = aa[2] / angle;
+    float s = sinf(angle), c1 = 1.0f - cosf(angle);
+    R[0] = 1.0f + c1 * (-(ry * ry + rz * rz));
+    R[1] = s * (-rz) + c1 * (rx * ry);
+    R[2] = s * ry + c1 * (rx * rz);
+    R[3] = s * rz + c1 * (rx * ry);
+    R[4] = 1.0f + c1 * (-(rx * rx + rz * rz));
+    R[5] = s * (-rx) + c1 * (ry * rz);
+    R[6] = s * (-ry) + c1 * (rx * rz);
+    R[7] = s * rx + c1 * (ry * rz);
+    R[8] = 1.0f + c1 * (-(rx * rx + ry * ry));
+}
+
+__global__ __launch_bounds__(64) void pose_fwd_kernel(LbsDev m, const float *__restrict__ betas, const float *__restrict__ pose,
+                                                      const float *__restrict__ transl, int B, float *__restrict__ feat,
+                                                      float *__restrict__ Rs, float *__restrict__ Jls, float *__restrict__ Gs,
+                                                      float *__restrict__ As, float *__restrict__ joints)
+{
+    const int b = blockIdx.x, j = threadIdx.x;
+    __shared__ float sJ[JP][3];
+    __shared__ float sG[JP][12];
+    const bool act = j < m.J;
+    float R[9], Jl[3] = {0, 0, 0};
+    if (act) {
+        rodrigues(pose + ((size_t)b * m.J + j) * 3, R);
+        for (int c = 0; c < 3; c++) {
+            float a = m.J_t[j * 3 + c];
+            for (int l = 0; l < m.NB; l++) a += m.J_s[(j * 3 + c) * m.NB + l] * betas[(size_t)b * m.NB + l];
+            Jl[c] = a;
+            sJ[j][c] = a;
+        }
+        for (int e = 0; e < 9; e++) Rs[((size_t)b * m.J + j) * 9 + e] = R[e];
+        for (int c = 0; c < 3; c++) Jls[((size_t)b * m.J + j) * 3 + c] = Jl[c];
+        float *f = feat + (size_t)b * m.Kpad;
+        if (j >= 1)
+            for (int e = 0; e < 9; e++) f[m.NB + (j - 1) * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+    }
+    {   // betas and the zero tail of the feature row
+        float *f = feat + (size_t)b * m.Kpad;
+        for (int l = j; l < m.NB; l += 64) f[l] = betas[(size_t)b * m.NB + l];
+        for (int l = m.K + j; l < m.Kpad; l += 64) f[l] = 0.0f;
+    }
+    __syncthreads();
+    const int par = act ? m.parents[j] : -1;
+    const int lvl = act ? m.level[j] : -1;
+    float rel[3] = {Jl[0], Jl[1], Jl[2]};
+    if (act && par >= 0)
+        for (int c = 0; c < 3; c++) rel[c] = Jl[c] - sJ[par][c];
+    float G[12];   // row-major 3x4: [R | t]
+    if (act && lvl == 0) {
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) G[r * 4 + c] = R[r * 3 + c];
+            G[r * 4 + 3] = rel[r];
+        }
+        for (int e = 0; e < 12; e++) sG[j][e] = G[e];
+    }
+    for (int L = 1; L <= m.maxlevel; L++) {
+        __syncthreads();
+        if (act && lvl == L) {
+            float P[12];
+            for (int e = 0; e < 12; e++) P[e] = sG[par][e];
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++)
+                    G[r * 4 + c] = P[r * 4 + 0] * R[0 * 3 + c] + P[r * 4 + 1] * R[1 * 3 + c] + P[r * 4 + 2] * R[2 * 3 + c];
+                G[r * 4 + 3] = P[r * 4 + 0] * rel[0] + P[r * 4 + 1] * rel[1] + P[r * 4 + 2] * rel[2] + P[r * 4 + 3];
+            }
+            for (int e = 0; e < 12; e++) sG[j][e] = G[e];
+        }
+    }
+    if (act) {
+        float *Go = Gs + ((size_t)b * m.J + j) * 12, *Ao = As + ((size_t)b * m.J + j) * 12;
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) {
+                Go[r * 4 + c] = G[r * 4 + c];
+                Ao[r * 4 + c] = G[r * 4 + c];
+            }
+            Go[r * 4 + 3] = G[r * 4 + 3];
+            // lbs.py:258-260: A = G - pad(G [J;0])
+            Ao[r * 4 + 3] = G[r * 4 + 3] - (G[r * 4 + 0] * Jl[0] + G[r * 4 + 1] * Jl[1] + G[r * 4 + 2] * Jl[2]);
+        }
+        if (joints)
+            for (int r = 0; r < 3; r++) joints[((size_t)b * m.J + j) * 3 + r] = G[r * 4 + 3] + (transl ? transl[(size_t)b * 3 + r] : 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// blend forward: v_posed[b][n] = v_template[n] + sum_k feat[b][k] dirs[k][n]      (MFMA f32 16x16x4)
+// workgroup = 4 waves = one 64-column tile; wave w contracts k in [w*Kpad/4, (w+1)*Kpad/4); LDS reduce.
+// B operand: each lane loads 16 B (4 consecutive columns of one dirs row): 4 rows x 256 B per wave-load.
+// MFMA c of a k-step uses element c of that float4, so its 16 output columns are n0 + 4*(lane&15) + c.
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void blend_fwd_kernel(LbsDev m, const float *__restrict__ feat, int B,
+                                                        float *__restrict__ v_posed)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 64;
+    const int b0 = blockIdx.y * 16 * MT;
+    const int kq = m.Kpad / 4;
+    const int li = lane & 15, lk = lane >> 4;
+    f4 acc[MT][4];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[t][c] = (f4){0, 0, 0, 0};
+    const float *arow[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) arow[t] = feat + (size_t)min(b0 + t * 16 + li, B - 1) * m.Kpad + w * kq + lk;
+    const float *brow = m.dirs + (size_t)(w * kq + lk) * m.Npad + n0 + 4 * li;
+#pragma unroll 4
+    for (int ks = 0; ks < kq; ks += 4) {
+        f4 q = *(const f4 *)(brow + (size_t)ks * m.Npad);
+        float a[MT];
+#pragma unroll
+        for (int t = 0; t < MT; t++) a[t] = arow[t][ks];
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], q[c], acc[t][c], 0, 0, 0);
+    }
+    // reduce the four k-quarters through LDS; wave w finishes accumulator register `w` (row (lane>>4)*4 + w)
+    __shared__ f4 red[4][MT][4][64];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) red[w][t][c][lane] = acc[t][c];
+    __syncthreads();
+    f4 vt = *(const f4 *)(m.v_template + n0 + 4 * li);
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        f4 o = vt;
+#pragma unroll
+        for (int ww = 0; ww < 4; ww++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) o[c] += ((const float *)&red[ww][t][c][lane])[w];
+        int b = b0 + t * 16 + lk * 4 + w;
+        if (b < B) *(f4 *)(v_posed + (size_t)b * m.Npad + n0 + 4 * li) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// skinning forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SKIN_BLK) void skin_fwd_kernel(LbsDev m, const float *__restrict__ As, const float *__restrict__ v_posed,
+                                                            const float *__restrict__ transl, const float *__restrict__ cam_ext,
+                                                            int B, float *__restrict__ verts)
+{
+    const int v = blockIdx.x * SKIN_BLK + threadIdx.x;
+    const int b0 = blockIdx.y * SKIN_BT;
+    float T[SKIN_BT][12];
+#pragma unroll
+    for (int i = 0; i < SKIN_BT; i++)
+#pragma unroll
+        for (int e = 0; e < 12; e++) T[i][e] = 0.0f;
+    for (int j = 0; j < m.J; j++) {
+        float wj = m.WT[(size_t)j * m.Vpad + v];
+#pragma unroll
+        for (int i = 0; i < SKIN_BT; i++) {
+            const float *A = As + ((size_t)min(b0 + i, B - 1) * m.J + j) * 12;   // wave-uniform -> scalar loads
+#pragma unroll
+            for (int e = 0; e < 12; e++) T[i][e] += wj * A[e];
+        }
+    }
+    if (v >= m.V) return;
+#pragma unroll
+    for (int i = 0; i < SKIN_BT; i++) {
+        int b = b0 + i;
+        if (b >= B) break;
+        const float *vp = v_posed + (size_t)b * m.Npad + (size_t)v * 3;
+        float px = vp[0], py = vp[1], pz = vp[2];
+        float x = T[i][0] * px + T[i][1] * py + T[i][2] * pz + T[i][3];
+        float y = T[i][4] * px + T[i][5] * py + T[i][6] * pz + T[i][7];
+        float z = T[i][8] * px + T[i][9] * py + T[i][10] * pz + T[i][11];
+        if (transl) {
+            x += transl[(size_t)b * 3 + 0];
+            y += transl[(size_t)b * 3 + 1];
+            z += transl[(size_t)b * 3 + 2];
+        }
+        if (cam_ext) {   // cvae.py:141-149: [v,1] @ cam_ext^T, drop w
+            const float *C = cam_ext + (size_t)b * 16;
+            float X = C[0] * x + C[1] * y + C[2] * z + C[3];
+            float Y = C[4] * x + C[5] * y + C[6] * z + C[7];
+            float Z = C[8] * x + C[9] * y + C[10] * z + C[11];
+            x = X; y = Y; z = Z;
+        }
+        float *o = verts + ((size_t)b * m.V + v) * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// skinning backward, per-vertex part: g_local, g_vposed, partial g_transl
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    return x;
+}
+
+__global__ __launch_bounds__(SKIN_BLK) void skin_bwd_v_kernel(LbsDev m, const float *__restrict__ As, const float *__restrict__ g_verts,
+                                                              const float *__restrict__ cam_ext, int B, float *__restrict__ gl,
+                                                              float *__restrict__ g_vp, float *__restrict__ gt_part)
+{
+    const int v = blockIdx.x * SKIN_BLK + threadIdx.x;
+    const int b0 = blockIdx.y * SKIN_BT;
+    float T[SKIN_BT][9];
+#pragma unroll
+    for (int i = 0; i < SKIN_BT; i++)
+#pragma unroll
+        for (int e = 0; e < 9; e++) T[i][e] = 0.0f;
+    for (int j = 0; j < m.J; j++) {
+        float wj = m.WT[(size_t)j * m.Vpad + v];
+#pragma unroll
+        for (int i = 0; i < SKIN_BT; i++) {
+            const float *A = As + ((size_t)min(b0 + i, B - 1) * m.J + j) * 12;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) T[i][r * 3 + c] += wj * A[r * 4 + c];
+        }
+    }
+    __shared__ float sh[SKIN_BLK / 64][SKIN_BT][3];
+    const bool live = v < m.V;
+#pragma unroll
+    for (int i = 0; i < SKIN_BT; i++) {
+        int b = b0 + i;
+        float lx = 0, ly = 0, lz = 0;
+        if (b < B && live) {
+            const float *g = g_verts + ((size_t)b * m.V + v) * 3;
+            float gx = g[0], gy = g[1], gz = g[2];
+            if (cam_ext) {   // g_local = R_c^T g
+                const float *C = cam_ext + (size_t)b * 16;
+                lx = C[0] * gx + C[4] * gy + C[8] * gz;
+                ly = C[1] * gx + C[5] * gy + C[9] * gz;
+                lz = C[2] * gx + C[6] * gy + C[10] * gz;
+            } else {
+                lx = gx; ly = gy; lz = gz;
+            }
+        }
+        if (b < B) {
+            float *o = gl + (size_t)b * m.Npad + (size_t)v * 3;
+            o[0] = lx; o[1] = ly; o[2] = lz;
+            float *p = g_vp + (size_t)b * m.Npad + (size_t)v * 3;   // T_R^T g_local
+            p[0] = T[i][0] * lx + T[i][3] * ly + T[i][6] * lz;
+            p[1] = T[i][1] * lx + T[i][4] * ly + T[i][7] * lz;
+            p[2] = T[i][2] * lx + T[i][5] * ly + T[i][8] * lz;
+        }
+        float sx = wave_sum(lx), sy = wave_sum(ly), sz = wave_sum(lz);
+        if ((threadIdx.x & 63) == 0) {
+            sh[threadIdx.x >> 6][i][0] = sx;
+            sh[threadIdx.x >> 6][i][1] = sy;
+            sh[threadIdx.x >> 6][i][2] = sz;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < SKIN_BT * 3) {
+        int i = threadIdx.x / 3, c = threadIdx.x % 3, b = b0 + i;
+        if (b < B) {
+            float s = 0;
+            for (int ww = 0; ww < SKIN_BLK / 64; ww++) s += sh[ww][i][c];
+            gt_part[((size_t)blockIdx.x * B + b) * 4 + c] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// skinning backward, joint part (MFMA): gA[b][j][r*4+s] = sum_v W[v][j] * g_local[b][v][r] * [v_posed;1][s]
+// wave = one body x one 256-vertex slice x all 64 padded joints (4 accumulators).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void skin_bwd_A_kernel(LbsDev m, const float *__restrict__ gl, const float *__restrict__ v_posed,
+                                                         int B, float *__restrict__ part)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.y * 4 + w;
+    if (b >= B) return;
+    const int vs = blockIdx.x * 256;
+    const int li = lane & 15, lk = lane >> 4;
+    const int r = li >> 2, s = li & 3;
+    f4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (f4){0, 0, 0, 0};
+    const float *glb = gl + (size_t)b * m.Npad;
+    const float *vpb = v_posed + (size_t)b * m.Npad;
+#pragma unroll 2
+    for (int st = 0; st < 16; st++) {
+        const int v0 = vs + st * 16 + 4 * lk;
+        f4 wa[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++) wa[jt] = *(const f4 *)(m.WT + (size_t)(jt * 16 + li) * m.Vpad + v0);
+        float bop[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            float g = (r < 3) ? glb[(size_t)(v0 + t) * 3 + r] : 0.0f;
+            float p = (s < 3) ? vpb[(size_t)(v0 + t) * 3 + s] : 1.0f;
+            bop[t] = g * p;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int jt = 0; jt < 4; jt++) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[jt][t], bop[t], acc[jt], 0, 0, 0);
+    }
+    float *o = part + ((size_t)blockIdx.x * B + b) * JP * 16;
+#pragma unroll
+    for (int jt = 0; jt < 4; jt++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[(jt * 16 + lk * 4 + e) * 16 + li] = acc[jt][e];
+}
+
+// ------------------------------------------------------------------------------------------------
+// blend backward (MFMA): g_feat[b][k] = sum_n g_vp[b][n] dirs[k][n]
+// workgroup = 4 waves sharing a 64-row k group and an n-slice; wave w takes n-steps w, w+4, ...; LDS reduce.
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void blend_bwd_kernel(LbsDev m, const float *__restrict__ g_vp, int B, int steps_per_slice,
+                                                        float *__restrict__ part)
+{
+    constexpr int KT = 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int k0 = blockIdx.x * 16 * KT;
+    const int slice = blockIdx.y;
+    const int b0 = blockIdx.z * 16 * MT;
+    const int total_steps = m.Npad / 16;
+    const int s_begin = slice * steps_per_slice;
+    const int s_end = min(s_begin + steps_per_slice, total_steps);
+    f4 acc[KT][MT];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[kt][t] = (f4){0, 0, 0, 0};
+    const float *grow[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) grow[t] = g_vp + (size_t)min(b0 + t * 16 + li, B - 1) * m.Npad + 4 * lk;
+    const float *drow[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) drow[kt] = m.dirs + (size_t)(k0 + kt * 16 + li) * m.Npad + 4 * lk;
+    for (int st = s_begin + w; st < s_end; st += 4) {
+        const int n0 = st * 16;
+        f4 ga[MT], db[KT];
+#pragma unroll
+        for (int t = 0; t < MT; t++) ga[t] = *(const f4 *)(grow[t] + n0);
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) db[kt] = *(const f4 *)(drow[kt] + n0);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+                for (int t = 0; t < MT; t++) acc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[t][e], db[kt][e], acc[kt][t], 0, 0, 0);
+    }
+    __shared__ f4 red[4][KT][MT][64];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int t = 0; t < MT; t++) red[w][kt][t][lane] = acc[kt][t];
+    __syncthreads();
+    // wave w finishes k-tile w: D[row = lk*4+e -> body][col = li -> k]
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        f4 o = red[0][w][t][lane] + red[1][w][t][lane] + red[2][w][t][lane] + red[3][w][t][lane];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            int b = b0 + t * 16 + lk * 4 + e;
+            if (b < B) part[((size_t)slice * B + b) * m.Kpad + k0 + w * 16 + li] = o[e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pose backward: one wave per body
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pose_bwd_kernel(LbsDev m, const float *__restrict__ betas, const float *__restrict__ pose,
+                                                      const float *__restrict__ Rs, const float *__restrict__ Jls,
+                                                      const float *__restrict__ Gs, const float *__restrict__ gA_part, int nsv,
+                                                      const float *__restrict__ gfeat_part, int nsn,
+                                                      const float *__restrict__ gt_part, int nvb, int B,
+                                                      float *__restrict__ g_betas, float *__restrict__ g_pose, float *__restrict__ g_transl)
+{
+    const int b = blockIdx.x, j = threadIdx.x;
+    const bool act = j < m.J;
+    __shared__ float sgG[JP][12];    // gradient wrt G_j (3x4)
+    __shared__ float sgJ[JP][3];     // gradient wrt the rest joint location J_j
+    __shared__ float sgrel[JP][3];
+    __shared__ float sRel[JP][3];
+    __shared__ float sR[JP][9];
+    __shared__ float sJ[JP][3];
+    float R[9], Jl[3], G[12], gG[12], gJ[3] = {0, 0, 0};
+    for (int e = 0; e < 12; e++) gG[e] = 0.0f;
+    if (act) {
+        for (int e = 0; e < 9; e++) { R[e] = Rs[((size_t)b * m.J + j) * 9 + e]; sR[j][e] = R[e]; }
+        for (int c = 0; c < 3; c++) { Jl[c] = Jls[((size_t)b * m.J + j) * 3 + c]; sJ[j][c] = Jl[c]; }
+        for (int e = 0; e < 12; e++) G[e] = Gs[((size_t)b * m.J + j) * 12 + e];
+        // reduce the skin_bwd_A partials for this joint
+        float gA[12];
+        for (int e = 0; e < 12; e++) gA[e] = 0.0f;
+        for (int sl = 0; sl < nsv; sl++) {
+            const float *p = gA_part + (((size_t)sl * B + b) * JP + j) * 16;
+            for (int e = 0; e < 12; e++) gA[e] += p[e];
+        }
+        // A = [G_R | G_t - G_R J]
+        for (int r = 0; r < 3; r++) {
+            float gt = gA[r * 4 + 3];
+            for (int c = 0; c < 3; c++) gG[r * 4 + c] = gA[r * 4 + c] - gt * Jl[c];
+            gG[r * 4 + 3] = gt;
+        }
+        for (int c = 0; c < 3; c++)
+            gJ[c] = -(G[0 * 4 + c] * gA[0 * 4 + 3] + G[1 * 4 + c] * gA[1 * 4 + 3] + G[2 * 4 + c] * gA[2 * 4 + 3]);
+        for (int e = 0; e < 12; e++) sgG[j][e] = gG[e];
+    }
+    __syncthreads();
+    const int par = act ? m.parents[j] : -1;
+    const int lvl = act ? m.level[j] : -1;
+    if (act) {
+        for (int c = 0; c < 3; c++) sRel[j][c] = (par >= 0) ? Jl[c] - sJ[par][c] : Jl[c];
+    }
+    __syncthreads();
+    // reverse sweep over levels: a joint first gathers from its children (whose gG are final), then publishes its own
+    for (int L = m.maxlevel - 1; L >= 0; L--) {
+        if (act && lvl == L) {
+            for (int ci = m.child_ptr[j]; ci < m.child_ptr[j + 1]; ci++) {
+                int ch = m.child_idx[ci];
+                // G_ch.R = G_j.R R_ch ; G_ch.t = G_j.R rel_ch + G_j.t
+                for (int r = 0; r < 3; r++) {
+                    for (int c = 0; c < 3; c++) {
+                        float a = 0;
+                        for (int k = 0; k < 3; k++) a += sgG[ch][r * 4 + k] * sR[ch][c * 3 + k];   // gG_ch.R R_ch^T
+                        gG[r * 4 + c] += a + sgG[ch][r * 4 + 3] * sRel[ch][c];
+                    }
+                    gG[r * 4 + 3] += sgG[ch][r * 4 + 3];
+                }
+            }
+            for (int e = 0; e < 12; e++) sgG[j][e] = gG[e];
+        }
+        __syncthreads();
+    }
+    // local gradients: gR_j = P_R^T gG_j.R, grel_j = P_R^T gG_j.t  (P = parent's G; root: identity)
+    float gR[9], grel[3] = {0, 0, 0};
+    for (int e = 0; e < 9; e++) gR[e] = 0.0f;
+    if (act) {
+        if (par >= 0) {
+            const float *P = Gs + ((size_t)b * m.J + par) * 12;
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++) gR[r * 3 + c] = P[0 * 4 + r] * gG[0 * 4 + c] + P[1 * 4 + r] * gG[1 * 4 + c] + P[2 * 4 + r] * gG[2 * 4 + c];
+                grel[r] = P[0 * 4 + r] * gG[0 * 4 + 3] + P[1 * 4 + r] * gG[1 * 4 + 3] + P[2 * 4 + r] * gG[2 * 4 + 3];
+            }
+        } else {
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++) gR[r * 3 + c] = gG[r * 4 + c];
+                grel[r] = gG[r * 4 + 3];
+            }
+        }
+        for (int c = 0; c < 3; c++) sgrel[j][c] = grel[c];
+    }
+    __syncthreads();
+    if (act) {
+        // rel_j = J_j - J_parent: own +grel, minus the children's
+        for (int c = 0; c < 3; c++) gJ[c] += grel[c];
+        for (int ci = m.child_ptr[j]; ci < m.child_ptr[j + 1]; ci++)
+            for (int c = 0; c < 3; c++) gJ[c] -= sgrel[m.child_idx[ci]][c];
+        for (int c = 0; c < 3; c++) sgJ[j][c] = gJ[c];
+    }
+    __syncthreads();
+    // feature gradient (reduced over n-slices): betas part and pose-feature part
+    if (g_betas) {
+        for (int l = j; l < m.NB; l += 64) {
+            float a = 0;
+            for (int sl = 0; sl < nsn; sl++) a += gfeat_part[((size_t)sl * B + b) * m.Kpad + l];
+            for (int jj = 0; jj < m.J; jj++)
+                for (int c = 0; c < 3; c++) a += sgJ[jj][c] * m.J_s[(jj * 3 + c) * m.NB + l];
+            g_betas[(size_t)b * m.NB + l] = a;
+        }
+    }
+    if (g_transl && j < 3) {
+        float a = 0;
+        for (int vb = 0; vb < nvb; vb++) a += gt_part[((size_t)vb * B + b) * 4 + j];
+        g_transl[(size_t)b * 3 + j] = a;
+    }
+    if (act && g_pose) {
+        if (j >= 1)
+            for (int e = 0; e < 9; e++) {
+                float a = 0;
+                for (int sl = 0; sl < nsn; sl++) a += gfeat_part[((size_t)sl * B + b) * m.Kpad + m.NB + (j - 1) * 9 + e];
+                gR[e] += a;
+            }
+        // Rodrigues backward (lbs.py:177-191)
+        const float *aa = pose + ((size_t)b * m.J + j) * 3;
+        float x = aa[0] + 1e-8f, y = aa[1] + 1e-8f, z = aa[2] + 1e-8f;
+        float th = sqrtf(x * x + y * y + z * z);
+        float d[3] = {aa[0] / th, aa[1] / th, aa[2] / th};
+        float s = sinf(th), c = cosf(th), c1 = 1.0f - c;
+        float K[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
+        float KK[9];
+        for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 3; q++) KK[r * 3 + q] = K[r * 3 + 0] * K[0 * 3 + q] + K[r * 3 + 1] * K[1 * 3 + q] + K[r * 3 + 2] * K[2 * 3 + q];
+        float gs = 0, gc1 = 0;
+        for (int e = 0; e < 9; e++) { gs += gR[e] * K[e]; gc1 += gR[e] * KK[e]; }
+        float gK[9];
+        for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 3; q++) {
+                float a = 0;
+                for (int k = 0; k < 3; k++) a += gR[r * 3 + k] * K[q * 3 + k] + K[k * 3 + r] * gR[k * 3 + q];   // gR K^T + K^T gR
+                gK[r * 3 + q] = s * gR[r * 3 + q] + c1 * a;
+            }
+        float gd[3] = {gK[7] - gK[5], gK[2] - gK[6], gK[3] - gK[1]};
+        float gth = gs * c + gc1 * s;                      // d sin = cos, d(1-cos) = sin
+        gth -= (gd[0] * aa[0] + gd[1] * aa[1] + gd[2] * aa[2]) / (th * th);
+        float ga[3] = {gd[0] / th + gth * x / th, gd[1] / th + gth * y / th, gd[2] / th + gth * z / th};
+        for (int q = 0; q < 3; q++) g_pose[((size_t)b * m.J + j) * 3 + q] = ga[q];
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host API
+// ------------------------------------------------------------------------------------------------
+extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, const float *h_shapedirs,
+                              const float *h_posedirs, const float *h_J_regressor, const float *h_weights,
+                              const int32_t *h_parents, int V, int J, int NB)
+{
+    PSI_REQUIRE(out && h_v_template && h_shapedirs && h_posedirs && h_J_regressor && h_weights && h_parents, "null pointer");
+    PSI_REQUIRE(V > 0 && J > 0 && J <= JP && NB >= 0, "unsupported model size (J <= 64)");
+    LbsDev d;
+    memset(&d, 0, sizeof(d));
+    d.V = V; d.J = J; d.NB = NB; d.P = (J - 1) * 9; d.K = NB + d.P;
+    d.Kpad = (d.K + 63) / 64 * 64;
+    d.N = 3 * V;
+    d.Vpad = (V + 255) / 256 * 256;
+    d.Npad = 3 * d.Vpad;
+    std::vector<int> level(J, 0), cptr(J + 1, 0), cidx;
+    d.maxlevel = 0;
+    for (int j = 0; j < J; j++) {
+        int p = h_parents[j];
+        PSI_REQUIRE(p < j, "parents must precede children (kintree order)");
+        level[j] = p < 0 ? 0 : level[p] + 1;
+        if (level[j] > d.maxlevel) d.maxlevel = level[j];
+    }
+    for (int j = 0; j < J; j++) {
+        cptr[j] = (int)cidx.size();
+        for (int c = j + 1; c < J; c++)
+            if (h_parents[c] == j) cidx.push_back(c);
+    }
+    cptr[J] = (int)cidx.size();
+    if (cidx.empty()) cidx.push_back(0);
+    // host staging
+    std::vector<float> dirs((size_t)d.Kpad * d.Npad, 0.0f), vt(d.Npad, 0.0f), WT((size_t)JP * d.Vpad, 0.0f);
+    for (int l = 0; l < NB; l++)
+        for (int n = 0; n < d.N; n++) dirs[(size_t)l * d.Npad + n] = h_shapedirs[(size_t)n * NB + l];   // [V,3,NB] -> [NB][3V]
+    for (int p = 0; p < d.P; p++) memcpy(&dirs[(size_t)(NB + p) * d.Npad], h_posedirs + (size_t)p * d.N, sizeof(float) * d.N);
+    memcpy(vt.data(), h_v_template, sizeof(float) * d.N);
+    for (int v = 0; v < V; v++)
+        for (int j = 0; j < J; j++) WT[(size_t)j * d.Vpad + v] = h_weights[(size_t)v * J + j];
+    std::vector<float> Jt((size_t)J * 3), Js((size_t)J * 3 * (NB > 0 ? NB : 1), 0.0f);
+    {
+        std::vector<double> acc((size_t)3 * (NB + 1));
+        for (int j = 0; j < J; j++) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            const float *jr = h_J_regressor + (size_t)j * V;
+            for (int v = 0; v < V; v++) {
+                double wv = jr[v];
+                if (wv == 0.0) continue;
+                for (int c = 0; c < 3; c++) {
+                    acc[c * (NB + 1) + NB] += wv * h_v_template[(size_t)v * 3 + c];
+                    const float *sd = h_shapedirs + ((size_t)v * 3 + c) * NB;
+                    for (int l = 0; l < NB; l++) acc[c * (NB + 1) + l] += wv * sd[l];
+                }
+            }
+            for (int c = 0; c < 3; c++) {
+                Jt[j * 3 + c] = (float)acc[c * (NB + 1) + NB];
+                for (int l = 0; l < NB; l++) Js[((size_t)j * 3 + c) * NB + l] = (float)acc[c * (NB + 1) + l];
+            }
+        }
+    }
+    // one device blob
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    size_t o_dirs = take(dirs.size() * 4), o_vt = take(vt.size() * 4), o_wt = take(WT.size() * 4), o_jt = take(Jt.size() * 4),
+           o_js = take(Js.size() * 4), o_par = take(J * 4), o_lvl = take(J * 4), o_cp = take((J + 1) * 4), o_ci = take(cidx.size() * 4);
+    char *blob = nullptr;
+    PSI_CHECK_HIP(hipMalloc((void **)&blob, o));
+    std::vector<int> par(h_parents, h_parents + J);
+    struct { size_t off; const void *src; size_t bytes; } cp[] = {
+        {o_dirs, dirs.data(), dirs.size() * 4}, {o_vt, vt.data(), vt.size() * 4}, {o_wt, WT.data(), WT.size() * 4},
+        {o_jt, Jt.data(), Jt.size() * 4}, {o_js, Js.data(), Js.size() * 4}, {o_par, par.data(), (size_t)J * 4},
+        {o_lvl, level.data(), (size_t)J * 4}, {o_cp, cptr.data(), (size_t)(J + 1) * 4}, {o_ci, cidx.data(), cidx.size() * 4}};
+    for (auto &c : cp) {
+        hipError_t e = hipMemcpy(blob + c.off, c.src, c.bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(blob);
+            psi_set_error("hipMemcpy failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    d.dirs = (const float *)(blob + o_dirs);
+    d.v_template = (const float *)(blob + o_vt);
+    d.WT = (const float *)(blob + o_wt);
+    d.J_t = (const float *)(blob + o_jt);
+    d.J_s = (const float *)(blob + o_js);
+    d.parents = (const int *)(blob + o_par);
+    d.level = (const int *)(blob + o_lvl);
+    d.child_ptr = (const int *)(blob + o_cp);
+    d.child_idx = (const int *)(blob + o_ci);
+    psi_lbs_model *mdl = new psi_lbs_model;
+    mdl->d = d;
+    mdl->blob = blob;
+    *out = mdl;
+    return 0;
+}
+
+extern "C" void psi_lbs_destroy(psi_lbs_model *m)
+{
+    if (!m) return;
+    (void)hipFree(m->blob);
+    delete m;
+}
+
+extern "C" size_t psi_lbs_workspace_floats(const psi_lbs_model *m, int B)
+{
+    if (!m || B <= 0) return 0;
+    return ws_layout(m->d, B).total;
+}
+
+extern "C" int psi_lbs_forward(const psi_lbs_model *mdl, const float *betas, const float *pose, const float *transl,
+                               const float *cam_ext, int B, float *verts, float *joints, float *ws, void *stream)
+{
+    PSI_REQUIRE(mdl && betas && pose && verts && ws, "null pointer");
+    PSI_REQUIRE(B > 0 && B <= 16384, "batch size out of range");
+    const LbsDev &m = mdl->d;
+    WsLayout L = ws_layout(m, B);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(B), dim3(64), 0, st, m, betas, pose, transl, B, ws + L.feat, ws + L.R, ws + L.Jl,
+                       ws + L.G, ws + L.A, joints);
+    PSI_CHECK_LAUNCH("pose_fwd_kernel");
+    if (B > 32)
+        hipLaunchKernelGGL(blend_fwd_kernel<4>, dim3(m.Npad / 64, psi_cdiv(B, 64)), dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
+    else if (B > 16)
+        hipLaunchKernelGGL(blend_fwd_kernel<2>, dim3(m.Npad / 64, 1), dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
+    else
+        hipLaunchKernelGGL(blend_fwd_kernel<1>, dim3(m.Npad / 64, 1), dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
+    PSI_CHECK_LAUNCH("blend_fwd_kernel");
+    hipLaunchKernelGGL(skin_fwd_kernel, dim3(m.Vpad / SKIN_BLK, psi_cdiv(B, SKIN_BT)), dim3(SKIN_BLK), 0, st, m, ws + L.A,
+                       ws + L.v_posed, transl, cam_ext, B, verts);
+    PSI_CHECK_LAUNCH("skin_fwd_kernel");
+    return 0;
+}
+
+extern "C" int psi_lbs_backward(const psi_lbs_model *mdl, const float *grad_verts, const float *betas, const float *pose,
+                                const float *cam_ext, int B, float *ws, float *grad_betas, float *grad_pose,
+                                float *grad_transl, void *stream)
+{
+    PSI_REQUIRE(mdl && grad_verts && betas && pose && ws, "null pointer");
+    PSI_REQUIRE(B > 0 && B <= 16384, "batch size out of range");
+    const LbsDev &m = mdl->d;
+    WsLayout L = ws_layout(m, B);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(skin_bwd_v_kernel, dim3(m.Vpad / SKIN_BLK, psi_cdiv(B, SKIN_BT)), dim3(SKIN_BLK), 0, st, m, ws + L.A, grad_verts,
+                       cam_ext, B, ws + L.gl, ws + L.g_vp, ws + L.gt_part);
+    PSI_CHECK_LAUNCH("skin_bwd_v_kernel");
+    hipLaunchKernelGGL(skin_bwd_A_kernel, dim3(L.nsv, psi_cdiv(B, 4)), dim3(256), 0, st, m, ws + L.gl, ws + L.v_posed, B, ws + L.gA_part);
+    PSI_CHECK_LAUNCH("skin_bwd_A_kernel");
+    const int steps = 48;
+    dim3 g(m.Kpad / 64, L.nsn, 1);
+    if (B > 32) {
+        g.z = psi_cdiv(B, 64);
+        hipLaunchKernelGGL(blend_bwd_kernel<4>, g, dim3(256), 0, st, m, ws + L.g_vp, B, steps, ws + L.gfeat_part);
+    } else if (B > 16) {
+        hipLaunchKernelGGL(blend_bwd_kernel<2>, g, dim3(256), 0, st, m, ws + L.g_vp, B, steps, ws + L.gfeat_part);
+    } else {
+        hipLaunchKernelGGL(blend_bwd_kernel<1>, g, dim3(256), 0, st, m, ws + L.g_vp, B, steps, ws + L.gfeat_part);
+    }
+    PSI_CHECK_LAUNCH("blend_bwd_kernel");
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(64), 0, st, m, betas, pose, ws + L.R, ws + L.Jl, ws + L.G, ws + L.gA_part, L.nsv,
+                       ws + L.gfeat_part, L.nsn, ws + L.gt_part, L.nvb, B, grad_betas, grad_pose, grad_transl);
+    PSI_CHECK_LAUNCH("pose_bwd_kernel");
+    return 0;
+}

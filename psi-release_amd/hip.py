@@ -28,6 +28,11 @@ SIGNATURES = {
     'psi_sdf_sample_forward': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p] * 3),
     'psi_sdf_sample_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'psi_sdf_penetration_stats': (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
+    'psi_lbs_create': (c_int, [c_void_p] * 7 + [c_int] * 3),
+    'psi_lbs_destroy': (None, [c_void_p]),
+    'psi_lbs_workspace_floats': (c_size_t, [c_void_p, c_int]),
+    'psi_lbs_forward': (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 4),
+    'psi_lbs_backward': (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 5),
 }
 
 
