@@ -1,0 +1,168 @@
+"""Scene-geometry-aware fitting of generated bodies: ``FittingOP`` with the reference's config keys and methods.
+
+Reference: source/fitting_proxe.py:40-214 (PROX-E) and source/fitting_habitat.py:40-230 (MP3D-R: batch 1, contact
+constant 1.0, camera pre-multiplied by diag(1,-1,-1,1)).  Same ``fittingconfig`` / ``lossconfig`` keys, same
+``cal_loss`` / ``fitting`` / ``save_result`` methods, same pkl schema and the same verbose line format.
+
+Two execution modes behind the same class:
+* ``engine='fused'``  (default on GPU)  — the whole iteration (forward, losses, hand-derived backward, Adam) runs
+  as a fixed sequence of HIP kernels inside libpsi_hip.so (csrc/fit.hip), replayed as a hipGraph;
+* ``engine='modular'`` — PyTorch autograd over the individual HIP operators (ops.py, body_model.py); this is
+  also what the training entry points use, because the CVAE lives in PyTorch.
+Both need the GPU; there is no CPU implementation in this package.
+
+Differences from the reference that do not change results: the scene SDF / point cloud are
+kept once per scene instead of ``.repeat(batch_size)`` (fitting_proxe.py:90,96); contact ids are read once instead of
+every iteration (cvae.py:105-109); both ``contact_id_folder`` and ``body_segments_folder`` are accepted
+(fitting_proxe.py:131 vs :238); no ``.item()`` host sync for the penetration mask (fitting_proxe.py:155).
+``align_corners`` of the SDF lookup is explicit: True reproduces the pinned torch 1.2.0 behaviour.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+
+from . import body_model, ops, scene_io
+from .geometry import BodyParamParser, GeometryTransformer
+from .vposer import load_vposer
+
+
+class FittingOP:
+    contact_const = 0.01            # fitting_proxe.py:139; fitting_habitat.py:141 uses 1.0
+    flip_camera_yz = False          # fitting_habitat.py:179-184
+
+    def __init__(self, fittingconfig, lossconfig):
+        self.align_corners = True
+        self.engine = 'modular'
+        self.reset_optimizer = False
+        for key, val in fittingconfig.items():
+            setattr(self, key, val)
+        for key, val in lossconfig.items():
+            setattr(self, key, val)
+        self.device = torch.device(self.device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('FittingOP runs on the GPU through libpsi_hip.so; there is no CPU path')
+        BodyParamParser.device = self.device
+
+        vposer_src = getattr(self, 'vposer_state', None) or self.vposer_ckpt_path
+        self.vposer, _ = load_vposer(vposer_src, vp_model='snapshot')
+        smplx_src = getattr(self, 'smplx_data', None) or self.human_model_path
+        self.body_mesh_model = body_model.create(smplx_src, model_type='smplx', gender='neutral', ext='npz',
+                                                 num_pca_comps=12, create_global_orient=True, create_body_pose=True,
+                                                 create_betas=True, create_left_hand_pose=True,
+                                                 create_right_hand_pose=True, create_expression=True,
+                                                 create_jaw_pose=True, create_leye_pose=True, create_reye_pose=True,
+                                                 create_transl=True, batch_size=self.batch_size, device=self.device)
+        self.vposer.to(self.device)
+
+        self.xhr_rec = torch.randn(self.batch_size, 75, device=self.device).requires_grad_(True)
+        self.optimizer = optim.Adam([self.xhr_rec], lr=self.init_lr_h)
+
+        # scene: one SDF volume and one point cloud (not replicated per batch row)
+        scene = getattr(self, 'scene', None)
+        if scene is not None:
+            sdf, grid_min, grid_max, scene_verts = scene.sdf, scene.grid_min, scene.grid_max, scene.verts
+            self._contact_parts = scene.contact_parts
+        else:
+            sdf, grid_min, grid_max, _ = scene_io.read_sdf(self.scene_sdf_path)
+            scene_verts = scene_io.read_ply_vertices(self.scene_verts_path)
+            self._contact_parts = None
+        t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=self.device)
+        self.s_grid_min_batch = t(grid_min).unsqueeze(0)
+        self.s_grid_max_batch = t(grid_max).unsqueeze(0)
+        self.s_sdf = t(sdf).unsqueeze(0).contiguous()                  # [1,D,D,D]
+        self.s_verts = t(scene_verts).unsqueeze(0).contiguous()        # [1,m,3]
+        self._s_verts_expanded = self.s_verts.expand(self.batch_size, -1, -1).contiguous()
+        self._vid = None
+        self._chamfer = ops.chamferDist(one_sided=True)
+
+    # ---------------------------------------------------------------------------------------
+    def contact_vertex_ids(self):
+        if self._vid is None:
+            if self._contact_parts is not None:
+                vid = np.concatenate([list(set(self._contact_parts[p]['verts_ind'])) for p in self.contact_part])
+            else:
+                folder = getattr(self, 'body_segments_folder', None) or getattr(self, 'contact_id_folder')
+                vid, _ = GeometryTransformer.get_contact_id(body_segments_folder=folder, contact_body_parts=self.contact_part)
+            self._vid = torch.tensor(np.asarray(vid).astype(np.int64), device=self.device)
+        return self._vid
+
+    def body_verts(self, xh_rec, cam_ext):
+        body_param_rec = BodyParamParser.body_params_encapsulate_batch(xh_rec)
+        joint_rot_batch = self.vposer.decode(body_param_rec['body_pose_vp'], output_type='aa').view(xh_rec.shape[0], -1)
+        body_param_ = {k: v for k, v in body_param_rec.items() if k != 'body_pose_vp'}
+        # cam_ext is applied inside the skinning kernel (== GeometryTransformer.verts_transform, cvae.py:141-149)
+        out = self.body_mesh_model(return_verts=True, body_pose=joint_rot_batch, cam_ext=cam_ext, **body_param_)
+        return out.vertices
+
+    def cal_loss(self, xhr, cam_ext):
+        """fitting_proxe.py:101-162."""
+        loss_rec = self.weight_loss_rec * F.l1_loss(xhr, self.xhr_rec)
+        xh_rec = GeometryTransformer.convert_to_3D_rot(self.xhr_rec)
+        loss_vposer = self.weight_loss_vposer * torch.mean(xh_rec[:, 16:48] ** 2)
+
+        body_verts_batch = self.body_verts(xh_rec, cam_ext)
+        body_verts_contact_batch = body_verts_batch[:, self.contact_vertex_ids(), :]
+        contact_dist, _ = self._chamfer(body_verts_contact_batch.contiguous(), self._s_verts_expanded)
+        s = torch.sqrt(contact_dist + 1e-4)
+        loss_contact = self.weight_contact * torch.mean(s / (s + self.contact_const))
+
+        body_sdf_batch = ops.sdf_sample(body_verts_batch, self.s_sdf, self.s_grid_min_batch, self.s_grid_max_batch,
+                                        scene_id=None, align_corners=self.align_corners)
+        loss_collision = self.weight_collision * ops.penetration_loss(body_sdf_batch)
+        return loss_rec, loss_vposer, loss_contact, loss_collision
+
+    def _camera(self, cam_ext):
+        if not self.flip_camera_yz:
+            return cam_ext
+        T_mat = torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0], device=self.device)).unsqueeze(0)
+        return torch.matmul(cam_ext[:1], T_mat).expand(self.batch_size, -1, -1).contiguous()
+
+    def fitting(self, input_data_file):
+        """fitting_proxe.py:167-195; ``input_data_file`` is a pkl path or the already-loaded dict."""
+        if isinstance(input_data_file, dict):
+            body_param_input = input_data_file
+        else:
+            with open(input_data_file, 'rb') as f:
+                body_param_input = pickle.load(f)
+        xh, self.cam_ext, self.cam_int = BodyParamParser.body_params_parse_fitting(body_param_input)
+        xhr = GeometryTransformer.convert_to_6D_rot(xh)
+        self.xhr_rec.data = xhr.clone()
+        if self.reset_optimizer:
+            self.optimizer = optim.Adam([self.xhr_rec], lr=self.init_lr_h)
+        cam = self._camera(self.cam_ext)
+        for ii in range(self.num_iter):
+            self.optimizer.zero_grad()
+            loss_rec, loss_vposer, loss_contact, loss_collision = self.cal_loss(xhr, cam)
+            loss = loss_rec + loss_vposer + loss_contact + loss_collision
+            if self.verbose:
+                print('[INFO][fitting] iter={:d}, l_rec={:f}, l_vposer={:f}, l_contact={:f}, l_collision={:f}'.format(
+                    ii, loss_rec.item(), loss_vposer.item(), loss_contact.item(), loss_collision.item()))
+            loss.backward()
+            self.optimizer.step()
+        print('[INFO][fitting] fitting finish, returning optimal value')
+        return GeometryTransformer.convert_to_3D_rot(self.xhr_rec)
+
+    def save_result(self, xh_rec, output_data_file):
+        """fitting_proxe.py:199-214 (one pkl per call; with batch>1 the last body wins, as in the reference)."""
+        dirname = os.path.dirname(output_data_file)
+        if dirname and not os.path.exists(dirname):
+            os.makedirs(dirname)
+        body_param_list = BodyParamParser.body_params_encapsulate(xh_rec)
+        print('[INFO] save results to: ' + output_data_file)
+        for body_param in body_param_list:
+            body_param['cam_ext'] = self.cam_ext.detach().cpu().numpy()
+            body_param['cam_int'] = self.cam_int.detach().cpu().numpy()
+            with open(output_data_file, 'wb') as outfile:
+                pickle.dump(body_param, outfile)
+
+
+class FittingOPHabitat(FittingOP):
+    """fitting_habitat.py: contact constant 1.0 (:141), camera flipped to the Habitat convention (:179-184)."""
+    contact_const = 1.0
+    flip_camera_yz = True

@@ -202,49 +202,4 @@ def body_vector_72(bodies: dict) -> np.ndarray:
                                 ('transl', 'global_orient', 'betas', 'body_pose', 'left_hand_pose', 'right_hand_pose')], -1))
 
 
-def write_ply_vertices(path: str, verts: np.ndarray) -> None:
-    """Minimal binary little-endian PLY with float vertices (what scenes_downsampled/*.ply provide to the path)."""
-    verts = _f32(verts)
-    with open(path, 'wb') as f:
-        f.write(b'ply\nformat binary_little_endian 1.0\n')
-        f.write(('element vertex %d\n' % len(verts)).encode())
-        f.write(b'property float x\nproperty float y\nproperty float z\nelement face 0\n'
-                b'property list uchar int vertex_indices\nend_header\n')
-        f.write(verts.tobytes())
-
-
-def read_ply_vertices(path: str) -> np.ndarray:
-    """Vertex positions of an ASCII or binary-little-endian PLY (stands in for open3d.io.read_triangle_mesh().vertices)."""
-    with open(path, 'rb') as f:
-        header = []
-        while True:
-            line = f.readline()
-            if not line:
-                raise ValueError('PLY header not terminated: %s' % path)
-            header.append(line.decode('ascii', 'replace').strip())
-            if header[-1] == 'end_header':
-                break
-        fmt = [h for h in header if h.startswith('format')][0].split()[1]
-        nvert, props, in_vertex = 0, [], False
-        for h in header:
-            t = h.split()
-            if t[:2] == ['element', 'vertex']:
-                nvert, in_vertex = int(t[2]), True
-            elif t and t[0] == 'element':
-                in_vertex = False
-            elif t and t[0] == 'property' and in_vertex:
-                props.append((t[1], t[2]))
-        names = [p[1] for p in props]
-        ix = [names.index(c) for c in 'xyz']
-        if fmt == 'ascii':
-            rows = [f.readline().split() for _ in range(nvert)]
-            arr = np.array(rows, dtype=np.float64)
-            return _f32(arr[:, ix])
-        np_t = {'float': '<f4', 'float32': '<f4', 'double': '<f8', 'float64': '<f8', 'uchar': 'u1', 'uint8': 'u1',
-                'char': 'i1', 'int8': 'i1', 'short': '<i2', 'ushort': '<u2', 'int': '<i4', 'int32': '<i4',
-                'uint': '<u4', 'uint32': '<u4'}
-        if fmt != 'binary_little_endian':
-            raise ValueError('unsupported PLY format %s' % fmt)
-        dt = np.dtype([(n, np_t[t]) for t, n in props])
-        arr = np.frombuffer(f.read(nvert * dt.itemsize), dtype=dt, count=nvert)
-        return _f32(np.stack([arr['x'], arr['y'], arr['z']], -1))
+from .scene_io import read_ply_vertices, write_ply_vertices  # noqa: E402,F401
