@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py — fitting iterations/sec of the PSI hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is ONE fitting iteration (fitting_proxe.py:177-189: zero_grad, cal_loss, backward, Adam step) over a
+batch of 32 bodies per GPU on synthetic PROX-E-shaped inputs (configs[1] of BASELINE.json: V=10475 SMPL-X-shaped
+model, VPoser(512,32,[1,21,3]), n_c=2048 contact vertices, m=32768 scene points, 256^3 SDF; all inputs resident in
+HBM before the timed region).  Weak scaling: every rank fits its own 32 bodies; the only data-path collective is
+the one 6-float all-reduce per iteration of the loss normalisers (psi-release_amd/dist.py).
+value = (N * K) / max-over-ranks wall time of the K timed steps  [batch-32 fitting iterations per second].
+
+The JSON line also carries
+  roofline     — the dominant kernel (brute-force Chamfer NN, fp32-VALU bound): algorithmic flops per launch
+                 (8 flop per query/target pair) / its average launch duration measured with
+                 HIP events on the launch stream; peak = 157.3 TFLOP/s (fp32 vector = fp32 MFMA peak, MI355X guide);
+  cpu_baseline — the oracle (oracle/psi_oracle.py + oracle/chamfer_oracle.c, a CPU port of the reference path,
+                 validated against the reference's golden vectors) timed on this box's host cores on a bounded
+                 sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='bodies per GPU (BASELINE: 32)')
+    ap.add_argument('--m', type=int, default=32768, help='scene points')
+    ap.add_argument('--nc', type=int, default=2048, help='contact vertices')
+    ap.add_argument('--D', type=int, default=256, help='SDF grid dimension')
+    ap.add_argument('--engine', default=os.environ.get('PSI_ENGINE', 'auto'), choices=['auto', 'fused', 'modular'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='time budget of the CPU baseline sample')
+    return ap.parse_args()
+
+
+def make_op(args, rank, device):
+    from psi_release_amd import fitting, synth
+    smplx = synth.make_smplx(7)
+    vposer = synth.make_vposer_state(3)
+    scene = synth.make_scene(0, args.m, args.D, args.nc)
+    cfg = {'scene_verts_path': None, 'scene_sdf_path': None, 'human_model_path': None, 'vposer_ckpt_path': None,
+           'init_lr_h': 0.1, 'num_iter': 1, 'batch_size': args.batch, 'device': device,
+           'contact_part': synth.CONTACT_PARTS, 'contact_id_folder': None, 'verbose': False,
+           'smplx_data': smplx, 'vposer_state': vposer, 'scene': scene, 'engine': args.engine_resolved}
+    loss = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1, 'weight_collision': 0.5}
+    op = fitting.FittingOP(cfg, loss)
+    bodies = synth.make_bodies(11 + rank, args.batch)
+    return op, bodies, (smplx, vposer, scene)
+
+
+def time_chamfer_kernel(op, args, reps=20):
+    """Average duration of one Chamfer NN launch (body->scene direction, the one PSI consumes) with HIP events on the
+    stream the kernel is launched on, on the live contact vertices of the bench state."""
+    from psi_release_amd import hip
+    B, n, m = args.batch, args.nc, args.m
+    x = torch.randn(B, n, 3, device=op.device) * 0.5
+    y = op._s_verts_expanded
+    d = torch.zeros(B, n, device=op.device)
+    i = torch.zeros(B, n, dtype=torch.int32, device=op.device)
+    L = hip.lib()
+    ws = torch.empty(L.psi_chamfer_workspace_bytes(B, n, m), dtype=torch.uint8, device=op.device)
+    st = torch.cuda.current_stream()
+    call = lambda: L.psi_chamfer_forward(x.data_ptr(), y.data_ptr(), B, n, m, d.data_ptr(), i.data_ptr(), None, None,
+                                         ws.data_ptr(), st.cuda_stream)
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        call()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def cpu_baseline(args, assets, budget_s):
+    """Oracle fitting iterations on the host cores: bounded sample of the SAME workload (same B, m, n_c, D)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import psi_oracle as O
+    from psi_release_amd import synth
+    smplx, vposer, scene = assets
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    os.environ['OMP_NUM_THREADS'] = str(cores)
+    fo = O.FittingOracle(O.SMPLXOracle(smplx), vposer, scene.verts, scene.sdf, scene.grid_min, scene.grid_max,
+                         synth.contact_ids_from_parts(scene.contact_parts), args.batch)
+    bodies = synth.make_bodies(11, args.batch)
+    xh = synth.body_vector_72(bodies)
+    fo.fitting(xh, bodies['cam_ext'], 1)                    # untimed warm-up iteration (page-in, thread pools)
+    n, t0 = 0, time.time()
+    while True:
+        fo.fitting(xh, bodies['cam_ext'], 1)
+        n += 1
+        el = time.time() - t0
+        if (el >= budget_s and n >= 2) or n >= 50:
+            break
+    return {'value': round(n / el, 4), 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d fitting iterations (B=%d, n_c=%d, m=%d, D=%d) of oracle/psi_oracle.py FittingOracle '
+                      '(torch-CPU fp32 + C/OpenMP Chamfer restatement) in %.1f s' % (n, args.batch, args.nc, args.m, args.D, el)}
+
+
+def main():
+    args = parse()
+    from psi_release_amd import dist as pd
+    rank, local_rank, world = pd.init_from_env('nccl')
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path is the only implementation')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    from psi_release_amd import fitting
+    args.engine_resolved = ('fused' if getattr(fitting, 'HAS_FUSED_ENGINE', False) else 'modular') if args.engine == 'auto' else args.engine
+
+    op, bodies, assets = make_op(args, rank, device)
+    runner = op.make_step_runner(bodies)          # everything resident in HBM from here on
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = runner.last_losses()
+
+    out = None
+    if rank == 0:
+        t_ch = time_chamfer_kernel(op, args)
+        flops = 8.0 * args.batch * args.nc * args.m
+        ach = flops / t_ch * 1e-12
+        out = {
+            'metric': 'fitting iters/sec (SMPL-X+SDF+Chamfer), PROX-E batch=32',
+            'value': round(world * args.steps / dt, 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'fitting_proxe 100-iter loop: one Adam fitting iteration per step, batch=%d bodies per GPU, '
+                                   'V=10475, n_c=%d, m=%d, SDF %d^3, synthetic SMPL-X/VPoser/scene (BASELINE configs[1])'
+                                   % (args.batch, args.nc, args.m, args.D),
+                       'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'engine': args.engine_resolved,
+                       'parallelism': 'dp%d (rows sharded, one 6-float all-reduce per iteration)' % world,
+                       'final_losses': [round(float(x), 6) for x in losses]},
+            'roofline': {'bound': 'mfma', 'kernel': 'nn_partial_kernel (Chamfer NN brute force, fp32 VALU)',
+                         'achieved': round(ach, 2), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(ach / PEAK_FP32_TFLOPS, 4), 'traffic': None,
+                         'avg_launch_ms': round(t_ch * 1e3, 4), 'flops_per_launch': flops,
+                         'note': 'fp32 has no faster MFMA than the vector rate on gfx950, so the fp32 peak is both; '
+                                 '8 flop/pair (3 sub, 3 mul, 2 add) without FMA contraction caps the fraction at 8/18'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(args, assets, args.cpu_seconds)
+            except Exception as e:  # the oracle needs gcc; report rather than fail the GPU number
+                out['cpu_baseline'] = {'value': None, 'unit': 'iters/s', 'cores': os.cpu_count(), 'kind': 'port',
+                                       'sample': 'failed: %r' % (e,)}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,95 @@
+"""Data-parallel fitting over the GPUs of one node: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI).  The reference has no distributed code at all; this is new.
+
+Batch rows are independent bodies, so rank r owns its rows of ``xhr_rec`` and their Adam state; scene and model
+buffers are replicated.  The only cross-rank coupling of the fitting objective is through its normalisers:
+the three mean-type losses divide by the GLOBAL batch and the penetration loss divides by the GLOBAL count of
+penetrating vertices (fitting_proxe.py:155-158).  One all-reduce of a 6-float vector per iteration, issued
+between forward and backward, makes every rank's gradient identical to what the single-process full batch would
+give for its rows; no gradient all-reduce is needed (disjoint parameters, element-wise Adam).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+
+from . import hip
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def init_from_env(backend=None):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); no-op for one process."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws <= 1:
+        return 0, 0, 1
+    rk = int(os.environ.get('RANK', '0'))
+    lrk = int(os.environ.get('LOCAL_RANK', str(rk)))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(lrk)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rk, world_size=ws)
+    return rk, lrk, ws
+
+
+def shard_rows(n_rows, r=None, w=None):
+    """Contiguous row range of rank r: rows [lo, hi)."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    per = (n_rows + w - 1) // w
+    lo = min(r * per, n_rows)
+    return lo, min(lo + per, n_rows)
+
+
+def penetration_stats(vals):
+    """[sum_{v<0} |v|, count(v<0)] of a GPU tensor (HIP reduction, no host sync).  GPU only: hip.ptr raises on CPU
+    tensors (the world_size-2 gloo tests substitute this function to exercise the reduction logic on CPU)."""
+    stats = torch.zeros(2, device=vals.device)
+    hip.check(hip.lib().psi_sdf_penetration_stats(hip.ptr(vals.contiguous()), vals.numel(), hip.ptr(stats), hip.stream()),
+              'psi_sdf_penetration_stats')
+    return stats
+
+
+class _FittingLossReduce(Function):
+    """(local mean losses x3, local body_sdf) -> the four GLOBAL-batch losses, with the single all-reduce inside."""
+
+    @staticmethod
+    def forward(ctx, l_rec, l_vp, l_contact, body_sdf, group):
+        W = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        st = penetration_stats(body_sdf.detach())
+        buf = torch.stack([l_rec.detach(), l_vp.detach(), l_contact.detach(), st[0], st[1], torch.zeros_like(st[0])])
+        if W > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        n_glob = buf[4]
+        ctx.W = W
+        ctx.save_for_backward(body_sdf, n_glob)
+        pen = torch.where(n_glob > 0, buf[3] / n_glob.clamp(min=1.0), torch.zeros_like(n_glob))
+        return buf[0] / W, buf[1] / W, buf[2] / W, pen
+
+    @staticmethod
+    def backward(ctx, g_rec, g_vp, g_c, g_pen):
+        body_sdf, n_glob = ctx.saved_tensors
+        W = ctx.W
+        scale = torch.where(n_glob > 0, -g_pen / n_glob.clamp(min=1.0), torch.zeros_like(n_glob))
+        return g_rec / W, g_vp / W, g_c / W, (body_sdf < 0).to(body_sdf.dtype) * scale, None
+
+
+def fitting_loss_reduce(l_rec, l_vp, l_contact, body_sdf, group=None):
+    return _FittingLossReduce.apply(l_rec, l_vp, l_contact, body_sdf, group)

@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 import torch.optim as optim
 
-from . import body_model, ops, scene_io
+from . import body_model, dist as psi_dist, ops, scene_io
 from .geometry import BodyParamParser, GeometryTransformer
 from .vposer import load_vposer
 
@@ -114,7 +114,13 @@ class FittingOP:
 
         body_sdf_batch = ops.sdf_sample(body_verts_batch, self.s_sdf, self.s_grid_min_batch, self.s_grid_max_batch,
                                         scene_id=None, align_corners=self.align_corners)
-        loss_collision = self.weight_collision * ops.penetration_loss(body_sdf_batch)
+        if psi_dist.is_dist():
+            # data-parallel batch: global-batch normalisers through ONE all-reduce (dist.py)
+            loss_rec, loss_vposer, loss_contact, pen = psi_dist.fitting_loss_reduce(loss_rec, loss_vposer, loss_contact,
+                                                                                  body_sdf_batch)
+            loss_collision = self.weight_collision * pen
+        else:
+            loss_collision = self.weight_collision * ops.penetration_loss(body_sdf_batch)
         return loss_rec, loss_vposer, loss_contact, loss_collision
 
     def _camera(self, cam_ext):
@@ -123,8 +129,9 @@ class FittingOP:
         T_mat = torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0], device=self.device)).unsqueeze(0)
         return torch.matmul(cam_ext[:1], T_mat).expand(self.batch_size, -1, -1).contiguous()
 
-    def fitting(self, input_data_file):
-        """fitting_proxe.py:167-195; ``input_data_file`` is a pkl path or the already-loaded dict."""
+    def make_step_runner(self, input_data_file):
+        """Parse one generated-body record and return an object whose ``step()`` runs ONE fitting iteration
+        (fitting_proxe.py:179-189) with every input already resident in HBM; ``fitting`` loops over it."""
         if isinstance(input_data_file, dict):
             body_param_input = input_data_file
         else:
@@ -135,16 +142,17 @@ class FittingOP:
         self.xhr_rec.data = xhr.clone()
         if self.reset_optimizer:
             self.optimizer = optim.Adam([self.xhr_rec], lr=self.init_lr_h)
-        cam = self._camera(self.cam_ext)
+        return _ModularRunner(self, xhr, self._camera(self.cam_ext))
+
+    def fitting(self, input_data_file):
+        """fitting_proxe.py:167-195; ``input_data_file`` is a pkl path or the already-loaded dict."""
+        runner = self.make_step_runner(input_data_file)
         for ii in range(self.num_iter):
-            self.optimizer.zero_grad()
-            loss_rec, loss_vposer, loss_contact, loss_collision = self.cal_loss(xhr, cam)
-            loss = loss_rec + loss_vposer + loss_contact + loss_collision
+            runner.step()
             if self.verbose:
+                l = runner.last_losses()
                 print('[INFO][fitting] iter={:d}, l_rec={:f}, l_vposer={:f}, l_contact={:f}, l_collision={:f}'.format(
-                    ii, loss_rec.item(), loss_vposer.item(), loss_contact.item(), loss_collision.item()))
-            loss.backward()
-            self.optimizer.step()
+                    ii, l[0], l[1], l[2], l[3]))
         print('[INFO][fitting] fitting finish, returning optimal value')
         return GeometryTransformer.convert_to_3D_rot(self.xhr_rec)
 
@@ -160,6 +168,26 @@ class FittingOP:
             body_param['cam_int'] = self.cam_int.detach().cpu().numpy()
             with open(output_data_file, 'wb') as outfile:
                 pickle.dump(body_param, outfile)
+
+
+class _ModularRunner:
+    """One fitting iteration = zero_grad, cal_loss, backward, Adam step (autograd over the HIP operators)."""
+
+    def __init__(self, op, xhr, cam):
+        self.op, self.xhr, self.cam = op, xhr, cam
+        self._losses = None
+
+    def step(self):
+        op = self.op
+        op.optimizer.zero_grad()
+        losses = op.cal_loss(self.xhr, self.cam)
+        self._losses = [l.detach() for l in losses]
+        (losses[0] + losses[1] + losses[2] + losses[3]).backward()
+        op.optimizer.step()
+
+    def last_losses(self):
+        """Loss values evaluated at the START of the last step (what the reference prints), as Python floats."""
+        return [float(l) for l in self._losses]
 
 
 class FittingOPHabitat(FittingOP):
