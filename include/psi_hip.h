@@ -106,6 +106,53 @@ int psi_lbs_backward(const psi_lbs_model *model, const float *grad_verts, const 
                      const float *cam_ext, int B, float *ws, float *grad_betas, float *grad_pose,
                      float *grad_transl, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused fitting engine — replaces the loop body of FittingOP.fitting / cal_loss
+ *   for ii in range(num_iter): optimizer.zero_grad(); cal_loss(...); loss.backward(); optimizer.step()
+ *                                                                      fitting_proxe.py:101-162,177-189
+ * (fitting_habitat.py:103-208 is the same with contact_const = 1.0 and a pre-multiplied camera).
+ * One iteration = ~16 stream-ordered HIP kernels, no autograd, no host sync; psi_fit_iterate replays it
+ * as a hipGraph.  State (device, owned by the engine): x = xhr_rec [B,75] (transl 3 | 6D rot 6 | betas 10 |
+ * VPoser latent 32 | hand PCA 12+12), Adam moments and step count (fitting_proxe.py:73-74: the optimizer
+ * persists across files unless reset).
+ * psi_fit_create: h_* are HOST arrays.  VPoser decoder weights in nn.Linear layout [out,in]
+ * (bodyprior_dec_fc1 [512,32], _fc2 [512,512], _out [126,512], vposer_smpl.py:83-89); hand PCA components
+ * [num_pca_comps,45] each; pose_mean [165]; contact vertex ids [n_contact] in the order
+ * GeometryTransformer.get_contact_id returns them (cvae.py:99-115).  d_scene_verts [m,3] and d_sdf [D,D,D]
+ * are DEVICE arrays owned by the caller and must outlive the engine (one copy per scene, shared by the batch).
+ * Data parallel: world_size > 1 scales the loss normalisers by the global batch B*world_size; the caller
+ * runs psi_fit_forward(stats) -> all-reduce(sum) of stats[0..5] -> psi_fit_backward_step(stats) per iteration
+ * (stats = [sum|xhr-x|, sum z^2, sum s/(s+c), sum|sdf<0|, count(sdf<0), 0], a caller-owned device buffer).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct psi_fit_engine psi_fit_engine;
+typedef struct psi_fit_config {
+    int B, n_contact, m_scene, D, align_corners, world_size, num_pca_comps, max_history;
+    float w_rec, w_vposer, w_contact, w_collision, contact_const;
+    float lr, beta1, beta2, eps;
+} psi_fit_config;
+int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, const psi_fit_config *cfg,
+                   const float *h_w1, const float *h_b1, const float *h_w2, const float *h_b2,
+                   const float *h_w3, const float *h_b3, const float *h_lh_comp, const float *h_rh_comp,
+                   const float *h_pose_mean, const int32_t *h_contact_ids,
+                   const float *d_scene_verts, const float *d_sdf, const float *h_gmin, const float *h_gmax);
+void psi_fit_destroy(psi_fit_engine *engine);
+/* xhr = target body vectors [B,75]; x_init = starting parameters (NULL: start at xhr, fitting_proxe.py:175);
+ * cam_ext [B,4,4]; reset_optimizer != 0 zeroes the Adam state and step count. */
+int psi_fit_set_problem(psi_fit_engine *engine, const float *d_xhr, const float *d_x_init, const float *d_cam_ext,
+                        int reset_optimizer, void *stream);
+int psi_fit_forward(psi_fit_engine *engine, float *d_stats, void *stream);
+int psi_fit_backward_step(psi_fit_engine *engine, const float *d_stats, void *stream);
+/* n_iter full iterations on one GPU; use_graph != 0 captures one iteration once (stream must not be the
+ * NULL stream) and replays it with hipGraphLaunch. */
+int psi_fit_iterate(psi_fit_engine *engine, int n_iter, int use_graph, void *stream);
+/* Copies x [B,75] and the first n_hist rows of the loss-history RING [max_history,4] (row = (adam_step-1) % max_history) =
+ * (l_rec, l_vposer, l_contact, l_collision as printed by fitting_proxe.py:184-186) to device buffers;
+ * h_step (host, nullable) receives the Adam step count and forces a stream sync. */
+int psi_fit_read(psi_fit_engine *engine, float *d_x_out, float *d_history_out, int n_hist, int *h_step, void *stream);
+/* Test/diagnostic copy of an engine-owned device buffer by name ("verts" [B,V,3], "g_verts", "pose" [B,165],
+ * "g_pose", "g_rot" [B,55,9], "stats" [8], "adam_m"/"adam_v" [B,75]) into d_out (device). */
+int psi_fit_copy_buffer(psi_fit_engine *engine, const char *name, float *d_out, long n_floats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

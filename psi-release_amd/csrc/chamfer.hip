@@ -39,13 +39,15 @@ __device__ __forceinline__ float sqdist(float tx, float ty, float tz, float qx, 
 template <int Q>
 __global__ __launch_bounds__(BLK) void nn_partial_kernel(const float *__restrict__ xyz1, const float *__restrict__ xyz2,
                                                          int B, int n, int m, int total_chunks, int chunks_per_slice,
-                                                         float *__restrict__ pd, int *__restrict__ pc)
+                                                         float *__restrict__ pd, int *__restrict__ pc,
+                                                         const int *__restrict__ qidx, long qstride, long tstride)
 {
+    // queries: row qidx[j] (or j) of a [qstride/3-row] table per body; targets: tstride floats between bodies (0 = shared)
     const int b = blockIdx.z;
     const int s = blockIdx.y;
     const int jbase = blockIdx.x * (BLK * Q) + threadIdx.x;
-    const float *__restrict__ qb = xyz1 + (size_t)b * n * 3;
-    const float *__restrict__ tb = xyz2 + (size_t)b * m * 3;
+    const float *__restrict__ qb = xyz1 + (size_t)b * qstride;
+    const float *__restrict__ tb = xyz2 + (size_t)b * tstride;
 
     float qx[Q], qy[Q], qz[Q], best[Q];
     int bchunk[Q];
@@ -54,9 +56,10 @@ __global__ __launch_bounds__(BLK) void nn_partial_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < Q; i++) {
         int j = min(jbase + i * BLK, n - 1);
-        qx[i] = qb[j * 3 + 0];
-        qy[i] = qb[j * 3 + 1];
-        qz[i] = qb[j * 3 + 2];
+        if (qidx) j = qidx[j];
+        qx[i] = qb[(size_t)j * 3 + 0];
+        qy[i] = qb[(size_t)j * 3 + 1];
+        qz[i] = qb[(size_t)j * 3 + 2];
         best[i] = INFINITY;
         bchunk[i] = c_begin;
     }
@@ -100,40 +103,69 @@ __global__ __launch_bounds__(BLK) void nn_partial_kernel(const float *__restrict
 }
 
 // Combine slices (ascending, strict '<') and rescan the winning chunk for the lowest minimiser.
+// CONTACT: fused epilogue of the contact loss (fitting_proxe.py:139): f = s/(s+c), s = sqrt(d+1e-4);
+// writes gq[b,j,:] = gscale * df/dd * 2 (q - t*) and one partial sum of f per workgroup.
+template <bool CONTACT>
 __global__ __launch_bounds__(BLK) void nn_resolve_kernel(const float *__restrict__ xyz1, const float *__restrict__ xyz2,
                                                          int B, int n, int m, int nslices,
                                                          const float *__restrict__ pd, const int *__restrict__ pc,
-                                                         float *__restrict__ dist, int *__restrict__ idx)
+                                                         float *__restrict__ dist, int *__restrict__ idx,
+                                                         const int *__restrict__ qidx, long qstride, long tstride,
+                                                         float cconst, float gscale, float *__restrict__ gq,
+                                                         float *__restrict__ fpart)
 {
     const int b = blockIdx.y;
     const int j = blockIdx.x * BLK + threadIdx.x;
-    if (j >= n) return;
-    size_t o = (size_t)b * n + j;
-    float best = pd[o];
-    int chunk = pc[o];
-    for (int s = 1; s < nslices; s++) {
-        size_t os = ((size_t)s * B + b) * n + j;
-        float d = pd[os];
-        if (d < best) {
-            best = d;
-            chunk = pc[os];
+    float fval = 0.0f;
+    if (j < n) {
+        size_t o = (size_t)b * n + j;
+        float best = pd[o];
+        int chunk = pc[o];
+        for (int s = 1; s < nslices; s++) {
+            size_t os = ((size_t)s * B + b) * n + j;
+            float d = pd[os];
+            if (d < best) {
+                best = d;
+                chunk = pc[os];
+            }
+        }
+        const size_t qrow = qidx ? (size_t)qidx[j] : (size_t)j;
+        const float *__restrict__ qp = xyz1 + (size_t)b * qstride + qrow * 3;
+        const float qx = qp[0], qy = qp[1], qz = qp[2];
+        const float *__restrict__ tb = xyz2 + (size_t)b * tstride;
+        const int k0 = chunk * CH;
+        const int kend = min(k0 + CH, m);
+        float bd = 0.0f;
+        int bi = k0;
+        for (int k = k0; k < kend; k++) {
+            float d = sqdist(tb[k * 3 + 0], tb[k * 3 + 1], tb[k * 3 + 2], qx, qy, qz);
+            if (k == k0 || d < bd) {
+                bd = d;
+                bi = k;
+            }
+        }
+        if (dist) dist[o] = bd;
+        if (idx) idx[o] = bi;
+        if (CONTACT) {
+            float sq = sqrtf(bd + 1e-4f);
+            float den = sq + cconst;
+            fval = sq / den;
+            float dfdd = cconst / (2.0f * sq * den * den);     // d/dd [ s/(s+c) ],  s = sqrt(d + 1e-4)
+            float g = gscale * dfdd * 2.0f;
+            gq[o * 3 + 0] = g * (qx - tb[(size_t)bi * 3 + 0]);
+            gq[o * 3 + 1] = g * (qy - tb[(size_t)bi * 3 + 1]);
+            gq[o * 3 + 2] = g * (qz - tb[(size_t)bi * 3 + 2]);
         }
     }
-    const float qx = xyz1[o * 3 + 0], qy = xyz1[o * 3 + 1], qz = xyz1[o * 3 + 2];
-    const float *__restrict__ tb = xyz2 + (size_t)b * m * 3;
-    const int k0 = chunk * CH;
-    const int kend = min(k0 + CH, m);
-    float bd = 0.0f;
-    int bi = k0;
-    for (int k = k0; k < kend; k++) {
-        float d = sqdist(tb[k * 3 + 0], tb[k * 3 + 1], tb[k * 3 + 2], qx, qy, qz);
-        if (k == k0 || d < bd) {
-            bd = d;
-            bi = k;
-        }
+    if (CONTACT) {
+        __shared__ float sh[BLK / 64];
+        float v = fval;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_down(v, o2, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) fpart[(size_t)b * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
     }
-    dist[o] = bd;
-    idx[o] = bi;
 }
 
 // grad_q[b,j] += 2*g*(q - t[idx]);  optionally grad_t[b,idx] -= the same (hardware fp32 atomics).
@@ -191,23 +223,47 @@ size_t nn_ws_bytes(int B, int n, int m)
     return (size_t)p.nslices * B * n * 8;
 }
 
-int launch_nn(const float *q, const float *t, int B, int n, int m, float *dist, int32_t *idx, void *ws, hipStream_t st)
+int launch_nn_ex(const float *q, const float *t, int B, int n, int m, float *dist, int32_t *idx, void *ws, hipStream_t st,
+                 const int *qidx, long qstride, long tstride, bool contact, float cconst, float gscale, float *gq, float *fpart)
 {
     NNPlan p = plan_nn(B, n, m);
     float *pd = (float *)ws;
     int *pc = (int *)(pd + (size_t)p.nslices * B * n);
     dim3 grid(p.qblocks, p.nslices, B);
     if (p.Q == 2)
-        hipLaunchKernelGGL(nn_partial_kernel<2>, grid, dim3(BLK), 0, st, q, t, B, n, m, p.total_chunks, p.chunks_per_slice, pd, pc);
+        hipLaunchKernelGGL(nn_partial_kernel<2>, grid, dim3(BLK), 0, st, q, t, B, n, m, p.total_chunks, p.chunks_per_slice, pd, pc,
+                           qidx, qstride, tstride);
     else
-        hipLaunchKernelGGL(nn_partial_kernel<1>, grid, dim3(BLK), 0, st, q, t, B, n, m, p.total_chunks, p.chunks_per_slice, pd, pc);
+        hipLaunchKernelGGL(nn_partial_kernel<1>, grid, dim3(BLK), 0, st, q, t, B, n, m, p.total_chunks, p.chunks_per_slice, pd, pc,
+                           qidx, qstride, tstride);
     PSI_CHECK_LAUNCH("nn_partial_kernel");
-    hipLaunchKernelGGL(nn_resolve_kernel, dim3(psi_cdiv(n, BLK), B), dim3(BLK), 0, st, q, t, B, n, m, p.nslices, pd, pc, dist, idx);
+    dim3 rg(psi_cdiv(n, BLK), B);
+    if (contact)
+        hipLaunchKernelGGL(nn_resolve_kernel<true>, rg, dim3(BLK), 0, st, q, t, B, n, m, p.nslices, pd, pc, dist, idx, qidx, qstride,
+                           tstride, cconst, gscale, gq, fpart);
+    else
+        hipLaunchKernelGGL(nn_resolve_kernel<false>, rg, dim3(BLK), 0, st, q, t, B, n, m, p.nslices, pd, pc, dist, idx, qidx, qstride,
+                           tstride, 0.0f, 0.0f, nullptr, nullptr);
     PSI_CHECK_LAUNCH("nn_resolve_kernel");
     return 0;
 }
 
+int launch_nn(const float *q, const float *t, int B, int n, int m, float *dist, int32_t *idx, void *ws, hipStream_t st)
+{
+    return launch_nn_ex(q, t, B, n, m, dist, idx, ws, st, nullptr, (long)n * 3, (long)m * 3, false, 0, 0, nullptr, nullptr);
+}
+
 }  // namespace
+
+// internal (psi_internal.h): contact-loss NN for the fused fitting engine — queries gathered from the vertex table,
+// one scene cloud shared by all bodies, loss epilogue fused into the resolve pass.
+int psi_nn_contact(const float *verts, long vstride, const int *vid, const float *scene, int B, int n, int m, void *ws,
+                   float cconst, float gscale, float *gq, float *fpart, int *idx_out, hipStream_t st)
+{
+    return launch_nn_ex(verts, scene, B, n, m, nullptr, idx_out, ws, st, vid, vstride, 0, true, cconst, gscale, gq, fpart);
+}
+int psi_nn_contact_fparts(int n) { return psi_cdiv(n, BLK); }
+size_t psi_nn_ws_bytes(int B, int n, int m) { return nn_ws_bytes(B, n, m); }
 
 extern "C" size_t psi_chamfer_workspace_bytes(int B, int n, int m)
 {

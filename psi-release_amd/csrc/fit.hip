@@ -1,0 +1,649 @@
+// Fused fitting engine for gfx950: ONE fitting iteration of the reference's loop
+//   for ii in range(num_iter): zero_grad; cal_loss; (loss_rec+loss_vposer+loss_contact+loss_collision).backward(); Adam.step()
+//                                                                                        source/fitting_proxe.py:101-162,177-189
+// as a fixed sequence of HIP kernels with a hand-derived backward, replayable as a hipGraph (no host sync, no autograd).
+//
+//   head_fwd          per body: L1 / latent-prior partial sums (fitting_proxe.py:105-110); convert_to_3D_rot (cvae.py:128-137);
+//                     VPoser.decode 32->512->512->126 -> 21 x (6D -> R -> angle-axis) (vposer_smpl.py:107-121,152-161);
+//                     SMPL-X hand PCA + pose_mean (smplx 0.1.13 forward)
+//   lbs forward       pose_fwd, blend_fwd (MFMA), skin_fwd incl. cam_ext                  (lbs.hip)
+//   sdf_pen           trilinear SDF + analytic gradient + penetration partial sums       (fitting_proxe.py:144-158)
+//   nn_contact        Chamfer NN of the gathered contact vertices + contact-loss epilogue (chamfer.hip; fitting_proxe.py:131-139)
+//   loss_finalize     deterministic reduction of all partial sums -> stats[6] = [sum|dx|, sum z^2, sum f, sum|sdf-|, N, 0]
+//   --- data-parallel runs all-reduce `stats` here (one 6-float RCCL all-reduce per iteration) ---
+//   grad_verts        d loss / d verts = penetration part (needs the GLOBAL count N) + contact part
+//   lbs backward      skin_bwd_v, skin_bwd_A (MFMA), blend_bwd (MFMA), reduce, pose_bwd      (lbs.hip)
+//   head_bwd_adam     Gram-Schmidt / VPoser-MLP / hand-PCA backward, + L1 and prior gradients, Adam update (torch.optim.Adam defaults)
+//
+// Gradient through "6D -> R -> angle-axis -> Rodrigues -> R'": the forward evaluates the reference's chain literally;
+// the backward uses that R' == R on SO(3) and that Gram-Schmidt only moves along SO(3), so J_GS^T dL/dR' is the exact
+// gradient (requires pose_mean == 0 for global_orient/body joints, which holds for SMPL-X; checked at creation).
+#include "psi_internal.h"
+#include "sdf_device.h"
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+constexpr int NH = 512;        // VPoser hidden width (vposer_smpl.py:75-89 with num_neurons=512)
+constexpr int NZ = 32;         // VPoser latent
+constexpr int NJ6 = 126;       // 21 joints x 6D
+constexpr int XD = 75;         // body vector with 6D global rotation (cvae.py:117-126)
+constexpr int HB = 256;        // threads per body in the head kernels
+
+struct FitDev {
+    int B, V, J, NB, n_c, m, D, align_corners, world, ncomp, nfp, nsdfblk;
+    float w_rec, w_vp, w_contact, w_col, cconst;
+    float lr, beta1, beta2, eps;
+    // model constants
+    const float *W1T, *b1, *W2T, *b2, *W3T, *b3;      // transposed [in][out] for the forward
+    const float *W1, *W2, *W3;                        // original [out][in] for the backward
+    const float *lhc, *rhc, *pose_mean;               // [ncomp][45] x2, [J*3]
+    const int *vid;                                   // [n_c] contact vertex ids
+    const int *cs_ptr, *cs_idx;                       // vertex -> contact slots (CSR, V+1 / n_c)
+    const float *scene, *sdf, *gmin, *gmax;           // scene cloud [m,3], volume [D^3], bounds [3]
+    // state
+    float *x, *xhr, *cam, *adam_m, *adam_v;
+    int *step;
+    // per-iteration buffers
+    float *h1, *h2, *o6, *betas20, *pose, *transl, *verts, *og, *g_verts, *gq, *fpart, *penpart, *recpart, *vppart;
+    float *g_betas, *g_pose, *g_transl, *g_rot;
+    float *history;      // [max_hist][4] loss values per iteration
+    int max_hist;
+};
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.0f ? v : v * slope; }
+
+// ContinousRotReprDecoder.decode (cvae.py:58-68): a = view(3,2); columns b1,b2,b3
+__device__ __forceinline__ void gs_forward(const float *x6, float *R)
+{
+    float a1[3] = {x6[0], x6[2], x6[4]}, a2[3] = {x6[1], x6[3], x6[5]};
+    float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-12f);
+    float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    float u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    float n2 = fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-12f);
+    float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+    for (int r = 0; r < 3; r++) {
+        R[r * 3 + 0] = b1[r];
+        R[r * 3 + 1] = b2[r];
+        R[r * 3 + 2] = b3[r];
+    }
+}
+
+// gradient of gs_forward: gR [3x3 row-major] -> g6
+__device__ __forceinline__ void gs_backward(const float *x6, const float *gR, float *g6)
+{
+    float a1[3] = {x6[0], x6[2], x6[4]}, a2[3] = {x6[1], x6[3], x6[5]};
+    float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-12f);
+    float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    float u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    float n2 = fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-12f);
+    float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    float gb1[3] = {gR[0], gR[3], gR[6]}, gb2[3] = {gR[1], gR[4], gR[7]}, gb3[3] = {gR[2], gR[5], gR[8]};
+    // b3 = b1 x b2:  gb1 += b2 x gb3,  gb2 += gb3 x b1
+    gb1[0] += b2[1] * gb3[2] - b2[2] * gb3[1];
+    gb1[1] += b2[2] * gb3[0] - b2[0] * gb3[2];
+    gb1[2] += b2[0] * gb3[1] - b2[1] * gb3[0];
+    gb2[0] += gb3[1] * b1[2] - gb3[2] * b1[1];
+    gb2[1] += gb3[2] * b1[0] - gb3[0] * b1[2];
+    gb2[2] += gb3[0] * b1[1] - gb3[1] * b1[0];
+    // b2 = u / |u|
+    float p = b2[0] * gb2[0] + b2[1] * gb2[1] + b2[2] * gb2[2];
+    float gu[3] = {(gb2[0] - b2[0] * p) / n2, (gb2[1] - b2[1] * p) / n2, (gb2[2] - b2[2] * p) / n2};
+    // u = a2 - (b1.a2) b1
+    float q = gu[0] * b1[0] + gu[1] * b1[1] + gu[2] * b1[2];
+    float ga2[3] = {gu[0] - b1[0] * q, gu[1] - b1[1] * q, gu[2] - b1[2] * q};
+    for (int i = 0; i < 3; i++) gb1[i] += -d * gu[i] - q * a2[i];
+    // b1 = a1 / |a1|
+    float r = b1[0] * gb1[0] + b1[1] * gb1[1] + b1[2] * gb1[2];
+    float ga1[3] = {(gb1[0] - b1[0] * r) / n1, (gb1[1] - b1[1] * r) / n1, (gb1[2] - b1[2] * r) / n1};
+    g6[0] = ga1[0]; g6[2] = ga1[1]; g6[4] = ga1[2];
+    g6[1] = ga2[0]; g6[3] = ga2[1]; g6[5] = ga2[2];
+}
+
+// torchgeometry 0.1.2 rotation_matrix_to_angle_axis (quaternion route); R row-major 3x3
+__device__ __forceinline__ void rotmat_to_aa(const float *R, float *aa)
+{
+    // m = R^T
+    const float m00 = R[0], m01 = R[3], m02 = R[6], m10 = R[1], m11 = R[4], m12 = R[7], m20 = R[2], m21 = R[5], m22 = R[8];
+    float q[4], t;
+    if (m22 < 1e-6f) {
+        if (m00 > m11) {
+            t = 1 + m00 - m11 - m22;
+            q[0] = m12 - m21; q[1] = t; q[2] = m01 + m10; q[3] = m20 + m02;
+        } else {
+            t = 1 - m00 + m11 - m22;
+            q[0] = m20 - m02; q[1] = m01 + m10; q[2] = t; q[3] = m12 + m21;
+        }
+    } else {
+        if (m00 < -m11) {
+            t = 1 - m00 - m11 + m22;
+            q[0] = m01 - m10; q[1] = m20 + m02; q[2] = m12 + m21; q[3] = t;
+        } else {
+            t = 1 + m00 + m11 + m22;
+            q[0] = t; q[1] = m12 - m21; q[2] = m20 - m02; q[3] = m01 - m10;
+        }
+    }
+    float sc = sqrtf(t);
+    for (int i = 0; i < 4; i++) q[i] = q[i] / sc * 0.5f;
+    float s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    float s = sqrtf(s2);
+    float two_theta = 2.0f * (q[0] < 0.0f ? atan2f(-s, -q[0]) : atan2f(s, q[0]));
+    float k = s2 > 0.0f ? two_theta / s : 2.0f;
+    aa[0] = q[1] * k; aa[1] = q[2] * k; aa[2] = q[3] * k;
+}
+
+__device__ __forceinline__ float block_sum(float v, float *sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += sh[i];
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    __shared__ float sx[XD + 5], sh1[NH], sh2[NH], so6[128], red[HB / 64];
+    const float *x = f.x + (size_t)b * XD;
+    if (t < XD) sx[t] = x[t];
+    __syncthreads();
+    // loss partial sums (fitting_proxe.py:105, :109-110)
+    float dr = t < XD ? fabsf(f.xhr[(size_t)b * XD + t] - sx[t]) : 0.0f;
+    float sr = block_sum(dr, red);
+    float dz = t < NZ ? sx[19 + t] * sx[19 + t] : 0.0f;     // latent = xh_rec[:,16:48] = x[:,19:51] in the 75-D layout
+    float sz = block_sum(dz, red);
+    if (t == 0) {
+        f.recpart[b] = sr;
+        f.vppart[b] = sz;
+    }
+    // VPoser decoder
+    const float *z = sx + 19;
+    for (int o = t; o < NH; o += HB) {
+        float a = f.b1[o];
+#pragma unroll 8
+        for (int k = 0; k < NZ; k++) a += f.W1T[k * NH + o] * z[k];
+        sh1[o] = leaky(a, 0.2f);
+    }
+    __syncthreads();
+    for (int o = t; o < NH; o += HB) {
+        float a0 = f.b2[o], a1 = 0, a2 = 0, a3 = 0;
+        for (int k = 0; k < NH; k += 4) {
+            a0 += f.W2T[(k + 0) * NH + o] * sh1[k + 0];
+            a1 += f.W2T[(k + 1) * NH + o] * sh1[k + 1];
+            a2 += f.W2T[(k + 2) * NH + o] * sh1[k + 2];
+            a3 += f.W2T[(k + 3) * NH + o] * sh1[k + 3];
+        }
+        sh2[o] = leaky((a0 + a1) + (a2 + a3), 0.2f);
+    }
+    __syncthreads();
+    if (t < NJ6) {
+        float a0 = f.b3[t], a1 = 0, a2 = 0, a3 = 0;
+        for (int k = 0; k < NH; k += 4) {
+            a0 += f.W3T[(k + 0) * NJ6 + t] * sh2[k + 0];
+            a1 += f.W3T[(k + 1) * NJ6 + t] * sh2[k + 1];
+            a2 += f.W3T[(k + 2) * NJ6 + t] * sh2[k + 2];
+            a3 += f.W3T[(k + 3) * NJ6 + t] * sh2[k + 3];
+        }
+        so6[t] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    for (int o = t; o < NH; o += HB) {
+        f.h1[(size_t)b * NH + o] = sh1[o];
+        f.h2[(size_t)b * NH + o] = sh2[o];
+    }
+    if (t < NJ6) f.o6[(size_t)b * 128 + t] = so6[t];
+    float *pose = f.pose + (size_t)b * f.J * 3;
+    // rotations: thread 0 = global orient (x[3:9]), threads 1..21 = VPoser body joints
+    if (t < 22) {
+        float R[9], aa[3];
+        gs_forward(t == 0 ? sx + 3 : so6 + (t - 1) * 6, R);
+        rotmat_to_aa(R, aa);
+        for (int c = 0; c < 3; c++) pose[t * 3 + c] = aa[c] + f.pose_mean[t * 3 + c];
+    } else if (t >= 64 && t < 64 + 9) {
+        int e = 66 + (t - 64);                               // jaw, leye, reye: zero parameters + mean
+        pose[e] = f.pose_mean[e];
+    } else if (t >= 128 && t < 128 + 90) {
+        int e = t - 128;                                     // hand PCA: 12 -> 45 per hand
+        const float *comp = e < 45 ? f.lhc : f.rhc;
+        const float *hx = sx + (e < 45 ? 51 : 63);
+        int c = e < 45 ? e : e - 45;
+        float a = 0;
+        for (int i = 0; i < f.ncomp; i++) a += hx[i] * comp[i * 45 + c];
+        pose[75 + e] = a + f.pose_mean[75 + e];
+    }
+    if (t < f.NB) f.betas20[(size_t)b * f.NB + t] = t < 10 ? sx[9 + t] : 0.0f;
+    if (t < 3) f.transl[(size_t)b * 3 + t] = sx[t];
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdf_pen_kernel(FitDev f)
+{
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    float val = 0.0f, g[3] = {0, 0, 0};
+    if (v < f.V) {
+        const float *p = f.verts + ((size_t)b * f.V + v) * 3;
+        val = psi_trilinear(f.sdf, f.gmin, f.gmax, p[0], p[1], p[2], f.D, f.align_corners, g);
+    }
+    const bool neg = (v < f.V) && (val < 0.0f);
+    if (v < f.V) {
+        float *o = f.og + ((size_t)b * f.V + v) * 3;
+        o[0] = neg ? g[0] : 0.0f;
+        o[1] = neg ? g[1] : 0.0f;
+        o[2] = neg ? g[2] : 0.0f;
+    }
+    __shared__ float red[4];
+    float s = block_sum(neg ? -val : 0.0f, red);
+    float c = block_sum(neg ? 1.0f : 0.0f, red);
+    if (threadIdx.x == 0) {
+        size_t o = ((size_t)b * gridDim.x + blockIdx.x) * 2;
+        f.penpart[o] = s;
+        f.penpart[o + 1] = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_finalize_kernel(FitDev f, float *stats)
+{
+    __shared__ float red[4];
+    const int t = threadIdx.x;
+    float a = 0;
+    for (int i = t; i < f.B; i += 256) a += f.recpart[i];
+    float s_rec = block_sum(a, red);
+    a = 0;
+    for (int i = t; i < f.B; i += 256) a += f.vppart[i];
+    float s_vp = block_sum(a, red);
+    a = 0;
+    for (int i = t; i < f.B * f.nfp; i += 256) a += f.fpart[i];
+    float s_f = block_sum(a, red);
+    a = 0;
+    float c = 0;
+    for (int i = t; i < f.B * f.nsdfblk; i += 256) {
+        a += f.penpart[2 * i];
+        c += f.penpart[2 * i + 1];
+    }
+    float s_pen = block_sum(a, red);
+    float n_pen = block_sum(c, red);
+    if (t == 0) {
+        stats[0] = s_rec; stats[1] = s_vp; stats[2] = s_f; stats[3] = s_pen; stats[4] = n_pen; stats[5] = 0.0f;
+        *f.step += 1;
+    }
+}
+
+// g_verts = penetration part (global count) + contact part (vertex -> contact slots); block 0 records the loss values
+__global__ __launch_bounds__(256) void grad_verts_kernel(FitDev f, const float *__restrict__ stats)
+{
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const float Bg = (float)f.B * (float)f.world;
+    const float N = stats[4];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        int it = *f.step - 1;
+        if (it >= 0) {
+            float *h = f.history + (size_t)(it % f.max_hist) * 4;     // ring buffer
+            h[0] = f.w_rec * stats[0] / (Bg * XD);
+            h[1] = f.w_vp * stats[1] / (Bg * NZ);
+            h[2] = f.w_contact * stats[2] / (Bg * f.n_c);
+            h[3] = N > 0.0f ? f.w_col * stats[3] / N : 0.0f;
+        }
+    }
+    if (v >= f.V) return;
+    const float sp = N > 0.0f ? -f.w_col / N : 0.0f;       // d/d sdf_k of w * sum(-sdf)/N on the penetrating entries
+    const size_t o = ((size_t)b * f.V + v) * 3;
+    float gx = sp * f.og[o + 0], gy = sp * f.og[o + 1], gz = sp * f.og[o + 2];
+    for (int ci = f.cs_ptr[v]; ci < f.cs_ptr[v + 1]; ci++) {
+        const float *q = f.gq + ((size_t)b * f.n_c + f.cs_idx[ci]) * 3;
+        gx += q[0]; gy += q[1]; gz += q[2];
+    }
+    f.g_verts[o + 0] = gx; f.g_verts[o + 1] = gy; f.g_verts[o + 2] = gz;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    __shared__ float sx[XD + 5], sg6[128], sga2[NH], sga1[NH], sgx[XD + 5], part[8][NZ];
+    const float *x = f.x + (size_t)b * XD;
+    if (t < XD) { sx[t] = x[t]; sgx[t] = 0.0f; }
+    if (t < 128) sg6[t] = 0.0f;
+    __syncthreads();
+    const float *grot = f.g_rot + (size_t)b * f.J * 9;
+    const float *gpose = f.g_pose + (size_t)b * f.J * 3;
+    if (t == 0) {
+        float g6[6];
+        gs_backward(sx + 3, grot, g6);
+        for (int i = 0; i < 6; i++) sgx[3 + i] = g6[i];
+    } else if (t >= 1 && t < 22) {
+        float g6[6];
+        gs_backward(f.o6 + (size_t)b * 128 + (t - 1) * 6, grot + t * 9, g6);
+        for (int i = 0; i < 6; i++) sg6[(t - 1) * 6 + i] = g6[i];
+    } else if (t >= 64 && t < 64 + 2 * f.ncomp) {
+        int i = t - 64;                                   // hand PCA backward
+        const float *comp = i < f.ncomp ? f.lhc : f.rhc;
+        int ii = i < f.ncomp ? i : i - f.ncomp;
+        const float *gp = gpose + (i < f.ncomp ? 75 : 120);
+        float a = 0;
+        for (int c = 0; c < 45; c++) a += comp[ii * 45 + c] * gp[c];
+        sgx[(i < f.ncomp ? 51 : 63) + ii] = a;
+    } else if (t >= 128 && t < 128 + 3) {
+        sgx[t - 128] = f.g_transl[(size_t)b * 3 + (t - 128)];
+    } else if (t >= 160 && t < 160 + 10) {
+        sgx[9 + (t - 160)] = f.g_betas[(size_t)b * f.NB + (t - 160)];
+    }
+    __syncthreads();
+    // VPoser MLP backward (weights are constants)
+    const float *h1 = f.h1 + (size_t)b * NH, *h2 = f.h2 + (size_t)b * NH;
+    for (int k = t; k < NH; k += HB) {
+        float a = 0;
+        for (int o = 0; o < NJ6; o++) a += f.W3[o * NH + k] * sg6[o];
+        sga2[k] = a * (h2[k] > 0.0f ? 1.0f : 0.2f);
+    }
+    __syncthreads();
+    for (int k = t; k < NH; k += HB) {
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int o = 0; o < NH; o += 4) {
+            a0 += f.W2[(o + 0) * NH + k] * sga2[o + 0];
+            a1 += f.W2[(o + 1) * NH + k] * sga2[o + 1];
+            a2 += f.W2[(o + 2) * NH + k] * sga2[o + 2];
+            a3 += f.W2[(o + 3) * NH + k] * sga2[o + 3];
+        }
+        sga1[k] = ((a0 + a1) + (a2 + a3)) * (h1[k] > 0.0f ? 1.0f : 0.2f);
+    }
+    __syncthreads();
+    {
+        int k = t & 31, pp = t >> 5;                       // 8 partial sums of 64 outputs each
+        float a = 0;
+        for (int o = pp * 64; o < pp * 64 + 64; o++) a += f.W1[o * NZ + k] * sga1[o];
+        part[pp][k] = a;
+    }
+    __syncthreads();
+    if (t < NZ) {
+        float a = 0;
+        for (int pp = 0; pp < 8; pp++) a += part[pp][t];
+        sgx[19 + t] = a;
+    }
+    __syncthreads();
+    if (t < XD) {
+        const float Bg = (float)f.B * (float)f.world;
+        float g = sgx[t];
+        // d/dx of w_rec * mean|xhr - x|  (fitting_proxe.py:105)
+        float df = f.xhr[(size_t)b * XD + t] - sx[t];
+        g += f.w_rec / (Bg * XD) * (df > 0.0f ? -1.0f : (df < 0.0f ? 1.0f : 0.0f));
+        // d/dz of w_vp * mean(z^2)       (fitting_proxe.py:109-110)
+        if (t >= 19 && t < 19 + NZ) g += f.w_vp / (Bg * NZ) * 2.0f * sx[t];
+        // torch.optim.Adam (defaults: amsgrad False, weight_decay 0), fitting_proxe.py:73-74
+        const int step = *f.step;
+        size_t o = (size_t)b * XD + t;
+        float m = f.adam_m[o] * f.beta1 + (1.0f - f.beta1) * g;
+        float v = f.adam_v[o] * f.beta2 + (1.0f - f.beta2) * g * g;
+        f.adam_m[o] = m;
+        f.adam_v[o] = v;
+        double bc1 = 1.0 - pow((double)f.beta1, (double)step);
+        double bc2 = 1.0 - pow((double)f.beta2, (double)step);
+        float step_size = (float)((double)f.lr / bc1);
+        float bc2_sqrt = (float)sqrt(bc2);
+        float denom = sqrtf(v) / bc2_sqrt + f.eps;
+        f.x[o] = sx[t] - step_size * (m / denom);
+    }
+}
+
+__global__ void adam_reset_kernel(float *m, float *v, int *step, int n)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { m[i] = 0.0f; v[i] = 0.0f; }
+    if (i == 0) *step = 0;
+}
+
+}  // namespace
+
+struct psi_fit_engine {
+    FitDev d;
+    const psi_lbs_model *lbs;
+    float *lbs_ws;
+    void *nn_ws;
+    char *blob;
+    float *stats_local;           // engine-owned stats buffer (single-GPU path)
+    hipGraph_t graph;
+    hipGraphExec_t graph_exec;
+    bool graph_ready;
+};
+
+static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st)
+{
+    FitDev &f = e->d;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(f.B), dim3(HB), 0, st, f);
+    PSI_CHECK_LAUNCH("head_fwd_kernel");
+    int rc = psi_lbs_forward(e->lbs, f.betas20, f.pose, f.transl, f.cam, f.B, f.verts, nullptr, e->lbs_ws, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sdf_pen_kernel, dim3(f.nsdfblk, f.B), dim3(256), 0, st, f);
+    PSI_CHECK_LAUNCH("sdf_pen_kernel");
+    float gscale = f.w_contact / ((float)f.B * (float)f.world * (float)f.n_c);
+    rc = psi_nn_contact(f.verts, (long)f.V * 3, f.vid, f.scene, f.B, f.n_c, f.m, e->nn_ws, f.cconst, gscale, f.gq, f.fpart, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, f, stats);
+    PSI_CHECK_LAUNCH("loss_finalize_kernel");
+    return 0;
+}
+
+static int fit_backward(psi_fit_engine *e, const float *stats, hipStream_t st)
+{
+    FitDev &f = e->d;
+    hipLaunchKernelGGL(grad_verts_kernel, dim3(f.nsdfblk, f.B), dim3(256), 0, st, f, stats);
+    PSI_CHECK_LAUNCH("grad_verts_kernel");
+    PsiLbsGradOut out = {f.g_betas, f.g_pose, f.g_transl, f.g_rot};
+    int rc = psi_lbs_backward_ex(e->lbs, f.g_verts, f.betas20, f.pose, f.cam, f.B, e->lbs_ws, out, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_bwd_adam_kernel, dim3(f.B), dim3(HB), 0, st, f);
+    PSI_CHECK_LAUNCH("head_bwd_adam_kernel");
+    return 0;
+}
+
+extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, const psi_fit_config *cfg,
+                              const float *h_w1, const float *h_b1, const float *h_w2, const float *h_b2,
+                              const float *h_w3, const float *h_b3, const float *h_lh_comp, const float *h_rh_comp,
+                              const float *h_pose_mean, const int32_t *h_contact_ids,
+                              const float *d_scene_verts, const float *d_sdf, const float *h_gmin, const float *h_gmax)
+{
+    PSI_REQUIRE(out && lbs && cfg && h_w1 && h_b1 && h_w2 && h_b2 && h_w3 && h_b3 && h_lh_comp && h_rh_comp && h_pose_mean &&
+                h_contact_ids && d_scene_verts && d_sdf && h_gmin && h_gmax, "null pointer");
+    int V, J, NB;
+    psi_lbs_dims(lbs, &V, &J, &NB);
+    PSI_REQUIRE(J == 55 && NB >= 10, "the fused engine is SMPL-X shaped (J=55, >=10 betas)");
+    PSI_REQUIRE(cfg->B > 0 && cfg->n_contact > 0 && cfg->m_scene > 0 && cfg->D >= 2 && cfg->world_size >= 1, "bad sizes");
+    PSI_REQUIRE(cfg->num_pca_comps > 0 && cfg->num_pca_comps <= 12, "1..12 hand PCA components");
+    for (int i = 0; i < 66; i++) PSI_REQUIRE(h_pose_mean[i] == 0.0f, "pose_mean must be zero for global_orient/body joints");
+    for (int i = 0; i < cfg->n_contact; i++) PSI_REQUIRE(h_contact_ids[i] >= 0 && h_contact_ids[i] < V, "contact id out of range");
+    psi_fit_engine *e = new psi_fit_engine;
+    memset(e, 0, sizeof(*e));
+    e->lbs = lbs;
+    FitDev &f = e->d;
+    f.B = cfg->B; f.V = V; f.J = J; f.NB = NB; f.n_c = cfg->n_contact; f.m = cfg->m_scene; f.D = cfg->D;
+    f.align_corners = cfg->align_corners; f.world = cfg->world_size; f.ncomp = cfg->num_pca_comps;
+    f.w_rec = cfg->w_rec; f.w_vp = cfg->w_vposer; f.w_contact = cfg->w_contact; f.w_col = cfg->w_collision; f.cconst = cfg->contact_const;
+    f.lr = cfg->lr; f.beta1 = cfg->beta1; f.beta2 = cfg->beta2; f.eps = cfg->eps;
+    f.nfp = psi_nn_contact_fparts(f.n_c);
+    f.nsdfblk = psi_cdiv(V, 256);
+    f.max_hist = cfg->max_history > 0 ? cfg->max_history : 1024;
+    f.scene = d_scene_verts;
+    f.sdf = d_sdf;
+    const int B = f.B;
+    // host staging of constants
+    std::vector<float> W1T((size_t)NZ * NH), W2T((size_t)NH * NH), W3T((size_t)NH * NJ6);
+    for (int o = 0; o < NH; o++) for (int k = 0; k < NZ; k++) W1T[(size_t)k * NH + o] = h_w1[(size_t)o * NZ + k];
+    for (int o = 0; o < NH; o++) for (int k = 0; k < NH; k++) W2T[(size_t)k * NH + o] = h_w2[(size_t)o * NH + k];
+    for (int o = 0; o < NJ6; o++) for (int k = 0; k < NH; k++) W3T[(size_t)k * NJ6 + o] = h_w3[(size_t)o * NH + k];
+    std::vector<int> cs_ptr(V + 1, 0), cs_idx(f.n_c);
+    for (int i = 0; i < f.n_c; i++) cs_ptr[h_contact_ids[i] + 1]++;
+    for (int v = 0; v < V; v++) cs_ptr[v + 1] += cs_ptr[v];
+    {
+        std::vector<int> fill(cs_ptr.begin(), cs_ptr.end() - 1);
+        for (int i = 0; i < f.n_c; i++) cs_idx[fill[h_contact_ids[i]]++] = i;   // ascending slot order per vertex
+    }
+    struct Item { const void *src; size_t bytes; size_t off; };
+    std::vector<Item> items;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    auto cst = [&](const void *src, size_t bytes) { size_t r = take(bytes); items.push_back({src, bytes, r}); return r; };
+    size_t o_w1t = cst(W1T.data(), W1T.size() * 4), o_b1 = cst(h_b1, NH * 4), o_w2t = cst(W2T.data(), W2T.size() * 4), o_b2 = cst(h_b2, NH * 4),
+           o_w3t = cst(W3T.data(), W3T.size() * 4), o_b3 = cst(h_b3, NJ6 * 4), o_w1 = cst(h_w1, (size_t)NH * NZ * 4),
+           o_w2 = cst(h_w2, (size_t)NH * NH * 4), o_w3 = cst(h_w3, (size_t)NJ6 * NH * 4), o_lh = cst(h_lh_comp, (size_t)f.ncomp * 45 * 4),
+           o_rh = cst(h_rh_comp, (size_t)f.ncomp * 45 * 4), o_pm = cst(h_pose_mean, (size_t)J * 3 * 4), o_vid = cst(h_contact_ids, (size_t)f.n_c * 4),
+           o_cp = cst(cs_ptr.data(), cs_ptr.size() * 4), o_ci = cst(cs_idx.data(), cs_idx.size() * 4), o_gmin = cst(h_gmin, 12), o_gmax = cst(h_gmax, 12);
+    size_t zero_begin = o;
+    size_t o_x = take((size_t)B * XD * 4), o_xhr = take((size_t)B * XD * 4), o_cam = take((size_t)B * 16 * 4), o_am = take((size_t)B * XD * 4),
+           o_av = take((size_t)B * XD * 4), o_step = take(256), o_h1 = take((size_t)B * NH * 4), o_h2 = take((size_t)B * NH * 4),
+           o_o6 = take((size_t)B * 128 * 4), o_b20 = take((size_t)B * NB * 4), o_pose = take((size_t)B * J * 3 * 4), o_tr = take((size_t)B * 3 * 4),
+           o_verts = take((size_t)B * V * 3 * 4), o_og = take((size_t)B * V * 3 * 4), o_gv = take((size_t)B * V * 3 * 4),
+           o_gq = take((size_t)B * f.n_c * 3 * 4), o_fp = take((size_t)B * f.nfp * 4), o_pp = take((size_t)B * f.nsdfblk * 2 * 4),
+           o_rp = take((size_t)B * 4), o_vp = take((size_t)B * 4), o_gb = take((size_t)B * NB * 4), o_gp = take((size_t)B * J * 3 * 4),
+           o_gt = take((size_t)B * 3 * 4), o_gr = take((size_t)B * J * 9 * 4), o_hist = take((size_t)f.max_hist * 4 * 4), o_stats = take(256);
+    size_t lbs_floats = psi_lbs_workspace_floats(lbs, B);
+    size_t o_lws = take(lbs_floats * 4), o_nws = take(psi_nn_ws_bytes(B, f.n_c, f.m));
+    hipError_t err = hipMalloc((void **)&e->blob, o);
+    if (err != hipSuccess) {
+        delete e;
+        psi_set_error("psi_fit_create: hipMalloc(%zu) failed: %s", o, hipGetErrorString(err));
+        return (int)err;
+    }
+    err = hipMemset(e->blob + zero_begin, 0, o - zero_begin);
+    for (auto &it : items)
+        if (err == hipSuccess) err = hipMemcpy(e->blob + it.off, it.src, it.bytes, hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        (void)hipFree(e->blob);
+        delete e;
+        psi_set_error("psi_fit_create: upload failed: %s", hipGetErrorString(err));
+        return (int)err;
+    }
+    char *bl = e->blob;
+    auto F = [&](size_t off) { return (float *)(bl + off); };
+    f.W1T = F(o_w1t); f.b1 = F(o_b1); f.W2T = F(o_w2t); f.b2 = F(o_b2); f.W3T = F(o_w3t); f.b3 = F(o_b3);
+    f.W1 = F(o_w1); f.W2 = F(o_w2); f.W3 = F(o_w3); f.lhc = F(o_lh); f.rhc = F(o_rh); f.pose_mean = F(o_pm);
+    f.vid = (const int *)(bl + o_vid); f.cs_ptr = (const int *)(bl + o_cp); f.cs_idx = (const int *)(bl + o_ci);
+    f.gmin = F(o_gmin); f.gmax = F(o_gmax);
+    f.x = F(o_x); f.xhr = F(o_xhr); f.cam = F(o_cam); f.adam_m = F(o_am); f.adam_v = F(o_av); f.step = (int *)(bl + o_step);
+    f.h1 = F(o_h1); f.h2 = F(o_h2); f.o6 = F(o_o6); f.betas20 = F(o_b20); f.pose = F(o_pose); f.transl = F(o_tr);
+    f.verts = F(o_verts); f.og = F(o_og); f.g_verts = F(o_gv); f.gq = F(o_gq); f.fpart = F(o_fp); f.penpart = F(o_pp);
+    f.recpart = F(o_rp); f.vppart = F(o_vp); f.g_betas = F(o_gb); f.g_pose = F(o_gp); f.g_transl = F(o_gt); f.g_rot = F(o_gr);
+    f.history = F(o_hist);
+    e->stats_local = F(o_stats);
+    e->lbs_ws = F(o_lws);
+    e->nn_ws = bl + o_nws;
+    *out = e;
+    return 0;
+}
+
+extern "C" void psi_fit_destroy(psi_fit_engine *e)
+{
+    if (!e) return;
+    if (e->graph_ready) {
+        (void)hipGraphExecDestroy(e->graph_exec);
+        (void)hipGraphDestroy(e->graph);
+    }
+    (void)hipFree(e->blob);
+    delete e;
+}
+
+extern "C" int psi_fit_set_problem(psi_fit_engine *e, const float *d_xhr, const float *d_x_init, const float *d_cam_ext,
+                                   int reset_optimizer, void *stream)
+{
+    PSI_REQUIRE(e && d_xhr && d_cam_ext, "null pointer");
+    FitDev &f = e->d;
+    hipStream_t st = (hipStream_t)stream;
+    size_t nb = (size_t)f.B * XD * 4;
+    PSI_CHECK_HIP(hipMemcpyAsync(f.xhr, d_xhr, nb, hipMemcpyDeviceToDevice, st));
+    PSI_CHECK_HIP(hipMemcpyAsync(f.x, d_x_init ? d_x_init : d_xhr, nb, hipMemcpyDeviceToDevice, st));
+    PSI_CHECK_HIP(hipMemcpyAsync(f.cam, d_cam_ext, (size_t)f.B * 16 * 4, hipMemcpyDeviceToDevice, st));
+    if (reset_optimizer) {
+        hipLaunchKernelGGL(adam_reset_kernel, dim3(psi_cdiv((long)f.B * XD, 256)), dim3(256), 0, st, f.adam_m, f.adam_v, f.step, f.B * XD);
+        PSI_CHECK_LAUNCH("adam_reset_kernel");
+    }
+    return 0;
+}
+
+extern "C" int psi_fit_forward(psi_fit_engine *e, float *d_stats, void *stream)
+{
+    PSI_REQUIRE(e, "null engine");
+    return fit_forward(e, d_stats ? d_stats : e->stats_local, (hipStream_t)stream);
+}
+
+extern "C" int psi_fit_backward_step(psi_fit_engine *e, const float *d_stats, void *stream)
+{
+    PSI_REQUIRE(e, "null engine");
+    return fit_backward(e, d_stats ? d_stats : e->stats_local, (hipStream_t)stream);
+}
+
+extern "C" int psi_fit_iterate(psi_fit_engine *e, int n_iter, int use_graph, void *stream)
+{
+    PSI_REQUIRE(e && n_iter >= 0, "bad arguments");
+    PSI_REQUIRE(e->d.world == 1, "psi_fit_iterate is the single-process path; data-parallel runs call forward / all-reduce / backward_step");
+    hipStream_t st = (hipStream_t)stream;
+    if (!use_graph) {
+        for (int i = 0; i < n_iter; i++) {
+            int rc = fit_forward(e, e->stats_local, st);
+            if (rc) return rc;
+            rc = fit_backward(e, e->stats_local, st);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    if (!e->graph_ready) {
+        PSI_REQUIRE(st != nullptr, "graph capture needs a non-default stream");
+        PSI_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        int rc = fit_forward(e, e->stats_local, st);
+        if (!rc) rc = fit_backward(e, e->stats_local, st);
+        hipError_t ce = hipStreamEndCapture(st, &e->graph);
+        if (rc) return rc;
+        PSI_CHECK_HIP(ce);
+        PSI_CHECK_HIP(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+        e->graph_ready = true;
+    }
+    for (int i = 0; i < n_iter; i++) PSI_CHECK_HIP(hipGraphLaunch(e->graph_exec, st));
+    return 0;
+}
+
+extern "C" int psi_fit_read(psi_fit_engine *e, float *d_x_out, float *d_history_out, int n_hist, int *h_step, void *stream)
+{
+    PSI_REQUIRE(e, "null engine");
+    FitDev &f = e->d;
+    hipStream_t st = (hipStream_t)stream;
+    if (d_x_out) PSI_CHECK_HIP(hipMemcpyAsync(d_x_out, f.x, (size_t)f.B * XD * 4, hipMemcpyDeviceToDevice, st));
+    if (d_history_out && n_hist > 0) {
+        if (n_hist > f.max_hist) n_hist = f.max_hist;
+        PSI_CHECK_HIP(hipMemcpyAsync(d_history_out, f.history, (size_t)n_hist * 16, hipMemcpyDeviceToDevice, st));
+    }
+    if (h_step) {
+        PSI_CHECK_HIP(hipMemcpyAsync(h_step, f.step, 4, hipMemcpyDeviceToHost, st));
+        PSI_CHECK_HIP(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+extern "C" int psi_fit_copy_buffer(psi_fit_engine *e, const char *name, float *d_out, long n_floats, void *stream)
+{
+    PSI_REQUIRE(e && name && d_out && n_floats >= 0, "bad arguments");
+    FitDev &f = e->d;
+    const float *src = nullptr;
+    long cap = 0;
+    if (!strcmp(name, "verts")) { src = f.verts; cap = (long)f.B * f.V * 3; }
+    else if (!strcmp(name, "g_verts")) { src = f.g_verts; cap = (long)f.B * f.V * 3; }
+    else if (!strcmp(name, "pose")) { src = f.pose; cap = (long)f.B * f.J * 3; }
+    else if (!strcmp(name, "g_pose")) { src = f.g_pose; cap = (long)f.B * f.J * 3; }
+    else if (!strcmp(name, "g_rot")) { src = f.g_rot; cap = (long)f.B * f.J * 9; }
+    else if (!strcmp(name, "stats")) { src = e->stats_local; cap = 8; }
+    else if (!strcmp(name, "adam_m")) { src = f.adam_m; cap = (long)f.B * XD; }
+    else if (!strcmp(name, "adam_v")) { src = f.adam_v; cap = (long)f.B * XD; }
+    PSI_REQUIRE(src != nullptr, "unknown buffer name");
+    PSI_REQUIRE(n_floats <= cap, "buffer is smaller than requested");
+    PSI_CHECK_HIP(hipMemcpyAsync(d_out, src, (size_t)n_floats * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}

@@ -20,7 +20,7 @@
 //   blend_bwd  (MFMA)              g_feat = g_vposed @ dirs^T                (contraction over N, dirs streamed again)
 //   pose_bwd   (1 wave per body)   chain reverse sweep, Rodrigues derivative, joint/shape gradients
 // The f32 MFMA (v_mfma_f32_16x16x4_f32) is bit-identical to an fmaf chain, so these are exact-f32 GEMMs.
-#include "psi_common.h"
+#include "psi_internal.h"
 #include <math.h>
 #include <vector>
 #include <string.h>
@@ -52,7 +52,7 @@ namespace {
 // workspace layout (floats)
 // ------------------------------------------------------------------------------------------------
 struct WsLayout {
-    size_t feat, R, Jl, G, A, v_posed, gl, g_vp, gA_part, gfeat_part, gt_part, gA, total;
+    size_t feat, R, Jl, G, A, v_posed, gl, g_vp, gA_part, gfeat_part, gt_part, gA, gfeat, total;
     int nsv, nsn, nvb;
 };
 
@@ -76,6 +76,7 @@ WsLayout ws_layout(const LbsDev &m, int B)
     w.gfeat_part = take((size_t)w.nsn * B * m.Kpad);
     w.gt_part = take((size_t)w.nvb * B * 4);
     w.gA = take((size_t)B * JP * 16);
+    w.gfeat = take((size_t)B * m.Kpad);
     w.total = o;
     return w;
 }
@@ -460,12 +461,40 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(LbsDev m, const float *_
 // ------------------------------------------------------------------------------------------------
 // pose backward: one wave per body
 // ------------------------------------------------------------------------------------------------
+// sum the split-contraction partials: gA[b][j][16] over v-slices, g_feat[b][k] over n-slices, g_transl over vertex blocks
+__global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int Kpad, const float *__restrict__ gA_part, int nsv,
+                                                              const float *__restrict__ gfeat_part, int nsn,
+                                                              const float *__restrict__ gt_part, int nvb,
+                                                              float *__restrict__ gA, float *__restrict__ gfeat,
+                                                              float *__restrict__ g_transl)
+{
+    const long nA = (long)B * JP * 16, nF = (long)B * Kpad, nT = (long)B * 4;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nA) {
+        float a = 0;
+        for (int sl = 0; sl < nsv; sl++) a += gA_part[(size_t)sl * nA + i];
+        gA[i] = a;
+    } else if (i < nA + nF) {
+        long k = i - nA;
+        float a = 0;
+        for (int sl = 0; sl < nsn; sl++) a += gfeat_part[(size_t)sl * nF + k];
+        gfeat[k] = a;
+    } else if (i < nA + nF + nT) {
+        long k = i - nA - nF;
+        int b = (int)(k >> 2), c = (int)(k & 3);
+        if (c < 3 && g_transl) {
+            float a = 0;
+            for (int vb = 0; vb < nvb; vb++) a += gt_part[((size_t)vb * B + b) * 4 + c];
+            g_transl[(size_t)b * 3 + c] = a;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void pose_bwd_kernel(LbsDev m, const float *__restrict__ betas, const float *__restrict__ pose,
                                                       const float *__restrict__ Rs, const float *__restrict__ Jls,
-                                                      const float *__restrict__ Gs, const float *__restrict__ gA_part, int nsv,
-                                                      const float *__restrict__ gfeat_part, int nsn,
-                                                      const float *__restrict__ gt_part, int nvb, int B,
-                                                      float *__restrict__ g_betas, float *__restrict__ g_pose, float *__restrict__ g_transl)
+                                                      const float *__restrict__ Gs, const float *__restrict__ gAr,
+                                                      const float *__restrict__ gfeat, int B,
+                                                      float *__restrict__ g_betas, float *__restrict__ g_pose, float *__restrict__ g_rot)
 {
     const int b = blockIdx.x, j = threadIdx.x;
     const bool act = j < m.J;
@@ -481,13 +510,8 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(LbsDev m, const float *__r
         for (int e = 0; e < 9; e++) { R[e] = Rs[((size_t)b * m.J + j) * 9 + e]; sR[j][e] = R[e]; }
         for (int c = 0; c < 3; c++) { Jl[c] = Jls[((size_t)b * m.J + j) * 3 + c]; sJ[j][c] = Jl[c]; }
         for (int e = 0; e < 12; e++) G[e] = Gs[((size_t)b * m.J + j) * 12 + e];
-        // reduce the skin_bwd_A partials for this joint
         float gA[12];
-        for (int e = 0; e < 12; e++) gA[e] = 0.0f;
-        for (int sl = 0; sl < nsv; sl++) {
-            const float *p = gA_part + (((size_t)sl * B + b) * JP + j) * 16;
-            for (int e = 0; e < 12; e++) gA[e] += p[e];
-        }
+        for (int e = 0; e < 12; e++) gA[e] = gAr[((size_t)b * JP + j) * 16 + e];
         // A = [G_R | G_t - G_R J]
         for (int r = 0; r < 3; r++) {
             float gt = gA[r * 4 + 3];
@@ -554,25 +578,19 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(LbsDev m, const float *__r
     // feature gradient (reduced over n-slices): betas part and pose-feature part
     if (g_betas) {
         for (int l = j; l < m.NB; l += 64) {
-            float a = 0;
-            for (int sl = 0; sl < nsn; sl++) a += gfeat_part[((size_t)sl * B + b) * m.Kpad + l];
+            float a = gfeat[(size_t)b * m.Kpad + l];
             for (int jj = 0; jj < m.J; jj++)
                 for (int c = 0; c < 3; c++) a += sgJ[jj][c] * m.J_s[(jj * 3 + c) * m.NB + l];
             g_betas[(size_t)b * m.NB + l] = a;
         }
     }
-    if (g_transl && j < 3) {
-        float a = 0;
-        for (int vb = 0; vb < nvb; vb++) a += gt_part[((size_t)vb * B + b) * 4 + j];
-        g_transl[(size_t)b * 3 + j] = a;
+    if (act && (g_pose || g_rot)) {
+        if (j >= 1)
+            for (int e = 0; e < 9; e++) gR[e] += gfeat[(size_t)b * m.Kpad + m.NB + (j - 1) * 9 + e];
+        if (g_rot)
+            for (int e = 0; e < 9; e++) g_rot[((size_t)b * m.J + j) * 9 + e] = gR[e];
     }
     if (act && g_pose) {
-        if (j >= 1)
-            for (int e = 0; e < 9; e++) {
-                float a = 0;
-                for (int sl = 0; sl < nsn; sl++) a += gfeat_part[((size_t)sl * B + b) * m.Kpad + m.NB + (j - 1) * 9 + e];
-                gR[e] += a;
-            }
         // Rodrigues backward (lbs.py:177-191)
         const float *aa = pose + ((size_t)b * m.J + j) * 3;
         float x = aa[0] + 1e-8f, y = aa[1] + 1e-8f, z = aa[2] + 1e-8f;
@@ -735,15 +753,13 @@ extern "C" int psi_lbs_forward(const psi_lbs_model *mdl, const float *betas, con
     return 0;
 }
 
-extern "C" int psi_lbs_backward(const psi_lbs_model *mdl, const float *grad_verts, const float *betas, const float *pose,
-                                const float *cam_ext, int B, float *ws, float *grad_betas, float *grad_pose,
-                                float *grad_transl, void *stream)
+int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const float *betas, const float *pose,
+                        const float *cam_ext, int B, float *ws, PsiLbsGradOut out, hipStream_t st)
 {
     PSI_REQUIRE(mdl && grad_verts && betas && pose && ws, "null pointer");
     PSI_REQUIRE(B > 0 && B <= 16384, "batch size out of range");
     const LbsDev &m = mdl->d;
     WsLayout L = ws_layout(m, B);
-    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(skin_bwd_v_kernel, dim3(m.Vpad / SKIN_BLK, psi_cdiv(B, SKIN_BT)), dim3(SKIN_BLK), 0, st, m, ws + L.A, grad_verts,
                        cam_ext, B, ws + L.gl, ws + L.g_vp, ws + L.gt_part);
     PSI_CHECK_LAUNCH("skin_bwd_v_kernel");
@@ -760,8 +776,27 @@ extern "C" int psi_lbs_backward(const psi_lbs_model *mdl, const float *grad_vert
         hipLaunchKernelGGL(blend_bwd_kernel<1>, g, dim3(256), 0, st, m, ws + L.g_vp, B, steps, ws + L.gfeat_part);
     }
     PSI_CHECK_LAUNCH("blend_bwd_kernel");
-    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(64), 0, st, m, betas, pose, ws + L.R, ws + L.Jl, ws + L.G, ws + L.gA_part, L.nsv,
-                       ws + L.gfeat_part, L.nsn, ws + L.gt_part, L.nvb, B, grad_betas, grad_pose, grad_transl);
+    long nred = (long)B * JP * 16 + (long)B * m.Kpad + (long)B * 4;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(psi_cdiv(nred, 256)), dim3(256), 0, st, B, m.Kpad, ws + L.gA_part, L.nsv,
+                       ws + L.gfeat_part, L.nsn, ws + L.gt_part, L.nvb, ws + L.gA, ws + L.gfeat, out.g_transl);
+    PSI_CHECK_LAUNCH("reduce_partials_kernel");
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(64), 0, st, m, betas, pose, ws + L.R, ws + L.Jl, ws + L.G, ws + L.gA,
+                       ws + L.gfeat, B, out.g_betas, out.g_pose, out.g_rot);
     PSI_CHECK_LAUNCH("pose_bwd_kernel");
     return 0;
+}
+
+void psi_lbs_dims(const psi_lbs_model *mdl, int *V, int *J, int *NB)
+{
+    if (V) *V = mdl->d.V;
+    if (J) *J = mdl->d.J;
+    if (NB) *NB = mdl->d.NB;
+}
+
+extern "C" int psi_lbs_backward(const psi_lbs_model *mdl, const float *grad_verts, const float *betas, const float *pose,
+                                const float *cam_ext, int B, float *ws, float *grad_betas, float *grad_pose,
+                                float *grad_transl, void *stream)
+{
+    PsiLbsGradOut out = {grad_betas, grad_pose, grad_transl, nullptr};
+    return psi_lbs_backward_ex(mdl, grad_verts, betas, pose, cam_ext, B, ws, out, (hipStream_t)stream);
 }

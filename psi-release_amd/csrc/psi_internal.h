@@ -1,0 +1,22 @@
+// Host-side launchers shared between translation units of libpsi_hip.so (not part of the C ABI).
+#pragma once
+#include "psi_common.h"
+
+struct psi_lbs_model;
+
+// chamfer.hip
+int psi_nn_contact(const float *verts, long vstride, const int *vid, const float *scene, int B, int n, int m, void *ws,
+                   float cconst, float gscale, float *gq, float *fpart, int *idx_out, hipStream_t st);
+int psi_nn_contact_fparts(int n);
+size_t psi_nn_ws_bytes(int B, int n, int m);
+
+// lbs.hip
+struct PsiLbsGradOut {
+    float *g_betas;    // [B,NB]
+    float *g_pose;     // [B,J*3]  axis-angle gradient (through Rodrigues)
+    float *g_transl;   // [B,3]
+    float *g_rot;      // [B,J,9]  gradient wrt the rotation matrices themselves (before the Rodrigues derivative), nullable
+};
+int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const float *betas, const float *pose,
+                        const float *cam_ext, int B, float *ws, PsiLbsGradOut out, hipStream_t st);
+void psi_lbs_dims(const psi_lbs_model *mdl, int *V, int *J, int *NB);

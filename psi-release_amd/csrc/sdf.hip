@@ -9,41 +9,12 @@
 // The gradient d sdf/d vert is produced in the SAME pass (the 8 corner values are already in
 // registers), so backward never touches the volume again: grad_verts += grad_sdf * out_grad.
 #include "psi_common.h"
+#include "sdf_device.h"
 #include <math.h>
 
 namespace {
 
 constexpr int BLK = 256;
-
-struct Axis {
-    int i0, i1;
-    float w1, du;   // weight of the upper corner; d(u)/d(vert) (0 when clamped by the border rule)
-};
-
-__device__ __forceinline__ Axis axis_setup(float v, float mn, float mx, int D, int align_corners)
-{
-    // fitting_proxe.py:147: (v - min) / (max - min) * 2 - 1, in this operation order
-    float nrm = (v - mn) / (mx - mn) * 2.0f - 1.0f;
-    float u, scale;
-    if (align_corners) {
-        u = (nrm + 1.0f) / 2.0f * (float)(D - 1);
-        scale = (float)(D - 1) / 2.0f;
-    } else {
-        u = ((nrm + 1.0f) * (float)D - 1.0f) / 2.0f;
-        scale = (float)D / 2.0f;
-    }
-    // padding_mode='border': clip to [0, D-1]; the clipped coordinate has zero gradient
-    float g = scale;
-    if (!(u > 0.0f)) { u = 0.0f; g = 0.0f; }
-    else if (u >= (float)(D - 1)) { u = (float)(D - 1); g = 0.0f; }
-    float fl = floorf(u);
-    Axis a;
-    a.i0 = (int)fl;
-    a.w1 = u - fl;
-    a.i1 = min(a.i0 + 1, D - 1);     // upper corner of the last cell has weight 0; clamp keeps the load in bounds
-    a.du = g * 2.0f / (mx - mn);
-    return a;
-}
 
 __global__ __launch_bounds__(BLK) void sdf_sample_kernel(const float *__restrict__ sdf, const int *__restrict__ scene_id,
                                                          const float *__restrict__ gmin, const float *__restrict__ gmax,
@@ -54,34 +25,14 @@ __global__ __launch_bounds__(BLK) void sdf_sample_kernel(const float *__restrict
     const int v = blockIdx.x * BLK + threadIdx.x;
     if (v >= V) return;
     const int s = scene_id ? scene_id[b] : 0;
-    const float *__restrict__ vol = sdf + (size_t)s * D * D * D;
     const size_t o = (size_t)b * V + v;
-    Axis ax = axis_setup(verts[o * 3 + 0], gmin[s * 3 + 0], gmax[s * 3 + 0], D, align_corners);
-    Axis ay = axis_setup(verts[o * 3 + 1], gmin[s * 3 + 1], gmax[s * 3 + 1], D, align_corners);
-    Axis az = axis_setup(verts[o * 3 + 2], gmin[s * 3 + 2], gmax[s * 3 + 2], D, align_corners);
-    const size_t x0 = (size_t)ax.i0 * D, x1 = (size_t)ax.i1 * D;
-    const size_t r00 = (x0 + ay.i0) * D, r01 = (x0 + ay.i1) * D, r10 = (x1 + ay.i0) * D, r11 = (x1 + ay.i1) * D;
-    // 8 gathers; the two z-neighbours of each row are adjacent dwords
-    float c000 = vol[r00 + az.i0], c001 = vol[r00 + az.i1];
-    float c010 = vol[r01 + az.i0], c011 = vol[r01 + az.i1];
-    float c100 = vol[r10 + az.i0], c101 = vol[r10 + az.i1];
-    float c110 = vol[r11 + az.i0], c111 = vol[r11 + az.i1];
-    const float wx1 = ax.w1, wx0 = 1.0f - ax.w1;
-    const float wy1 = ay.w1, wy0 = 1.0f - ay.w1;
-    const float wz1 = az.w1, wz0 = 1.0f - az.w1;
-    // interpolate along z, then y, then x
-    float c00 = c000 * wz0 + c001 * wz1, c01 = c010 * wz0 + c011 * wz1;
-    float c10 = c100 * wz0 + c101 * wz1, c11 = c110 * wz0 + c111 * wz1;
-    float c0 = c00 * wy0 + c01 * wy1, c1 = c10 * wy0 + c11 * wy1;
-    out[o] = c0 * wx0 + c1 * wx1;
+    float g[3];
+    out[o] = psi_trilinear(sdf + (size_t)s * D * D * D, gmin + s * 3, gmax + s * 3, verts[o * 3 + 0], verts[o * 3 + 1],
+                           verts[o * 3 + 2], D, align_corners, out_grad ? g : nullptr);
     if (out_grad) {
-        float gx = c1 - c0;
-        float gy = (c01 - c00) * wx0 + (c11 - c10) * wx1;
-        float d00 = c001 - c000, d01 = c011 - c010, d10 = c101 - c100, d11 = c111 - c110;
-        float gz = (d00 * wy0 + d01 * wy1) * wx0 + (d10 * wy0 + d11 * wy1) * wx1;
-        out_grad[o * 3 + 0] = gx * ax.du;
-        out_grad[o * 3 + 1] = gy * ay.du;
-        out_grad[o * 3 + 2] = gz * az.du;
+        out_grad[o * 3 + 0] = g[0];
+        out_grad[o * 3 + 1] = g[1];
+        out_grad[o * 3 + 2] = g[2];
     }
 }
 

@@ -1,0 +1,65 @@
+// Device-side trilinear SDF interpolation shared by sdf.hip (operator) and fit.hip (fused engine).
+// Semantics: torch grid_sample (5-D, bilinear, padding_mode='border') as called at fitting_proxe.py:144-151,
+// including the world->[-1,1] normalisation of fitting_proxe.py:147; SURVEY.md Appendix C.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct PsiAxis {
+    int i0, i1;
+    float w1, du;   // weight of the upper corner; d(u)/d(vert) (0 when clamped by the border rule)
+};
+
+__device__ __forceinline__ PsiAxis psi_axis_setup(float v, float mn, float mx, int D, int align_corners)
+{
+    float nrm = (v - mn) / (mx - mn) * 2.0f - 1.0f;     // fitting_proxe.py:147, in this operation order
+    float u, scale;
+    if (align_corners) {
+        u = (nrm + 1.0f) / 2.0f * (float)(D - 1);
+        scale = (float)(D - 1) / 2.0f;
+    } else {
+        u = ((nrm + 1.0f) * (float)D - 1.0f) / 2.0f;
+        scale = (float)D / 2.0f;
+    }
+    float g = scale;                                    // border: clip to [0, D-1], clipped coordinate has zero gradient
+    if (!(u > 0.0f)) { u = 0.0f; g = 0.0f; }
+    else if (u >= (float)(D - 1)) { u = (float)(D - 1); g = 0.0f; }
+    float fl = floorf(u);
+    PsiAxis a;
+    a.i0 = (int)fl;
+    a.w1 = u - fl;
+    a.i1 = min(a.i0 + 1, D - 1);                        // upper corner of the last cell has weight 0
+    a.du = g * 2.0f / (mx - mn);
+    return a;
+}
+
+// value at world point (x,y,z); grad[3] = d value / d (x,y,z).  vol is [D][D][D] indexed [ix][iy][iz].
+__device__ __forceinline__ float psi_trilinear(const float *__restrict__ vol, const float *__restrict__ gmin,
+                                               const float *__restrict__ gmax, float x, float y, float z, int D,
+                                               int align_corners, float *grad)
+{
+    PsiAxis ax = psi_axis_setup(x, gmin[0], gmax[0], D, align_corners);
+    PsiAxis ay = psi_axis_setup(y, gmin[1], gmax[1], D, align_corners);
+    PsiAxis az = psi_axis_setup(z, gmin[2], gmax[2], D, align_corners);
+    const size_t x0 = (size_t)ax.i0 * D, x1 = (size_t)ax.i1 * D;
+    const size_t r00 = (x0 + ay.i0) * D, r01 = (x0 + ay.i1) * D, r10 = (x1 + ay.i0) * D, r11 = (x1 + ay.i1) * D;
+    float c000 = vol[r00 + az.i0], c001 = vol[r00 + az.i1];
+    float c010 = vol[r01 + az.i0], c011 = vol[r01 + az.i1];
+    float c100 = vol[r10 + az.i0], c101 = vol[r10 + az.i1];
+    float c110 = vol[r11 + az.i0], c111 = vol[r11 + az.i1];
+    const float wx1 = ax.w1, wx0 = 1.0f - ax.w1;
+    const float wy1 = ay.w1, wy0 = 1.0f - ay.w1;
+    const float wz1 = az.w1, wz0 = 1.0f - az.w1;
+    float c00 = c000 * wz0 + c001 * wz1, c01 = c010 * wz0 + c011 * wz1;
+    float c10 = c100 * wz0 + c101 * wz1, c11 = c110 * wz0 + c111 * wz1;
+    float c0 = c00 * wy0 + c01 * wy1, c1 = c10 * wy0 + c11 * wy1;
+    if (grad) {
+        float gx = c1 - c0;
+        float gy = (c01 - c00) * wx0 + (c11 - c10) * wx1;
+        float d00 = c001 - c000, d01 = c011 - c010, d10 = c101 - c100, d11 = c111 - c110;
+        float gz = (d00 * wy0 + d01 * wy1) * wx0 + (d10 * wy0 + d11 * wy1) * wx1;
+        grad[0] = gx * ax.du;
+        grad[1] = gy * ay.du;
+        grad[2] = gz * az.du;
+    }
+    return c0 * wx0 + c1 * wx1;
+}

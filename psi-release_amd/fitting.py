@@ -19,6 +19,7 @@ every iteration (cvae.py:105-109); both ``contact_id_folder`` and ``body_segment
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import pickle
 
@@ -27,9 +28,12 @@ import torch
 import torch.nn.functional as F
 import torch.optim as optim
 
-from . import body_model, dist as psi_dist, ops, scene_io
+from . import body_model, dist as psi_dist, hip, ops, scene_io
 from .geometry import BodyParamParser, GeometryTransformer
 from .vposer import load_vposer
+
+
+HAS_FUSED_ENGINE = True
 
 
 class FittingOP:
@@ -38,7 +42,8 @@ class FittingOP:
 
     def __init__(self, fittingconfig, lossconfig):
         self.align_corners = True
-        self.engine = 'modular'
+        self.engine = 'fused'
+        self.use_graph = True
         self.reset_optimizer = False
         for key, val in fittingconfig.items():
             setattr(self, key, val)
@@ -142,6 +147,8 @@ class FittingOP:
         self.xhr_rec.data = xhr.clone()
         if self.reset_optimizer:
             self.optimizer = optim.Adam([self.xhr_rec], lr=self.init_lr_h)
+        if self.engine == 'fused':
+            return _FusedRunner(self, xhr, self._camera(self.cam_ext))
         return _ModularRunner(self, xhr, self._camera(self.cam_ext))
 
     def fitting(self, input_data_file):
@@ -153,6 +160,7 @@ class FittingOP:
                 l = runner.last_losses()
                 print('[INFO][fitting] iter={:d}, l_rec={:f}, l_vposer={:f}, l_contact={:f}, l_collision={:f}'.format(
                     ii, l[0], l[1], l[2], l[3]))
+        runner.finish()
         print('[INFO][fitting] fitting finish, returning optimal value')
         return GeometryTransformer.convert_to_3D_rot(self.xhr_rec)
 
@@ -188,6 +196,122 @@ class _ModularRunner:
     def last_losses(self):
         """Loss values evaluated at the START of the last step (what the reference prints), as Python floats."""
         return [float(l) for l in self._losses]
+
+    def finish(self):
+        pass
+
+
+class FusedEngine:
+    """Owns a ``psi_fit_engine`` (include/psi_hip.h): the whole iteration as HIP kernels, replayed as a hipGraph."""
+
+    def __init__(self, op):
+        self.op = op
+        dev = op.device
+        sd = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in op.vposer.state_dict().items() if 'dec' in k}
+        bm = op.body_mesh_model
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        w1, b1 = f32(sd['bodyprior_dec_fc1.weight']), f32(sd['bodyprior_dec_fc1.bias'])
+        w2, b2 = f32(sd['bodyprior_dec_fc2.weight']), f32(sd['bodyprior_dec_fc2.bias'])
+        w3, b3 = f32(sd['bodyprior_dec_out.weight']), f32(sd['bodyprior_dec_out.bias'])
+        if w1.shape != (512, 32) or w2.shape != (512, 512) or w3.shape != (126, 512):
+            raise hip.PsiHipError('the fused engine expects VPoser(512, 32, [1,21,3])')
+        lhc, rhc = f32(bm.left_hand_components.cpu().numpy()), f32(bm.right_hand_components.cpu().numpy())
+        pm = f32(bm.pose_mean.cpu().numpy())
+        vid = np.ascontiguousarray(op.contact_vertex_ids().cpu().numpy(), dtype=np.int32)
+        gmin, gmax = f32(op.s_grid_min_batch.cpu().numpy().reshape(3)), f32(op.s_grid_max_batch.cpu().numpy().reshape(3))
+        world = psi_dist.world_size()
+        self.world = world
+        cfg = hip.FitConfig(B=op.batch_size, n_contact=len(vid), m_scene=op.s_verts.shape[1], D=op.s_sdf.shape[1],
+                            align_corners=int(bool(op.align_corners)), world_size=world, num_pca_comps=lhc.shape[0],
+                            max_history=4096, w_rec=op.weight_loss_rec, w_vposer=op.weight_loss_vposer,
+                            w_contact=op.weight_contact, w_collision=op.weight_collision, contact_const=op.contact_const,
+                            lr=op.init_lr_h, beta1=0.9, beta2=0.999, eps=1e-8)
+        self._keep = (op.s_verts, op.s_sdf)                    # device arrays the engine points into
+        h = ctypes.c_void_p()
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        with torch.cuda.device(dev):
+            hip.check(hip.lib().psi_fit_create(ctypes.byref(h), bm.lbs_model.handle, ctypes.byref(cfg), p(w1), p(b1), p(w2), p(b2),
+                                               p(w3), p(b3), p(lhc), p(rhc), p(pm), p(vid), hip.ptr(op.s_verts), hip.ptr(op.s_sdf),
+                                               p(gmin), p(gmax)), 'psi_fit_create')
+        self.handle = h
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stats = torch.zeros(8, device=dev)
+        self.max_history = 4096
+
+    def set_problem(self, xhr, x_init, cam, reset):
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        self._args = (xhr.contiguous(), x_init.contiguous(), cam.contiguous())
+        hip.check(hip.lib().psi_fit_set_problem(self.handle, hip.ptr(self._args[0]), hip.ptr(self._args[1]), hip.ptr(self._args[2]),
+                                                int(bool(reset)), self.stream.cuda_stream), 'psi_fit_set_problem')
+
+    def iterate(self, n, use_graph=True):
+        L = hip.lib()
+        if self.world == 1:
+            hip.check(L.psi_fit_iterate(self.handle, n, int(bool(use_graph)), self.stream.cuda_stream), 'psi_fit_iterate')
+            return
+        import torch.distributed as tdist
+        with torch.cuda.stream(self.stream):
+            for _ in range(n):
+                hip.check(L.psi_fit_forward(self.handle, hip.ptr(self.stats), self.stream.cuda_stream), 'psi_fit_forward')
+                tdist.all_reduce(self.stats, op=tdist.ReduceOp.SUM)           # the one collective of the data path
+                hip.check(L.psi_fit_backward_step(self.handle, hip.ptr(self.stats), self.stream.cuda_stream), 'psi_fit_backward_step')
+
+    def read(self, n_hist=0):
+        op = self.op
+        x = torch.empty(op.batch_size, 75, device=op.device)
+        hist = torch.empty(max(n_hist, 1), 4, device=op.device)
+        step = ctypes.c_int(0)
+        hip.check(hip.lib().psi_fit_read(self.handle, hip.ptr(x), hip.ptr(hist), n_hist, ctypes.byref(step), self.stream.cuda_stream),
+                  'psi_fit_read')
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return x, hist[:n_hist], step.value
+
+    def buffer(self, name, shape):
+        """Copy of an engine-owned device buffer (tests / diagnostics)."""
+        out = torch.empty(*shape, device=self.op.device)
+        hip.check(hip.lib().psi_fit_copy_buffer(self.handle, name.encode(), hip.ptr(out), out.numel(), self.stream.cuda_stream),
+                  'psi_fit_copy_buffer')
+        self.stream.synchronize()
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                torch.cuda.synchronize()
+                hip.lib().psi_fit_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class _FusedRunner:
+    """step() = one hipGraph replay (single GPU) or forward / all-reduce / backward (data parallel)."""
+
+    def __init__(self, op, xhr, cam):
+        self.op = op
+        if getattr(op, '_fused', None) is None:
+            op._fused = FusedEngine(op)
+            first = True
+        else:
+            first = False
+        self.eng = op._fused
+        self.eng.set_problem(xhr, op.xhr_rec.data, cam, reset=op.reset_optimizer and not first)
+        _, _, self.step0 = self.eng.read(0)
+        self.n = 0
+
+    def step(self):
+        self.eng.iterate(1, self.op.use_graph)
+        self.n += 1
+
+    def last_losses(self):
+        idx = self.step0 + self.n                       # Adam step count after the last step
+        _, hist, _ = self.eng.read(self.eng.max_history)
+        return [float(v) for v in hist[(idx - 1) % self.eng.max_history].cpu()]
+
+    def finish(self):
+        x, _, _ = self.eng.read(0)
+        self.op.xhr_rec.data = x
 
 
 class FittingOPHabitat(FittingOP):

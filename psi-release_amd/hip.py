@@ -33,7 +33,23 @@ SIGNATURES = {
     'psi_lbs_workspace_floats': (c_size_t, [c_void_p, c_int]),
     'psi_lbs_forward': (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 4),
     'psi_lbs_backward': (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 5),
+    'psi_fit_create': (c_int, [c_void_p] * 17),
+    'psi_fit_destroy': (None, [c_void_p]),
+    'psi_fit_set_problem': (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
+    'psi_fit_forward': (c_int, [c_void_p] * 3),
+    'psi_fit_backward_step': (c_int, [c_void_p] * 3),
+    'psi_fit_iterate': (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    'psi_fit_read': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'psi_fit_copy_buffer': (c_int, [c_void_p, ctypes.c_char_p, c_void_p, c_long, c_void_p]),
 }
+
+
+class FitConfig(ctypes.Structure):
+    """struct psi_fit_config (include/psi_hip.h)."""
+    _fields_ = [('B', c_int), ('n_contact', c_int), ('m_scene', c_int), ('D', c_int), ('align_corners', c_int),
+                ('world_size', c_int), ('num_pca_comps', c_int), ('max_history', c_int),
+                ('w_rec', c_float), ('w_vposer', c_float), ('w_contact', c_float), ('w_collision', c_float),
+                ('contact_const', c_float), ('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float)]
 
 
 class PsiHipError(RuntimeError):

@@ -45,7 +45,7 @@ def test_cal_loss_and_gradient_golden(smplx_data, vposer_sd, engine, tag):
         assert rel_err(v.detach().cpu(), g['verts0']) < 1e-4
 
 
-@pytest.mark.parametrize('engine', ['modular'])
+@pytest.mark.parametrize('engine', ['modular', 'fused'])
 @pytest.mark.parametrize('tag', ['ac1', 'ac0'])
 def test_five_iteration_trajectory_golden(smplx_data, vposer_sd, engine, tag, capsys):
     g = golden('fitting_proxe')
@@ -66,3 +66,63 @@ def test_five_iteration_trajectory_golden(smplx_data, vposer_sd, engine, tag, ca
     assert np.abs(rec - g['traj_loss_' + tag]).max() < 2e-5          # printed with 6 decimals
     assert rel_err(op.xhr_rec.detach().cpu(), g['traj_final_xhr_' + tag]) < 1e-4
     assert np.abs(xh.detach().cpu().numpy() - g['traj_final_' + tag]).max() < 1e-3
+
+
+@pytest.mark.parametrize('tag', ['ac1', 'ac0'])
+def test_fused_engine_losses_and_first_gradient(smplx_data, vposer_sd, tag):
+    """Fused engine at the golden perturbed point: loss values, body vertices and d(loss)/d(verts)-driven first Adam
+    step agree with the reference (loss0 / verts0 / grad0 of tests/golden/fitting_proxe.npz)."""
+    g = golden('fitting_proxe')
+    B, m, n_c, D = int(g['B']), int(g['m']), int(g['n_c']), int(g['D'])
+    scene = synth.make_scene(0, m, D, n_c)
+    op = make_op(smplx_data, vposer_sd, scene, B, 'fused', align_corners=(tag == 'ac1'))
+    eng = fitting.FusedEngine(op)
+    x0 = T(g['xhr_rec0_' + tag])
+    eng.set_problem(T(g['xhr_' + tag]), x0, T(g['cam_ext']), reset=True)
+    eng.iterate(1, use_graph=False)
+    x1, hist, step = eng.read(1)
+    assert step == 1
+    assert np.abs(hist[0].cpu().numpy() - g['loss0_' + tag]).max() < 1e-5
+    if tag == 'ac1':
+        assert rel_err(eng.buffer('verts', (B, 10475, 3)).cpu(), g['verts0']) < 1e-4
+    # first Adam step from zero state: x1 = x0 - lr * g/(|g| + eps*sqrt-terms)  =>  recover sign and size of g
+    m1 = eng.buffer('adam_m', (B, 75)).cpu().numpy() / 0.1            # m = (1-beta1) g
+    assert rel_err(m1, g['grad0_' + tag]) < 2e-4
+    gref = g['grad0_' + tag]
+    expect = g['xhr_rec0_' + tag] - 0.1 * gref / (np.abs(gref) + 1e-8)
+    big = np.abs(gref) > 1e-6
+    assert np.abs(x1.cpu().numpy() - expect)[big].max() < 1e-4
+
+
+@pytest.mark.parametrize('B,cls,lr,graph', [(3, fitting.FittingOP, 0.05, True), (1, fitting.FittingOPHabitat, 0.1, True),
+                                           (6, fitting.FittingOP, 0.1, False)])
+def test_fused_matches_modular(smplx_data, vposer_sd, B, cls, lr, graph):
+    """Same trajectory from the hand-derived fused backward and from autograd over the HIP operators (random camera,
+    other batch sizes, Habitat variant: contact constant 1.0 + flipped camera).  Horizon 3 iterations: Adam's
+    normalised steps make the loop chaotic (a 3e-7 gradient difference grows ~5x per iteration and jumps when a
+    vertex crosses the sdf<0 mask or switches nearest neighbour), so longer horizons only measure that."""
+    scene = synth.make_scene(3, 3000, 24, 300)
+    bodies = synth.make_bodies(21, B)
+    bodies['cam_ext'] = synth.make_cam_ext(7, B)
+    res = {}
+    for engine in ('modular', 'fused'):
+        op = make_op(smplx_data, vposer_sd, scene, B, engine, num_iter=3, cls=cls, lr=lr)
+        op.use_graph = graph
+        xh = op.fitting(dict(bodies))
+        res[engine] = (xh.detach().cpu().numpy(), op.xhr_rec.detach().cpu().numpy())
+    assert np.abs(res['fused'][1] - res['modular'][1]).max() < 2e-4
+    assert np.abs(res['fused'][0] - res['modular'][0]).max() < 1e-3
+
+
+def test_fused_adam_state_persists_and_resets(smplx_data, vposer_sd):
+    """fitting_proxe.py:74,175: the optimizer is created once and reused for every file."""
+    scene = synth.make_scene(3, 2000, 16, 200)
+    B = 2
+    outs = {}
+    for engine in ('modular', 'fused'):
+        op = make_op(smplx_data, vposer_sd, scene, B, engine, num_iter=2)
+        a = op.fitting(synth.make_bodies(31, B))
+        b = op.fitting(synth.make_bodies(32, B))          # second file: Adam moments carried over
+        outs[engine] = (a.detach().cpu().numpy(), b.detach().cpu().numpy())
+    assert np.abs(outs['fused'][0] - outs['modular'][0]).max() < 1e-3
+    assert np.abs(outs['fused'][1] - outs['modular'][1]).max() < 1e-3
