@@ -55,6 +55,15 @@ int psi_chamfer_backward(const float *xyz1, const float *xyz2, float *gradxyz1, 
                          const float *graddist1, const float *graddist2,
                          const int32_t *idx1, const int32_t *idx2, int B, int n, int m, void *stream);
 
+/* Exact NN index over a STATIC target cloud (one scene's vertices, fitting_proxe.py:93-96 loads them once per
+ * FittingOP).  psi_nn_index_query returns exactly what psi_chamfer_forward returns for direction 1 against that
+ * cloud (bit-identical dist1 / idx1, same first-minimum rule) at a fraction of the pair evaluations: a kd-tree
+ * prunes only targets that provably cannot attain or tie the minimum.  h_points: HOST [m,3]. */
+typedef struct psi_nn_index psi_nn_index;
+int psi_nn_index_create(psi_nn_index **out, const float *h_points, int m);
+void psi_nn_index_destroy(psi_nn_index *index);
+int psi_nn_index_query(const psi_nn_index *index, const float *xyz1, int B, int n, float *dist1, int32_t *idx1, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Trilinear SDF lookup with analytic gradient — replaces
  *   F.grid_sample(sdf[B,1,D,D,D], norm_verts[:,:,[2,1,0]].view(-1,V,1,1,3), padding_mode='border')
@@ -127,6 +136,7 @@ int psi_lbs_backward(const psi_lbs_model *model, const float *grad_verts, const 
 typedef struct psi_fit_engine psi_fit_engine;
 typedef struct psi_fit_config {
     int B, n_contact, m_scene, D, align_corners, world_size, num_pca_comps, max_history;
+    int nn_mode;   /* 0 = brute-force Chamfer kernel, 1 = exact kd-tree index built from the scene cloud at create */
     float w_rec, w_vposer, w_contact, w_collision, contact_const;
     float lr, beta1, beta2, eps;
 } psi_fit_config;

@@ -409,6 +409,7 @@ __global__ void adam_reset_kernel(float *m, float *v, int *step, int n)
 struct psi_fit_engine {
     FitDev d;
     const psi_lbs_model *lbs;
+    psi_nn_index *nn_index;
     float *lbs_ws;
     void *nn_ws;
     char *blob;
@@ -428,7 +429,10 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st)
     hipLaunchKernelGGL(sdf_pen_kernel, dim3(f.nsdfblk, f.B), dim3(256), 0, st, f);
     PSI_CHECK_LAUNCH("sdf_pen_kernel");
     float gscale = f.w_contact / ((float)f.B * (float)f.world * (float)f.n_c);
-    rc = psi_nn_contact(f.verts, (long)f.V * 3, f.vid, f.scene, f.B, f.n_c, f.m, e->nn_ws, f.cconst, gscale, f.gq, f.fpart, nullptr, st);
+    if (e->nn_index)
+        rc = psi_nn_index_contact(e->nn_index, f.verts, (long)f.V * 3, f.vid, f.B, f.n_c, f.cconst, gscale, f.gq, f.fpart, st);
+    else
+        rc = psi_nn_contact(f.verts, (long)f.V * 3, f.vid, f.scene, f.B, f.n_c, f.m, e->nn_ws, f.cconst, gscale, f.gq, f.fpart, nullptr, st);
     if (rc) return rc;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, f, stats);
     PSI_CHECK_LAUNCH("loss_finalize_kernel");
@@ -471,7 +475,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.align_corners = cfg->align_corners; f.world = cfg->world_size; f.ncomp = cfg->num_pca_comps;
     f.w_rec = cfg->w_rec; f.w_vp = cfg->w_vposer; f.w_contact = cfg->w_contact; f.w_col = cfg->w_collision; f.cconst = cfg->contact_const;
     f.lr = cfg->lr; f.beta1 = cfg->beta1; f.beta2 = cfg->beta2; f.eps = cfg->eps;
-    f.nfp = psi_nn_contact_fparts(f.n_c);
+    f.nfp = cfg->nn_mode == 1 ? psi_nn_index_fparts(f.n_c) : psi_nn_contact_fparts(f.n_c);
     f.nsdfblk = psi_cdiv(V, 256);
     f.max_hist = cfg->max_history > 0 ? cfg->max_history : 1024;
     f.scene = d_scene_verts;
@@ -538,6 +542,16 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     e->stats_local = F(o_stats);
     e->lbs_ws = F(o_lws);
     e->nn_ws = bl + o_nws;
+    if (cfg->nn_mode == 1) {
+        std::vector<float> hs((size_t)f.m * 3);
+        err = hipMemcpy(hs.data(), d_scene_verts, hs.size() * 4, hipMemcpyDeviceToHost);
+        int rc = err == hipSuccess ? psi_nn_index_create(&e->nn_index, hs.data(), f.m) : (int)err;
+        if (rc) {
+            (void)hipFree(e->blob);
+            delete e;
+            return rc;
+        }
+    }
     *out = e;
     return 0;
 }
@@ -545,6 +559,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
 extern "C" void psi_fit_destroy(psi_fit_engine *e)
 {
     if (!e) return;
+    if (e->nn_index) psi_nn_index_destroy(e->nn_index);
     if (e->graph_ready) {
         (void)hipGraphExecDestroy(e->graph_exec);
         (void)hipGraphDestroy(e->graph);

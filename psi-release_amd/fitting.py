@@ -44,6 +44,7 @@ class FittingOP:
         self.align_corners = True
         self.engine = 'fused'
         self.use_graph = True
+        self.nn_mode = 'kdtree'          # 'kdtree' (exact index over the static scene cloud) | 'bruteforce'
         self.reset_optimizer = False
         for key, val in fittingconfig.items():
             setattr(self, key, val)
@@ -113,7 +114,12 @@ class FittingOP:
 
         body_verts_batch = self.body_verts(xh_rec, cam_ext)
         body_verts_contact_batch = body_verts_batch[:, self.contact_vertex_ids(), :]
-        contact_dist, _ = self._chamfer(body_verts_contact_batch.contiguous(), self._s_verts_expanded)
+        if self.nn_mode == 'kdtree':
+            if getattr(self, '_nn_index', None) is None:
+                self._nn_index = ops.SceneNNIndex(self.s_verts[0], self.device)
+            contact_dist = ops.chamfer_to_scene(body_verts_contact_batch.contiguous(), self._nn_index)
+        else:
+            contact_dist, _ = self._chamfer(body_verts_contact_batch.contiguous(), self._s_verts_expanded)
         s = torch.sqrt(contact_dist + 1e-4)
         loss_contact = self.weight_contact * torch.mean(s / (s + self.contact_const))
 
@@ -223,7 +229,7 @@ class FusedEngine:
         self.world = world
         cfg = hip.FitConfig(B=op.batch_size, n_contact=len(vid), m_scene=op.s_verts.shape[1], D=op.s_sdf.shape[1],
                             align_corners=int(bool(op.align_corners)), world_size=world, num_pca_comps=lhc.shape[0],
-                            max_history=4096, w_rec=op.weight_loss_rec, w_vposer=op.weight_loss_vposer,
+                            max_history=4096, nn_mode=1 if op.nn_mode == 'kdtree' else 0, w_rec=op.weight_loss_rec, w_vposer=op.weight_loss_vposer,
                             w_contact=op.weight_contact, w_collision=op.weight_collision, contact_const=op.contact_const,
                             lr=op.init_lr_h, beta1=0.9, beta2=0.999, eps=1e-8)
         self._keep = (op.s_verts, op.s_sdf)                    # device arrays the engine points into

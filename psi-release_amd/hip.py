@@ -25,6 +25,9 @@ SIGNATURES = {
     'psi_chamfer_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     'psi_chamfer_backward': (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    'psi_nn_index_create': (c_int, [c_void_p, c_void_p, c_int]),
+    'psi_nn_index_destroy': (None, [c_void_p]),
+    'psi_nn_index_query': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'psi_sdf_sample_forward': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p] * 3),
     'psi_sdf_sample_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'psi_sdf_penetration_stats': (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
@@ -47,7 +50,7 @@ SIGNATURES = {
 class FitConfig(ctypes.Structure):
     """struct psi_fit_config (include/psi_hip.h)."""
     _fields_ = [('B', c_int), ('n_contact', c_int), ('m_scene', c_int), ('D', c_int), ('align_corners', c_int),
-                ('world_size', c_int), ('num_pca_comps', c_int), ('max_history', c_int),
+                ('world_size', c_int), ('num_pca_comps', c_int), ('max_history', c_int), ('nn_mode', c_int),
                 ('w_rec', c_float), ('w_vposer', c_float), ('w_contact', c_float), ('w_collision', c_float),
                 ('contact_const', c_float), ('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float)]
 

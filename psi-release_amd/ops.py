@@ -162,3 +162,62 @@ class _PenLoss(Function):
 
 def penetration_loss(body_sdf):
     return _PenLoss.apply(body_sdf)
+
+
+# ------------------------------------------------------------------------------------------
+# Exact NN index over a static scene cloud
+# ------------------------------------------------------------------------------------------
+class SceneNNIndex:
+    """kd-tree over one scene's points (psi_nn_index_*).  ``query`` returns exactly what ``chamfer.forward`` returns for
+    the body->scene direction against that cloud (bit-identical dist1 / idx1)."""
+
+    def __init__(self, points, device='cuda'):
+        import ctypes
+        import numpy as np
+        pts = points.detach().cpu().numpy() if torch.is_tensor(points) else np.asarray(points)
+        pts = np.ascontiguousarray(pts.reshape(-1, 3), dtype=np.float32)
+        self.m = pts.shape[0]
+        self.device = torch.device(device)
+        self.points = torch.tensor(pts, device=self.device)           # for the backward gather
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            hip.check(hip.lib().psi_nn_index_create(ctypes.byref(h), pts.ctypes.data_as(ctypes.c_void_p), self.m),
+                      'psi_nn_index_create')
+        self.handle = h
+
+    def query(self, xyz1):
+        xyz1 = xyz1.contiguous().float()
+        B, n, _ = xyz1.shape
+        dist = torch.empty(B, n, device=xyz1.device)
+        idx = torch.empty(B, n, dtype=torch.int32, device=xyz1.device)
+        hip.check(hip.lib().psi_nn_index_query(self.handle, hip.ptr(xyz1), B, n, hip.ptr(dist), hip.ptr(idx), hip.stream()),
+                  'psi_nn_index_query')
+        return dist, idx
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                hip.lib().psi_nn_index_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class _IndexedChamfer(Function):
+    @staticmethod
+    def forward(ctx, xyz1, index):
+        dist, idx = index.query(xyz1)
+        ctx.index = index
+        ctx.save_for_backward(xyz1, idx)
+        return dist
+
+    @staticmethod
+    def backward(ctx, gdist):
+        xyz1, idx = ctx.saved_tensors
+        nn = ctx.index.points[idx.long()]                                  # [B,n,3]
+        return 2.0 * gdist.unsqueeze(-1) * (xyz1 - nn), None               # chamfer.cu:155-174, query side
+
+
+def chamfer_to_scene(xyz1, index: SceneNNIndex):
+    """dist1 [B,n] of ``chamferDist()(xyz1, scene.repeat(B))`` through the scene's exact NN index."""
+    return _IndexedChamfer.apply(xyz1, index)

@@ -114,6 +114,22 @@ def test_fused_matches_modular(smplx_data, vposer_sd, B, cls, lr, graph):
     assert np.abs(res['fused'][0] - res['modular'][0]).max() < 1e-3
 
 
+def test_nn_modes_agree(smplx_data, vposer_sd):
+    """kd-tree index and brute-force Chamfer give the same fitting step in both engines (they are bit-identical ops)."""
+    scene = synth.make_scene(3, 3000, 16, 300)
+    B = 3
+    bodies = synth.make_bodies(41, B)
+    out = {}
+    for engine in ('fused', 'modular'):
+        for mode in ('kdtree', 'bruteforce'):
+            op = make_op(smplx_data, vposer_sd, scene, B, engine, num_iter=2)
+            op.nn_mode = mode
+            op.fitting(dict(bodies))
+            out[(engine, mode)] = op.xhr_rec.detach().cpu().numpy()
+    assert np.array_equal(out[('fused', 'kdtree')], out[('fused', 'bruteforce')])
+    assert np.abs(out[('modular', 'kdtree')] - out[('modular', 'bruteforce')]).max() < 1e-6
+
+
 def test_fused_adam_state_persists_and_resets(smplx_data, vposer_sd):
     """fitting_proxe.py:74,175: the optimizer is created once and reused for every file."""
     scene = synth.make_scene(3, 2000, 16, 200)

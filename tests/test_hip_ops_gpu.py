@@ -135,3 +135,52 @@ def test_sdf_multi_scene_and_penetration_loss():
     l0 = ops.penetration_loss(ops.sdf_sample(far, T(a.sdf), T(a.grid_min), T(a.grid_max)))
     l0.backward()
     assert float(l0) == 0.0 and float(far.grad.abs().max()) == 0.0
+
+
+def _clouds(kind, m, rs):
+    if kind == 'uniform':
+        return rs.uniform(-1.5, 1.5, (m, 3)).astype(np.float32)
+    if kind == 'surface':                                   # points on a sphere + a floor plane: scene-like, non-uniform
+        a = rs.standard_normal((m // 2, 3))
+        a = a / np.linalg.norm(a, axis=1, keepdims=True) * 1.3
+        f = np.stack([rs.uniform(-2, 2, m - m // 2), rs.uniform(-2, 2, m - m // 2), np.full(m - m // 2, -1.0)], 1)
+        return np.concatenate([a, f]).astype(np.float32)
+    if kind == 'lattice':                                   # exact ties everywhere
+        g = np.stack(np.meshgrid(*[np.arange(-4, 4)] * 3, indexing='ij'), -1).reshape(-1, 3).astype(np.float32) * 0.25
+        return np.concatenate([g, g[::3]])[:m] if m <= len(g) + len(g[::3]) else g
+
+
+@pytest.mark.parametrize('kind,m', [('uniform', 1), ('uniform', 7), ('uniform', 9), ('uniform', 4096), ('surface', 5000),
+                                    ('lattice', 600), ('uniform', 32768)])
+def test_kdtree_index_bit_exact_vs_bruteforce(kind, m):
+    """psi_nn_index_query == psi_chamfer_forward direction 1 (indices and distances bit-identical), incl. exact ties,
+    queries far outside the cloud and queries that coincide with targets."""
+    rs = np.random.RandomState(m)
+    y = _clouds(kind, m, rs)
+    m = len(y)
+    B, n = 3, 700
+    x = rs.uniform(-2.5, 2.5, (B, n, 3)).astype(np.float32)
+    x[0, :50] = y[rs.randint(0, m, 50)]                     # zero distances
+    x[1, :20] *= 40.0                                       # far outside
+    if kind == 'lattice':
+        x[2] = np.round(x[2] * 4) / 4 + 0.125               # equidistant to several lattice points
+    index = ops.SceneNNIndex(y, DEV)
+    d, i = index.query(T(x))
+    rd, ri, _, _ = ops.chamfer_forward_raw(T(x), T(np.broadcast_to(y, (B, m, 3)).copy()), both=False)
+    assert torch.equal(i, ri) and torch.equal(d, rd)
+    od, oi, _, _ = O.chamfer_nn_np(x[:1, :200], y[None], both=False)
+    assert np.array_equal(i[:1, :200].cpu().numpy(), oi) and np.array_equal(d[:1, :200].cpu().numpy(), od)
+
+
+def test_kdtree_backward_matches_bruteforce():
+    rs = np.random.RandomState(5)
+    y = rs.uniform(-1, 1, (3000, 3)).astype(np.float32)
+    x = rs.uniform(-1, 1, (2, 400, 3)).astype(np.float32)
+    w = T(rs.standard_normal((2, 400)))
+    index = ops.SceneNNIndex(y, DEV)
+    a = T(x).requires_grad_()
+    (ops.chamfer_to_scene(a, index) * w).sum().backward()
+    b = T(x).requires_grad_()
+    d1, _ = ops.chamferDist(one_sided=True)(b, T(np.broadcast_to(y, (2, 3000, 3)).copy()))
+    (d1 * w).sum().backward()
+    assert rel_err(a.grad.cpu(), b.grad.cpu()) < 1e-6
