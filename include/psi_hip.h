@@ -62,7 +62,10 @@ int psi_chamfer_backward(const float *xyz1, const float *xyz2, float *gradxyz1, 
 typedef struct psi_nn_index psi_nn_index;
 int psi_nn_index_create(psi_nn_index **out, const float *h_points, int m);
 void psi_nn_index_destroy(psi_nn_index *index);
-int psi_nn_index_query(const psi_nn_index *index, const float *xyz1, int B, int n, float *dist1, int32_t *idx1, void *stream);
+/* hint (device int32 [B,n], nullable): warm start — on entry the target index that won for each query last time
+ * (-1 = none), on exit this call's idx1.  It only seeds the search bound with a real candidate; results are unchanged. */
+int psi_nn_index_query(const psi_nn_index *index, const float *xyz1, int B, int n, float *dist1, int32_t *idx1,
+                       int32_t *hint, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Trilinear SDF lookup with analytic gradient — replaces

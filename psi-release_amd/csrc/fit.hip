@@ -49,6 +49,7 @@ struct FitDev {
     // per-iteration buffers
     float *h1, *h2, *o6, *betas20, *pose, *transl, *verts, *og, *g_verts, *gq, *fpart, *penpart, *recpart, *vppart;
     float *g_betas, *g_pose, *g_transl, *g_rot;
+    int *nn_hint;        // [B,n_c] previous nearest-neighbour indices (warm start of the kd-tree search), -1 = none
     float *history;      // [max_hist][4] loss values per iteration
     int max_hist;
 };
@@ -430,7 +431,7 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st)
     PSI_CHECK_LAUNCH("sdf_pen_kernel");
     float gscale = f.w_contact / ((float)f.B * (float)f.world * (float)f.n_c);
     if (e->nn_index)
-        rc = psi_nn_index_contact(e->nn_index, f.verts, (long)f.V * 3, f.vid, f.B, f.n_c, f.cconst, gscale, f.gq, f.fpart, st);
+        rc = psi_nn_index_contact(e->nn_index, f.verts, (long)f.V * 3, f.vid, f.B, f.n_c, f.cconst, gscale, f.gq, f.fpart, f.nn_hint, st);
     else
         rc = psi_nn_contact(f.verts, (long)f.V * 3, f.vid, f.scene, f.B, f.n_c, f.m, e->nn_ws, f.cconst, gscale, f.gq, f.fpart, nullptr, st);
     if (rc) return rc;
@@ -510,7 +511,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
            o_verts = take((size_t)B * V * 3 * 4), o_og = take((size_t)B * V * 3 * 4), o_gv = take((size_t)B * V * 3 * 4),
            o_gq = take((size_t)B * f.n_c * 3 * 4), o_fp = take((size_t)B * f.nfp * 4), o_pp = take((size_t)B * f.nsdfblk * 2 * 4),
            o_rp = take((size_t)B * 4), o_vp = take((size_t)B * 4), o_gb = take((size_t)B * NB * 4), o_gp = take((size_t)B * J * 3 * 4),
-           o_gt = take((size_t)B * 3 * 4), o_gr = take((size_t)B * J * 9 * 4), o_hist = take((size_t)f.max_hist * 4 * 4), o_stats = take(256);
+           o_gt = take((size_t)B * 3 * 4), o_gr = take((size_t)B * J * 9 * 4), o_hist = take((size_t)f.max_hist * 4 * 4), o_stats = take(256), o_hint = take((size_t)B * f.n_c * 4);
     size_t lbs_floats = psi_lbs_workspace_floats(lbs, B);
     size_t o_lws = take(lbs_floats * 4), o_nws = take(psi_nn_ws_bytes(B, f.n_c, f.m));
     hipError_t err = hipMalloc((void **)&e->blob, o);
@@ -520,6 +521,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
         return (int)err;
     }
     err = hipMemset(e->blob + zero_begin, 0, o - zero_begin);
+    if (err == hipSuccess) err = hipMemset(e->blob + o_hint, 0xff, (size_t)B * f.n_c * 4);   // -1 = no hint
     for (auto &it : items)
         if (err == hipSuccess) err = hipMemcpy(e->blob + it.off, it.src, it.bytes, hipMemcpyHostToDevice);
     if (err != hipSuccess) {
@@ -539,6 +541,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.verts = F(o_verts); f.og = F(o_og); f.g_verts = F(o_gv); f.gq = F(o_gq); f.fpart = F(o_fp); f.penpart = F(o_pp);
     f.recpart = F(o_rp); f.vppart = F(o_vp); f.g_betas = F(o_gb); f.g_pose = F(o_gp); f.g_transl = F(o_gt); f.g_rot = F(o_gr);
     f.history = F(o_hist);
+    f.nn_hint = (int *)(bl + o_hint);
     e->stats_local = F(o_stats);
     e->lbs_ws = F(o_lws);
     e->nn_ws = bl + o_nws;
@@ -578,6 +581,7 @@ extern "C" int psi_fit_set_problem(psi_fit_engine *e, const float *d_xhr, const 
     PSI_CHECK_HIP(hipMemcpyAsync(f.xhr, d_xhr, nb, hipMemcpyDeviceToDevice, st));
     PSI_CHECK_HIP(hipMemcpyAsync(f.x, d_x_init ? d_x_init : d_xhr, nb, hipMemcpyDeviceToDevice, st));
     PSI_CHECK_HIP(hipMemcpyAsync(f.cam, d_cam_ext, (size_t)f.B * 16 * 4, hipMemcpyDeviceToDevice, st));
+    PSI_CHECK_HIP(hipMemsetAsync(f.nn_hint, 0xff, (size_t)f.B * f.n_c * 4, st));
     if (reset_optimizer) {
         hipLaunchKernelGGL(adam_reset_kernel, dim3(psi_cdiv((long)f.B * XD, 256)), dim3(256), 0, st, f.adam_m, f.adam_v, f.step, f.B * XD);
         PSI_CHECK_LAUNCH("adam_reset_kernel");

@@ -5,8 +5,8 @@
 // target index attaining it.  The index only prunes: every target whose computed d could be <= the final minimum is
 // still evaluated with the identical expression, so distances and indices are bit-identical to brute force.
 //
-//   build (host, once per scene): balanced kd-tree, median split on the widest axis, leaves of <= 8 points; every node
-//     stores its exact AABB; points are re-ordered by leaf and stored as float4 {x, y, z, bitcast(original index)}.
+//   build (host, once per scene): balanced kd-tree, median split on the widest axis, leaves of <= 8 points (padded to 8 records); every
+//     internal node stores the exact AABBs of both children (one 64-byte record per visit); points are re-ordered by leaf and stored as float4 {x, y, z, bitcast(original index)}.
 //   query (one lane per query, per-lane stack in LDS): depth-first, nearer child first.  A node is skipped when
 //       d2box * 0.999999f > best,  d2box = squared distance from the query to the node's AABB evaluated in fp32.
 //     Safety: for any point p in the box, d_hat(p) >= true(p) (1 - 3e-7) >= trueBox (1 - 3e-7) >= d2box_hat (1 - 3e-7)^2,
@@ -27,26 +27,31 @@
 
 namespace {
 
-constexpr int LEAF = 8;
-constexpr int MAXDEPTH = 40;
+constexpr int LEAF = 8;             // points per leaf; leaves are PADDED to exactly 8 records (copies of the last point)
+                                    // so the scan is a fixed, fully unrolled batch of 8 independent 16-byte loads
+constexpr int MAXDEPTH = 32;
 constexpr int QBLK = 64;            // one wave per workgroup: per-lane stacks live in LDS [MAXDEPTH][64]
 
-struct KdNode {                     // 32 bytes
-    float bmin[3], bmax[3];
-    int a, b;                       // internal: a = left child, b = right child;  leaf: a = -(first point + 1), b = count
+// Fat node: the AABBs of BOTH children (one 64-byte record per visit, no child re-load on pop).
+// Child reference: >= 0 internal node index;  < 0 leaf number L encoded -(L) - 1; its 8 records start at pts[8*L].
+struct KdNode {
+    float lmin[3], lmax[3], rmin[3], rmax[3];
+    int left, right, pad0, pad1;
 };
 
 struct KdDev {
     const KdNode *nodes;
-    const float4 *pts;              // leaf-ordered {x,y,z,bitcast(orig index)}
-    int n_nodes, m;
+    const float4 *pts;              // leaf-ordered, 8 records per leaf: {x,y,z,bitcast(orig index)}
+    const float4 *opts;             // original order {x,y,z,bitcast(index)}: warm-start lookups
+    int root;                       // child-reference of the root (a leaf when m <= LEAF)
+    int m;
 };
 
-__device__ __forceinline__ float box_d2(const KdNode &nd, float qx, float qy, float qz)
+__device__ __forceinline__ float box_d2(const float *mn, const float *mx, float qx, float qy, float qz)
 {
-    float dx = fmaxf(fmaxf(nd.bmin[0] - qx, qx - nd.bmax[0]), 0.0f);
-    float dy = fmaxf(fmaxf(nd.bmin[1] - qy, qy - nd.bmax[1]), 0.0f);
-    float dz = fmaxf(fmaxf(nd.bmin[2] - qz, qz - nd.bmax[2]), 0.0f);
+    float dx = fmaxf(fmaxf(mn[0] - qx, qx - mx[0]), 0.0f);
+    float dy = fmaxf(fmaxf(mn[1] - qy, qy - mx[1]), 0.0f);
+    float dz = fmaxf(fmaxf(mn[2] - qz, qz - mx[2]), 0.0f);
     return dx * dx + dy * dy + dz * dz;
 }
 
@@ -54,9 +59,11 @@ __device__ __forceinline__ float box_d2(const KdNode &nd, float qx, float qy, fl
 template <bool CONTACT>
 __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T, const float *__restrict__ xyz1, const int *__restrict__ qidx,
                                                         long qstride, int n, float *__restrict__ dist, int *__restrict__ idx,
-                                                        float cconst, float gscale, float *__restrict__ gq, float *__restrict__ fpart)
+                                                        float cconst, float gscale, float *__restrict__ gq, float *__restrict__ fpart,
+                                                        int *__restrict__ hint)
 {
-    __shared__ int stack[MAXDEPTH][QBLK];
+    __shared__ int stk_n[MAXDEPTH][QBLK];
+    __shared__ float stk_d[MAXDEPTH][QBLK];
     const int lane = threadIdx.x;
     const int b = blockIdx.y;
     const int j = blockIdx.x * QBLK + lane;
@@ -68,17 +75,40 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T, const float *__
         float best = INFINITY;
         int besti = 0x7fffffff;
         float bx = 0, by = 0, bz = 0;
+        const size_t o = (size_t)b * n + j;
+        if (hint) {
+            // warm start: the target that won for this query last time is evaluated first (an ordinary candidate, so
+            // the result is unchanged); a good initial `best` prunes almost every far child on the way down
+            int h = hint[o];
+            if (h >= 0 && h < T.m) {
+                const float4 p = T.opts[h];
+                float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
+                best = x2 * x2 + y2 * y2 + z2 * z2;
+                besti = h;
+                bx = p.x; by = p.y; bz = p.z;
+            }
+        }
         int sp = 0;
-        stack[0][lane] = 0;
-        sp = 1;
-        while (sp > 0) {
-            const int ni = stack[--sp][lane];
-            const KdNode nd = T.nodes[ni];
-            if (box_d2(nd, qx, qy, qz) * 0.999999f > best) continue;
-            if (nd.a < 0) {
-                const int first = -nd.a - 1;
-                for (int k = 0; k < nd.b; k++) {
-                    const float4 p = T.pts[first + k];
+        int cur = T.root;
+        float curd = 0.0f;
+        bool have = true;
+        while (true) {
+            if (!have) {
+                if (sp == 0) break;
+                --sp;
+                cur = stk_n[sp][lane];
+                curd = stk_d[sp][lane];
+            }
+            have = false;
+            if (curd * 0.999999f > best) continue;
+            if (cur < 0) {
+                const float4 *lp = T.pts + (size_t)(-cur - 1) * LEAF;
+                float4 pp[LEAF];
+#pragma unroll
+                for (int k = 0; k < LEAF; k++) pp[k] = lp[k];
+#pragma unroll
+                for (int k = 0; k < LEAF; k++) {
+                    const float4 p = pp[k];
                     float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
                     float d = x2 * x2 + y2 * y2 + z2 * z2;
                     int pi = __float_as_int(p.w);
@@ -89,17 +119,27 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T, const float *__
                     }
                 }
             } else {
-                const float dl = box_d2(T.nodes[nd.a], qx, qy, qz), dr = box_d2(T.nodes[nd.b], qx, qy, qz);
+                const float4 *np = (const float4 *)(T.nodes + cur);
+                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                const float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
+                const float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
+                const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+                const float dl = box_d2(lmin, lmax, qx, qy, qz), dr = box_d2(rmin, rmax, qx, qy, qz);
                 const bool left_first = dl <= dr;
-                const int nearc = left_first ? nd.a : nd.b, farc = left_first ? nd.b : nd.a;
-                const float dfar = left_first ? dr : dl;
-                if (dfar * 0.999999f <= best) stack[sp++][lane] = farc;
-                stack[sp++][lane] = nearc;
+                const float dnear = left_first ? dl : dr, dfar = left_first ? dr : dl;
+                if (dfar * 0.999999f <= best) {
+                    stk_n[sp][lane] = left_first ? right : left;
+                    stk_d[sp][lane] = dfar;
+                    sp++;
+                }
+                cur = left_first ? left : right;      // descend into the nearer child without an LDS round trip
+                curd = dnear;
+                have = true;
             }
         }
-        const size_t o = (size_t)b * n + j;
         if (dist) dist[o] = best;
         if (idx) idx[o] = besti;
+        if (hint) hint[o] = besti;
         if (CONTACT) {
             float sq = sqrtf(best + 1e-4f);
             float den = sq + cconst;
@@ -122,29 +162,30 @@ struct Builder {
     const float *p;
     std::vector<int> order;
     std::vector<KdNode> nodes;
+    std::vector<std::pair<int, int>> leaves;     // (first, count) into `order`
     int depth_max = 0;
 
-    int build(int lo, int hi, int depth)
+    void bounds(int lo, int hi, float *mn, float *mx)
     {
-        int me = (int)nodes.size();
-        nodes.push_back(KdNode());
-        if (depth > depth_max) depth_max = depth;
-        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int c = 0; c < 3; c++) { mn[c] = INFINITY; mx[c] = -INFINITY; }
         for (int i = lo; i < hi; i++)
             for (int c = 0; c < 3; c++) {
                 float v = p[(size_t)order[i] * 3 + c];
                 mn[c] = std::min(mn[c], v);
                 mx[c] = std::max(mx[c], v);
             }
-        for (int c = 0; c < 3; c++) {
-            nodes[me].bmin[c] = mn[c];
-            nodes[me].bmax[c] = mx[c];
-        }
+    }
+
+    // returns the child reference of the subtree over order[lo:hi)
+    int build(int lo, int hi, int depth)
+    {
+        if (depth > depth_max) depth_max = depth;
         if (hi - lo <= LEAF) {
-            nodes[me].a = -(lo + 1);
-            nodes[me].b = hi - lo;
-            return me;
+            leaves.push_back({lo, hi - lo});
+            return -((int)leaves.size() - 1) - 1;
         }
+        float mn[3], mx[3];
+        bounds(lo, hi, mn, mx);
         int ax = 0;
         if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
         if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
@@ -154,10 +195,17 @@ struct Builder {
             float a = pp[(size_t)u * 3 + ax], b = pp[(size_t)v * 3 + ax];
             return a < b || (a == b && u < v);
         });
+        int me = (int)nodes.size();
+        nodes.push_back(KdNode());
         int l = build(lo, mid, depth + 1);
         int r = build(mid, hi, depth + 1);
-        nodes[me].a = l;
-        nodes[me].b = r;
+        KdNode nd;
+        memset(&nd, 0, sizeof(nd));
+        bounds(lo, mid, nd.lmin, nd.lmax);
+        bounds(mid, hi, nd.rmin, nd.rmax);
+        nd.left = l;
+        nd.right = r;
+        nodes[me] = nd;
         return me;
     }
 };
@@ -171,28 +219,38 @@ struct psi_nn_index {
 
 extern "C" int psi_nn_index_create(psi_nn_index **out, const float *h_points, int m)
 {
-    PSI_REQUIRE(out && h_points && m > 0, "bad arguments");
+    PSI_REQUIRE(out && h_points && m > 0 && m < (1 << 24), "bad arguments (0 < m < 2^24)");
     Builder bd;
     bd.p = h_points;
     bd.order.resize(m);
     for (int i = 0; i < m; i++) bd.order[i] = i;
     bd.nodes.reserve((size_t)2 * (m / LEAF + 2));
-    bd.build(0, m, 0);
+    int root = bd.build(0, m, 0);
     PSI_REQUIRE(bd.depth_max + 2 < MAXDEPTH, "kd-tree too deep");
-    std::vector<float4> pts(m);
-    for (int i = 0; i < m; i++) {
-        int oi = bd.order[i];
-        pts[i].x = h_points[(size_t)oi * 3 + 0];
-        pts[i].y = h_points[(size_t)oi * 3 + 1];
-        pts[i].z = h_points[(size_t)oi * 3 + 2];
-        memcpy(&pts[i].w, &oi, 4);
-    }
-    size_t nb_nodes = bd.nodes.size() * sizeof(KdNode), nb_pts = pts.size() * sizeof(float4);
+    auto rec = [&](int oi) {
+        float4 r;
+        r.x = h_points[(size_t)oi * 3 + 0];
+        r.y = h_points[(size_t)oi * 3 + 1];
+        r.z = h_points[(size_t)oi * 3 + 2];
+        memcpy(&r.w, &oi, 4);
+        return r;
+    };
+    std::vector<float4> pts(bd.leaves.size() * LEAF), opts(m);
+    for (size_t L = 0; L < bd.leaves.size(); L++)
+        for (int k = 0; k < LEAF; k++) {
+            int kk = k < bd.leaves[L].second ? k : bd.leaves[L].second - 1;     // pad with copies of the last point
+            pts[L * LEAF + k] = rec(bd.order[bd.leaves[L].first + kk]);
+        }
+    for (int i = 0; i < m; i++) opts[i] = rec(i);
+    if (bd.nodes.empty()) bd.nodes.push_back(KdNode());
+    size_t nb_nodes = bd.nodes.size() * sizeof(KdNode), nb_pts = pts.size() * sizeof(float4), nb_opts = opts.size() * sizeof(float4);
     size_t off_pts = (nb_nodes + 255) & ~(size_t)255;
+    size_t off_opts = (off_pts + nb_pts + 255) & ~(size_t)255;
     char *blob = nullptr;
-    PSI_CHECK_HIP(hipMalloc((void **)&blob, off_pts + nb_pts));
+    PSI_CHECK_HIP(hipMalloc((void **)&blob, off_opts + nb_opts));
     hipError_t e = hipMemcpy(blob, bd.nodes.data(), nb_nodes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(blob + off_pts, pts.data(), nb_pts, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(blob + off_opts, opts.data(), nb_opts, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(blob);
         psi_set_error("psi_nn_index_create: upload failed: %s", hipGetErrorString(e));
@@ -202,7 +260,8 @@ extern "C" int psi_nn_index_create(psi_nn_index **out, const float *h_points, in
     ix->blob = blob;
     ix->d.nodes = (const KdNode *)blob;
     ix->d.pts = (const float4 *)(blob + off_pts);
-    ix->d.n_nodes = (int)bd.nodes.size();
+    ix->d.opts = (const float4 *)(blob + off_opts);
+    ix->d.root = root;
     ix->d.m = m;
     *out = ix;
     return 0;
@@ -215,24 +274,25 @@ extern "C" void psi_nn_index_destroy(psi_nn_index *ix)
     delete ix;
 }
 
-extern "C" int psi_nn_index_query(const psi_nn_index *ix, const float *xyz1, int B, int n, float *dist1, int32_t *idx1, void *stream)
+extern "C" int psi_nn_index_query(const psi_nn_index *ix, const float *xyz1, int B, int n, float *dist1, int32_t *idx1,
+                                  int32_t *hint, void *stream)
 {
     PSI_REQUIRE(ix && B >= 0 && n >= 0, "bad arguments");
     if (B == 0 || n == 0) return 0;
     PSI_REQUIRE(xyz1 && dist1 && idx1, "null pointer");
     PSI_REQUIRE(B <= 65535, "B exceeds grid.y");
     hipLaunchKernelGGL(kd_query_kernel<false>, dim3(psi_cdiv(n, QBLK), B), dim3(QBLK), 0, (hipStream_t)stream, ix->d, xyz1,
-                       (const int *)nullptr, (long)n * 3, n, dist1, idx1, 0.0f, 0.0f, (float *)nullptr, (float *)nullptr);
+                       (const int *)nullptr, (long)n * 3, n, dist1, idx1, 0.0f, 0.0f, (float *)nullptr, (float *)nullptr, hint);
     PSI_CHECK_LAUNCH("kd_query_kernel");
     return 0;
 }
 
 // internal (psi_internal.h): contact-loss NN through the index, same outputs as psi_nn_contact
 int psi_nn_index_contact(const psi_nn_index *ix, const float *verts, long vstride, const int *vid, int B, int n, float cconst,
-                         float gscale, float *gq, float *fpart, hipStream_t st)
+                         float gscale, float *gq, float *fpart, int *hint, hipStream_t st)
 {
     hipLaunchKernelGGL(kd_query_kernel<true>, dim3(psi_cdiv(n, QBLK), B), dim3(QBLK), 0, st, ix->d, verts, vid, vstride, n,
-                       (float *)nullptr, (int *)nullptr, cconst, gscale, gq, fpart);
+                       (float *)nullptr, (int *)nullptr, cconst, gscale, gq, fpart, hint);
     PSI_CHECK_LAUNCH("kd_query_kernel<contact>");
     return 0;
 }

@@ -13,7 +13,7 @@ size_t psi_nn_ws_bytes(int B, int n, int m);
 // nnindex.hip
 struct psi_nn_index;
 int psi_nn_index_contact(const psi_nn_index *ix, const float *verts, long vstride, const int *vid, int B, int n, float cconst,
-                         float gscale, float *gq, float *fpart, hipStream_t st);
+                         float gscale, float *gq, float *fpart, int *hint, hipStream_t st);
 int psi_nn_index_fparts(int n);
 
 // lbs.hip

@@ -185,13 +185,14 @@ class SceneNNIndex:
                       'psi_nn_index_create')
         self.handle = h
 
-    def query(self, xyz1):
+    def query(self, xyz1, hint=None):
+        """hint: int32 [B,n] warm-start buffer (previous winners, -1 = none), updated in place; results do not depend on it."""
         xyz1 = xyz1.contiguous().float()
         B, n, _ = xyz1.shape
         dist = torch.empty(B, n, device=xyz1.device)
         idx = torch.empty(B, n, dtype=torch.int32, device=xyz1.device)
-        hip.check(hip.lib().psi_nn_index_query(self.handle, hip.ptr(xyz1), B, n, hip.ptr(dist), hip.ptr(idx), hip.stream()),
-                  'psi_nn_index_query')
+        hip.check(hip.lib().psi_nn_index_query(self.handle, hip.ptr(xyz1), B, n, hip.ptr(dist), hip.ptr(idx), hip.ptr(hint),
+                                               hip.stream()), 'psi_nn_index_query')
         return dist, idx
 
     def __del__(self):

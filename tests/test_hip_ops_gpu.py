@@ -168,6 +168,12 @@ def test_kdtree_index_bit_exact_vs_bruteforce(kind, m):
     d, i = index.query(T(x))
     rd, ri, _, _ = ops.chamfer_forward_raw(T(x), T(np.broadcast_to(y, (B, m, 3)).copy()), both=False)
     assert torch.equal(i, ri) and torch.equal(d, rd)
+    # warm-start hints (good, bad, absent) never change the result and come back as the winners
+    hint = torch.tensor(rs.randint(-1, m, (B, n)), dtype=torch.int32, device=DEV)
+    d2, i2 = index.query(T(x), hint=hint)
+    assert torch.equal(i2, i) and torch.equal(d2, d) and torch.equal(hint, i)
+    d3, i3 = index.query(T(x), hint=hint)
+    assert torch.equal(i3, i) and torch.equal(d3, d)
     od, oi, _, _ = O.chamfer_nn_np(x[:1, :200], y[None], both=False)
     assert np.array_equal(i[:1, :200].cpu().numpy(), oi) and np.array_equal(d[:1, :200].cpu().numpy(), od)
 
