@@ -30,7 +30,8 @@ constexpr int NH = 512;        // VPoser hidden width (vposer_smpl.py:75-89 with
 constexpr int NZ = 32;         // VPoser latent
 constexpr int NJ6 = 126;       // 21 joints x 6D
 constexpr int XD = 75;         // body vector with 6D global rotation (cvae.py:117-126)
-constexpr int HB = 256;        // threads per body in the head kernels
+constexpr int HB = 512;        // threads per body in the head kernels: 128 output quads x 4 K-quarters
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct FitDev {
     int B, V, J, NB, n_c, m, D, align_corners, world, ncomp, nfp, nsdfblk;
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f)
 {
     const int b = blockIdx.x, t = threadIdx.x;
     __shared__ float sx[XD + 5], sh1[NH], sh2[NH], so6[128], red[HB / 64];
+    __shared__ f4 part4[4][128], part3[16][32];
     const float *x = f.x + (size_t)b * XD;
     if (t < XD) sx[t] = x[t];
     __syncthreads();
@@ -167,35 +169,55 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f)
         f.recpart[b] = sr;
         f.vppart[b] = sz;
     }
-    // VPoser decoder
+    // VPoser decoder.  Each thread owns 4 adjacent outputs (one 16-byte weight load per k) and one quarter of K;
+    // the four K-quarters are summed through LDS.  Many independent 16-byte loads in flight per lane: the weights
+    // (1.3 MB, L2 resident) stream at bandwidth instead of one dependent 4-byte load at a time.
     const float *z = sx + 19;
-    for (int o = t; o < NH; o += HB) {
-        float a = f.b1[o];
+    const int og = t & 127, kq = t >> 7;
+    {   // fc1: 32 -> 512, K-quarter = 8
+        f4 a = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = kq * 8; k < kq * 8 + 8; k++) a += *(const f4 *)(f.W1T + (size_t)k * NH + og * 4) * z[k];
+        part4[kq][og] = a;
+    }
+    __syncthreads();
+    if (t < 128) {
+        f4 a = part4[0][t] + part4[1][t] + part4[2][t] + part4[3][t] + *(const f4 *)(f.b1 + t * 4);
+        for (int c = 0; c < 4; c++) sh1[t * 4 + c] = leaky(a[c], 0.2f);
+    }
+    __syncthreads();
+    {   // fc2: 512 -> 512, K-quarter = 128
+        f4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+        const float *w = f.W2T + (size_t)(kq * 128) * NH + og * 4;
+        const float *h = sh1 + kq * 128;
 #pragma unroll 8
-        for (int k = 0; k < NZ; k++) a += f.W1T[k * NH + o] * z[k];
-        sh1[o] = leaky(a, 0.2f);
+        for (int k = 0; k < 128; k += 2) {
+            a0 += *(const f4 *)(w + (size_t)k * NH) * h[k];
+            a1 += *(const f4 *)(w + (size_t)(k + 1) * NH) * h[k + 1];
+        }
+        __syncthreads();
+        part4[kq][og] = a0 + a1;
     }
     __syncthreads();
-    for (int o = t; o < NH; o += HB) {
-        float a0 = f.b2[o], a1 = 0, a2 = 0, a3 = 0;
-        for (int k = 0; k < NH; k += 4) {
-            a0 += f.W2T[(k + 0) * NH + o] * sh1[k + 0];
-            a1 += f.W2T[(k + 1) * NH + o] * sh1[k + 1];
-            a2 += f.W2T[(k + 2) * NH + o] * sh1[k + 2];
-            a3 += f.W2T[(k + 3) * NH + o] * sh1[k + 3];
-        }
-        sh2[o] = leaky((a0 + a1) + (a2 + a3), 0.2f);
+    if (t < 128) {
+        f4 a = part4[0][t] + part4[1][t] + part4[2][t] + part4[3][t] + *(const f4 *)(f.b2 + t * 4);
+        for (int c = 0; c < 4; c++) sh2[t * 4 + c] = leaky(a[c], 0.2f);
     }
     __syncthreads();
-    if (t < NJ6) {
-        float a0 = f.b3[t], a1 = 0, a2 = 0, a3 = 0;
-        for (int k = 0; k < NH; k += 4) {
-            a0 += f.W3T[(k + 0) * NJ6 + t] * sh2[k + 0];
-            a1 += f.W3T[(k + 1) * NJ6 + t] * sh2[k + 1];
-            a2 += f.W3T[(k + 2) * NJ6 + t] * sh2[k + 2];
-            a3 += f.W3T[(k + 3) * NJ6 + t] * sh2[k + 3];
-        }
-        so6[t] = (a0 + a1) + (a2 + a3);
+    {   // fc3: 512 -> 126 (rows padded to 128): 32 output quads x 16 K-slices of 32
+        const int og3 = t & 31, ks = t >> 5;
+        f4 a = {0, 0, 0, 0};
+        const float *w = f.W3T + (size_t)(ks * 32) * 128 + og3 * 4;
+        const float *h = sh2 + ks * 32;
+#pragma unroll 8
+        for (int k = 0; k < 32; k++) a += *(const f4 *)(w + (size_t)k * 128) * h[k];
+        part3[ks][og3] = a;
+    }
+    __syncthreads();
+    if (t < 32) {
+        f4 a = *(const f4 *)(f.b3 + t * 4);
+        for (int ks = 0; ks < 16; ks++) a += part3[ks][t];
+        for (int c = 0; c < 4; c++) so6[t * 4 + c] = a[c];
     }
     __syncthreads();
     for (int o = t; o < NH; o += HB) {
@@ -313,7 +335,8 @@ __global__ __launch_bounds__(256) void grad_verts_kernel(FitDev f, const float *
 __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f)
 {
     const int b = blockIdx.x, t = threadIdx.x;
-    __shared__ float sx[XD + 5], sg6[128], sga2[NH], sga1[NH], sgx[XD + 5], part[8][NZ];
+    __shared__ float sx[XD + 5], sg6[128], sga2[NH], sga1[NH], sgx[XD + 5];
+    __shared__ f4 part4[4][128], part1[64][8];
     const float *x = f.x + (size_t)b * XD;
     if (t < XD) { sx[t] = x[t]; sgx[t] = 0.0f; }
     if (t < 128) sg6[t] = 0.0f;
@@ -342,36 +365,52 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f)
         sgx[9 + (t - 160)] = f.g_betas[(size_t)b * f.NB + (t - 160)];
     }
     __syncthreads();
-    // VPoser MLP backward (weights are constants)
+    // VPoser MLP backward (weights are constants): same 16-byte / K-split scheme on the [out][in] layouts
     const float *h1 = f.h1 + (size_t)b * NH, *h2 = f.h2 + (size_t)b * NH;
-    for (int k = t; k < NH; k += HB) {
-        float a = 0;
-        for (int o = 0; o < NJ6; o++) a += f.W3[o * NH + k] * sg6[o];
-        sga2[k] = a * (h2[k] > 0.0f ? 1.0f : 0.2f);
+    const int og = t & 127, kq = t >> 7;
+    {   // g_h2[k] = sum_o W3[o][k] g6[o]: 128 k-quads x 4 o-quarters (126 rows -> 32,32,32,30)
+        f4 a = {0, 0, 0, 0};
+        const int o0 = kq * 32, o1 = min(o0 + 32, NJ6);
+#pragma unroll 8
+        for (int o = o0; o < o1; o++) a += *(const f4 *)(f.W3 + (size_t)o * NH + og * 4) * sg6[o];
+        part4[kq][og] = a;
     }
     __syncthreads();
-    for (int k = t; k < NH; k += HB) {
-        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int o = 0; o < NH; o += 4) {
-            a0 += f.W2[(o + 0) * NH + k] * sga2[o + 0];
-            a1 += f.W2[(o + 1) * NH + k] * sga2[o + 1];
-            a2 += f.W2[(o + 2) * NH + k] * sga2[o + 2];
-            a3 += f.W2[(o + 3) * NH + k] * sga2[o + 3];
+    if (t < 128) {
+        f4 a = part4[0][t] + part4[1][t] + part4[2][t] + part4[3][t];
+        for (int c = 0; c < 4; c++) sga2[t * 4 + c] = a[c] * (h2[t * 4 + c] > 0.0f ? 1.0f : 0.2f);
+    }
+    __syncthreads();
+    {   // g_h1[k] = sum_o W2[o][k] g_a2[o]
+        f4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+        const float *w = f.W2 + (size_t)(kq * 128) * NH + og * 4;
+        const float *g = sga2 + kq * 128;
+#pragma unroll 8
+        for (int o = 0; o < 128; o += 2) {
+            a0 += *(const f4 *)(w + (size_t)o * NH) * g[o];
+            a1 += *(const f4 *)(w + (size_t)(o + 1) * NH) * g[o + 1];
         }
-        sga1[k] = ((a0 + a1) + (a2 + a3)) * (h1[k] > 0.0f ? 1.0f : 0.2f);
+        __syncthreads();
+        part4[kq][og] = a0 + a1;
     }
     __syncthreads();
-    {
-        int k = t & 31, pp = t >> 5;                       // 8 partial sums of 64 outputs each
-        float a = 0;
-        for (int o = pp * 64; o < pp * 64 + 64; o++) a += f.W1[o * NZ + k] * sga1[o];
-        part[pp][k] = a;
+    if (t < 128) {
+        f4 a = part4[0][t] + part4[1][t] + part4[2][t] + part4[3][t];
+        for (int c = 0; c < 4; c++) sga1[t * 4 + c] = a[c] * (h1[t * 4 + c] > 0.0f ? 1.0f : 0.2f);
     }
     __syncthreads();
-    if (t < NZ) {
-        float a = 0;
-        for (int pp = 0; pp < 8; pp++) a += part[pp][t];
-        sgx[19 + t] = a;
+    {   // g_z[k] = sum_o W1[o][k] g_a1[o]: 8 k-quads x 64 o-slices of 8
+        const int kg = t & 7, os = t >> 3;
+        f4 a = {0, 0, 0, 0};
+#pragma unroll
+        for (int o = os * 8; o < os * 8 + 8; o++) a += *(const f4 *)(f.W1 + (size_t)o * NZ + kg * 4) * sga1[o];
+        part1[os][kg] = a;
+    }
+    __syncthreads();
+    if (t < 8) {
+        f4 a = {0, 0, 0, 0};
+        for (int os = 0; os < 64; os++) a += part1[os][t];
+        for (int c = 0; c < 4; c++) sgx[19 + t * 4 + c] = a[c];
     }
     __syncthreads();
     if (t < XD) {
@@ -483,10 +522,11 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.sdf = d_sdf;
     const int B = f.B;
     // host staging of constants
-    std::vector<float> W1T((size_t)NZ * NH), W2T((size_t)NH * NH), W3T((size_t)NH * NJ6);
+    std::vector<float> W1T((size_t)NZ * NH), W2T((size_t)NH * NH), W3T((size_t)NH * 128, 0.0f), b3p(128, 0.0f);
+    memcpy(b3p.data(), h_b3, NJ6 * 4);
     for (int o = 0; o < NH; o++) for (int k = 0; k < NZ; k++) W1T[(size_t)k * NH + o] = h_w1[(size_t)o * NZ + k];
     for (int o = 0; o < NH; o++) for (int k = 0; k < NH; k++) W2T[(size_t)k * NH + o] = h_w2[(size_t)o * NH + k];
-    for (int o = 0; o < NJ6; o++) for (int k = 0; k < NH; k++) W3T[(size_t)k * NJ6 + o] = h_w3[(size_t)o * NH + k];
+    for (int o = 0; o < NJ6; o++) for (int k = 0; k < NH; k++) W3T[(size_t)k * 128 + o] = h_w3[(size_t)o * NH + k];
     std::vector<int> cs_ptr(V + 1, 0), cs_idx(f.n_c);
     for (int i = 0; i < f.n_c; i++) cs_ptr[h_contact_ids[i] + 1]++;
     for (int v = 0; v < V; v++) cs_ptr[v + 1] += cs_ptr[v];
@@ -500,7 +540,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     auto cst = [&](const void *src, size_t bytes) { size_t r = take(bytes); items.push_back({src, bytes, r}); return r; };
     size_t o_w1t = cst(W1T.data(), W1T.size() * 4), o_b1 = cst(h_b1, NH * 4), o_w2t = cst(W2T.data(), W2T.size() * 4), o_b2 = cst(h_b2, NH * 4),
-           o_w3t = cst(W3T.data(), W3T.size() * 4), o_b3 = cst(h_b3, NJ6 * 4), o_w1 = cst(h_w1, (size_t)NH * NZ * 4),
+           o_w3t = cst(W3T.data(), W3T.size() * 4), o_b3 = cst(b3p.data(), 128 * 4), o_w1 = cst(h_w1, (size_t)NH * NZ * 4),
            o_w2 = cst(h_w2, (size_t)NH * NH * 4), o_w3 = cst(h_w3, (size_t)NJ6 * NH * 4), o_lh = cst(h_lh_comp, (size_t)f.ncomp * 45 * 4),
            o_rh = cst(h_rh_comp, (size_t)f.ncomp * 45 * 4), o_pm = cst(h_pose_mean, (size_t)J * 3 * 4), o_vid = cst(h_contact_ids, (size_t)f.n_c * 4),
            o_cp = cst(cs_ptr.data(), cs_ptr.size() * 4), o_ci = cst(cs_idx.data(), cs_idx.size() * 4), o_gmin = cst(h_gmin, 12), o_gmax = cst(h_gmax, 12);

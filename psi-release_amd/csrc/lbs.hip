@@ -26,6 +26,7 @@
 #include <string.h>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -238,20 +239,31 @@ __global__ __launch_bounds__(SKIN_BLK) void skin_fwd_kernel(LbsDev m, const floa
 {
     const int v = blockIdx.x * SKIN_BLK + threadIdx.x;
     const int b0 = blockIdx.y * SKIN_BT;
+    // packed accumulation: A_j rows are wave-uniform (scalar loads), w_j is per lane;  v_pk_fma_f32 with a broadcast
+    // SGPR pair issues two FMAs per slot (a plain v_fma with an SGPR operand is half rate on gfx950)
+    f2 T2[SKIN_BT][6];
+#pragma unroll
+    for (int i = 0; i < SKIN_BT; i++)
+#pragma unroll
+        for (int e = 0; e < 6; e++) T2[i][e] = (f2){0.0f, 0.0f};
+    for (int j = 0; j < m.J; j++) {
+        float wj = m.WT[(size_t)j * m.Vpad + v];
+        f2 w2 = {wj, wj};
+#pragma unroll
+        for (int i = 0; i < SKIN_BT; i++) {
+            const f2 *A = (const f2 *)(As + ((size_t)min(b0 + i, B - 1) * m.J + j) * 12);   // wave-uniform -> scalar loads
+#pragma unroll
+            for (int e = 0; e < 6; e++) T2[i][e] = __builtin_elementwise_fma(w2, A[e], T2[i][e]);
+        }
+    }
     float T[SKIN_BT][12];
 #pragma unroll
     for (int i = 0; i < SKIN_BT; i++)
 #pragma unroll
-        for (int e = 0; e < 12; e++) T[i][e] = 0.0f;
-    for (int j = 0; j < m.J; j++) {
-        float wj = m.WT[(size_t)j * m.Vpad + v];
-#pragma unroll
-        for (int i = 0; i < SKIN_BT; i++) {
-            const float *A = As + ((size_t)min(b0 + i, B - 1) * m.J + j) * 12;   // wave-uniform -> scalar loads
-#pragma unroll
-            for (int e = 0; e < 12; e++) T[i][e] += wj * A[e];
+        for (int e = 0; e < 6; e++) {
+            T[i][2 * e] = T2[i][e].x;
+            T[i][2 * e + 1] = T2[i][e].y;
         }
-    }
     if (v >= m.V) return;
 #pragma unroll
     for (int i = 0; i < SKIN_BT; i++) {
@@ -295,22 +307,30 @@ __global__ __launch_bounds__(SKIN_BLK) void skin_bwd_v_kernel(LbsDev m, const fl
 {
     const int v = blockIdx.x * SKIN_BLK + threadIdx.x;
     const int b0 = blockIdx.y * SKIN_BT;
-    float T[SKIN_BT][9];
+    f2 T2[SKIN_BT][6];
 #pragma unroll
     for (int i = 0; i < SKIN_BT; i++)
 #pragma unroll
-        for (int e = 0; e < 9; e++) T[i][e] = 0.0f;
+        for (int e = 0; e < 6; e++) T2[i][e] = (f2){0.0f, 0.0f};
     for (int j = 0; j < m.J; j++) {
         float wj = m.WT[(size_t)j * m.Vpad + v];
+        f2 w2 = {wj, wj};
 #pragma unroll
         for (int i = 0; i < SKIN_BT; i++) {
-            const float *A = As + ((size_t)min(b0 + i, B - 1) * m.J + j) * 12;
+            const f2 *A = (const f2 *)(As + ((size_t)min(b0 + i, B - 1) * m.J + j) * 12);
 #pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) T[i][r * 3 + c] += wj * A[r * 4 + c];
+            for (int e = 0; e < 6; e++) T2[i][e] = __builtin_elementwise_fma(w2, A[e], T2[i][e]);
         }
     }
+    float T[SKIN_BT][9];     // rotation part, row-major 3x3
+#pragma unroll
+    for (int i = 0; i < SKIN_BT; i++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            T[i][r * 3 + 0] = T2[i][2 * r].x;
+            T[i][r * 3 + 1] = T2[i][2 * r].y;
+            T[i][r * 3 + 2] = T2[i][2 * r + 1].x;
+        }
     __shared__ float sh[SKIN_BLK / 64][SKIN_BT][3];
     const bool live = v < m.V;
 #pragma unroll
@@ -362,40 +382,47 @@ __global__ __launch_bounds__(SKIN_BLK) void skin_bwd_v_kernel(LbsDev m, const fl
 __global__ __launch_bounds__(256) void skin_bwd_A_kernel(LbsDev m, const float *__restrict__ gl, const float *__restrict__ v_posed,
                                                          int B, float *__restrict__ part)
 {
+    // workgroup = one body x one 256-vertex slice; wave w contracts vertices [64w, 64w+64) of the slice (4 MFMA steps,
+    // all operand loads issued up front); the four waves are summed through LDS -> one partial per workgroup.
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = blockIdx.y * 4 + w;
-    if (b >= B) return;
-    const int vs = blockIdx.x * 256;
+    const int b = blockIdx.y;
+    const int vs = blockIdx.x * 256 + w * 64;
     const int li = lane & 15, lk = lane >> 4;
     const int r = li >> 2, s = li & 3;
-    f4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = (f4){0, 0, 0, 0};
     const float *glb = gl + (size_t)b * m.Npad;
     const float *vpb = v_posed + (size_t)b * m.Npad;
-#pragma unroll 2
-    for (int st = 0; st < 16; st++) {
-        const int v0 = vs + st * 16 + 4 * lk;
-        f4 wa[4];
+    f4 wa[4][4];
+    float bop[4][4];
 #pragma unroll
-        for (int jt = 0; jt < 4; jt++) wa[jt] = *(const f4 *)(m.WT + (size_t)(jt * 16 + li) * m.Vpad + v0);
-        float bop[4];
+    for (int st = 0; st < 4; st++) {
+        const int v0 = vs + st * 16 + 4 * lk;
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++) wa[st][jt] = *(const f4 *)(m.WT + (size_t)(jt * 16 + li) * m.Vpad + v0);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             float g = (r < 3) ? glb[(size_t)(v0 + t) * 3 + r] : 0.0f;
             float p = (s < 3) ? vpb[(size_t)(v0 + t) * 3 + s] : 1.0f;
-            bop[t] = g * p;
+            bop[st][t] = g * p;
         }
+    }
+    f4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (f4){0, 0, 0, 0};
+#pragma unroll
+    for (int st = 0; st < 4; st++)
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
-            for (int jt = 0; jt < 4; jt++) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[jt][t], bop[t], acc[jt], 0, 0, 0);
-    }
+            for (int jt = 0; jt < 4; jt++) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[st][jt][t], bop[st][t], acc[jt], 0, 0, 0);
+    __shared__ f4 red[4][4][64];
+#pragma unroll
+    for (int jt = 0; jt < 4; jt++) red[w][jt][lane] = acc[jt];
+    __syncthreads();
+    // wave w finishes joint tile w: D[row = lk*4+e -> joint][col = li -> r*4+s]
+    f4 o4 = red[0][w][lane] + red[1][w][lane] + red[2][w][lane] + red[3][w][lane];
     float *o = part + ((size_t)blockIdx.x * B + b) * JP * 16;
 #pragma unroll
-    for (int jt = 0; jt < 4; jt++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) o[(jt * 16 + lk * 4 + e) * 16 + li] = acc[jt][e];
+    for (int e = 0; e < 4; e++) o[(w * 16 + lk * 4 + e) * 16 + li] = o4[e];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -471,14 +498,28 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int Kpad, c
     const long nA = (long)B * JP * 16, nF = (long)B * Kpad, nT = (long)B * 4;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < nA) {
-        float a = 0;
-        for (int sl = 0; sl < nsv; sl++) a += gA_part[(size_t)sl * nA + i];
-        gA[i] = a;
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int sl = 0;
+        for (; sl + 4 <= nsv; sl += 4) {       // 4 independent loads in flight
+            a0 += gA_part[(size_t)(sl + 0) * nA + i];
+            a1 += gA_part[(size_t)(sl + 1) * nA + i];
+            a2 += gA_part[(size_t)(sl + 2) * nA + i];
+            a3 += gA_part[(size_t)(sl + 3) * nA + i];
+        }
+        for (; sl < nsv; sl++) a0 += gA_part[(size_t)sl * nA + i];
+        gA[i] = (a0 + a1) + (a2 + a3);
     } else if (i < nA + nF) {
         long k = i - nA;
-        float a = 0;
-        for (int sl = 0; sl < nsn; sl++) a += gfeat_part[(size_t)sl * nF + k];
-        gfeat[k] = a;
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int sl = 0;
+        for (; sl + 4 <= nsn; sl += 4) {
+            a0 += gfeat_part[(size_t)(sl + 0) * nF + k];
+            a1 += gfeat_part[(size_t)(sl + 1) * nF + k];
+            a2 += gfeat_part[(size_t)(sl + 2) * nF + k];
+            a3 += gfeat_part[(size_t)(sl + 3) * nF + k];
+        }
+        for (; sl < nsn; sl++) a0 += gfeat_part[(size_t)sl * nF + k];
+        gfeat[k] = (a0 + a1) + (a2 + a3);
     } else if (i < nA + nF + nT) {
         long k = i - nA - nF;
         int b = (int)(k >> 2), c = (int)(k & 3);
@@ -763,7 +804,7 @@ int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const
     hipLaunchKernelGGL(skin_bwd_v_kernel, dim3(m.Vpad / SKIN_BLK, psi_cdiv(B, SKIN_BT)), dim3(SKIN_BLK), 0, st, m, ws + L.A, grad_verts,
                        cam_ext, B, ws + L.gl, ws + L.g_vp, ws + L.gt_part);
     PSI_CHECK_LAUNCH("skin_bwd_v_kernel");
-    hipLaunchKernelGGL(skin_bwd_A_kernel, dim3(L.nsv, psi_cdiv(B, 4)), dim3(256), 0, st, m, ws + L.gl, ws + L.v_posed, B, ws + L.gA_part);
+    hipLaunchKernelGGL(skin_bwd_A_kernel, dim3(L.nsv, B), dim3(256), 0, st, m, ws + L.gl, ws + L.v_posed, B, ws + L.gA_part);
     PSI_CHECK_LAUNCH("skin_bwd_A_kernel");
     const int steps = 48;
     dim3 g(m.Kpad / 64, L.nsn, 1);
