@@ -308,6 +308,73 @@ def gen_chamfer_known_answer():
     save('chamfer_known_answer', p1=p1, p2=p2, mydist1=torch.min(P, 2)[0], mydist2=torch.min(P, 1)[0])
 
 
+def gen_training(data, vposer_sd):
+    """TrainOP.cal_loss of train_s1.py / train_s2.py (values + a few parameter gradients) on a synthetic batch."""
+    import human_body_prior.tools.model_loader as ML
+    ML.load_vposer = lambda *a, **k: (ref_vposer(vposer_sd), None)
+    h5 = types.ModuleType('h5py')
+    sys.modules['h5py'] = h5
+    torch.cuda.get_device_name = lambda *a, **k: 'cpu'
+    import train_s1 as TS1
+    import train_s2 as TS2
+    B, m_pts, n_c, D = 4, 2048, 256, 16
+    scene = synth.make_scene(seed=2, m=m_pts, D=D, n_contact=n_c)
+    inp = synth.make_cvae_inputs(13, B)
+    bodies = synth.make_bodies(17, B)
+    xh = synth.body_vector_72(bodies)
+    xh[:, 2] = np.abs(xh[:, 2]) + 2.0
+    cam_ext = synth.make_cam_ext(9, B)
+    cam_int = bodies['cam_int']
+    max_d = np.full(B, 6.0, np.float32)
+    out = {'xh': xh, 'cam_ext': cam_ext, 'cam_int': cam_int, 'max_d': max_d}
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = scene.write_prox_layout(tmp, 'S')
+        os.makedirs(os.path.join(tmp, 'smplx'))
+        np.savez(os.path.join(tmp, 'smplx', 'SMPLX_NEUTRAL.npz'), f=data.f)
+        cfg = {'human_model_path': tmp, 'vposer_ckpt_path': '', 'scene_model_ckpt': None, 'init_lr_h': 1e-4, 'batch_size': B,
+               'epoch': 100, 'loss_weight_anealing': True, 'device': torch.device('cpu'), 'save_dir': os.path.join(tmp, 'ckpt'),
+               'contact_id_folder': paths['contact_id_folder'], 'contact_part': synth.CONTACT_PARTS, 'verbose': False,
+               'use_cont_rot': True, 'resume_training': False}
+        lw = {'weight_loss_rec_s': 1.0, 'weight_loss_rec_h': 1.0, 'weight_loss_vposer': 1e-3, 'weight_loss_kl': 1e-1,
+              'weight_contact': 1e-1, 'weight_collision': 1e-1}
+        args = dict(xs=T(inp['xs']), xh=T(xh), cam_ext=T(cam_ext), cam_int=T(cam_int), max_d=T(max_d),
+                    scene_verts=T(scene.verts)[None].repeat(B, 1, 1), scene_face=None,
+                    s_grid_min_batch=T(scene.grid_min)[None].repeat(B, 1), s_grid_max_batch=T(scene.grid_max)[None].repeat(B, 1),
+                    s_grid_sdf_batch=T(scene.sdf)[None].repeat(B, 1, 1, 1))
+        for name, MOD, seed in (('s1', TS1, 0), ('s2', TS2, 1)):
+            orig = F.grid_sample
+            MOD.F.grid_sample = lambda *a, _o=orig, **k: _o(*a, align_corners=True, **k)
+            MOD.load_vposer = ML.load_vposer
+            try:
+                op = MOD.TrainOP(cfg, lw)
+                shapes = {k: tuple(v.shape) for k, v in op.model_h.state_dict().items()}
+                op.model_h.load_state_dict({k: torch.tensor(v) for k, v in synth.make_state_like(shapes, seed).items()})
+                op.model_h.train()
+                if name == 's1':
+                    op.model_h._sampler = lambda mu, lv: T(inp['eps32']) * torch.exp(0.5 * lv) + mu
+                else:
+                    op.model_h.trans_vae.sampler = lambda mu, lv: T(inp['eps32']) * torch.exp(0.5 * lv) + mu
+                    op.model_h.pose_vae.sampler = lambda mu, lv: T(inp['eps32b']) * torch.exp(0.5 * lv) + mu
+                for ep in (10, 90):                       # before / after the 0.75*epoch gate of the scene losses
+                    op.model_h.load_state_dict({k: torch.tensor(v) for k, v in synth.make_state_like(shapes, seed).items()})
+                    op.model_h.zero_grad()
+                    if name == 's1':
+                        losses = op.cal_loss(ep=ep, **args)
+                    else:
+                        losses = op.cal_loss(eps_g=None, eps_l=None, ep=ep, **args)
+                    sum(losses).backward()
+                    out['%s_ep%d_losses' % (name, ep)] = np.array([float(l) for l in losses], np.float32)
+                    sd = dict(op.model_h.named_parameters())
+                    keys = ['linear_out.weight', 'resnet.0.weight', 'mu_enc.bias'] if name == 's1' else \
+                        ['pose_vae.decode.3.weight', 'trans_vae.resnet.0.weight', 'trans_vae.decode.3.bias']
+                    for k in keys:
+                        g = sd[k].grad
+                        out['%s_ep%d_grad_%s' % (name, ep, k)] = g.numpy().copy() if g.numel() < 20000 else g.numpy().reshape(-1)[:20000].copy()
+            finally:
+                MOD.F.grid_sample = orig
+    save('training', B=B, m=m_pts, n_c=n_c, D=D, **out)
+
+
 SCENE_HOLDER = {}
 
 
@@ -335,6 +402,8 @@ def main(which):
         gen_chamfer_known_answer()
     if 'fitting' in which:
         gen_fitting(data, vsd)
+    if 'training' in which:
+        gen_training(data, vsd)
     if 'cvae' in which:
         import make_golden_cvae
         make_golden_cvae.gen(save)

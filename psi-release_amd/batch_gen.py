@@ -1,0 +1,133 @@
+"""Training data feed with the reference's batch contract.
+
+Reference: source/batch_gen_hdf5.py:33-265 (``BatchGeneratorWithSceneMesh``) and the HDF5 schema written by
+utils/utils_convert2hdf5.py:55-61 — datasets ``sceneid [N]``, ``depth``/``seg [N,1,128,128]``, ``body [N,72]``,
+``cam_ext [N,4,4]``, ``cam_int [N,3,3]``, ``max_d [N]`` with a placeholder row 0.  ``next_batch`` returns the same
+12 tensors in the same order (train_s1.py:258-262):
+    depth, seg, body, cam_ext, cam_int, max_d, s_verts [B,m,3], s_faces, s_grid_min [B,3], s_grid_max [B,3],
+    s_grid_dim [B], s_grid_sdf
+Kept behaviours: short last batch dropped (:198-199), ``sorted`` indices inside a batch (:201), batches with
+|z| > max_d skipped (:211-214), train/test scene split by name (:108-117), reshuffle on ``reset``.
+Changed: scene clouds / SDF volumes are uploaded ONCE and stay in HBM; the reference re-uploads
+67 MB x B per step (:222-257).  With ``indirect_sdf=True`` the last element is ``(sdf_table [S,D,D,D], scene_id [B], gmin_table [S,3], gmax_table [S,3])``
+instead of a dense [B,D,D,D] copy — ``TrainOP.cal_loss`` and ``ops.sdf_sample`` accept both.
+``s_faces`` is never read by any loss (train_s1.py:95-207) and is returned empty.
+Files: ``.hdf5`` needs ``h5py`` (not installed in this image -> clear error); ``.npz`` with the same dataset names works
+everywhere; ``from_arrays`` takes in-memory dicts (tests, bench).
+"""
+from __future__ import annotations
+
+import glob
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import scene_io
+
+PROX_SCENES = ['BasementSittingBooth', 'MPH1Library', 'MPH8', 'MPH11', 'MPH16', 'MPH112', 'N0SittingBooth', 'N0Sofa',
+               'N3Library', 'N3Office', 'N3OpenArea', 'Werkraum']                          # batch_gen_hdf5.py:103-105
+PROX_TRAIN = ['BasementSittingBooth', 'MPH8', 'MPH11', 'MPH112', 'N0Sofa', 'N3Library', 'N3Office', 'Werkraum']
+PROX_TEST = ['MPH16', 'MPH1Library', 'N0SittingBooth', 'N3OpenArea']
+_STREAMS = ('depth', 'seg', 'body', 'cam_ext', 'cam_int', 'max_d', 'sceneid')
+
+
+def _read_table(path):
+    if path.endswith('.npz'):
+        d = np.load(path)
+        return {k: d[k] for k in _STREAMS}
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError('reading %s needs h5py, which is not installed; convert the file to .npz with the same '
+                          'dataset names (depth, seg, body, cam_ext, cam_int, max_d, sceneid)' % path) from e
+    with h5py.File(path, 'r') as f:
+        return {k: f[k][...] for k in _STREAMS}
+
+
+class BatchGeneratorWithSceneMesh:
+    def __init__(self, dataset_path, device, scene_verts_path, scene_sdf_path, mode='train', read_all_to_ram=True,
+                 indirect_sdf=False, scene_name_list=None, scene_sub_list=None, _tables=None, _scenes=None):
+        self.device = torch.device(device)
+        self.index_rec = 0
+        self.indirect_sdf = indirect_sdf
+        self.scene_name_list = list(scene_name_list or PROX_SCENES)
+        # ---- sample streams (row 0 of every file is a placeholder: batch_gen_hdf5.py:61-67, :85)
+        if _tables is None:
+            paths = [dataset_path] if isinstance(dataset_path, str) else list(dataset_path)
+            _tables = [_read_table(p) for p in paths]
+        cat = {k: np.concatenate([np.asarray(t[k])[1:] for t in _tables], axis=0) for k in _STREAMS}
+        self.depth_stream, self.seg_stream, self.body_stream = cat['depth'], cat['seg'], cat['body']
+        self.cam_ext_stream, self.cam_int_stream = cat['cam_ext'], cat['cam_int']
+        self.max_d_stream, self.sceneid_stream = cat['max_d'], cat['sceneid']
+        n_all = self.depth_stream.shape[0]
+        if mode != 'all':
+            sub = scene_sub_list or (PROX_TRAIN if mode == 'train' else PROX_TEST)
+            sub_id = [self.scene_name_list.index(x) for x in sub if x in self.scene_name_list]
+            self.index = [i for i in range(n_all) if int(self.sceneid_stream[i]) in sub_id]
+            random.shuffle(self.index)
+        else:
+            self.index = list(range(n_all))
+        self.n_samples = len(self.index)
+        print('[INFO][BatchGeneratorWithSceneMesh] n_samples={:d}'.format(self.n_samples))
+        # ---- scenes: uploaded once
+        if _scenes is None:
+            _scenes = {}
+            for scenefile in sorted(glob.glob(os.path.join(scene_verts_path, '*'))):
+                name = os.path.basename(scenefile)[:-4]
+                sdf, gmin, gmax, dim = scene_io.read_sdf(os.path.join(scene_sdf_path, name))
+                _scenes[name] = {'verts': scene_io.read_ply_vertices(scenefile), 'sdf': sdf, 'grid_min': gmin,
+                                 'grid_max': gmax, 'grid_dim': dim}
+        self.scene_names = [n for n in self.scene_name_list if n in _scenes]
+        if not self.scene_names:
+            raise ValueError('no scene of scene_name_list found')
+        ms = {_scenes[n]['verts'].shape[0] for n in self.scene_names}
+        ds = {int(_scenes[n]['grid_dim']) for n in self.scene_names}
+        if len(ms) != 1 or len(ds) != 1:
+            raise ValueError('scenes must share the vertex count and SDF dim (the reference concatenates them: '
+                             'batch_gen_hdf5.py:252); got m=%s D=%s' % (sorted(ms), sorted(ds)))
+        t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=self.device)
+        self.slot_of_name = {n: i for i, n in enumerate(self.scene_names)}
+        self.verts_table = torch.stack([t(_scenes[n]['verts']) for n in self.scene_names])          # [S,m,3]
+        self.sdf_table = torch.stack([t(_scenes[n]['sdf']) for n in self.scene_names])              # [S,D,D,D]
+        self.gmin_table = torch.stack([t(_scenes[n]['grid_min']) for n in self.scene_names])        # [S,3]
+        self.gmax_table = torch.stack([t(_scenes[n]['grid_max']) for n in self.scene_names])
+        self.gdim_table = torch.tensor([float(_scenes[n]['grid_dim']) for n in self.scene_names], device=self.device)
+
+    @classmethod
+    def from_arrays(cls, table: dict, scenes: dict, device, mode='all', **kw):
+        """table: {stream: array with placeholder row 0}; scenes: {name: {'verts','sdf','grid_min','grid_max','grid_dim'}}."""
+        return cls(None, device, None, None, mode=mode, _tables=[table], _scenes=scenes,
+                   scene_name_list=kw.pop('scene_name_list', list(scenes.keys())), **kw)
+
+    def reset(self):
+        self.index_rec = 0
+        random.shuffle(self.index)
+        self.n_samples = len(self.index)
+        print('[INFO][BatchGeneratorWithSceneMesh] reset dataset')
+
+    def has_next_batch(self):
+        return self.index_rec < self.n_samples
+
+    def next_batch(self, batch_size):
+        lb = self.index_rec
+        ub = min(self.index_rec + batch_size, self.n_samples)
+        self.index_rec += batch_size
+        if ub - lb < batch_size:
+            return None
+        idx_ = sorted(self.index[lb:ub])
+        t = lambda a: torch.tensor(a[idx_], dtype=torch.float32, device=self.device)
+        depth, seg, body = t(self.depth_stream), t(self.seg_stream), t(self.body_stream)
+        cam_ext, cam_int, max_d = t(self.cam_ext_stream), t(self.cam_int_stream), t(self.max_d_stream)
+        if np.abs(self.body_stream[idx_][:, 2]).max() > np.abs(self.max_d_stream[idx_]).max():
+            print('[INFO][BatchGeneratorWithSceneMesh] encounter wrong prox fitting')
+            return None
+        names = [self.scene_name_list[int(i)] for i in self.sceneid_stream[idx_]]
+        slot = torch.tensor([self.slot_of_name[n] for n in names], dtype=torch.long, device=self.device)
+        s_verts = self.verts_table[slot]                                      # device gather, [B,m,3]
+        s_faces = torch.empty(batch_size, 0, 3, 3, device=self.device)
+        sdf = ((self.sdf_table, slot.to(torch.int32), self.gmin_table, self.gmax_table) if self.indirect_sdf
+               else self.sdf_table[slot])
+        return [depth, seg, body, cam_ext, cam_int, max_d, s_verts, s_faces, self.gmin_table[slot], self.gmax_table[slot],
+                self.gdim_table[slot], sdf]

@@ -1,0 +1,224 @@
+"""Conditional VAEs of PSI with the reference's checkpoint (state_dict) layout.
+
+* ``HumanCVAES1``  <- source/cvae.py:411-534   (one-stage: global translation + local pose sampled together)
+* ``HumanCVAES2``  <- source/cvae.py:341-400 = ``BodyGlobalPoseVAE`` + ``BodyLocalPoseVAE`` (source/net_layers.py:47-234)
+* ``ResBlock``     <- source/net_layers.py:28-43
+* scene encoder: ``Conv2d(2,64,7,2,3,bias=False)`` + ``children()[1:6]`` of torchvision 0.4.0 ``resnet18`` (bn1, relu,
+  maxpool, layer1, layer2; cvae.py:427-435).  torchvision is a third-party package that is neither in the reference
+  tree nor installed, so the BasicBlock stack is restated here with the SAME attribute names — the state_dict keys
+  (``resnet.0.weight``, ``resnet.4.0.conv1.weight``, ``resnet.5.0.downsample.0.weight`` ...) and shapes are those of
+  SURVEY.md Appendix B, so reference checkpoints (``epoch-*.ckp`` -> ``model_h_state_dict``) load with strict=True.
+
+These are genuine contractions (conv / linear): they run on the matrix cores through PyTorch-ROCm (MIOpen / hipBLASLt);
+``autocast_bf16=True`` wraps the trunk in bf16 autocast (losses stay fp32).  Differences from the reference that do not
+change arithmetic: the reparameterisation noise is drawn on the model's device (the reference draws it with the CPU
+generator and copies it, net_layers.py:88-92) and can be injected (``eps=``) for reproducible tests.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+
+class ResBlock(nn.Module):
+    def __init__(self, n_dim):
+        super().__init__()
+        self.n_dim = n_dim
+        self.fc1 = nn.Linear(n_dim, n_dim)
+        self.fc2 = nn.Linear(n_dim, n_dim)
+        self.acfun = nn.LeakyReLU()
+
+    def forward(self, x0):
+        x = self.acfun(self.fc1(x0))
+        x = self.acfun(self.fc2(x))
+        return x + x0
+
+
+class _BasicBlock(nn.Module):
+    """ResNet BasicBlock with torchvision's attribute names (conv1, bn1, relu, conv2, bn2, downsample)."""
+
+    def __init__(self, inplanes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != planes:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + identity)
+
+
+def scene_trunk(in_dim=2):
+    """``nn.Sequential(Conv2d(in_dim,64,7,2,3,bias=False), bn1, relu, maxpool, layer1, layer2)`` -> [B,128,16,16] for 128x128 input."""
+    return nn.Sequential(
+        nn.Conv2d(in_dim, 64, kernel_size=7, stride=2, padding=3, bias=False),
+        nn.BatchNorm2d(64),
+        nn.ReLU(inplace=True),
+        nn.MaxPool2d(kernel_size=3, stride=2, padding=1),
+        nn.Sequential(_BasicBlock(64, 64), _BasicBlock(64, 64)),
+        nn.Sequential(_BasicBlock(64, 128, 2), _BasicBlock(128, 128)))
+
+
+def load_pretrained_resnet18(trunk, ckpt_path):
+    """``data/resnet18.pth`` (a missing blob in the reference tree): torchvision resnet18 state_dict -> trunk children 1..5."""
+    sd = torch.load(ckpt_path, map_location='cpu')
+    remap = {'bn1.': '1.', 'layer1.': '4.', 'layer2.': '5.'}
+    own = trunk.state_dict()
+    for k, v in sd.items():
+        for src, dst in remap.items():
+            if k.startswith(src) and dst + k[len(src):] in own:
+                own[dst + k[len(src):]] = v
+    trunk.load_state_dict(own)
+
+
+def _reparam(mu, logvar, eps=None):
+    std = torch.exp(0.5 * logvar)
+    if eps is None:
+        eps = torch.randn_like(std)
+    return eps * std + mu
+
+
+class _SceneCond(nn.Module):
+    """Shared shape of the three scene-conditioned VAEs: trunk -> conv -> fc."""
+
+    def _scene_feature(self, scene):
+        b = scene.size(0)
+        if getattr(self, 'autocast_bf16', False) and scene.is_cuda:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                f = self.conv(self.resnet(scene))
+                return self.fc(f.reshape(b, -1)).float()
+        f = self.conv(self.resnet(scene))
+        return self.fc(f.reshape(b, -1))
+
+
+class BodyGlobalPoseVAE(_SceneCond):
+    """net_layers.py:47-134: global translation (3-D) conditioned on the scene."""
+
+    def __init__(self, zdim, num_hidden=512, f_dim=32, test=False, in_dim=3, pretrained_resnet=None):
+        super().__init__()
+        self.test, self.zdim = test, zdim
+        self.resnet = scene_trunk(in_dim)
+        if pretrained_resnet is not None:
+            load_pretrained_resnet18(self.resnet, pretrained_resnet)
+        self.conv = nn.Conv2d(128, f_dim, 3, 1, 1)
+        self.fc = nn.Linear(f_dim * 16 * 16, num_hidden)
+        self.torso_linear = nn.Linear(3, num_hidden)
+        self.encode = nn.Sequential(ResBlock(2 * num_hidden), ResBlock(2 * num_hidden))
+        self.mean_linear = nn.Linear(2 * num_hidden, zdim)
+        self.log_var_linear = nn.Linear(2 * num_hidden, zdim)
+        self.decode = nn.Sequential(nn.Linear(num_hidden + zdim, f_dim), ResBlock(f_dim), ResBlock(f_dim), nn.Linear(f_dim, 3))
+
+    def forward(self, scene, torso=None, eps=None):
+        z_s = self._scene_feature(scene)
+        if self.test:
+            z = torch.randn(scene.size(0), self.zdim, device=scene.device) if eps is None else eps
+            return self.decode(torch.cat([z, z_s], dim=1))
+        feature = self.encode(torch.cat((z_s, self.torso_linear(torso)), dim=1))            # net_layers.py:118
+        mean, log_var = self.mean_linear(feature), self.log_var_linear(feature)
+        z = _reparam(mean, log_var, eps)
+        return self.decode(torch.cat([z, z_s], dim=1)), mean, log_var                       # net_layers.py:131
+
+
+class BodyLocalPoseVAE(_SceneCond):
+    """net_layers.py:144-234: the remaining 72 dims conditioned on scene and (reconstructed) translation."""
+
+    def __init__(self, zdim, num_hidden=512, f_dim=128, test=False, in_dim=3, pretrained_resnet=None):
+        super().__init__()
+        self.test, self.zdim = test, zdim
+        self.resnet = scene_trunk(in_dim)
+        if pretrained_resnet is not None:
+            load_pretrained_resnet18(self.resnet, pretrained_resnet)
+        self.conv = nn.Conv2d(128, f_dim, 3, 1, 1)
+        self.fc = nn.Linear(f_dim * 16 * 16, num_hidden)
+        self.torso_linear = nn.Linear(3, num_hidden)
+        self.pose_linear = nn.Linear(72, num_hidden)
+        self.encode = nn.Sequential(ResBlock(3 * num_hidden), ResBlock(3 * num_hidden))
+        self.mean_linear = nn.Linear(3 * num_hidden, zdim)
+        self.log_var_linear = nn.Linear(3 * num_hidden, zdim)
+        self.decode = nn.Sequential(nn.Linear(2 * num_hidden + zdim, f_dim), ResBlock(f_dim), ResBlock(f_dim), nn.Linear(f_dim, 72))
+
+    def forward(self, scene, torso=None, pose=None, eps=None):
+        z_s = self._scene_feature(scene)
+        z_g = self.torso_linear(torso)
+        if self.test:
+            z = torch.randn(scene.size(0), self.zdim, device=scene.device) if eps is None else eps
+            return self.decode(torch.cat([z, z_g, z_s], dim=1))
+        feature = self.encode(torch.cat([self.pose_linear(pose), z_g, z_s], dim=1))         # net_layers.py:220
+        mean, log_var = self.mean_linear(feature), self.log_var_linear(feature)
+        z = _reparam(mean, log_var, eps)
+        return self.decode(torch.cat([z, z_g, z_s], dim=1)), mean, log_var                  # net_layers.py:231
+
+
+class HumanCVAES2(nn.Module):
+    """cvae.py:341-400.  ``eps_g`` / ``eps_l`` of the reference signature are unused there (cvae.py:369-385); here they are
+    honoured only when ``use_eps=True`` (tests), otherwise noise is drawn internally like the reference does."""
+
+    def __init__(self, latentD_g=512, latentD_l=512, scene_model_ckpt=None, n_dim_body=72, n_dim_scene=128, test=False,
+                 autocast_bf16=False):
+        super().__init__()
+        self.latentD_g, self.latentD_l = latentD_g, latentD_l
+        self.n_dim_g, self.n_dim_l = 3, n_dim_body - 3
+        self.trans_vae = BodyGlobalPoseVAE(zdim=32, in_dim=2, num_hidden=latentD_g, pretrained_resnet=scene_model_ckpt, test=test)
+        self.pose_vae = BodyLocalPoseVAE(zdim=32, in_dim=2, num_hidden=latentD_g, pretrained_resnet=scene_model_ckpt, test=test)
+        self.trans_vae.autocast_bf16 = self.pose_vae.autocast_bf16 = autocast_bf16
+
+    def forward(self, x_body, eps_g, eps_l, x_s, use_eps=False):
+        x_g, x_l = x_body[:, :3], x_body[:, 3:]
+        x_g_rec, mu_g, lv_g = self.trans_vae(x_s, x_g, eps=eps_g if use_eps else None)
+        x_l_rec, mu_l, lv_l = self.pose_vae(x_s, x_g_rec, x_l, eps=eps_l if use_eps else None)
+        return torch.cat([x_g_rec, x_l_rec], dim=1), mu_g, lv_g, mu_l, lv_l
+
+    def sample(self, x_s, eps_g=None, eps_l=None, use_eps=False):
+        x_g = self.trans_vae(x_s, eps=eps_g if use_eps else None)
+        x_l = self.pose_vae(x_s, x_g, eps=eps_l if use_eps else None)
+        return torch.cat([x_g, x_l], dim=1)
+
+
+class HumanCVAES1(_SceneCond):
+    """cvae.py:411-534."""
+
+    def __init__(self, latentD=512, n_dim_body=75, scene_model_ckpt=None, test=False, autocast_bf16=False):
+        super().__init__()
+        self.test, self.eps_d, self.autocast_bf16 = test, 32, autocast_bf16
+        self.resnet = scene_trunk(2)
+        if scene_model_ckpt is not None:
+            print('[INFO][SceneNet] Using pretrained resnet18 weights.')
+            load_pretrained_resnet18(self.resnet, scene_model_ckpt)
+        self.conv = nn.Conv2d(128, 32, 3, 1, 1)
+        self.fc = nn.Linear(32 * 16 * 16, latentD)
+        self.linear_in = nn.Linear(n_dim_body, latentD)
+        self.human_encoder = nn.Sequential(ResBlock(2 * latentD), ResBlock(2 * latentD))
+        self.mu_enc = nn.Linear(2 * latentD, self.eps_d)
+        self.logvar_enc = nn.Linear(2 * latentD, self.eps_d)
+        self.linear_latent = nn.Linear(self.eps_d, latentD)
+        self.human_decoder = nn.Sequential(ResBlock(2 * latentD), ResBlock(2 * latentD))
+        self.linear_out = nn.Linear(2 * latentD, n_dim_body)
+
+    def forward(self, x_body, x_s, eps=None):
+        z_s = self._scene_feature(x_s)
+        z_hs = self.human_encoder(torch.cat([self.linear_in(x_body), z_s], dim=1))         # cvae.py:480
+        mu, logvar = self.mu_enc(z_hs), self.logvar_enc(z_hs)
+        z_h = self.linear_latent(_reparam(mu, logvar, eps))
+        return self.linear_out(self.human_decoder(torch.cat([z_h, z_s], dim=1))), mu, logvar   # cvae.py:488
+
+    def _decode_latent(self, x_s, eps):
+        z_s = self._scene_feature(x_s)
+        return self.linear_out(self.human_decoder(torch.cat([self.linear_latent(eps), z_s], dim=1)))
+
+    def sample(self, x_s, eps=None, **kwargs):
+        if eps is None:
+            eps = torch.randn(x_s.shape[0], self.eps_d, dtype=torch.float32, device=x_s.device)
+        return self._decode_latent(x_s, eps)
+
+    def sample_line(self, x_s, **kwargs):
+        """cvae.py:516-534: latent swept along the diagonal from -3 to 3."""
+        b_ = x_s.shape[0]
+        eps = torch.arange(-3, 3, 6.0 / b_, dtype=torch.float32, device=x_s.device)[:b_].unsqueeze(1).repeat(1, self.eps_d)
+        return self._decode_latent(x_s, eps), eps

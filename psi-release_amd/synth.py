@@ -203,3 +203,38 @@ def body_vector_72(bodies: dict) -> np.ndarray:
 
 
 from .scene_io import read_ply_vertices, write_ply_vertices  # noqa: E402,F401
+
+
+def make_state_like(shapes: dict, seed: int = 0) -> dict:
+    """Synthetic state_dict for a module given {key: shape}: per-key generators (order independent), nn-style scales.
+
+    Used for the CVAE models, whose pretrained weights (``data/resnet18.pth``, PSI checkpoints) are licensed / missing."""
+    import zlib
+    out = {}
+    for key, shape in shapes.items():
+        rs = np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7fffffff)
+        shape = tuple(shape)
+        if key.endswith('num_batches_tracked'):
+            out[key] = np.zeros(shape, np.int64)
+        elif key.endswith('running_var'):
+            out[key] = _f32(rs.uniform(0.5, 1.5, shape))
+        elif key.endswith('running_mean'):
+            out[key] = _f32(rs.standard_normal(shape) * 0.1)
+        elif len(shape) == 1 and ('bn' in key or '.1.weight' in key or 'downsample.1' in key) and key.endswith('weight'):
+            out[key] = _f32(rs.uniform(0.5, 1.5, shape))
+        elif len(shape) == 1:
+            out[key] = _f32(rs.uniform(-0.05, 0.05, shape))
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            k = 1.0 / np.sqrt(fan_in)
+            out[key] = _f32(rs.uniform(-k, k, shape))
+    return out
+
+
+def make_cvae_inputs(seed: int = 13, B: int = 4) -> dict:
+    """Scene images (depth | semantics in [-1,1], [B,2,128,128]), body vectors and reparameterisation noise."""
+    rs = np.random.RandomState(seed)
+    return {'xs': _f32(rs.uniform(-1, 1, (B, 2, 128, 128))),
+            'x75': _f32(rs.standard_normal((B, 75)) * 0.5),
+            'eps32': _f32(rs.standard_normal((B, 32))),
+            'eps32b': _f32(rs.standard_normal((B, 32)))}

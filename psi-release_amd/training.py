@@ -1,0 +1,240 @@
+"""CVAE training with the scene losses: ``TrainOP`` for stage-1 and stage-2 models, reference config keys and flags.
+
+Reference: source/train_s1.py:37-338 (HumanCVAES1, one KL term) and source/train_s2.py:37-340 (HumanCVAES2, two KL terms).
+Same ``trainconfig`` / ``lossconfig`` keys, same ``cal_loss`` signatures and return order, same checkpoint schema
+``{'epoch', 'model_h_state_dict', 'optimizer_h_state_dict'}`` in ``{save_dir}/epoch-{ep+1:06d}.ckp`` every 10 epochs and
+every 2 h of wall clock, resume from the newest ``epoch-*.ckp`` by mtime (train_s1.py:220-233,303-321), same verbose
+lines.  The body / Chamfer / SDF sub-stack is the HIP operator set (ops.py, body_model.py); the CVAE trunk is PyTorch
+(MIOpen / hipBLASLt matrix-core path, optional bf16 autocast).  GPU only.
+
+Data parallel (new; the reference is single-GPU): wrap-free — gradients of the model parameters are all-reduced
+(averaged) across ranks after ``backward`` in one flattened bucket per dtype; the scene-loss normalisers follow the
+per-rank batch like the reference's single process (documented difference: the penetration mean is per rank).
+"""
+from __future__ import annotations
+
+import glob
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+
+from . import body_model, dist as psi_dist, ops
+from .geometry import BodyParamParser, GeometryTransformer
+from .models import HumanCVAES1, HumanCVAES2
+from .vposer import load_vposer
+
+
+class _TrainBase:
+    stage = None
+
+    def __init__(self, trainconfig, lossconfig):
+        self.align_corners = True
+        self.autocast_bf16 = False
+        self.resume_training = False
+        self.loss_weight_anealing = True
+        self.use_cont_rot = True
+        self.verbose = False
+        self.scene_model_ckpt = None
+        for key, val in trainconfig.items():
+            setattr(self, key, val)
+        for key, val in lossconfig.items():
+            setattr(self, key, val)
+        self.device = torch.device(self.device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('TrainOP runs on the GPU (HIP operators); there is no CPU path')
+        if not os.path.exists(self.save_dir):
+            os.makedirs(self.save_dir)
+        n_dim_body = 72 + 3 if self.use_cont_rot else 72
+        self.model_h_latentD = 256
+        self.model_h = self._make_model(n_dim_body)
+        self.optimizer_h = optim.Adam(self.model_h.parameters(), lr=self.init_lr_h)
+        vposer_src = getattr(self, 'vposer_state', None) or self.vposer_ckpt_path
+        self.vposer, _ = load_vposer(vposer_src, vp_model='snapshot')
+        self.vposer.to(self.device)
+        smplx_src = getattr(self, 'smplx_data', None) or self.human_model_path
+        self.body_mesh_model = body_model.create(smplx_src, model_type='smplx', gender='neutral', ext='npz', num_pca_comps=12,
+                                                 batch_size=self.batch_size, device=self.device)
+        self._vid = None
+        self._contact_parts = getattr(self, 'contact_parts_data', None)
+        self._chamfer = ops.chamferDist(one_sided=True)
+        print('--[INFO] device: ' + str(torch.cuda.get_device_name(self.device)))
+
+    # -------------------------------------------------------------------------------------
+    def _contact_ids(self):
+        if self._vid is None:
+            if self._contact_parts is not None:
+                vid = np.concatenate([list(set(self._contact_parts[p]['verts_ind'])) for p in self.contact_part])
+            else:
+                vid, _ = GeometryTransformer.get_contact_id(body_segments_folder=self.contact_id_folder,
+                                                            contact_body_parts=self.contact_part)
+            self._vid = torch.tensor(np.asarray(vid).astype(np.int64), device=self.device)
+        return self._vid
+
+    def _scene_losses(self, xh_rec, cam_ext, scene_verts, s_grid_min_batch, s_grid_max_batch, s_grid_sdf_batch, ep):
+        """Shared tail of cal_loss: VPoser prior, contact (const 1.0) and penetration terms (train_s1.py:136-205)."""
+        loss_vposer = self.weight_loss_vposer * torch.mean(xh_rec[:, 16:48] ** 2)
+        body_param_rec = BodyParamParser.body_params_encapsulate_batch(xh_rec)
+        joint_rot_batch = self.vposer.decode(body_param_rec['body_pose_vp'], output_type='aa').view(xh_rec.shape[0], -1)
+        body_param_ = {k: v for k, v in body_param_rec.items() if k != 'body_pose_vp'}
+        body_verts_batch = self.body_mesh_model(return_verts=True, body_pose=joint_rot_batch, cam_ext=cam_ext, **body_param_).vertices
+        body_verts_contact_batch = body_verts_batch[:, self._contact_ids(), :]
+        contact_dist, _ = self._chamfer(body_verts_contact_batch.contiguous(), scene_verts.contiguous())
+        gate = 1.0 if ep > 0.75 * self.epoch else 0.0                           # train_s1.py:171-173,197-199
+        s = torch.sqrt(contact_dist + 1e-4)
+        loss_contact = gate * self.weight_contact * torch.mean(s / (s + 1.0))
+        if isinstance(s_grid_sdf_batch, tuple):                                 # (sdf_table, scene_id, gmin_table, gmax_table)
+            sdf_t, sid, gmin_t, gmax_t = s_grid_sdf_batch
+            body_sdf = ops.sdf_sample(body_verts_batch, sdf_t, gmin_t, gmax_t, scene_id=sid, align_corners=self.align_corners)
+        else:                                                                   # reference contract: dense [B,D,D,D]
+            sid = torch.arange(s_grid_sdf_batch.shape[0], dtype=torch.int32, device=self.device)
+            body_sdf = ops.sdf_sample(body_verts_batch, s_grid_sdf_batch, s_grid_min_batch, s_grid_max_batch, scene_id=sid,
+                                      align_corners=self.align_corners)
+        loss_sdf_pene = gate * self.weight_collision * ops.penetration_loss(body_sdf)
+        return loss_contact, loss_vposer, loss_sdf_pene
+
+    def _kl(self, mu, logsigma2, ep):
+        fca = 1.0
+        if self.loss_weight_anealing:
+            fca = min(1.0, max(float(ep) / (self.epoch * 0.75), 0))
+        return fca ** 2 * self.weight_loss_kl * 0.5 * torch.mean(torch.exp(logsigma2) + mu ** 2 - 1.0 - logsigma2)
+
+    # -------------------------------------------------------------------------------------
+    def _resume(self):
+        starting_ep = 0
+        if self.resume_training:
+            ckp_list = sorted(glob.glob(os.path.join(self.save_dir, 'epoch-*.ckp')), key=os.path.getmtime)
+            if len(ckp_list) > 0:
+                checkpoint = torch.load(ckp_list[-1], map_location=self.device)
+                self.model_h.load_state_dict(checkpoint['model_h_state_dict'])
+                self.optimizer_h.load_state_dict(checkpoint['optimizer_h_state_dict'])
+                starting_ep = checkpoint['epoch']
+                print('[INFO] --resuming training from {}'.format(ckp_list[-1]))
+        return starting_ep
+
+    def _save(self, ep):
+        if psi_dist.rank() != 0:
+            return
+        torch.save({'epoch': ep + 1, 'model_h_state_dict': self.model_h.state_dict(),
+                    'optimizer_h_state_dict': self.optimizer_h.state_dict()},
+                   self.save_dir + "/epoch-{:06d}".format(ep + 1) + ".ckp")
+
+    def _allreduce_grads(self):
+        """One flattened all-reduce of the model gradients per step (RCCL picks direct reduce-scatter/all-gather on xGMI)."""
+        if not psi_dist.is_dist():
+            return
+        import torch.distributed as tdist
+        grads = [p.grad for p in self.model_h.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        tdist.all_reduce(flat, op=tdist.ReduceOp.SUM)
+        flat /= psi_dist.world_size()
+        o = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[o:o + n].view_as(g))
+            o += n
+
+    def train_step(self, train_data, ep):
+        """One optimiser step on one batch (the body of the ``while batch_gen.has_next_batch()`` loop)."""
+        self.optimizer_h.zero_grad()
+        losses = self._losses_from_batch(train_data, ep)
+        loss_h = sum(losses)
+        loss_h.backward()
+        self._allreduce_grads()
+        self.optimizer_h.step()
+        return losses
+
+    def train(self, batch_gen):
+        self.model_h.train()
+        self.model_h.to(self.device)
+        self.vposer.to(self.device)
+        starting_ep = self._resume()
+        print('--[INFO] start training')
+        start_time = time.time()
+        for ep in range(starting_ep, self.epoch):
+            while batch_gen.has_next_batch():
+                train_data = batch_gen.next_batch(self.batch_size)
+                if train_data is None:
+                    continue
+                losses = self.train_step(train_data, ep)
+                if self.verbose:
+                    print(self._format(ep, losses))
+                if (time.time() - start_time) / 3600.0 >= 2:
+                    start_time = time.time()
+                    self._save(ep)
+            batch_gen.reset()
+            if (ep + 1) % 10 == 0:
+                self._save(ep)
+        if self.verbose:
+            print('[INFO]: Training completes!')
+            print()
+
+
+class TrainOP(_TrainBase):
+    """Stage-1 trainer, train_s1.py:37-338.  ``cal_loss`` returns [rec_t, rec_p, KL, contact, vposer, sdf_pene]."""
+    stage = 's1'
+
+    def _make_model(self, n_dim_body):
+        return HumanCVAES1(latentD=self.model_h_latentD, scene_model_ckpt=self.scene_model_ckpt, n_dim_body=n_dim_body,
+                           autocast_bf16=self.autocast_bf16).to(self.device)
+
+    def cal_loss(self, xs, xh, cam_ext, cam_int, max_d, scene_verts, scene_face, s_grid_min_batch, s_grid_max_batch,
+                 s_grid_sdf_batch, ep, eps=None):
+        xhn = GeometryTransformer.normalize_global_T(xh, cam_int, max_d)
+        xhnr = GeometryTransformer.convert_to_6D_rot(xhn)
+        xhnr_rec, mu, logsigma2 = self.model_h(xhnr, xs, eps=eps)
+        xhn_rec = GeometryTransformer.convert_to_3D_rot(xhnr_rec)
+        xh_rec = GeometryTransformer.recover_global_T(xhn_rec, cam_int, max_d)
+        loss_rec_t = self.weight_loss_rec_h * (0.5 * F.l1_loss(xhnr_rec[:, :3], xhnr[:, :3]) + 0.5 * F.l1_loss(xh_rec[:, :3], xh[:, :3]))
+        loss_rec_p = self.weight_loss_rec_h * F.l1_loss(xhnr_rec[:, 3:], xhnr[:, 3:])
+        loss_KL = self._kl(mu, logsigma2, ep)
+        loss_contact, loss_vposer, loss_sdf_pene = self._scene_losses(xh_rec, cam_ext, scene_verts, s_grid_min_batch,
+                                                                      s_grid_max_batch, s_grid_sdf_batch, ep)
+        return [loss_rec_t, loss_rec_p, loss_KL, loss_contact, loss_vposer, loss_sdf_pene]
+
+    def _losses_from_batch(self, d, ep):
+        return self.cal_loss(xs=torch.cat([d[0], d[1]], dim=1), xh=d[2], cam_ext=d[3], cam_int=d[4], max_d=d[5],
+                             scene_verts=d[6], scene_face=d[7], s_grid_min_batch=d[8], s_grid_max_batch=d[9],
+                             s_grid_sdf_batch=d[11], ep=ep)
+
+    def _format(self, ep, l):
+        return "---in [epoch {:d}]: rec_t={:f}, rec_p={:f}, kl={:f}, vp={:f}, contact={:f}, collision={:f}".format(
+            ep + 1, l[0].item(), l[1].item(), l[2].item(), l[4].item(), l[3].item(), l[5].item())
+
+
+class TrainOPS2(_TrainBase):
+    """Stage-2 trainer, train_s2.py:37-340.  ``cal_loss`` returns (rec_t, rec_p, KL_g, KL_l, contact, vposer, sdf_pene)."""
+    stage = 's2'
+
+    def _make_model(self, n_dim_body):
+        return HumanCVAES2(latentD_g=self.model_h_latentD, latentD_l=self.model_h_latentD, scene_model_ckpt=self.scene_model_ckpt,
+                           n_dim_body=n_dim_body, autocast_bf16=self.autocast_bf16).to(self.device)
+
+    def cal_loss(self, xs, xh, eps_g, eps_l, cam_ext, cam_int, max_d, scene_verts, scene_face, s_grid_min_batch,
+                 s_grid_max_batch, s_grid_sdf_batch, ep, use_eps=False):
+        xhn = GeometryTransformer.normalize_global_T(xh, cam_int, max_d)
+        xhnr = GeometryTransformer.convert_to_6D_rot(xhn)
+        xhnr_rec, mu_g, lv_g, mu_l, lv_l = self.model_h(xhnr, eps_g, eps_l, xs, use_eps=use_eps)
+        xhn_rec = GeometryTransformer.convert_to_3D_rot(xhnr_rec)
+        xh_rec = GeometryTransformer.recover_global_T(xhn_rec, cam_int, max_d)
+        loss_rec_t = self.weight_loss_rec_h * (0.5 * F.l1_loss(xhnr_rec[:, :3], xhnr[:, :3]) + 0.5 * F.l1_loss(xh_rec[:, :3], xh[:, :3]))
+        loss_rec_p = self.weight_loss_rec_h * F.l1_loss(xhnr_rec[:, 3:], xhnr[:, 3:])
+        loss_KL_g, loss_KL_l = self._kl(mu_g, lv_g, ep), self._kl(mu_l, lv_l, ep)
+        loss_contact, loss_vposer, loss_sdf_pene = self._scene_losses(xh_rec, cam_ext, scene_verts, s_grid_min_batch,
+                                                                      s_grid_max_batch, s_grid_sdf_batch, ep)
+        return loss_rec_t, loss_rec_p, loss_KL_g, loss_KL_l, loss_contact, loss_vposer, loss_sdf_pene
+
+    def _losses_from_batch(self, d, ep):
+        B = d[2].shape[0]
+        noise_l = torch.randn([B, self.model_h_latentD], dtype=torch.float32, device=self.device)   # train_s2.py:262-267 (unused by the model)
+        noise_g = torch.randn([B, self.model_h_latentD], dtype=torch.float32, device=self.device)
+        return self.cal_loss(xs=torch.cat([d[0], d[1]], dim=1), xh=d[2], eps_g=noise_g, eps_l=noise_l, cam_ext=d[3], cam_int=d[4],
+                             max_d=d[5], scene_verts=d[6], scene_face=d[7], s_grid_min_batch=d[8], s_grid_max_batch=d[9],
+                             s_grid_sdf_batch=d[11], ep=ep)
+
+    def _format(self, ep, l):
+        return "---in [epoch {:d}]: rec_t={:f}, rec_p={:f}, kl_g={:f}, kl_l={:f}, vp={:f}, contact={:f}, collision={:f}".format(
+            ep + 1, l[0].item(), l[1].item(), l[2].item(), l[3].item(), l[5].item(), l[4].item(), l[6].item())
