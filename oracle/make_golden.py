@@ -375,6 +375,26 @@ def gen_training(data, vposer_sd):
     save('training', B=B, m=m_pts, n_c=n_c, D=D, **out)
 
 
+def gen_preproc():
+    """TestOP.data_preprocessing of test_habitat_s2.py:75-149 (wide and tall images, both modalities)."""
+    h5 = types.ModuleType('h5py')
+    sys.modules.setdefault('h5py', h5)
+    import test_habitat_s2 as TH
+    me = types.SimpleNamespace(device=torch.device('cpu'))
+    rs = np.random.RandomState(77)
+    out = {}
+    for tag, (H, W) in (('wide', (96, 160)), ('tall', (150, 90)), ('square', (64, 64))):
+        depth = (rs.uniform(0.3, 9.0, (H, W))).astype(np.float32)
+        seg = rs.randint(0, 60, (H, W)).astype(np.float32)
+        out[tag + '_depth_in'], out[tag + '_seg_in'] = depth, seg
+        for mod, arr in (('depth', depth), ('seg', seg)):
+            c, f, mx = TH.TestOP.data_preprocessing(me, T(arr.copy()), mod, target_domain_size=[128, 128])
+            out['%s_%s_canvas' % (tag, mod)] = c.numpy()
+            out['%s_%s_factor' % (tag, mod)] = np.float32(f)
+            out['%s_%s_max' % (tag, mod)] = np.float32(mx)
+    save('preproc', **out)
+
+
 SCENE_HOLDER = {}
 
 
@@ -402,6 +422,8 @@ def main(which):
         gen_chamfer_known_answer()
     if 'fitting' in which:
         gen_fitting(data, vsd)
+    if 'preproc' in which:
+        gen_preproc()
     if 'training' in which:
         gen_training(data, vsd)
     if 'cvae' in which:

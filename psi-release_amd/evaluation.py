@@ -1,0 +1,53 @@
+"""Physical-plausibility metrics of generated / fitted bodies.
+
+Reference: utils/utils_eval_collision_habitat.py:91-175 — per body: ``non-collision score`` = #(sdf > 0) / 10475 and
+``contact score`` = 1 if any vertex has sdf < 0 else 0 (with the all-outside convention: collision 1.0, contact 0).
+Same SMPL-X + SDF path as fitting (HIP operators), Habitat camera flip (:160-165).
+"""
+from __future__ import annotations
+
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import ops
+from .geometry import BodyParamParser, GeometryTransformer
+
+
+class PlausibilityEvaluator:
+    def __init__(self, fitting_op, flip_camera_yz=True):
+        """``fitting_op``: a FittingOP (supplies vposer, body model, scene SDF on the GPU)."""
+        self.op = fitting_op
+        self.flip = flip_camera_yz
+
+    @torch.no_grad()
+    def scores(self, body_param_input):
+        op = self.op
+        xh, cam_ext, _ = BodyParamParser.body_params_parse_fitting(body_param_input)
+        B = xh.shape[0]
+        cam = cam_ext
+        if self.flip:
+            T_mat = torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0], device=op.device)).unsqueeze(0)
+            cam = torch.matmul(cam_ext[:1], T_mat).expand(B, -1, -1).contiguous()
+        xh_rec = GeometryTransformer.convert_to_3D_rot(GeometryTransformer.convert_to_6D_rot(xh))
+        verts = op.body_verts(xh_rec, cam)
+        sdf = ops.sdf_sample(verts, op.s_sdf, op.s_grid_min_batch, op.s_grid_max_batch, align_corners=op.align_corners)
+        V = verts.shape[1]
+        n_neg = (sdf < 0).sum()
+        if int(n_neg) < 1:                                  # utils_eval_collision_habitat.py:131-135
+            return 1.0, 0.0
+        return float((sdf > 0).sum()) / float(V * B), 1.0
+
+    def eval_folder(self, folder, max_files=8000):
+        coll, cont = [], []
+        for ii in range(max_files):
+            fn = os.path.join(folder, 'body_gen_{:06d}.pkl'.format(ii))
+            if not os.path.exists(fn):
+                continue
+            with open(fn, 'rb') as f:
+                c, k = self.scores(pickle.load(f))
+            coll.append(c)
+            cont.append(k)
+        return coll, cont

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""python fitting_habitat.py GEN_PATH FIT_PATH     (source/fitting_habitat.py:230-289: MP3D-R rooms, batch 1, 50 iterations)"""
+import argparse
+import os
+
+import _common  # noqa: F401
+import torch
+
+from psi_release_amd.fitting import FittingOPHabitat
+
+ROOMS = ['17DRP5sb8fy-bedroom', '17DRP5sb8fy-familyroomlounge', '17DRP5sb8fy-livingroom', 'sKLMLpTHeUy-familyname_0_1',
+         'X7HyMhZNoso-livingroom_0_16', 'zsNo4HB9uLZ-bedroom0_0', 'zsNo4HB9uLZ-livingroom0_13']
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('gen_path', nargs='?')
+    ap.add_argument('fit_path')
+    ap.add_argument('--mp3dr_path', default='/is/cluster/yzhang/mp3d-rooms')
+    ap.add_argument('--human_model_path', default='/is/ps2/yzhang/body_models/VPoser')
+    ap.add_argument('--vposer_ckpt_path', default='/is/ps2/yzhang/body_models/VPoser/vposer_v1_0')
+    ap.add_argument('--contact_id_folder', default='/is/cluster/yzhang/PROXE/body_segments')
+    ap.add_argument('--scenes', nargs='*', default=ROOMS)
+    ap.add_argument('--num_iter', type=int, default=50)
+    ap.add_argument('--max_files', type=int, default=10000)
+    ap.add_argument('--engine', default='fused', choices=['fused', 'modular'])
+    ap.add_argument('--verbose', action='store_true')
+    ap.add_argument('--synthetic', default=None)
+    a = ap.parse_args(argv)
+    extra = {}
+    if a.synthetic:
+        root, a.gen_path, extra['smplx_data'], extra['vposer_state'] = _common.synthetic_prox_tree(a.synthetic, a.scenes, batch=1)
+        sdf_dir, ply_dir, a.contact_id_folder = os.path.join(root, 'scenes_sdf'), os.path.join(root, 'scenes_downsampled'), os.path.join(root, 'body_segments')
+    else:
+        sdf_dir, ply_dir = os.path.join(a.mp3dr_path, 'sdf'), os.path.join(a.mp3dr_path, 'mesh')
+    for scenename in a.scenes:
+        cfg = {'scene_verts_path': os.path.join(ply_dir, scenename + '.ply'), 'scene_sdf_path': os.path.join(sdf_dir, scenename),
+               'human_model_path': a.human_model_path, 'vposer_ckpt_path': a.vposer_ckpt_path, 'init_lr_h': 0.1,
+               'num_iter': a.num_iter, 'batch_size': 1, 'device': torch.device('cuda' if torch.cuda.is_available() else 'cpu'),
+               'contact_part': ['back', 'butt', 'L_Hand', 'R_Hand', 'L_Leg', 'R_Leg', 'thighs'],
+               'contact_id_folder': a.contact_id_folder, 'verbose': a.verbose, 'engine': a.engine}
+        cfg.update(extra)
+        lossconfig = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1, 'weight_collision': 0.5}
+        fop = FittingOPHabitat(cfg, lossconfig)
+        for ii in range(a.max_files):
+            inp = os.path.join(a.gen_path, scenename + '/body_gen_{:06d}.pkl'.format(ii))
+            if not os.path.exists(inp):
+                continue
+            outp = os.path.join(a.fit_path, scenename + '/body_gen_{:06d}.pkl'.format(ii))
+            if os.path.exists(outp):
+                continue
+            fop.save_result(fop.fitting(inp), outp)
+
+
+if __name__ == '__main__':
+    main()
