@@ -91,6 +91,26 @@ def time_chamfer_kernel(op, args, reps=20):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
+def kernel_work(args, op):
+    """Algorithmic work per launch of the kernels of one fitting iteration: ('flop'|'byte', amount, note)."""
+    B, V, nc, m = args.batch, 10475, args.nc, args.m
+    Kpad, Npad, Vpad = 512, 31488, 10496
+    dirs = Kpad * Npad * 4
+    return {
+        'nn_partial_kernel': ('flop', 8.0 * B * nc * m, 'brute-force NN: 8 flop per query/target pair, fp32 VALU (no FMA contraction)'),
+        'kd_query_kernel': ('byte', B * nc * (12 + 12 + 8) + m * 16.0,
+                            'exact kd-tree NN (latency-bound pointer chase): queries in, gradients + hints out, scene once'),
+        'blend_fwd_kernel': ('byte', dirs + B * Npad * 4.0 + B * Kpad * 4.0, 'v_posed = v_t + feat @ dirs: dirs (64.5 MB) streamed once + output'),
+        'blend_bwd_kernel': ('byte', dirs + B * Npad * 4.0 + 41 * B * Kpad * 4.0, 'g_feat = g_vposed @ dirs^T: dirs streamed once + input + partials'),
+        'skin_fwd_kernel': ('byte', 55 * Vpad * 4.0 + B * Npad * 4.0 + B * V * 12.0, 'weights + v_posed in, vertices out (660 FMA per vertex: VALU-heavy)'),
+        'skin_bwd_v_kernel': ('byte', 55 * Vpad * 4.0 + B * V * 12.0 + 2 * B * Npad * 4.0, 'weights + grad in, g_local + g_vposed out'),
+        'skin_bwd_A_kernel': ('byte', 64 * Vpad * 4.0 + 2 * B * Npad * 4.0 + 41 * B * 1024 * 4.0, 'weights + g_local + v_posed in, partials out'),
+        'sdf_pen_kernel': ('byte', B * V * (12 + 32 + 12.0), '12 B vertex + 8 gathers + 12 B gradient per vertex'),
+        'head_fwd_kernel': ('byte', 1.4e6 + B * 4000.0, 'VPoser decoder weights (L2 resident) + per-body state'),
+        'head_bwd_adam_kernel': ('byte', 1.4e6 + B * 4000.0, 'VPoser decoder weights (L2 resident) + per-body state'),
+    }
+
+
 def cpu_baseline(args, assets, budget_s):
     """Oracle fitting iterations on the host cores: bounded sample of the SAME workload (same B, m, n_c, D)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -120,11 +140,13 @@ def cpu_baseline(args, assets, budget_s):
 def main():
     args = parse()
     from psi_release_amd import dist as pd
-    rank, local_rank, world = pd.init_from_env('nccl')
+    # RCCL (backend 'nccl') over xGMI; PSI_DIST_BACKEND=gloo lets a single-GPU box exercise the N>1 code path
+    rank, local_rank, world = pd.init_from_env(os.environ.get('PSI_DIST_BACKEND', 'nccl'))
     if world != args.gpus and world > 1:
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path is the only implementation')
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     from psi_release_amd import fitting
@@ -154,9 +176,38 @@ def main():
 
     out = None
     if rank == 0:
+        # ---- per-kernel times of one iteration: HIP events recorded on the launch stream after every kernel launch
+        kernels = None
+        if args.engine_resolved == 'fused' and world == 1:
+            kernels = runner.eng.profile(20)
+        work = kernel_work(args, op)
         t_ch = time_chamfer_kernel(op, args)
         flops = 8.0 * args.batch * args.nc * args.m
-        ach = flops / t_ch * 1e-12
+        bf = {'bound': 'mfma', 'kernel': 'nn_partial_kernel + nn_resolve_kernel (brute-force Chamfer NN op, fp32 VALU)',
+              'achieved': round(flops / t_ch * 1e-12, 2), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+              'frac': round(flops / t_ch * 1e-12 / PEAK_FP32_TFLOPS, 4), 'avg_launch_ms': round(t_ch * 1e3, 4), 'flops_per_launch': flops,
+              'note': 'fp32 vector peak == fp32 MFMA peak on gfx950; 8 flop/pair without FMA contraction caps the fraction near 8/18'}
+        roof = dict(bf, traffic=None)
+        kernels_us = None
+        if kernels:
+            agg = {}
+            for nm, ms in kernels:
+                agg[nm] = agg.get(nm, 0.0) + ms
+            kernels_us = {k: round(v * 1e3, 2) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])}
+            dom = max(agg, key=agg.get)
+            w = work.get(dom)
+            if w is not None:
+                t_dom = agg[dom] * 1e-3
+                if w[0] == 'flop':
+                    ach = w[1] / t_dom * 1e-12
+                    roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                            'frac': round(ach / PEAK_FP32_TFLOPS, 4), 'traffic': None, 'avg_launch_ms': round(agg[dom], 4),
+                            'flops_per_launch': w[1], 'note': w[2]}
+                else:
+                    ach = w[1] / t_dom * 1e-9
+                    roof = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                            'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None, 'avg_launch_ms': round(agg[dom], 4),
+                            'bytes_per_launch': w[1], 'note': w[2]}
         out = {
             'metric': 'fitting iters/sec (SMPL-X+SDF+Chamfer), PROX-E batch=32',
             'value': round(world * args.steps / dt, 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
@@ -166,15 +217,21 @@ def main():
                                    'V=10475, n_c=%d, m=%d, SDF %d^3, synthetic SMPL-X/VPoser/scene (BASELINE configs[1])'
                                    % (args.batch, args.nc, args.m, args.D),
                        'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'engine': args.engine_resolved,
+                       'nn': op.nn_mode,
                        'parallelism': 'dp%d (rows sharded, one 6-float all-reduce per iteration)' % world,
                        'final_losses': [round(float(x), 6) for x in losses]},
-            'roofline': {'bound': 'mfma', 'kernel': 'nn_partial_kernel (Chamfer NN brute force, fp32 VALU)',
-                         'achieved': round(ach, 2), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach / PEAK_FP32_TFLOPS, 4), 'traffic': None,
-                         'avg_launch_ms': round(t_ch * 1e3, 4), 'flops_per_launch': flops,
-                         'note': 'fp32 has no faster MFMA than the vector rate on gfx950, so the fp32 peak is both; '
-                                 '8 flop/pair (3 sub, 3 mul, 2 add) without FMA contraction caps the fraction at 8/18'},
+            'roofline': roof,
         }
+        if kernels_us:
+            out['kernels_us'] = kernels_us
+            out['roofline_bruteforce_nn'] = bf
+            # the largest HBM-streaming kernel, reported next to the dominant one
+            if 'blend_fwd_kernel' in agg and roof.get('kernel') != 'blend_fwd_kernel':
+                w = work['blend_fwd_kernel']
+                ach = w[1] / (agg['blend_fwd_kernel'] * 1e-3) * 1e-9
+                out['roofline_hbm_stream'] = {'bound': 'hbm', 'kernel': 'blend_fwd_kernel', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS,
+                                              'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4), 'bytes_per_launch': w[1],
+                                              'avg_launch_ms': round(agg['blend_fwd_kernel'], 4), 'note': w[2]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(args, assets, args.cpu_seconds)

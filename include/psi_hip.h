@@ -162,6 +162,11 @@ int psi_fit_iterate(psi_fit_engine *engine, int n_iter, int use_graph, void *str
  * (l_rec, l_vposer, l_contact, l_collision as printed by fitting_proxe.py:184-186) to device buffers;
  * h_step (host, nullable) receives the Adam step count and forces a stream sync. */
 int psi_fit_read(psi_fit_engine *engine, float *d_x_out, float *d_history_out, int n_hist, int *h_step, void *stream);
+/* Per-kernel timing of one fitting iteration with HIP events on the launch stream (an event is recorded right after
+ * every kernel launch of the sequence psi_fit_iterate runs; ungraphed), averaged over n_rep iterations.  Advances the
+ * optimisation by n_rep steps.  h_names: [max_stages][name_stride] chars, h_ms: [max_stages] milliseconds. */
+int psi_fit_profile(psi_fit_engine *engine, int n_rep, char *h_names, int name_stride, float *h_ms, int max_stages,
+                    int *h_n_stages, void *stream);
 /* Test/diagnostic copy of an engine-owned device buffer by name ("verts" [B,V,3], "g_verts", "pose" [B,165],
  * "g_pose", "g_rot" [B,55,9], "stats" [8], "adam_m"/"adam_v" [B,75]) into d_out (device). */
 int psi_fit_copy_buffer(psi_fit_engine *engine, const char *name, float *d_out, long n_floats, void *stream);

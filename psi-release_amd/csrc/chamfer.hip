@@ -16,7 +16,7 @@
 //     fed to the VALU as scalar operands — no LDS staging, no barriers, no VGPRs spent on targets.
 //   * the target range is cut into slices so that the grid has >= ~2k workgroups for 256 CUs even at
 //     B*n = 65k queries; slices are combined in ascending order with strict '<' (lowest index wins).
-#include "psi_common.h"
+#include "psi_internal.h"
 #include <math.h>
 
 #ifndef PSI_CHAMFER_ALLOW_FMA   // development A/B only; the shipped library never defines it
@@ -237,6 +237,7 @@ int launch_nn_ex(const float *q, const float *t, int B, int n, int m, float *dis
         hipLaunchKernelGGL(nn_partial_kernel<1>, grid, dim3(BLK), 0, st, q, t, B, n, m, p.total_chunks, p.chunks_per_slice, pd, pc,
                            qidx, qstride, tstride);
     PSI_CHECK_LAUNCH("nn_partial_kernel");
+    psi_mark("nn_partial_kernel", st);
     dim3 rg(psi_cdiv(n, BLK), B);
     if (contact)
         hipLaunchKernelGGL(nn_resolve_kernel<true>, rg, dim3(BLK), 0, st, q, t, B, n, m, p.nslices, pd, pc, dist, idx, qidx, qstride,
@@ -245,6 +246,7 @@ int launch_nn_ex(const float *q, const float *t, int B, int n, int m, float *dis
         hipLaunchKernelGGL(nn_resolve_kernel<false>, rg, dim3(BLK), 0, st, q, t, B, n, m, p.nslices, pd, pc, dist, idx, qidx, qstride,
                            tstride, 0.0f, 0.0f, nullptr, nullptr);
     PSI_CHECK_LAUNCH("nn_resolve_kernel");
+    psi_mark("nn_resolve_kernel", st);
     return 0;
 }
 
@@ -305,10 +307,12 @@ extern "C" int psi_chamfer_backward(const float *xyz1, const float *xyz2, float 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(nn_grad_kernel, dim3(psi_cdiv(n, BLK), B), dim3(BLK), 0, st, xyz1, xyz2, graddist1, idx1, n, m, gradxyz1, gradxyz2);
     PSI_CHECK_LAUNCH("nn_grad_kernel");
+    psi_mark("nn_grad_kernel", st);
     if (graddist2) {
         // direction 2 (chamfer.cu:185): own side is gradxyz2 (skipped when NULL), scatter side is gradxyz1
         hipLaunchKernelGGL(nn_grad_kernel, dim3(psi_cdiv(m, BLK), B), dim3(BLK), 0, st, xyz2, xyz1, graddist2, idx2, m, n, gradxyz2, gradxyz1);
         PSI_CHECK_LAUNCH("nn_grad_kernel(dir2)");
+    psi_mark("nn_grad_kernel", st);
     }
     return 0;
 }

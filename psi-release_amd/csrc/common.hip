@@ -1,5 +1,5 @@
 // libpsi_hip.so: error reporting, device facts, growable scratch.
-#include "psi_common.h"
+#include "psi_internal.h"
 #include <stdarg.h>
 #include <mutex>
 
@@ -57,3 +57,5 @@ void *psi_scratch(size_t bytes)
     }
     return g_scratch[dev];
 }
+
+thread_local PsiStageTimer *g_psi_timer = nullptr;

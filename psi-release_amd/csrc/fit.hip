@@ -464,10 +464,12 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st)
     FitDev &f = e->d;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(f.B), dim3(HB), 0, st, f);
     PSI_CHECK_LAUNCH("head_fwd_kernel");
+    psi_mark("head_fwd_kernel", st);
     int rc = psi_lbs_forward(e->lbs, f.betas20, f.pose, f.transl, f.cam, f.B, f.verts, nullptr, e->lbs_ws, st);
     if (rc) return rc;
     hipLaunchKernelGGL(sdf_pen_kernel, dim3(f.nsdfblk, f.B), dim3(256), 0, st, f);
     PSI_CHECK_LAUNCH("sdf_pen_kernel");
+    psi_mark("sdf_pen_kernel", st);
     float gscale = f.w_contact / ((float)f.B * (float)f.world * (float)f.n_c);
     if (e->nn_index)
         rc = psi_nn_index_contact(e->nn_index, f.verts, (long)f.V * 3, f.vid, f.B, f.n_c, f.cconst, gscale, f.gq, f.fpart, f.nn_hint, st);
@@ -476,6 +478,7 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st)
     if (rc) return rc;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, f, stats);
     PSI_CHECK_LAUNCH("loss_finalize_kernel");
+    psi_mark("loss_finalize_kernel", st);
     return 0;
 }
 
@@ -484,11 +487,13 @@ static int fit_backward(psi_fit_engine *e, const float *stats, hipStream_t st)
     FitDev &f = e->d;
     hipLaunchKernelGGL(grad_verts_kernel, dim3(f.nsdfblk, f.B), dim3(256), 0, st, f, stats);
     PSI_CHECK_LAUNCH("grad_verts_kernel");
+    psi_mark("grad_verts_kernel", st);
     PsiLbsGradOut out = {f.g_betas, f.g_pose, f.g_transl, f.g_rot};
     int rc = psi_lbs_backward_ex(e->lbs, f.g_verts, f.betas20, f.pose, f.cam, f.B, e->lbs_ws, out, st);
     if (rc) return rc;
     hipLaunchKernelGGL(head_bwd_adam_kernel, dim3(f.B), dim3(HB), 0, st, f);
     PSI_CHECK_LAUNCH("head_bwd_adam_kernel");
+    psi_mark("head_bwd_adam_kernel", st);
     return 0;
 }
 
@@ -625,6 +630,7 @@ extern "C" int psi_fit_set_problem(psi_fit_engine *e, const float *d_xhr, const 
     if (reset_optimizer) {
         hipLaunchKernelGGL(adam_reset_kernel, dim3(psi_cdiv((long)f.B * XD, 256)), dim3(256), 0, st, f.adam_m, f.adam_v, f.step, f.B * XD);
         PSI_CHECK_LAUNCH("adam_reset_kernel");
+    psi_mark("adam_reset_kernel", st);
     }
     return 0;
 }
@@ -667,6 +673,49 @@ extern "C" int psi_fit_iterate(psi_fit_engine *e, int n_iter, int use_graph, voi
         e->graph_ready = true;
     }
     for (int i = 0; i < n_iter; i++) PSI_CHECK_HIP(hipGraphLaunch(e->graph_exec, st));
+    return 0;
+}
+
+extern "C" int psi_fit_profile(psi_fit_engine *e, int n_rep, char *h_names, int name_stride, float *h_ms, int max_stages,
+                               int *h_n_stages, void *stream)
+{
+    // Per-kernel durations of ONE fitting iteration measured with HIP events recorded on the launch stream right after
+    // every kernel launch (ungraphed replay of exactly the sequence psi_fit_iterate runs), averaged over n_rep iterations.
+    PSI_REQUIRE(e && h_names && h_ms && h_n_stages && n_rep > 0 && max_stages > 0 && name_stride >= 16, "bad arguments");
+    PSI_REQUIRE(e->d.world == 1, "profile the single-process path");
+    hipStream_t st = (hipStream_t)stream;
+    PsiStageTimer tm;
+    memset(&tm, 0, sizeof(tm));
+    for (int i = 0; i < 48; i++) PSI_CHECK_HIP(hipEventCreate(&tm.ev[i]));
+    std::vector<double> acc(48, 0.0);
+    int n_st = 0, rc = 0;
+    for (int r = 0; r < n_rep && !rc; r++) {
+        tm.n = 0;
+        (void)hipEventRecord(tm.ev[0], st);
+        tm.name[0] = "start";
+        tm.n = 1;
+        g_psi_timer = &tm;
+        rc = fit_forward(e, e->stats_local, st);
+        if (!rc) rc = fit_backward(e, e->stats_local, st);
+        g_psi_timer = nullptr;
+        if (rc) break;
+        PSI_CHECK_HIP(hipStreamSynchronize(st));
+        n_st = tm.n - 1;
+        for (int i = 1; i < tm.n; i++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, tm.ev[i - 1], tm.ev[i]);
+            acc[i - 1] += ms;
+        }
+    }
+    for (int i = 0; i < 48; i++) (void)hipEventDestroy(tm.ev[i]);
+    if (rc) return rc;
+    if (n_st > max_stages) n_st = max_stages;
+    for (int i = 0; i < n_st; i++) {
+        h_ms[i] = (float)(acc[i] / n_rep);
+        strncpy(h_names + (size_t)i * name_stride, tm.name[i + 1], name_stride - 1);
+        h_names[(size_t)i * name_stride + name_stride - 1] = 0;
+    }
+    *h_n_stages = n_st;
     return 0;
 }
 

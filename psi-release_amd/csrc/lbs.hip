@@ -781,6 +781,7 @@ extern "C" int psi_lbs_forward(const psi_lbs_model *mdl, const float *betas, con
     hipLaunchKernelGGL(pose_fwd_kernel, dim3(B), dim3(64), 0, st, m, betas, pose, transl, B, ws + L.feat, ws + L.R, ws + L.Jl,
                        ws + L.G, ws + L.A, joints);
     PSI_CHECK_LAUNCH("pose_fwd_kernel");
+    psi_mark("pose_fwd_kernel", st);
     if (B > 32)
         hipLaunchKernelGGL(blend_fwd_kernel<4>, dim3(m.Npad / 64, psi_cdiv(B, 64)), dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
     else if (B > 16)
@@ -788,9 +789,11 @@ extern "C" int psi_lbs_forward(const psi_lbs_model *mdl, const float *betas, con
     else
         hipLaunchKernelGGL(blend_fwd_kernel<1>, dim3(m.Npad / 64, 1), dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
     PSI_CHECK_LAUNCH("blend_fwd_kernel");
+    psi_mark("blend_fwd_kernel", st);
     hipLaunchKernelGGL(skin_fwd_kernel, dim3(m.Vpad / SKIN_BLK, psi_cdiv(B, SKIN_BT)), dim3(SKIN_BLK), 0, st, m, ws + L.A,
                        ws + L.v_posed, transl, cam_ext, B, verts);
     PSI_CHECK_LAUNCH("skin_fwd_kernel");
+    psi_mark("skin_fwd_kernel", st);
     return 0;
 }
 
@@ -804,8 +807,10 @@ int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const
     hipLaunchKernelGGL(skin_bwd_v_kernel, dim3(m.Vpad / SKIN_BLK, psi_cdiv(B, SKIN_BT)), dim3(SKIN_BLK), 0, st, m, ws + L.A, grad_verts,
                        cam_ext, B, ws + L.gl, ws + L.g_vp, ws + L.gt_part);
     PSI_CHECK_LAUNCH("skin_bwd_v_kernel");
+    psi_mark("skin_bwd_v_kernel", st);
     hipLaunchKernelGGL(skin_bwd_A_kernel, dim3(L.nsv, B), dim3(256), 0, st, m, ws + L.gl, ws + L.v_posed, B, ws + L.gA_part);
     PSI_CHECK_LAUNCH("skin_bwd_A_kernel");
+    psi_mark("skin_bwd_A_kernel", st);
     const int steps = 48;
     dim3 g(m.Kpad / 64, L.nsn, 1);
     if (B > 32) {
@@ -817,13 +822,16 @@ int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const
         hipLaunchKernelGGL(blend_bwd_kernel<1>, g, dim3(256), 0, st, m, ws + L.g_vp, B, steps, ws + L.gfeat_part);
     }
     PSI_CHECK_LAUNCH("blend_bwd_kernel");
+    psi_mark("blend_bwd_kernel", st);
     long nred = (long)B * JP * 16 + (long)B * m.Kpad + (long)B * 4;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(psi_cdiv(nred, 256)), dim3(256), 0, st, B, m.Kpad, ws + L.gA_part, L.nsv,
                        ws + L.gfeat_part, L.nsn, ws + L.gt_part, L.nvb, ws + L.gA, ws + L.gfeat, out.g_transl);
     PSI_CHECK_LAUNCH("reduce_partials_kernel");
+    psi_mark("reduce_partials_kernel", st);
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(64), 0, st, m, betas, pose, ws + L.R, ws + L.Jl, ws + L.G, ws + L.gA,
                        ws + L.gfeat, B, out.g_betas, out.g_pose, out.g_rot);
     PSI_CHECK_LAUNCH("pose_bwd_kernel");
+    psi_mark("pose_bwd_kernel", st);
     return 0;
 }
 

@@ -284,6 +284,7 @@ extern "C" int psi_nn_index_query(const psi_nn_index *ix, const float *xyz1, int
     hipLaunchKernelGGL(kd_query_kernel<false>, dim3(psi_cdiv(n, QBLK), B), dim3(QBLK), 0, (hipStream_t)stream, ix->d, xyz1,
                        (const int *)nullptr, (long)n * 3, n, dist1, idx1, 0.0f, 0.0f, (float *)nullptr, (float *)nullptr, hint);
     PSI_CHECK_LAUNCH("kd_query_kernel");
+    psi_mark("kd_query_kernel", (hipStream_t)stream);
     return 0;
 }
 
@@ -294,6 +295,7 @@ int psi_nn_index_contact(const psi_nn_index *ix, const float *verts, long vstrid
     hipLaunchKernelGGL(kd_query_kernel<true>, dim3(psi_cdiv(n, QBLK), B), dim3(QBLK), 0, st, ix->d, verts, vid, vstride, n,
                        (float *)nullptr, (int *)nullptr, cconst, gscale, gq, fpart, hint);
     PSI_CHECK_LAUNCH("kd_query_kernel<contact>");
+    psi_mark("kd_query_kernel", st);
     return 0;
 }
 int psi_nn_index_fparts(int n) { return psi_cdiv(n, QBLK); }

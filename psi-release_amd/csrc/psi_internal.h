@@ -4,6 +4,24 @@
 
 struct psi_lbs_model;
 
+// Optional per-stage HIP-event timer (psi_fit_profile): when active, every kernel launch site marks an event on the
+// launch stream right after the launch; inactive (nullptr) in normal operation and under graph capture.
+struct PsiStageTimer {
+    hipEvent_t ev[48];
+    const char *name[48];
+    int n;
+};
+extern thread_local PsiStageTimer *g_psi_timer;
+static inline void psi_mark(const char *nm, hipStream_t st)
+{
+    PsiStageTimer *t = g_psi_timer;
+    if (t && t->n < 48) {
+        (void)hipEventRecord(t->ev[t->n], st);
+        t->name[t->n] = nm;
+        t->n++;
+    }
+}
+
 // chamfer.hip
 int psi_nn_contact(const float *verts, long vstride, const int *vid, const float *scene, int B, int n, int m, void *ws,
                    float cconst, float gscale, float *gq, float *fpart, int *idx_out, hipStream_t st);

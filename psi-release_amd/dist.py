@@ -43,7 +43,7 @@ def init_from_env(backend=None):
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     if backend == 'nccl':
-        torch.cuda.set_device(lrk)
+        torch.cuda.set_device(lrk % max(torch.cuda.device_count(), 1))
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rk, world_size=ws)
     return rk, lrk, ws

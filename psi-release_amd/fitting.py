@@ -273,6 +273,18 @@ class FusedEngine:
         torch.cuda.current_stream().wait_stream(self.stream)
         return x, hist[:n_hist], step.value
 
+    def profile(self, n_rep=20):
+        """{kernel name: average ms} of one iteration, HIP events on the launch stream (psi_fit_profile)."""
+        names = ctypes.create_string_buffer(48 * 48)
+        ms = (ctypes.c_float * 48)()
+        n = ctypes.c_int(0)
+        hip.check(hip.lib().psi_fit_profile(self.handle, n_rep, names, 48, ms, 48, ctypes.byref(n), self.stream.cuda_stream),
+                  'psi_fit_profile')
+        out = []
+        for i in range(n.value):
+            out.append((names.raw[i * 48:(i + 1) * 48].split(b'\0')[0].decode(), float(ms[i])))
+        return out
+
     def buffer(self, name, shape):
         """Copy of an engine-owned device buffer (tests / diagnostics)."""
         out = torch.empty(*shape, device=self.op.device)
