@@ -153,8 +153,9 @@ void psi_fit_destroy(psi_fit_engine *engine);
  * cam_ext [B,4,4]; reset_optimizer != 0 zeroes the Adam state and step count. */
 int psi_fit_set_problem(psi_fit_engine *engine, const float *d_xhr, const float *d_x_init, const float *d_cam_ext,
                         int reset_optimizer, void *stream);
-int psi_fit_forward(psi_fit_engine *engine, float *d_stats, void *stream);
-int psi_fit_backward_step(psi_fit_engine *engine, const float *d_stats, void *stream);
+/* use_graph != 0: each half is captured once into its own hipGraph (stats pointer baked in) and replayed. */
+int psi_fit_forward(psi_fit_engine *engine, float *d_stats, int use_graph, void *stream);
+int psi_fit_backward_step(psi_fit_engine *engine, const float *d_stats, int use_graph, void *stream);
 /* n_iter full iterations on one GPU; use_graph != 0 captures one iteration once (stream must not be the
  * NULL stream) and replays it with hipGraphLaunch. */
 int psi_fit_iterate(psi_fit_engine *engine, int n_iter, int use_graph, void *stream);

@@ -457,6 +457,11 @@ struct psi_fit_engine {
     hipGraph_t graph;
     hipGraphExec_t graph_exec;
     bool graph_ready;
+    // data-parallel path: forward and backward halves captured separately (the all-reduce sits between them)
+    hipGraph_t g_half[2];
+    hipGraphExec_t ge_half[2];
+    bool half_ready[2];
+    const float *half_stats[2];
 };
 
 static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st)
@@ -612,6 +617,11 @@ extern "C" void psi_fit_destroy(psi_fit_engine *e)
         (void)hipGraphExecDestroy(e->graph_exec);
         (void)hipGraphDestroy(e->graph);
     }
+    for (int i = 0; i < 2; i++)
+        if (e->half_ready[i]) {
+            (void)hipGraphExecDestroy(e->ge_half[i]);
+            (void)hipGraphDestroy(e->g_half[i]);
+        }
     (void)hipFree(e->blob);
     delete e;
 }
@@ -635,16 +645,39 @@ extern "C" int psi_fit_set_problem(psi_fit_engine *e, const float *d_xhr, const 
     return 0;
 }
 
-extern "C" int psi_fit_forward(psi_fit_engine *e, float *d_stats, void *stream)
+static int fit_half(psi_fit_engine *e, int which, float *stats, int use_graph, hipStream_t st)
 {
-    PSI_REQUIRE(e, "null engine");
-    return fit_forward(e, d_stats ? d_stats : e->stats_local, (hipStream_t)stream);
+    if (!use_graph) return which == 0 ? fit_forward(e, stats, st) : fit_backward(e, stats, st);
+    if (e->half_ready[which] && e->half_stats[which] != stats) {       // the captured graph bakes the stats pointer in
+        (void)hipGraphExecDestroy(e->ge_half[which]);
+        (void)hipGraphDestroy(e->g_half[which]);
+        e->half_ready[which] = false;
+    }
+    if (!e->half_ready[which]) {
+        PSI_REQUIRE(st != nullptr, "graph capture needs a non-default stream");
+        PSI_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        int rc = which == 0 ? fit_forward(e, stats, st) : fit_backward(e, stats, st);
+        hipError_t ce = hipStreamEndCapture(st, &e->g_half[which]);
+        if (rc) return rc;
+        PSI_CHECK_HIP(ce);
+        PSI_CHECK_HIP(hipGraphInstantiate(&e->ge_half[which], e->g_half[which], nullptr, nullptr, 0));
+        e->half_ready[which] = true;
+        e->half_stats[which] = stats;
+    }
+    PSI_CHECK_HIP(hipGraphLaunch(e->ge_half[which], st));
+    return 0;
 }
 
-extern "C" int psi_fit_backward_step(psi_fit_engine *e, const float *d_stats, void *stream)
+extern "C" int psi_fit_forward(psi_fit_engine *e, float *d_stats, int use_graph, void *stream)
 {
     PSI_REQUIRE(e, "null engine");
-    return fit_backward(e, d_stats ? d_stats : e->stats_local, (hipStream_t)stream);
+    return fit_half(e, 0, d_stats ? d_stats : e->stats_local, use_graph, (hipStream_t)stream);
+}
+
+extern "C" int psi_fit_backward_step(psi_fit_engine *e, const float *d_stats, int use_graph, void *stream)
+{
+    PSI_REQUIRE(e, "null engine");
+    return fit_half(e, 1, (float *)(d_stats ? d_stats : e->stats_local), use_graph, (hipStream_t)stream);
 }
 
 extern "C" int psi_fit_iterate(psi_fit_engine *e, int n_iter, int use_graph, void *stream)

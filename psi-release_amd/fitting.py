@@ -259,9 +259,9 @@ class FusedEngine:
         import torch.distributed as tdist
         with torch.cuda.stream(self.stream):
             for _ in range(n):
-                hip.check(L.psi_fit_forward(self.handle, hip.ptr(self.stats), self.stream.cuda_stream), 'psi_fit_forward')
+                hip.check(L.psi_fit_forward(self.handle, hip.ptr(self.stats), int(bool(use_graph)), self.stream.cuda_stream), 'psi_fit_forward')
                 tdist.all_reduce(self.stats, op=tdist.ReduceOp.SUM)           # the one collective of the data path
-                hip.check(L.psi_fit_backward_step(self.handle, hip.ptr(self.stats), self.stream.cuda_stream), 'psi_fit_backward_step')
+                hip.check(L.psi_fit_backward_step(self.handle, hip.ptr(self.stats), int(bool(use_graph)), self.stream.cuda_stream), 'psi_fit_backward_step')
 
     def read(self, n_hist=0):
         op = self.op

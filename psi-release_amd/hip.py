@@ -39,8 +39,8 @@ SIGNATURES = {
     'psi_fit_create': (c_int, [c_void_p] * 17),
     'psi_fit_destroy': (None, [c_void_p]),
     'psi_fit_set_problem': (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
-    'psi_fit_forward': (c_int, [c_void_p] * 3),
-    'psi_fit_backward_step': (c_int, [c_void_p] * 3),
+    'psi_fit_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'psi_fit_backward_step': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'psi_fit_iterate': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'psi_fit_read': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'psi_fit_profile': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
