@@ -117,24 +117,38 @@ def cpu_baseline(args, assets, budget_s):
     import psi_oracle as O
     from psi_release_amd import synth
     smplx, vposer, scene = assets
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    os.environ['OMP_NUM_THREADS'] = str(cores)
+    ncpu = os.cpu_count() or 1
     fo = O.FittingOracle(O.SMPLXOracle(smplx), vposer, scene.verts, scene.sdf, scene.grid_min, scene.grid_max,
                          synth.contact_ids_from_parts(scene.contact_parts), args.batch)
     bodies = synth.make_bodies(11, args.batch)
     xh = synth.body_vector_72(bodies)
-    fo.fitting(xh, bodies['cam_ext'], 1)                    # untimed warm-up iteration (page-in, thread pools)
+    # the oracle is memory/NUMA sensitive: all cores of a 256-thread host are ~200x SLOWER than 16 threads.  Report the
+    # best of a small sweep so the GPU/CPU ratio is not inflated by a badly configured baseline.
+    cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu})
+    best_c, best_t = cands[0], float('inf')
+    for c in cands:
+        O.set_threads(c)
+        fo.fitting(xh, bodies['cam_ext'], 1)                # untimed warm-up at this thread count
+        t0 = time.time()
+        fo.fitting(xh, bodies['cam_ext'], 1)
+        dt1 = time.time() - t0
+        if dt1 < best_t:
+            best_c, best_t = c, dt1
+        if dt1 > 4 * best_t:                                # clearly past the knee: skip larger counts
+            break
+    cores = best_c
+    O.set_threads(cores)
     n, t0 = 0, time.time()
     while True:
         fo.fitting(xh, bodies['cam_ext'], 1)
         n += 1
         el = time.time() - t0
-        if (el >= budget_s and n >= 2) or n >= 50:
+        if (el >= budget_s and n >= 2) or n >= 2000:
             break
     return {'value': round(n / el, 4), 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
             'sample': '%d fitting iterations (B=%d, n_c=%d, m=%d, D=%d) of oracle/psi_oracle.py FittingOracle '
-                      '(torch-CPU fp32 + C/OpenMP Chamfer restatement) in %.1f s' % (n, args.batch, args.nc, args.m, args.D, el)}
+                      '(torch-CPU fp32 + C/OpenMP AVX Chamfer restatement) in %.1f s at the best of %s threads on a %d-thread host'
+                      % (n, args.batch, args.nc, args.m, args.D, el, cands, ncpu)}
 
 
 def main():

@@ -27,6 +27,19 @@
 #include <string.h>
 #include <stdlib.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* thread count of the OpenMP loops (bench.py sweeps it to report the best CPU configuration) */
+void psi_oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 #define QB 16 /* queries per SIMD block: the inner loop over queries vectorises (fair CPU baseline) */
 
 /* chamfer.cu:12-134 (one direction): for every query j of batch i, min over targets k of the

@@ -60,6 +60,12 @@ def c_oracle():
     return _LIB
 
 
+def set_threads(n: int):
+    """Thread count for both halves of the oracle (torch intra-op pool and the OpenMP loops of the C file)."""
+    torch.set_num_threads(int(n))
+    c_oracle().psi_oracle_set_threads(int(n))
+
+
 def _fp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
