@@ -222,6 +222,16 @@ def main():
                     roof = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                             'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None, 'avg_launch_ms': round(agg[dom], 4),
                             'bytes_per_launch': w[1], 'note': w[2]}
+        # HBM traffic per launch from the committed PMC collection (profiles/r01_pmc_traffic.json; rocprofv3 --pmc cannot run
+        # inside this process).  Only attached for the default shape the counters were collected on.
+        pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        if os.path.exists(pmc_path) and (args.batch, args.nc, args.m, args.D) == (32, 2048, 32768, 256):
+            pmc = json.load(open(pmc_path))
+            kn = roof.get('kernel', '').split(' ')[0]
+            if kn in pmc:
+                roof['traffic'] = pmc[kn]['bytes']
+                roof['traffic_source'] = 'profiles/r01_pmc_traffic.json (FETCH_SIZE%s + WRITE_SIZE, separate rocprofv3 --pmc passes)' % (
+                    ' x2 (gfx950 wide-load correction)' if pmc[kn]['fetch_x2'] else '')
         out = {
             'metric': 'fitting iters/sec (SMPL-X+SDF+Chamfer), PROX-E batch=32',
             'value': round(world * args.steps / dt, 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
@@ -246,6 +256,8 @@ def main():
                 out['roofline_hbm_stream'] = {'bound': 'hbm', 'kernel': 'blend_fwd_kernel', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS,
                                               'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4), 'bytes_per_launch': w[1],
                                               'avg_launch_ms': round(agg['blend_fwd_kernel'], 4), 'note': w[2]}
+                if os.path.exists(pmc_path) and (args.batch, args.nc, args.m, args.D) == (32, 2048, 32768, 256):
+                    out['roofline_hbm_stream']['traffic'] = json.load(open(pmc_path))['blend_fwd_kernel']['bytes']
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(args, assets, args.cpu_seconds)
