@@ -5,7 +5,10 @@
 // `+ transl` and PSI's verts_transform (cvae.py:141-149).
 //
 // Data layout in HBM (built once by psi_lbs_create, fp32):
-//   dirs  [Kpad][Npad]   rows 0..NB-1 = shapedirs^T, rows NB..NB+P-1 = posedirs, zero padded; N = 3V.
+//   dirs  [Npad/64][Kpad][64]  column-tile-major: tile t holds columns 64t..64t+63 of the [Kpad][Npad] matrix whose rows
+//                        0..NB-1 = shapedirs^T and NB..NB+P-1 = posedirs (zero padded; N = 3V).  A workgroup's 64-column
+//                        strip is one contiguous 128 KB run, so the stream is sequential per CU instead of 256-byte
+//                        pieces 126 KB apart.
 //                        Shape and pose blendshapes are ONE contraction: v_posed = v_template + feat @ dirs,
 //                        feat[b] = [betas | (R_1..R_{J-1} - I)]  (lbs.py:81 and :94-99 fused; 64 MB streamed once).
 //   WT    [64][Vpad]     skinning weights transposed (coalesced per-vertex reads), zero padded.
@@ -181,8 +184,10 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(LbsDev m, const float *__r
 // B operand: each lane loads 16 B (4 consecutive columns of one dirs row): 4 rows x 256 B per wave-load.
 // MFMA c of a k-step uses element c of that float4, so its 16 output columns are n0 + 4*(lane&15) + c.
 // ------------------------------------------------------------------------------------------------
+// amdgpu_waves_per_eu(2,2): without it the scheduler targets 8 waves/SIMD, caps the kernel at ~40 VGPRs and sinks the
+// 16 prefetched dirs loads back next to their MFMAs (one load in flight per wave); the grid only supplies 2 waves/SIMD.
 template <int MT>
-__global__ __launch_bounds__(256) void blend_fwd_kernel(LbsDev m, const float *__restrict__ feat, int B,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blend_fwd_kernel(LbsDev m, const float *__restrict__ feat, int B,
                                                         float *__restrict__ v_posed)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -195,20 +200,27 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(LbsDev m, const float *_
     for (int t = 0; t < MT; t++)
 #pragma unroll
         for (int c = 0; c < 4; c++) acc[t][c] = (f4){0, 0, 0, 0};
-    const float *arow[MT];
+    // per chunk of 64 k (16 MFMA steps): the wave's A operands are loaded up front, then the fully unrolled k-steps carry
+    // only the 16-byte dirs loads (16 in flight per lane) and the MFMAs.  Kpad is a multiple of 256, so kq % 64 == 0.
+    const float *brow = m.dirs + ((size_t)blockIdx.x * m.Kpad + w * kq + lk) * 64 + 4 * li;   // tile-major: row stride 64 floats
+    for (int k0 = 0; k0 < kq; k0 += 64) {
+        float areg[MT][16];
 #pragma unroll
-    for (int t = 0; t < MT; t++) arow[t] = feat + (size_t)min(b0 + t * 16 + li, B - 1) * m.Kpad + w * kq + lk;
-    const float *brow = m.dirs + (size_t)(w * kq + lk) * m.Npad + n0 + 4 * li;
-#pragma unroll 4
-    for (int ks = 0; ks < kq; ks += 4) {
-        f4 q = *(const f4 *)(brow + (size_t)ks * m.Npad);
-        float a[MT];
+        for (int t = 0; t < MT; t++) {
+            const float *ar = feat + (size_t)min(b0 + t * 16 + li, B - 1) * m.Kpad + w * kq + lk + k0;
 #pragma unroll
-        for (int t = 0; t < MT; t++) a[t] = arow[t][ks];
+            for (int sidx = 0; sidx < 16; sidx++) areg[t][sidx] = ar[sidx * 4];
+        }
+        f4 q[16];
 #pragma unroll
-        for (int t = 0; t < MT; t++)
+        for (int sidx = 0; sidx < 16; sidx++) q[sidx] = *(const f4 *)(brow + (size_t)(k0 + sidx * 4) * 64);
+        __builtin_amdgcn_sched_barrier(0);       // keep all 16 dirs loads (16 KB per wave) in flight ahead of the MFMAs
 #pragma unroll
-            for (int c = 0; c < 4; c++) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], q[c], acc[t][c], 0, 0, 0);
+        for (int sidx = 0; sidx < 16; sidx++)
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[t][sidx], q[sidx][c], acc[t][c], 0, 0, 0);
     }
     // reduce the four k-quarters through LDS; wave w finishes accumulator register `w` (row (lane>>4)*4 + w)
     __shared__ f4 red[4][MT][4][64];
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(SKIN_BLK) void skin_bwd_v_kernel(LbsDev m, const fl
 // skinning backward, joint part (MFMA): gA[b][j][r*4+s] = sum_v W[v][j] * g_local[b][v][r] * [v_posed;1][s]
 // wave = one body x one 256-vertex slice x all 64 padded joints (4 accumulators).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void skin_bwd_A_kernel(LbsDev m, const float *__restrict__ gl, const float *__restrict__ v_posed,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void skin_bwd_A_kernel(LbsDev m, const float *__restrict__ gl, const float *__restrict__ v_posed,
                                                          int B, float *__restrict__ part)
 {
     // workgroup = one body x one 256-vertex slice; wave w contracts vertices [64w, 64w+64) of the slice (4 MFMA steps,
@@ -405,6 +417,7 @@ __global__ __launch_bounds__(256) void skin_bwd_A_kernel(LbsDev m, const float *
             bop[st][t] = g * p;
         }
     }
+    __builtin_amdgcn_sched_barrier(0);           // all operand loads of the 4 steps are issued before the first MFMA waits
     f4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = (f4){0, 0, 0, 0};
@@ -430,7 +443,7 @@ __global__ __launch_bounds__(256) void skin_bwd_A_kernel(LbsDev m, const float *
 // workgroup = 4 waves sharing a 64-row k group and an n-slice; wave w takes n-steps w, w+4, ...; LDS reduce.
 // ------------------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(256) void blend_bwd_kernel(LbsDev m, const float *__restrict__ g_vp, int B, int steps_per_slice,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void blend_bwd_kernel(LbsDev m, const float *__restrict__ g_vp, int B, int steps_per_slice,
                                                         float *__restrict__ part)
 {
     constexpr int KT = 4;
@@ -452,20 +465,34 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(LbsDev m, const float *_
     for (int t = 0; t < MT; t++) grow[t] = g_vp + (size_t)min(b0 + t * 16 + li, B - 1) * m.Npad + 4 * lk;
     const float *drow[KT];
 #pragma unroll
-    for (int kt = 0; kt < KT; kt++) drow[kt] = m.dirs + (size_t)(k0 + kt * 16 + li) * m.Npad + 4 * lk;
-    for (int st = s_begin + w; st < s_end; st += 4) {
-        const int n0 = st * 16;
-        f4 ga[MT], db[KT];
+    for (int kt = 0; kt < KT; kt++) drow[kt] = m.dirs + (size_t)(k0 + kt * 16 + li) * 64 + 4 * lk;   // + tile base per step
+    // each wave owns steps s_begin+w, +4, ...; three steps' operands (3 x (MT + KT) 16-byte loads) are issued before the
+    // first MFMA group waits, and the scheduler is fenced so it cannot sink them back next to their uses
+    constexpr int PF = 3;
+    for (int st0 = s_begin + w; st0 < s_end; st0 += 4 * PF) {
+        f4 ga[PF][MT], db[PF][KT];
 #pragma unroll
-        for (int t = 0; t < MT; t++) ga[t] = *(const f4 *)(grow[t] + n0);
+        for (int p = 0; p < PF; p++) {
+            const int st = min(st0 + 4 * p, total_steps - 1);
+            const int n0 = st * 16;
 #pragma unroll
-        for (int kt = 0; kt < KT; kt++) db[kt] = *(const f4 *)(drow[kt] + n0);
+            for (int t = 0; t < MT; t++) ga[p][t] = *(const f4 *)(grow[t] + n0);
 #pragma unroll
-        for (int e = 0; e < 4; e++)
+            for (int kt = 0; kt < KT; kt++) db[p][kt] = *(const f4 *)(drow[kt] + (size_t)(n0 >> 6) * m.Kpad * 64 + (n0 & 63));
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kt = 0; kt < KT; kt++)
+        for (int p = 0; p < PF; p++) {
+            if (st0 + 4 * p < s_end) {
 #pragma unroll
-                for (int t = 0; t < MT; t++) acc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[t][e], db[kt][e], acc[kt][t], 0, 0, 0);
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+                        for (int t = 0; t < MT; t++)
+                            acc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[p][t][e], db[p][kt][e], acc[kt][t], 0, 0, 0);
+            }
+        }
     }
     __shared__ f4 red[4][KT][MT][64];
 #pragma unroll
@@ -673,7 +700,7 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     LbsDev d;
     memset(&d, 0, sizeof(d));
     d.V = V; d.J = J; d.NB = NB; d.P = (J - 1) * 9; d.K = NB + d.P;
-    d.Kpad = (d.K + 63) / 64 * 64;
+    d.Kpad = (d.K + 255) / 256 * 256;
     d.N = 3 * V;
     d.Vpad = (V + 255) / 256 * 256;
     d.Npad = 3 * d.Vpad;
@@ -694,9 +721,11 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     if (cidx.empty()) cidx.push_back(0);
     // host staging
     std::vector<float> dirs((size_t)d.Kpad * d.Npad, 0.0f), vt(d.Npad, 0.0f), WT((size_t)JP * d.Vpad, 0.0f);
+    auto dirs_at = [&](int k, int n) -> float & { return dirs[((size_t)(n >> 6) * d.Kpad + k) * 64 + (n & 63)]; };
     for (int l = 0; l < NB; l++)
-        for (int n = 0; n < d.N; n++) dirs[(size_t)l * d.Npad + n] = h_shapedirs[(size_t)n * NB + l];   // [V,3,NB] -> [NB][3V]
-    for (int p = 0; p < d.P; p++) memcpy(&dirs[(size_t)(NB + p) * d.Npad], h_posedirs + (size_t)p * d.N, sizeof(float) * d.N);
+        for (int n = 0; n < d.N; n++) dirs_at(l, n) = h_shapedirs[(size_t)n * NB + l];                  // [V,3,NB] -> row l
+    for (int p = 0; p < d.P; p++)
+        for (int n = 0; n < d.N; n++) dirs_at(NB + p, n) = h_posedirs[(size_t)p * d.N + n];
     memcpy(vt.data(), h_v_template, sizeof(float) * d.N);
     for (int v = 0; v < V; v++)
         for (int j = 0; j < J; j++) WT[(size_t)j * d.Vpad + v] = h_weights[(size_t)v * J + j];
