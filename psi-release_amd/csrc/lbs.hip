@@ -66,9 +66,11 @@ WsLayout ws_layout(const LbsDev &m, int B)
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
     w.nsv = m.Vpad / 256;                 // v-slices of 256 vertices for skin_bwd_A
-    w.nsn = psi_cdiv(m.Npad / 16, 48);    // n-slices of 48 MFMA steps (768 columns) for blend_bwd
+    // blend_bwd: (Kpad/64) k-groups x nsn n-slices ~= 256 workgroups = one per CU (one wave per SIMD, single round)
+    w.nsn = 256 / (m.Kpad / 64) > 0 ? 256 / (m.Kpad / 64) : 1;
+    if (w.nsn > m.Npad / 16) w.nsn = m.Npad / 16;
     w.nvb = m.Vpad / SKIN_BLK;
-    w.feat = take((size_t)B * m.Kpad);
+    w.feat = take((size_t)((B + 15) & ~15) * m.Kpad);        // k-quad layout [Kpad/4][Bpad][4]
     w.R = take((size_t)B * m.J * 9);
     w.Jl = take((size_t)B * m.J * 3);
     w.G = take((size_t)B * m.J * 12);
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(LbsDev m, const float *__r
                                                       float *__restrict__ As, float *__restrict__ joints)
 {
     const int b = blockIdx.x, j = threadIdx.x;
+    const int Bpad = (B + 15) & ~15;
     __shared__ float sJ[JP][3];
     __shared__ float sG[JP][12];
     const bool act = j < m.J;
@@ -126,14 +129,15 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(LbsDev m, const float *__r
         }
         for (int e = 0; e < 9; e++) Rs[((size_t)b * m.J + j) * 9 + e] = R[e];
         for (int c = 0; c < 3; c++) Jls[((size_t)b * m.J + j) * 3 + c] = Jl[c];
-        float *f = feat + (size_t)b * m.Kpad;
         if (j >= 1)
-            for (int e = 0; e < 9; e++) f[m.NB + (j - 1) * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+            for (int e = 0; e < 9; e++) {
+                int k = m.NB + (j - 1) * 9 + e;
+                feat[((size_t)(k >> 2) * Bpad + b) * 4 + (k & 3)] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+            }
     }
-    {   // betas and the zero tail of the feature row
-        float *f = feat + (size_t)b * m.Kpad;
-        for (int l = j; l < m.NB; l += 64) f[l] = betas[(size_t)b * m.NB + l];
-        for (int l = m.K + j; l < m.Kpad; l += 64) f[l] = 0.0f;
+    {   // betas and the zero tail of the feature row (feat is stored as k-quads: [Kpad/4][Bpad][4])
+        for (int l = j; l < m.NB; l += 64) feat[((size_t)(l >> 2) * Bpad + b) * 4 + (l & 3)] = betas[(size_t)b * m.NB + l];
+        for (int l = m.K + j; l < m.Kpad; l += 64) feat[((size_t)(l >> 2) * Bpad + b) * 4 + (l & 3)] = 0.0f;
     }
     __syncthreads();
     const int par = act ? m.parents[j] : -1;
@@ -184,61 +188,93 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(LbsDev m, const float *__r
 // B operand: each lane loads 16 B (4 consecutive columns of one dirs row): 4 rows x 256 B per wave-load.
 // MFMA c of a k-step uses element c of that float4, so its 16 output columns are n0 + 4*(lane&15) + c.
 // ------------------------------------------------------------------------------------------------
-// amdgpu_waves_per_eu(2,2): without it the scheduler targets 8 waves/SIMD, caps the kernel at ~40 VGPRs and sinks the
-// 16 prefetched dirs loads back next to their MFMAs (one load in flight per wave); the grid only supplies 2 waves/SIMD.
+// One wave per SIMD by design (amdgpu_waves_per_eu(1,1)): two co-resident waves of this kernel contend for the SIMD's
+// matrix pipe and measured 30% slower (gpurun t18: 25.9 vs 19.9 us at B=32).  Latency is hidden inside the wave instead:
+// a rolling double buffer keeps the operands of the NEXT 64-k chunk (16 dirs loads = 16 KB + the A quads) in flight while the
+// current chunk's 32*MT MFMAs issue, across chunk and tile boundaries.  Without the waves_per_eu bound the scheduler would
+// target 8 waves/SIMD, cap the kernel near 40 VGPRs and sink the prefetched loads back next to their MFMAs.
 template <int MT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blend_fwd_kernel(LbsDev m, const float *__restrict__ feat, int B,
-                                                        float *__restrict__ v_posed)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void blend_fwd_kernel(LbsDev m, const float *__restrict__ feat, int B,
+                                                                                           float *__restrict__ v_posed, int tiles_per_block)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int n0 = blockIdx.x * 64;
     const int b0 = blockIdx.y * 16 * MT;
-    const int kq = m.Kpad / 4;
+    const int kq = m.Kpad / 4;                  // k range of this wave (Kpad % 256 == 0 -> kq % 64 == 0)
+    const int nch = kq / 64;                    // 64-k chunks per tile for this wave
     const int li = lane & 15, lk = lane >> 4;
+    const int Bpad = (B + 15) & ~15;
+    const int ntiles = m.Npad / 64;
+    const int tile0 = blockIdx.x * tiles_per_block;
+    const int nt = min(tiles_per_block, ntiles - tile0);
+    const int total = nt * nch;
+    __shared__ f4 red[4][MT][4][64];
+
+    // k order inside a 64-wide chunk: lane group lk owns k = base + 16*lk + s (s = MFMA step 0..15).  feat is stored as
+    // k-quads [Kpad/4][Bpad][4], so the A operands of four consecutive steps are ONE 16-byte load per lane.
+    auto load_chunk = [&](int it, f4 (&q)[16], f4 (&a4)[MT][4]) {
+        const int tile = tile0 + it / nch, ch = it % nch;
+        const int kb = w * kq + 64 * ch + 16 * lk;
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) a4[t][j] = *(const f4 *)(feat + ((size_t)(kb / 4 + j) * Bpad + b0 + t * 16 + li) * 4);
+        const float *brow = m.dirs + ((size_t)tile * m.Kpad + kb) * 64 + 4 * li;
+#pragma unroll
+        for (int sidx = 0; sidx < 16; sidx++) q[sidx] = *(const f4 *)(brow + (size_t)sidx * 64);
+    };
     f4 acc[MT][4];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int t = 0; t < MT; t++)
+        for (int t = 0; t < MT; t++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) acc[t][c] = (f4){0, 0, 0, 0};
-    // per chunk of 64 k (16 MFMA steps): the wave's A operands are loaded up front, then the fully unrolled k-steps carry
-    // only the 16-byte dirs loads (16 in flight per lane) and the MFMAs.  Kpad is a multiple of 256, so kq % 64 == 0.
-    const float *brow = m.dirs + ((size_t)blockIdx.x * m.Kpad + w * kq + lk) * 64 + 4 * li;   // tile-major: row stride 64 floats
-    for (int k0 = 0; k0 < kq; k0 += 64) {
-        float areg[MT][16];
-#pragma unroll
-        for (int t = 0; t < MT; t++) {
-            const float *ar = feat + (size_t)min(b0 + t * 16 + li, B - 1) * m.Kpad + w * kq + lk + k0;
-#pragma unroll
-            for (int sidx = 0; sidx < 16; sidx++) areg[t][sidx] = ar[sidx * 4];
-        }
-        f4 q[16];
-#pragma unroll
-        for (int sidx = 0; sidx < 16; sidx++) q[sidx] = *(const f4 *)(brow + (size_t)(k0 + sidx * 4) * 64);
-        __builtin_amdgcn_sched_barrier(0);       // keep all 16 dirs loads (16 KB per wave) in flight ahead of the MFMAs
+            for (int c = 0; c < 4; c++) acc[t][c] = (f4){0, 0, 0, 0};
+    };
+    auto mfma_chunk = [&](const f4 (&q)[16], const f4 (&a4)[MT][4]) {
 #pragma unroll
         for (int sidx = 0; sidx < 16; sidx++)
 #pragma unroll
             for (int t = 0; t < MT; t++)
 #pragma unroll
-                for (int c = 0; c < 4; c++) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[t][sidx], q[sidx][c], acc[t][c], 0, 0, 0);
-    }
-    // reduce the four k-quarters through LDS; wave w finishes accumulator register `w` (row (lane>>4)*4 + w)
-    __shared__ f4 red[4][MT][4][64];
+                for (int c = 0; c < 4; c++)
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t][sidx >> 2][sidx & 3], q[sidx][c], acc[t][c], 0, 0, 0);
+    };
+    auto finish_tile = [&](int it) {            // after the last chunk of a tile: 4-way k reduction through LDS, add template, store
+        if ((it % nch) != nch - 1) return;
+        const int n0 = (tile0 + it / nch) * 64;
 #pragma unroll
-    for (int t = 0; t < MT; t++)
+        for (int t = 0; t < MT; t++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) red[w][t][c][lane] = acc[t][c];
-    __syncthreads();
-    f4 vt = *(const f4 *)(m.v_template + n0 + 4 * li);
+            for (int c = 0; c < 4; c++) red[w][t][c][lane] = acc[t][c];
+        __syncthreads();
+        f4 vt = *(const f4 *)(m.v_template + n0 + 4 * li);
 #pragma unroll
-    for (int t = 0; t < MT; t++) {
-        f4 o = vt;
+        for (int t = 0; t < MT; t++) {
+            f4 o = vt;
 #pragma unroll
-        for (int ww = 0; ww < 4; ww++)
+            for (int ww = 0; ww < 4; ww++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) o[c] += ((const float *)&red[ww][t][c][lane])[w];
-        int b = b0 + t * 16 + lk * 4 + w;
-        if (b < B) *(f4 *)(v_posed + (size_t)b * m.Npad + n0 + 4 * li) = o;
+                for (int c = 0; c < 4; c++) o[c] += ((const float *)&red[ww][t][c][lane])[w];   // wave w finishes row lk*4 + w
+            int b = b0 + t * 16 + lk * 4 + w;
+            if (b < B) *(f4 *)(v_posed + (size_t)b * m.Npad + n0 + 4 * li) = o;
+        }
+        __syncthreads();
+        zero_acc();
+    };
+
+    f4 qA[16], qB[16], aA[MT][4], aB[MT][4];
+    zero_acc();
+    load_chunk(0, qA, aA);
+    for (int it = 0; it < total; it += 2) {
+        if (it + 1 < total) load_chunk(it + 1, qB, aB);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(qA, aA);
+        finish_tile(it);
+        if (it + 1 < total) {
+            if (it + 2 < total) load_chunk(it + 2, qA, aA);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(qB, aB);
+            finish_tile(it + 1);
+        }
     }
 }
 
@@ -443,7 +479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 // workgroup = 4 waves sharing a 64-row k group and an n-slice; wave w takes n-steps w, w+4, ...; LDS reduce.
 // ------------------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void blend_bwd_kernel(LbsDev m, const float *__restrict__ g_vp, int B, int steps_per_slice,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void blend_bwd_kernel(LbsDev m, const float *__restrict__ g_vp, int B, int steps_per_slice,
                                                         float *__restrict__ part)
 {
     constexpr int KT = 4;
@@ -811,12 +847,19 @@ extern "C" int psi_lbs_forward(const psi_lbs_model *mdl, const float *betas, con
                        ws + L.G, ws + L.A, joints);
     PSI_CHECK_LAUNCH("pose_fwd_kernel");
     psi_mark("pose_fwd_kernel", st);
-    if (B > 32)
-        hipLaunchKernelGGL(blend_fwd_kernel<4>, dim3(m.Npad / 64, psi_cdiv(B, 64)), dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
-    else if (B > 16)
-        hipLaunchKernelGGL(blend_fwd_kernel<2>, dim3(m.Npad / 64, 1), dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
-    else
-        hipLaunchKernelGGL(blend_fwd_kernel<1>, dim3(m.Npad / 64, 1), dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
+    {
+        const int ntiles = m.Npad / 64;
+        const int bgroups = B > 32 ? psi_cdiv(B, 64) : 1;
+        int tpb = psi_cdiv((long)ntiles * bgroups, 256);          // ~one workgroup (1 wave/SIMD) per CU, single round
+        if (tpb < 1) tpb = 1;
+        dim3 grid(psi_cdiv(ntiles, tpb), bgroups);
+        if (B > 32)
+            hipLaunchKernelGGL(blend_fwd_kernel<4>, grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed, tpb);
+        else if (B > 16)
+            hipLaunchKernelGGL(blend_fwd_kernel<2>, grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed, tpb);
+        else
+            hipLaunchKernelGGL(blend_fwd_kernel<1>, grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed, tpb);
+    }
     PSI_CHECK_LAUNCH("blend_fwd_kernel");
     psi_mark("blend_fwd_kernel", st);
     hipLaunchKernelGGL(skin_fwd_kernel, dim3(m.Vpad / SKIN_BLK, psi_cdiv(B, SKIN_BT)), dim3(SKIN_BLK), 0, st, m, ws + L.A,
@@ -840,7 +883,7 @@ int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const
     hipLaunchKernelGGL(skin_bwd_A_kernel, dim3(L.nsv, B), dim3(256), 0, st, m, ws + L.gl, ws + L.v_posed, B, ws + L.gA_part);
     PSI_CHECK_LAUNCH("skin_bwd_A_kernel");
     psi_mark("skin_bwd_A_kernel", st);
-    const int steps = 48;
+    const int steps = psi_cdiv(m.Npad / 16, L.nsn);
     dim3 g(m.Kpad / 64, L.nsn, 1);
     if (B > 32) {
         g.z = psi_cdiv(B, 64);

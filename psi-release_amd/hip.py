@@ -11,7 +11,7 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'lib', 'libpsi_hip.so')
+LIB_PATH = os.environ.get('PSI_HIP_LIB') or os.path.join(_PKG, 'lib', 'libpsi_hip.so')   # PSI_HIP_LIB: development A/B builds
 _lib = None
 
 c_void_p, c_int, c_long, c_size_t, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_float
@@ -69,6 +69,8 @@ def lib():
                               '(there is no CPU fallback)' % LIB_PATH)
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get('PSI_HIP_LIB') and not hasattr(l, name):
+                continue                    # partial development build
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
