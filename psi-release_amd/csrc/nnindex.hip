@@ -5,8 +5,8 @@
 // target index attaining it.  The index only prunes: every target whose computed d could be <= the final minimum is
 // still evaluated with the identical expression, so distances and indices are bit-identical to brute force.
 //
-//   build (host, once per scene): balanced kd-tree, median split on the widest axis, leaves of <= 8 points (padded to 8 records); every
-//     internal node stores the exact AABBs of both children (one 64-byte record per visit); points are re-ordered by leaf and stored as float4 {x, y, z, bitcast(original index)}.
+//   build (host, once per scene): balanced kd-tree (median split on the widest axis) collapsed three levels at a time into
+//     8-wide nodes; leaves of <= 8 points (padded to 8 records); every internal node stores the exact AABBs of its 8 children; points are re-ordered by leaf and stored as float4 {x, y, z, bitcast(original index)}.
 //   query (one lane per query, per-lane stack in LDS): depth-first, nearer child first.  A node is skipped when
 //       d2box * 0.999999f > best,  d2box = squared distance from the query to the node's AABB evaluated in fp32.
 //     Safety: for any point p in the box, d_hat(p) >= true(p) (1 - 3e-7) >= trueBox (1 - 3e-7) >= d2box_hat (1 - 3e-7)^2,
@@ -29,15 +29,25 @@ namespace {
 
 constexpr int LEAF = 8;             // points per leaf; leaves are PADDED to exactly 8 records (copies of the last point)
                                     // so the scan is a fixed, fully unrolled batch of 8 independent 16-byte loads
-constexpr int MAXDEPTH = 32;
-constexpr int QBLK = 64;            // one wave per workgroup: per-lane stacks live in LDS [MAXDEPTH][64]
+constexpr int WIDE = 8;             // children per internal node
+constexpr int MAXSTACK = 48;        // <= 7 pushes per level, ~5 levels for 2^24 points at fan-out 8
+constexpr int QBLK = 64;            // one wave per workgroup: per-lane stacks live in LDS [MAXSTACK][QPW]
+constexpr int QPW = 64;             // queries per wave.  The search is latency-bound (a chain of dependent node loads) and a
+                                    // batch has only B*n_c = 65536 queries: measured: 16 active lanes per wave (4096 waves) is SLOWER
+                                    // (72 vs 61 us): the kernel is bound by the summed per-lane traversal work, not by load latency.
+constexpr int EMPTY = (int)0x80000000;
 
-// Fat node: the AABBs of BOTH children (one 64-byte record per visit, no child re-load on pop).
-// Child reference: >= 0 internal node index;  < 0 leaf number L encoded -(L) - 1; its 8 records start at pts[8*L].
+// 8-wide node (256 bytes): the exact AABBs of all 8 children, structure-of-arrays, plus the 8 child references.
+// The tree is only ~log8(m/8) levels deep (4 for m = 32768): the per-query dependent-load chain is 4 node records and a
+// leaf instead of 12+ binary levels; the 14 16-byte loads of one record are independent and issued together.
+// Child reference: >= 0 internal node index;  < 0 leaf number L encoded -(L) - 1 (records pts[8L .. 8L+7]);  EMPTY = none
+// (its box is [+inf, -inf], i.e. infinitely far).
 struct KdNode {
-    float lmin[3], lmax[3], rmin[3], rmax[3];
-    int left, right, pad0, pad1;
+    float mn[3][WIDE], mx[3][WIDE];
+    int child[WIDE];
+    int pad[8];
 };
+static_assert(sizeof(KdNode) == 256, "node record is 256 bytes");
 
 struct KdDev {
     const KdNode *nodes;
@@ -47,13 +57,9 @@ struct KdDev {
     int m;
 };
 
-__device__ __forceinline__ float box_d2(const float *mn, const float *mx, float qx, float qy, float qz)
-{
-    float dx = fmaxf(fmaxf(mn[0] - qx, qx - mx[0]), 0.0f);
-    float dy = fmaxf(fmaxf(mn[1] - qy, qy - mx[1]), 0.0f);
-    float dz = fmaxf(fmaxf(mn[2] - qz, qz - mx[2]), 0.0f);
-    return dx * dx + dy * dy + dz * dz;
-}
+#ifdef PSI_KD_STATS
+__device__ unsigned long long g_kd_stats[4];     // development build only: node visits, leaf visits, wave iterations
+#endif
 
 // CONTACT: fused contact-loss epilogue, identical to nn_resolve_kernel<true> in chamfer.hip
 template <bool CONTACT>
@@ -62,13 +68,13 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T, const float *__
                                                         float cconst, float gscale, float *__restrict__ gq, float *__restrict__ fpart,
                                                         int *__restrict__ hint)
 {
-    __shared__ int stk_n[MAXDEPTH][QBLK];
-    __shared__ float stk_d[MAXDEPTH][QBLK];
+    __shared__ int stk_n[MAXSTACK][QPW];
+    __shared__ float stk_d[MAXSTACK][QPW];
     const int lane = threadIdx.x;
     const int b = blockIdx.y;
-    const int j = blockIdx.x * QBLK + lane;
+    const int j = blockIdx.x * QPW + lane;
     float fval = 0.0f;
-    if (j < n) {
+    if (lane < QPW && j < n) {
         const size_t qrow = qidx ? (size_t)qidx[j] : (size_t)j;
         const float *qp = xyz1 + (size_t)b * qstride + qrow * 3;
         const float qx = qp[0], qy = qp[1], qz = qp[2];
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T, const float *__
         const size_t o = (size_t)b * n + j;
         if (hint) {
             // warm start: the target that won for this query last time is evaluated first (an ordinary candidate, so
-            // the result is unchanged); a good initial `best` prunes almost every far child on the way down
+            // the result is unchanged); a good initial `best` prunes almost every sibling on the way down
             int h = hint[o];
             if (h >= 0 && h < T.m) {
                 const float4 p = T.opts[h];
@@ -93,6 +99,9 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T, const float *__
         float curd = 0.0f;
         bool have = true;
         while (true) {
+#ifdef PSI_KD_STATS
+            if (lane == __builtin_ffsll(__ballot(1)) - 1) atomicAdd(&g_kd_stats[2], 1ull);
+#endif
             if (!have) {
                 if (sp == 0) break;
                 --sp;
@@ -101,6 +110,9 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T, const float *__
             }
             have = false;
             if (curd * 0.999999f > best) continue;
+#ifdef PSI_KD_STATS
+            atomicAdd(&g_kd_stats[cur < 0 ? 1 : 0], 1ull);
+#endif
             if (cur < 0) {
                 const float4 *lp = T.pts + (size_t)(-cur - 1) * LEAF;
                 float4 pp[LEAF];
@@ -120,21 +132,40 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T, const float *__
                 }
             } else {
                 const float4 *np = (const float4 *)(T.nodes + cur);
-                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                const float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
-                const float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
-                const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-                const float dl = box_d2(lmin, lmax, qx, qy, qz), dr = box_d2(rmin, rmax, qx, qy, qz);
-                const bool left_first = dl <= dr;
-                const float dnear = left_first ? dl : dr, dfar = left_first ? dr : dl;
-                if (dfar * 0.999999f <= best) {
-                    stk_n[sp][lane] = left_first ? right : left;
-                    stk_d[sp][lane] = dfar;
-                    sp++;
+                float4 r[14];
+#pragma unroll
+                for (int k = 0; k < 14; k++) r[k] = np[k];                 // 6 x 8 box floats + 8 child refs, all independent
+                const float *f = (const float *)r;
+                float dc[WIDE];
+#pragma unroll
+                for (int c = 0; c < WIDE; c++) {
+                    float dx = fmaxf(fmaxf(f[0 * 8 + c] - qx, qx - f[24 + 0 * 8 + c]), 0.0f);
+                    float dy = fmaxf(fmaxf(f[1 * 8 + c] - qy, qy - f[24 + 1 * 8 + c]), 0.0f);
+                    float dz = fmaxf(fmaxf(f[2 * 8 + c] - qz, qz - f[24 + 2 * 8 + c]), 0.0f);
+                    dc[c] = dx * dx + dy * dy + dz * dz;                   // +inf for EMPTY children
                 }
-                cur = left_first ? left : right;      // descend into the nearer child without an LDS round trip
-                curd = dnear;
-                have = true;
+                float dmin = dc[0];
+                int cmin = 0;
+#pragma unroll
+                for (int c = 1; c < WIDE; c++)
+                    if (dc[c] < dmin) { dmin = dc[c]; cmin = c; }
+                // push the other children that can still matter; descend into the nearest without an LDS round trip
+#pragma unroll
+                for (int c = 0; c < WIDE; c++) {
+                    if (c != cmin && dc[c] * 0.999999f <= best) {
+                        stk_n[sp][lane] = __float_as_int(f[48 + c]);
+                        stk_d[sp][lane] = dc[c];
+                        sp++;
+                    }
+                }
+                int cref = __float_as_int(f[48]);
+#pragma unroll
+                for (int c = 1; c < WIDE; c++) cref = (c == cmin) ? __float_as_int(f[48 + c]) : cref;
+                if (dmin < INFINITY) {
+                    cur = cref;
+                    curd = dmin;
+                    have = true;
+                }
             }
         }
         if (dist) dist[o] = best;
@@ -176,14 +207,8 @@ struct Builder {
             }
     }
 
-    // returns the child reference of the subtree over order[lo:hi)
-    int build(int lo, int hi, int depth)
+    int median_split(int lo, int hi)             // reorders order[lo:hi) around the median of its widest axis
     {
-        if (depth > depth_max) depth_max = depth;
-        if (hi - lo <= LEAF) {
-            leaves.push_back({lo, hi - lo});
-            return -((int)leaves.size() - 1) - 1;
-        }
         float mn[3], mx[3];
         bounds(lo, hi, mn, mx);
         int ax = 0;
@@ -195,16 +220,46 @@ struct Builder {
             float a = pp[(size_t)u * 3 + ax], b = pp[(size_t)v * 3 + ax];
             return a < b || (a == b && u < v);
         });
+        return mid;
+    }
+
+    // returns the child reference of the subtree over order[lo:hi)
+    int build(int lo, int hi, int depth)
+    {
+        if (depth > depth_max) depth_max = depth;
+        if (hi - lo <= LEAF) {
+            leaves.push_back({lo, hi - lo});
+            return -((int)leaves.size() - 1) - 1;
+        }
+        // up to three rounds of median splits -> up to 8 ranges (fewer when the range is small)
+        std::vector<std::pair<int, int>> rg = {{lo, hi}};
+        for (int round = 0; round < 3; round++) {
+            std::vector<std::pair<int, int>> nx;
+            for (auto &r : rg) {
+                if (r.second - r.first > LEAF) {
+                    int mid = median_split(r.first, r.second);
+                    nx.push_back({r.first, mid});
+                    nx.push_back({mid, r.second});
+                } else {
+                    nx.push_back(r);
+                }
+            }
+            rg.swap(nx);
+        }
         int me = (int)nodes.size();
         nodes.push_back(KdNode());
-        int l = build(lo, mid, depth + 1);
-        int r = build(mid, hi, depth + 1);
         KdNode nd;
         memset(&nd, 0, sizeof(nd));
-        bounds(lo, mid, nd.lmin, nd.lmax);
-        bounds(mid, hi, nd.rmin, nd.rmax);
-        nd.left = l;
-        nd.right = r;
+        for (int c = 0; c < WIDE; c++) {
+            nd.child[c] = EMPTY;
+            for (int a = 0; a < 3; a++) { nd.mn[a][c] = INFINITY; nd.mx[a][c] = -INFINITY; }
+        }
+        for (size_t c = 0; c < rg.size(); c++) {
+            float mn[3], mx[3];
+            bounds(rg[c].first, rg[c].second, mn, mx);
+            for (int a = 0; a < 3; a++) { nd.mn[a][c] = mn[a]; nd.mx[a][c] = mx[a]; }
+            nd.child[c] = build(rg[c].first, rg[c].second, depth + 1);
+        }
         nodes[me] = nd;
         return me;
     }
@@ -226,7 +281,7 @@ extern "C" int psi_nn_index_create(psi_nn_index **out, const float *h_points, in
     for (int i = 0; i < m; i++) bd.order[i] = i;
     bd.nodes.reserve((size_t)2 * (m / LEAF + 2));
     int root = bd.build(0, m, 0);
-    PSI_REQUIRE(bd.depth_max + 2 < MAXDEPTH, "kd-tree too deep");
+    PSI_REQUIRE(7 * (bd.depth_max + 1) + 2 < MAXSTACK, "tree too deep for the traversal stack");
     auto rec = [&](int oi) {
         float4 r;
         r.x = h_points[(size_t)oi * 3 + 0];
@@ -281,7 +336,7 @@ extern "C" int psi_nn_index_query(const psi_nn_index *ix, const float *xyz1, int
     if (B == 0 || n == 0) return 0;
     PSI_REQUIRE(xyz1 && dist1 && idx1, "null pointer");
     PSI_REQUIRE(B <= 65535, "B exceeds grid.y");
-    hipLaunchKernelGGL(kd_query_kernel<false>, dim3(psi_cdiv(n, QBLK), B), dim3(QBLK), 0, (hipStream_t)stream, ix->d, xyz1,
+    hipLaunchKernelGGL(kd_query_kernel<false>, dim3(psi_cdiv(n, QPW), B), dim3(QBLK), 0, (hipStream_t)stream, ix->d, xyz1,
                        (const int *)nullptr, (long)n * 3, n, dist1, idx1, 0.0f, 0.0f, (float *)nullptr, (float *)nullptr, hint);
     PSI_CHECK_LAUNCH("kd_query_kernel");
     psi_mark("kd_query_kernel", (hipStream_t)stream);
@@ -292,10 +347,17 @@ extern "C" int psi_nn_index_query(const psi_nn_index *ix, const float *xyz1, int
 int psi_nn_index_contact(const psi_nn_index *ix, const float *verts, long vstride, const int *vid, int B, int n, float cconst,
                          float gscale, float *gq, float *fpart, int *hint, hipStream_t st)
 {
-    hipLaunchKernelGGL(kd_query_kernel<true>, dim3(psi_cdiv(n, QBLK), B), dim3(QBLK), 0, st, ix->d, verts, vid, vstride, n,
+    hipLaunchKernelGGL(kd_query_kernel<true>, dim3(psi_cdiv(n, QPW), B), dim3(QBLK), 0, st, ix->d, verts, vid, vstride, n,
                        (float *)nullptr, (int *)nullptr, cconst, gscale, gq, fpart, hint);
     PSI_CHECK_LAUNCH("kd_query_kernel<contact>");
     psi_mark("kd_query_kernel", st);
     return 0;
 }
-int psi_nn_index_fparts(int n) { return psi_cdiv(n, QBLK); }
+int psi_nn_index_fparts(int n) { return psi_cdiv(n, QPW); }
+#ifdef PSI_KD_STATS
+extern "C" int psi_kd_stats(unsigned long long *h4, int reset)
+{
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_kd_stats), z, 32); }
+    return (int)hipMemcpyFromSymbol(h4, HIP_SYMBOL(g_kd_stats), 32);
+}
+#endif
