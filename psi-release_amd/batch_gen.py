@@ -131,3 +131,51 @@ class BatchGeneratorWithSceneMesh:
                else self.sdf_table[slot])
         return [depth, seg, body, cam_ext, cam_int, max_d, s_verts, s_faces, self.gmin_table[slot], self.gmax_table[slot],
                 self.gdim_table[slot], sdf]
+
+
+class BatchGeneratorTest:
+    """Snapshot reader for the PROX-E generation drivers (source/batch_gen_hdf5.py:619-797): every ``*.mat`` under
+    ``dataset_path`` holds ``depth``, ``seg``, ``cam`` (``intrinsic``, ``extrinsic``) and ``body`` of one recording.
+    ``next_batch(batch_size)`` returns (depth, seg, max_d, cam_int, cam_ext, body); like the reference it always parses
+    ``rec_list[0]`` (:769), i.e. the batch repeats one snapshot."""
+
+    def __init__(self, dataset_path, device):
+        self.rec_list = glob.glob(os.path.join(dataset_path, '*.mat'))
+        self.index_rec = 0
+        self.device = torch.device(device)
+        random.shuffle(self.rec_list)
+
+    def reset(self):
+        self.index_rec = 0
+        random.shuffle(self.rec_list)
+
+    def has_next_batch(self):
+        return self.index_rec < len(self.rec_list)
+
+    def scipy_matfile_parse(self, filename):
+        import scipy.io as sio
+        from .generation import data_preprocessing
+        data = sio.loadmat(filename)
+        t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=self.device)
+        depth, _, max_d = data_preprocessing(t(data['depth']), 'depth', [128, 128])
+        seg, _, _ = data_preprocessing(t(data['seg']), 'seg', [128, 128])
+        cam = data['cam'][0][0]
+        cam_intrinsic = t(cam['intrinsic']).unsqueeze(0)
+        cam_extrinsic = t(np.linalg.inv(np.asarray(cam['extrinsic'], dtype=np.float64))).unsqueeze(0)   # :749-750
+        body = data['body'][0][0]
+        body_np = np.concatenate([body[k] for k in ('transl', 'global_orient', 'betas', 'body_pose', 'left_hand_pose',
+                                                    'right_hand_pose')], axis=-1)
+        return depth, seg, max_d.view(1), cam_intrinsic, cam_extrinsic, t(body_np)
+
+    def next_batch(self, batch_size):
+        cols = [[] for _ in range(6)]
+        for _ in range(batch_size):
+            if not self.has_next_batch():
+                return None
+            for c, v in zip(cols, self.scipy_matfile_parse(self.rec_list[0])):
+                c.append(v)
+        out = tuple(torch.cat(c, dim=0) for c in cols)
+        if torch.isnan(out[0]).any() or torch.isnan(out[1]).any():
+            print('[ERROR] nan in depth/seg batch')
+            return None
+        return out

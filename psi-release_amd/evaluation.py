@@ -51,3 +51,17 @@ class PlausibilityEvaluator:
             coll.append(c)
             cont.append(k)
         return coll, cont
+
+
+def diversity_scores(bodies_72: np.ndarray, n_clusters: int = 20, seed: int = 0):
+    """utils/utils_eval_diversity.py:93-104: k-means (k=20) on the generated body vectors; returns the entropy of the
+    cluster-size histogram and the mean distance of samples to their cluster centre."""
+    from sklearn.cluster import KMeans
+    x = np.asarray(bodies_72, dtype=np.float64)
+    k = min(n_clusters, len(x))
+    km = KMeans(n_clusters=k, random_state=seed, n_init=10).fit(x)
+    counts = np.bincount(km.labels_, minlength=k).astype(np.float64)
+    p = counts / counts.sum()
+    entropy = float(-(p[p > 0] * np.log(p[p > 0])).sum())
+    mean_dist = float(np.mean(np.linalg.norm(x - km.cluster_centers_[km.labels_], axis=1)))
+    return entropy, mean_dist

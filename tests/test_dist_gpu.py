@@ -59,3 +59,37 @@ def test_two_ranks_equal_full_batch(tmp_path, engine):
     mp.spawn(_worker, args=(2, port, str(tmp_path), engine), nprocs=2, join=True)
     got = np.concatenate([np.load(tmp_path / 'x0.npy'), np.load(tmp_path / 'x1.npy')])
     assert np.abs(got - full).max() < 5e-5
+
+
+def _train_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from test_training_gpu import _train_setup
+    op, batch = _train_setup(tmp, 2, rows=slice(2 * rank, 2 * rank + 2))
+    op.train_step(batch, ep=0)
+    if rank == 0:
+        torch.save({k: v.grad.detach().cpu() for k, v in op.model_h.named_parameters()}, os.path.join(tmp, 'dp.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_gradient_allreduce_equals_full_batch(tmp_path):
+    """TrainOP data parallel: averaged per-rank gradients == full-batch gradient (mean-type losses, equal shards, BN in
+    eval mode so that batch statistics do not differ between the shardings)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_training_gpu import _train_setup
+    op, batch = _train_setup(str(tmp_path), 4, rows=slice(0, 4))
+    op.train_step(batch, ep=0)
+    full = {k: v.grad.detach().cpu() for k, v in op.model_h.named_parameters()}
+    del op
+    torch.cuda.synchronize()
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    dp = torch.load(tmp_path / 'dp.pt')
+    # gradients (after the all-reduce) rather than parameters: Adam's first step is +-lr for any non-tiny gradient
+    for k in full:
+        scale = float(full[k].abs().max()) + 1e-12
+        assert float((dp[k] - full[k]).abs().max()) / scale < 1e-3, k

@@ -45,3 +45,30 @@ def test_sampling_pkl_schema_and_newest_checkpoint(tmp_path):
         b = pickle.load(f)
     assert set(b.keys()) == {'transl', 'global_orient', 'betas', 'body_pose', 'left_hand_pose', 'right_hand_pose', 'cam_ext', 'cam_int'}
     assert b['transl'].shape == (1, 3) and b['body_pose'].shape == (1, 32) and b['cam_ext'].shape == (3, 4, 4)
+
+
+def test_batch_generator_test_mat_files(tmp_path):
+    """BatchGeneratorTest over scipy .mat snapshots (batch_gen_hdf5.py:726-797)."""
+    import scipy.io as sio
+    from psi_release_amd import batch_gen
+    rs = np.random.RandomState(1)
+    bodies = synth.make_bodies(3, 1)
+    ext = synth.make_cam_ext(2, 1)[0]
+    sio.savemat(str(tmp_path / 'rec_000000.mat'), {
+        'depth': rs.uniform(0.5, 8, (90, 160)).astype(np.float32), 'seg': rs.randint(0, 50, (90, 160)).astype(np.float32),
+        'cam': {'intrinsic': bodies['cam_int'][0], 'extrinsic': ext},
+        'body': {k: bodies[k] for k in ('transl', 'global_orient', 'betas', 'body_pose', 'left_hand_pose', 'right_hand_pose')}})
+    bg = batch_gen.BatchGeneratorTest(str(tmp_path), 'cpu')
+    d, s, md, ci, ce, body = bg.next_batch(2)
+    assert d.shape == (2, 1, 128, 128) and s.shape == (2, 1, 128, 128) and md.shape == (2,) and ci.shape == (2, 3, 3)
+    assert ce.shape == (2, 4, 4) and body.shape == (2, 72)
+    assert np.allclose(ce[0].numpy() @ ext, np.eye(4), atol=1e-5)          # cam_ext is the INVERSE of the stored extrinsic
+    assert float(md[0]) == 6.0                                             # depth clipped at 6 m
+
+
+def test_diversity_scores():
+    from psi_release_amd import evaluation
+    rs = np.random.RandomState(0)
+    x = np.concatenate([rs.standard_normal((50, 72)) * 0.05 + c for c in (0.0, 3.0, -3.0)])
+    ent, dist = evaluation.diversity_scores(x, n_clusters=3)
+    assert abs(ent - np.log(3)) < 1e-6 and dist < 1.0

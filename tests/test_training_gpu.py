@@ -118,3 +118,28 @@ def test_batch_contract_and_training_loop_checkpoint_resume(tmp_path, smplx_data
     op2 = training.TrainOPS2(cfg, dict(LW))
     assert op2._resume() == 10
     assert torch.equal(op2.model_h.pose_vae.decode[3].weight.detach().cpu(), sd['model_h_state_dict']['pose_vae.decode.3.weight'])
+
+
+def _train_setup(tmp, B, rows):
+    """Deterministic stage-1 TrainOP (eval-mode BN, fixed weights) and rows `rows` of a fixed 4-sample batch."""
+    import types
+    smplx_data, vposer_sd = synth.make_smplx(7), synth.make_vposer_state(3)
+    scene = synth.make_scene(2, 1500, 16, 200)
+    cfg = make_cfg(tmp, smplx_data, vposer_sd, scene, B)
+    cfg['resume_training'] = False
+    op = training.TrainOP(cfg, dict(LW))
+    _load(op.model_h, 0)
+    op.model_h.eval()
+    torch.manual_seed(0)
+    eps = torch.randn(4, 32, device=DEV)[rows]
+    inp = synth.make_cvae_inputs(13, 4)
+    bodies = synth.make_bodies(17, 4)
+    xh = synth.body_vector_72(bodies)
+    xh[:, 2] = np.abs(xh[:, 2]) + 2.0
+    n = len(range(4)[rows])
+    rep = lambda a: T(a)[None].repeat(n, *([1] * np.asarray(a).ndim))
+    batch = [T(inp['xs'][rows, :1]), T(inp['xs'][rows, 1:]), T(xh[rows]), T(synth.make_cam_ext(9, 4)[rows]), T(bodies['cam_int'][rows]),
+             T(np.full(n, 6.0, np.float32)), rep(scene.verts), None, rep(scene.grid_min), rep(scene.grid_max), None, rep(scene.sdf)]
+    cal = op.cal_loss
+    op.cal_loss = lambda **kw: cal(eps=eps, **kw)           # fixed reparameterisation noise for both shardings
+    return op, batch
