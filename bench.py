@@ -46,6 +46,10 @@ def parse():
     ap.add_argument('--nc', type=int, default=2048, help='contact vertices')
     ap.add_argument('--D', type=int, default=256, help='SDF grid dimension')
     ap.add_argument('--engine', default=os.environ.get('PSI_ENGINE', 'auto'), choices=['auto', 'fused', 'modular'])
+    ap.add_argument('--workload', default='fitting', choices=['fitting', 'train_s2'],
+                    help="'fitting' = BASELINE metric (configs[1]); 'train_s2' = secondary line for configs[2] (train_s2 step, batch 128)")
+    ap.add_argument('--graph', type=int, default=1, help='train_s2: replay the whole optimiser step as one HIP graph')
+    ap.add_argument('--bf16', type=int, default=1, help='train_s2: bf16 autocast for the CVAE trunk')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='time budget of the CPU baseline sample')
     return ap.parse_args()
@@ -151,8 +155,60 @@ def cpu_baseline(args, assets, budget_s):
                       % (n, args.batch, args.nc, args.m, args.D, el, cands, ncpu)}
 
 
+def bench_train_s2(args):
+    """Secondary workload (BASELINE configs[2]): train_s2.py optimiser steps at batch 128 on synthetic PROX-shaped data
+    (two scenes with 256^3 SDFs held once in HBM, indirect scene ids), CVAE trunk on the matrix cores via MIOpen/hipBLASLt."""
+    import tempfile
+    from psi_release_amd import batch_gen, synth, training
+    dev = torch.device('cuda', 0)
+    B = 128 if args.batch == 32 else args.batch
+    names = ['SynA', 'SynB']
+    sd = {n: synth.make_scene(i, args.m, args.D, args.nc) for i, n in enumerate(names)}
+    scenes = {n: {'verts': s.verts, 'sdf': s.sdf, 'grid_min': s.grid_min, 'grid_max': s.grid_max, 'grid_dim': s.grid_dim} for n, s in sd.items()}
+    rs = np.random.RandomState(0)
+    n = B * 4
+    body = synth.body_vector_72(synth.make_bodies(0, n))
+    body[:, 2] = np.abs(body[:, 2]) + 2.0
+    t = {'depth': rs.uniform(-1, 1, (n, 1, 128, 128)), 'seg': rs.uniform(-1, 1, (n, 1, 128, 128)), 'body': body,
+         'cam_ext': synth.make_cam_ext(0, n), 'cam_int': synth.make_bodies(0, n)['cam_int'], 'max_d': np.full(n, 6.0),
+         'sceneid': rs.randint(0, 2, n).astype(np.float32)}
+    table = {k: np.concatenate([np.zeros_like(np.asarray(v)[:1]), np.asarray(v)]).astype(np.float32) for k, v in t.items()}
+    bg = batch_gen.BatchGeneratorWithSceneMesh.from_arrays(table, scenes, dev, indirect_sdf=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = {'human_model_path': None, 'vposer_ckpt_path': None, 'scene_model_ckpt': None, 'init_lr_h': 1e-4, 'batch_size': B, 'epoch': 10,
+               'loss_weight_anealing': True, 'device': dev, 'save_dir': tmp, 'contact_id_folder': None, 'contact_part': synth.CONTACT_PARTS,
+               'verbose': False, 'use_cont_rot': True, 'resume_training': False, 'smplx_data': synth.make_smplx(7),
+               'vposer_state': synth.make_vposer_state(3), 'contact_parts_data': sd['SynA'].contact_parts, 'autocast_bf16': bool(args.bf16), 'use_graph': bool(args.graph)}
+        lw = {'weight_loss_rec_s': 1.0, 'weight_loss_rec_h': 1.0, 'weight_loss_vposer': 1e-3, 'weight_loss_kl': 1e-1, 'weight_contact': 1e-1,
+              'weight_collision': 1e-1}
+        op = training.TrainOPS2(cfg, lw)
+        op.model_h.train()
+        batches = []
+        while bg.has_next_batch():
+            d = bg.next_batch(B)
+            if d is not None:
+                batches.append(d)
+        step = lambda i: op.train_step(batches[i % len(batches)], ep=9)       # ep > 0.75*epoch: scene losses active
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(json.dumps({'metric': 'train_s2 optimiser steps/sec (HumanCVAES2 + SMPL-X + Chamfer + SDF), batch=%d' % B,
+                      'value': round(args.steps / dt, 3), 'unit': 'steps/s', 'samples_per_s': round(args.steps * B / dt, 1), 'n_gpus': 1,
+                      'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+                      'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 trunk / f32 losses' if args.bf16 else 'f32', 'data': 'synthetic',
+                      'config': {'workload': 'train_s2.py step, batch=%d, 2 scenes (m=%d, SDF %d^3, indirect scene ids), n_c=%d (BASELINE configs[2])'
+                                             % (B, args.m, args.D, args.nc), 'hip_graph': bool(args.graph)}}))
+
+
 def main():
     args = parse()
+    if args.workload == 'train_s2':
+        return bench_train_s2(args)
     from psi_release_amd import dist as pd
     # RCCL (backend 'nccl') over xGMI; PSI_DIST_BACKEND=gloo lets a single-GPU box exercise the N>1 code path
     rank, local_rank, world = pd.init_from_env(os.environ.get('PSI_DIST_BACKEND', 'nccl'))

@@ -67,6 +67,17 @@ void psi_nn_index_destroy(psi_nn_index *index);
 int psi_nn_index_query(const psi_nn_index *index, const float *xyz1, int B, int n, float *dist1, int32_t *idx1,
                        int32_t *hint, void *stream);
 
+/* A set of scene indices queried in ONE launch with a per-body scene slot: body b is searched in indices[slot[b]]
+ * (slot: device int32 [B], values in [0,S)).  This is the training-time pattern — every body of a batch brings its own
+ * PROX scene (train_s1.py:159-169 gathers scene_verts [B,m,3] from batch_gen_hdf5.py:222-257 and calls chamfer.forward);
+ * dist1/idx1 are bit-identical to psi_chamfer_forward on that gathered [B,m,3] tensor.  The set borrows the indices,
+ * which must outlive it. */
+typedef struct psi_nn_index_set psi_nn_index_set;
+int psi_nn_index_set_create(psi_nn_index_set **out, const psi_nn_index *const *indices, int S);
+void psi_nn_index_set_destroy(psi_nn_index_set *set);
+int psi_nn_index_set_query(const psi_nn_index_set *set, const int32_t *slot, const float *xyz1, int B, int n,
+                           float *dist1, int32_t *idx1, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Trilinear SDF lookup with analytic gradient — replaces
  *   F.grid_sample(sdf[B,1,D,D,D], norm_verts[:,:,[2,1,0]].view(-1,V,1,1,3), padding_mode='border')

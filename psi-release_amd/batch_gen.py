@@ -9,8 +9,8 @@ utils/utils_convert2hdf5.py:55-61 — datasets ``sceneid [N]``, ``depth``/``seg 
 Kept behaviours: short last batch dropped (:198-199), ``sorted`` indices inside a batch (:201), batches with
 |z| > max_d skipped (:211-214), train/test scene split by name (:108-117), reshuffle on ``reset``.
 Changed: scene clouds / SDF volumes are uploaded ONCE and stay in HBM; the reference re-uploads
-67 MB x B per step (:222-257).  With ``indirect_sdf=True`` the last element is ``(sdf_table [S,D,D,D], scene_id [B], gmin_table [S,3], gmax_table [S,3])``
-instead of a dense [B,D,D,D] copy — ``TrainOP.cal_loss`` and ``ops.sdf_sample`` accept both.
+67 MB x B per step (:222-257).  With ``indirect_sdf=True`` the last element is ``(sdf_table [S,D,D,D], scene_id [B], gmin_table [S,3], gmax_table [S,3], ops.SceneSet)``
+instead of a dense [B,D,D,D] copy (the SceneSet carries one exact NN index per scene for the contact term) — ``TrainOP.cal_loss`` and ``ops.sdf_sample`` accept both.
 ``s_faces`` is never read by any loss (train_s1.py:95-207) and is returned empty.
 Files: ``.hdf5`` needs ``h5py`` (not installed in this image -> clear error); ``.npz`` with the same dataset names works
 everywhere; ``from_arrays`` takes in-memory dicts (tests, bench).
@@ -52,6 +52,7 @@ class BatchGeneratorWithSceneMesh:
         self.device = torch.device(device)
         self.index_rec = 0
         self.indirect_sdf = indirect_sdf
+        self._scene_set = None
         self.scene_name_list = list(scene_name_list or PROX_SCENES)
         # ---- sample streams (row 0 of every file is a placeholder: batch_gen_hdf5.py:61-67, :85)
         if _tables is None:
@@ -127,8 +128,13 @@ class BatchGeneratorWithSceneMesh:
         slot = torch.tensor([self.slot_of_name[n] for n in names], dtype=torch.long, device=self.device)
         s_verts = self.verts_table[slot]                                      # device gather, [B,m,3]
         s_faces = torch.empty(batch_size, 0, 3, 3, device=self.device)
-        sdf = ((self.sdf_table, slot.to(torch.int32), self.gmin_table, self.gmax_table) if self.indirect_sdf
-               else self.sdf_table[slot])
+        if self.indirect_sdf:
+            if self._scene_set is None:
+                from . import ops
+                self._scene_set = ops.SceneSet(self.verts_table, self.device)
+            sdf = (self.sdf_table, slot.to(torch.int32), self.gmin_table, self.gmax_table, self._scene_set)
+        else:
+            sdf = self.sdf_table[slot]
         return [depth, seg, body, cam_ext, cam_int, max_d, s_verts, s_faces, self.gmin_table[slot], self.gmax_table[slot],
                 self.gdim_table[slot], sdf]
 

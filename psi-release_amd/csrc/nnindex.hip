@@ -62,16 +62,19 @@ __device__ unsigned long long g_kd_stats[4];     // development build only: node
 #endif
 
 // CONTACT: fused contact-loss epilogue, identical to nn_resolve_kernel<true> in chamfer.hip
-template <bool CONTACT>
-__global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T, const float *__restrict__ xyz1, const int *__restrict__ qidx,
+// MULTI: body b is searched in tab[slot[b]] (a set of scenes, one launch) instead of the single tree T0
+template <bool CONTACT, bool MULTI = false>
+__global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *__restrict__ xyz1, const int *__restrict__ qidx,
                                                         long qstride, int n, float *__restrict__ dist, int *__restrict__ idx,
                                                         float cconst, float gscale, float *__restrict__ gq, float *__restrict__ fpart,
-                                                        int *__restrict__ hint)
+                                                        int *__restrict__ hint, const KdDev *__restrict__ tab = nullptr,
+                                                        const int *__restrict__ slot = nullptr)
 {
     __shared__ int stk_n[MAXSTACK][QPW];
     __shared__ float stk_d[MAXSTACK][QPW];
     const int lane = threadIdx.x;
     const int b = blockIdx.y;
+    const KdDev T = MULTI ? tab[slot[b]] : T0;
     const int j = blockIdx.x * QPW + lane;
     float fval = 0.0f;
     if (lane < QPW && j < n) {
@@ -339,6 +342,56 @@ extern "C" int psi_nn_index_query(const psi_nn_index *ix, const float *xyz1, int
     hipLaunchKernelGGL(kd_query_kernel<false>, dim3(psi_cdiv(n, QPW), B), dim3(QBLK), 0, (hipStream_t)stream, ix->d, xyz1,
                        (const int *)nullptr, (long)n * 3, n, dist1, idx1, 0.0f, 0.0f, (float *)nullptr, (float *)nullptr, hint);
     PSI_CHECK_LAUNCH("kd_query_kernel");
+    psi_mark("kd_query_kernel", (hipStream_t)stream);
+    return 0;
+}
+
+struct psi_nn_index_set {
+    KdDev *tab;             // device [S]
+    int S;
+};
+
+extern "C" int psi_nn_index_set_create(psi_nn_index_set **out, const psi_nn_index *const *indices, int S)
+{
+    PSI_REQUIRE(out && indices && S > 0, "bad arguments");
+    std::vector<KdDev> h(S);
+    for (int s = 0; s < S; s++) {
+        PSI_REQUIRE(indices[s], "null index in set");
+        h[s] = indices[s]->d;
+    }
+    KdDev *tab = nullptr;
+    PSI_CHECK_HIP(hipMalloc((void **)&tab, sizeof(KdDev) * S));
+    hipError_t e = hipMemcpy(tab, h.data(), sizeof(KdDev) * S, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(tab);
+        psi_set_error("psi_nn_index_set_create: upload failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    psi_nn_index_set *st = new psi_nn_index_set;
+    st->tab = tab;
+    st->S = S;
+    *out = st;
+    return 0;
+}
+
+extern "C" void psi_nn_index_set_destroy(psi_nn_index_set *set)
+{
+    if (!set) return;
+    (void)hipFree(set->tab);
+    delete set;
+}
+
+extern "C" int psi_nn_index_set_query(const psi_nn_index_set *set, const int32_t *slot, const float *xyz1, int B, int n,
+                                      float *dist1, int32_t *idx1, void *stream)
+{
+    PSI_REQUIRE(set && B >= 0 && n >= 0, "bad arguments");
+    if (B == 0 || n == 0) return 0;
+    PSI_REQUIRE(slot && xyz1 && dist1 && idx1, "null pointer");
+    PSI_REQUIRE(B <= 65535, "B exceeds grid.y");
+    hipLaunchKernelGGL((kd_query_kernel<false, true>), dim3(psi_cdiv(n, QPW), B), dim3(QBLK), 0, (hipStream_t)stream, KdDev(), xyz1,
+                       (const int *)nullptr, (long)n * 3, n, dist1, idx1, 0.0f, 0.0f, (float *)nullptr, (float *)nullptr,
+                       (int *)nullptr, (const KdDev *)set->tab, (const int *)slot);
+    PSI_CHECK_LAUNCH("kd_query_kernel<multi>");
     psi_mark("kd_query_kernel", (hipStream_t)stream);
     return 0;
 }

@@ -28,6 +28,9 @@ SIGNATURES = {
     'psi_nn_index_create': (c_int, [c_void_p, c_void_p, c_int]),
     'psi_nn_index_destroy': (None, [c_void_p]),
     'psi_nn_index_query': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'psi_nn_index_set_create': (c_int, [c_void_p, c_void_p, c_int]),
+    'psi_nn_index_set_destroy': (None, [c_void_p]),
+    'psi_nn_index_set_query': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'psi_sdf_sample_forward': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p] * 3),
     'psi_sdf_sample_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'psi_sdf_penetration_stats': (c_int, [c_void_p, c_long, c_void_p, c_void_p]),

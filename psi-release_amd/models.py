@@ -91,6 +91,11 @@ class _SceneCond(nn.Module):
     def _scene_feature(self, scene):
         b = scene.size(0)
         if getattr(self, 'autocast_bf16', False) and scene.is_cuda:
+            if not getattr(self, '_nhwc', False):           # MIOpen's bf16 implicit-GEMM convs are NHWC: keep weights and
+                self.resnet.to(memory_format=torch.channels_last)   # activations in that layout instead of transposing around every conv
+                self.conv.to(memory_format=torch.channels_last)
+                self._nhwc = True
+            scene = scene.contiguous(memory_format=torch.channels_last)
             with torch.autocast('cuda', dtype=torch.bfloat16):
                 f = self.conv(self.resnet(scene))
                 return self.fc(f.reshape(b, -1)).float()

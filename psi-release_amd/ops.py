@@ -222,3 +222,59 @@ class _IndexedChamfer(Function):
 def chamfer_to_scene(xyz1, index: SceneNNIndex):
     """dist1 [B,n] of ``chamferDist()(xyz1, scene.repeat(B))`` through the scene's exact NN index."""
     return _IndexedChamfer.apply(xyz1, index)
+
+
+class SceneSet:
+    """The static scenes of a training set: one exact NN index per scene slot, queried in ONE launch with the per-body
+    scene slot (psi_nn_index_set_query).  ``chamfer_to_scenes`` equals ``chamferDist()(xyz1, verts_table[slot])[0]`` bit for
+    bit (train_s1.py:159-169) without the O(n*m) scan or the [B,m,3] gather, and its launch shape does not depend on
+    which scenes a batch mixes (so a whole training step can live in one HIP graph)."""
+
+    def __init__(self, verts_table, device='cuda'):
+        import ctypes
+        self.verts_table = verts_table.contiguous()                     # [S,m,3] device (backward gather)
+        self.device = torch.device(device)
+        self.indices = [SceneNNIndex(self.verts_table[s], self.device) for s in range(self.verts_table.shape[0])]
+        arr = (ctypes.c_void_p * len(self.indices))(*[ix.handle.value for ix in self.indices])
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            hip.check(hip.lib().psi_nn_index_set_create(ctypes.byref(h), arr, len(self.indices)), 'psi_nn_index_set_create')
+        self.handle = h
+
+    def query(self, xyz1, slot):
+        xyz1 = xyz1.contiguous().float()
+        B, n, _ = xyz1.shape
+        dist = torch.empty(B, n, device=xyz1.device)
+        idx = torch.empty(B, n, dtype=torch.int32, device=xyz1.device)
+        hip.check(hip.lib().psi_nn_index_set_query(self.handle, hip.ptr(slot), hip.ptr(xyz1), B, n, hip.ptr(dist), hip.ptr(idx),
+                                                   hip.stream()), 'psi_nn_index_set_query')
+        return dist, idx
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                hip.lib().psi_nn_index_set_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class _SceneSetChamfer(Function):
+    @staticmethod
+    def forward(ctx, xyz1, scenes, slot):
+        dist, idx = scenes.query(xyz1, slot)
+        ctx.scenes = scenes
+        ctx.save_for_backward(xyz1, idx, slot)
+        return dist
+
+    @staticmethod
+    def backward(ctx, gdist):
+        xyz1, idx, slot = ctx.saved_tensors
+        nn = ctx.scenes.verts_table[slot.long().unsqueeze(1), idx.long()]     # [B,n,3]
+        return 2.0 * gdist.unsqueeze(-1) * (xyz1 - nn), None, None            # chamfer.cu:155-174, query side
+
+
+def chamfer_to_scenes(xyz1, scenes: SceneSet, slot):
+    """dist1 [B,n] of every body against its own scene.  slot: int32 device [B]."""
+    assert slot.dtype == torch.int32 and slot.is_contiguous()
+    return _SceneSetChamfer.apply(xyz1, scenes, slot)

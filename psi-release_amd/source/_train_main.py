@@ -27,6 +27,7 @@ def main(stage, argv=None):
     p.add_argument('--vposer_ckpt_path', default='/is/ps2/yzhang/body_models/VPoser/vposer_v1_0')
     p.add_argument('--scene_model_ckpt', default=None, help='data/resnet18.pth (a missing blob in the reference tree)')
     p.add_argument('--bf16', type=int, default=0, help='bf16 autocast for the CVAE trunk (losses stay fp32)')
+    p.add_argument('--use_graph', type=int, default=0, help='replay each optimiser step as one HIP graph (single process)')
     p.add_argument('--synthetic', type=int, default=0, help='N>0: train on N synthetic samples (licensed data absent)')
     a = p.parse_args(argv)
     if a.save_dir == 'None':
@@ -40,7 +41,7 @@ def main(stage, argv=None):
         'device': device, 'fine_tuning': None, 'save_dir': a.save_dir,
         'contact_id_folder': os.path.join(a.dataset_path, 'body_segments'),
         'contact_part': ['back', 'butt', 'L_Hand', 'R_Hand', 'L_Leg', 'R_Leg', 'thighs'], 'saving_per_X_ep': 2, 'verbose': True,
-        'use_cont_rot': True, 'resume_training': True, 'autocast_bf16': bool(a.bf16)}
+        'use_cont_rot': True, 'resume_training': True, 'autocast_bf16': bool(a.bf16), 'use_graph': bool(a.use_graph)}
     lossconfig = {'weight_loss_rec_s': 1.0, 'weight_loss_rec_h': 1.0, 'weight_loss_vposer': a.weight_loss_vposer,
                   'weight_loss_kl': a.weight_loss_kl, 'weight_contact': a.weight_loss_contact, 'weight_collision': a.weight_loss_collision}
     if a.synthetic > 0:

@@ -39,6 +39,9 @@ class _TrainBase:
         self.use_cont_rot = True
         self.verbose = False
         self.scene_model_ckpt = None
+        self.use_graph = False          # capture the whole optimiser step (forward, backward, Adam) in one HIP graph
+        self._graphs = {}
+        self._fca_t = None
         for key, val in trainconfig.items():
             setattr(self, key, val)
         for key, val in lossconfig.items():
@@ -77,17 +80,25 @@ class _TrainBase:
     def _scene_losses(self, xh_rec, cam_ext, scene_verts, s_grid_min_batch, s_grid_max_batch, s_grid_sdf_batch, ep):
         """Shared tail of cal_loss: VPoser prior, contact (const 1.0) and penetration terms (train_s1.py:136-205)."""
         loss_vposer = self.weight_loss_vposer * torch.mean(xh_rec[:, 16:48] ** 2)
+        if not ep > 0.75 * self.epoch and getattr(self, 'skip_gated_losses', True):
+            # train_s1.py:171-173,197-199 multiply both scene terms by 0 for the first 75% of the epochs; their value and
+            # gradient are exactly 0 there, so the body mesh, NN search and SDF lookup are not evaluated at all.
+            zero = xh_rec.new_zeros(())
+            return zero, loss_vposer, zero
         body_param_rec = BodyParamParser.body_params_encapsulate_batch(xh_rec)
         joint_rot_batch = self.vposer.decode(body_param_rec['body_pose_vp'], output_type='aa').view(xh_rec.shape[0], -1)
         body_param_ = {k: v for k, v in body_param_rec.items() if k != 'body_pose_vp'}
         body_verts_batch = self.body_mesh_model(return_verts=True, body_pose=joint_rot_batch, cam_ext=cam_ext, **body_param_).vertices
         body_verts_contact_batch = body_verts_batch[:, self._contact_ids(), :]
-        contact_dist, _ = self._chamfer(body_verts_contact_batch.contiguous(), scene_verts.contiguous())
+        if isinstance(s_grid_sdf_batch, tuple) and len(s_grid_sdf_batch) == 5 and getattr(self, 'use_scene_index', True):
+            contact_dist = ops.chamfer_to_scenes(body_verts_contact_batch.contiguous(), s_grid_sdf_batch[4], s_grid_sdf_batch[1])
+        else:
+            contact_dist, _ = self._chamfer(body_verts_contact_batch.contiguous(), scene_verts.contiguous())
         gate = 1.0 if ep > 0.75 * self.epoch else 0.0                           # train_s1.py:171-173,197-199
         s = torch.sqrt(contact_dist + 1e-4)
         loss_contact = gate * self.weight_contact * torch.mean(s / (s + 1.0))
         if isinstance(s_grid_sdf_batch, tuple):                                 # (sdf_table, scene_id, gmin_table, gmax_table)
-            sdf_t, sid, gmin_t, gmax_t = s_grid_sdf_batch
+            sdf_t, sid, gmin_t, gmax_t = s_grid_sdf_batch[:4]
             body_sdf = ops.sdf_sample(body_verts_batch, sdf_t, gmin_t, gmax_t, scene_id=sid, align_corners=self.align_corners)
         else:                                                                   # reference contract: dense [B,D,D,D]
             sid = torch.arange(s_grid_sdf_batch.shape[0], dtype=torch.int32, device=self.device)
@@ -96,10 +107,13 @@ class _TrainBase:
         loss_sdf_pene = gate * self.weight_collision * ops.penetration_loss(body_sdf)
         return loss_contact, loss_vposer, loss_sdf_pene
 
+    def _fca(self, ep):
+        if not self.loss_weight_anealing:
+            return 1.0
+        return min(1.0, max(float(ep) / (self.epoch * 0.75), 0))
+
     def _kl(self, mu, logsigma2, ep):
-        fca = 1.0
-        if self.loss_weight_anealing:
-            fca = min(1.0, max(float(ep) / (self.epoch * 0.75), 0))
+        fca = self._fca(ep) if self._fca_t is None else self._fca_t      # graph mode: a device scalar refreshed per step
         return fca ** 2 * self.weight_loss_kl * 0.5 * torch.mean(torch.exp(logsigma2) + mu ** 2 - 1.0 - logsigma2)
 
     # -------------------------------------------------------------------------------------
@@ -137,8 +151,95 @@ class _TrainBase:
             g.copy_(flat[o:o + n].view_as(g))
             o += n
 
+    # ---- whole-step HIP graph ------------------------------------------------------------------------------------
+    # A train_s{1,2} step is ~2500 small launches (rotation glue, BN, Adam, ...) and is bound by the host issuing them.
+    # All shapes are static (fixed batch size; the per-body scene slot is data, not shape), so the step is captured once
+    # per loss phase (scene terms gated off / on, train_s1.py:171-173) and replayed; the KL annealing factor is a device
+    # scalar.  Replays read the batch from static buffers.
+    def _static_batch(self, d):
+        keep = lambda x: x.clone() if torch.is_tensor(x) else x
+        st = [keep(x) for x in d[:11]]
+        last = d[11]
+        st.append(tuple(keep(x) for x in last) if isinstance(last, tuple) else keep(last))
+        return st
+
+    @staticmethod
+    def _load_batch(st, d):
+        indexed = isinstance(d[11], tuple) and len(d[11]) == 5
+        for i in range(11):
+            if i == 6 and indexed:
+                continue                                   # the gathered [B,m,3] scene clouds are not read on the indexed path
+            if torch.is_tensor(st[i]) and st[i].numel():
+                st[i].copy_(d[i])
+        if isinstance(d[11], tuple):
+            st[11][1].copy_(d[11][1])                      # per-body scene slot; the tables themselves are shared
+        else:
+            st[11].copy_(d[11])
+
+    def _capture(self, d, ep):
+        import copy
+        for g in self.optimizer_h.param_groups:
+            g['capturable'] = True
+        if self._fca_t is None:
+            self._fca_t = torch.tensor(float(self._fca(ep)), device=self.device)
+        self._fca_t.fill_(float(self._fca(ep)))
+        st = self._static_batch(d)
+        # warm-up on a side stream (MIOpen find, workspace growth) — on a snapshot, so that it does not train
+        snap_m = copy.deepcopy(self.model_h.state_dict())
+        snap_o = copy.deepcopy(self.optimizer_h.state_dict())
+        rng = torch.cuda.get_rng_state(self.device)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self.optimizer_h.zero_grad(set_to_none=True)
+                sum(self._losses_from_batch(st, ep)).backward()
+                self.optimizer_h.step()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.model_h.load_state_dict(snap_m)
+        self.optimizer_h.load_state_dict(snap_o)
+        for g in self.optimizer_h.param_groups:
+            g['capturable'] = True
+        if not self.optimizer_h.state:                     # fresh optimiser: materialise its state outside the graph
+            self.optimizer_h.zero_grad(set_to_none=True)
+            for p in self.model_h.parameters():
+                if p.requires_grad:
+                    p.grad = torch.zeros_like(p)
+            lr = [g['lr'] for g in self.optimizer_h.param_groups]
+            for g in self.optimizer_h.param_groups:
+                g['lr'] = 0.0
+            self.optimizer_h.step()                        # lr 0: creates exp_avg / exp_avg_sq / step and moves nothing
+            for g, v in zip(self.optimizer_h.param_groups, lr):
+                g['lr'] = v
+            for stt in self.optimizer_h.state.values():
+                stt['step'].zero_()
+                stt['exp_avg'].zero_()
+                stt['exp_avg_sq'].zero_()
+        torch.cuda.set_rng_state(rng, self.device)
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer_h.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            losses = self._losses_from_batch(st, ep)
+            sum(losses).backward()
+            self._allreduce_grads()
+            self.optimizer_h.step()
+        return {'graph': graph, 'batch': st, 'losses': losses}
+
+    def _train_step_graph(self, train_data, ep):
+        key = bool(ep > 0.75 * self.epoch)
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = self._capture(train_data, ep)
+        self._fca_t.fill_(float(self._fca(ep)))
+        self._load_batch(g['batch'], train_data)
+        g['graph'].replay()
+        return g['losses']
+
     def train_step(self, train_data, ep):
         """One optimiser step on one batch (the body of the ``while batch_gen.has_next_batch()`` loop)."""
+        if self.use_graph:
+            return self._train_step_graph(train_data, ep)
         self.optimizer_h.zero_grad()
         losses = self._losses_from_batch(train_data, ep)
         loss_h = sum(losses)

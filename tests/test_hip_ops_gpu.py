@@ -190,3 +190,23 @@ def test_kdtree_backward_matches_bruteforce():
     d1, _ = ops.chamferDist(one_sided=True)(b, T(np.broadcast_to(y, (2, 3000, 3)).copy()))
     (d1 * w).sum().backward()
     assert rel_err(a.grad.cpu(), b.grad.cpu()) < 1e-6
+
+
+def test_scene_set_query_equals_chamfer_on_gathered_clouds():
+    """psi_nn_index_set_query (per-body scene slot, one launch) is bit-identical to chamfer.forward on verts_table[slot]."""
+    rs = np.random.RandomState(5)
+    S, m, B, n = 3, 3000, 7, 333
+    table = torch.tensor(rs.uniform(-1, 1, (S, m, 3)).astype(np.float32), device=DEV)
+    table[1, 100] = table[1, 7]                                       # duplicate points: the lower index must win
+    slot = torch.tensor(rs.randint(0, S, B).astype(np.int32), device=DEV)
+    xyz1 = torch.tensor(rs.uniform(-1.2, 1.2, (B, n, 3)).astype(np.float32), device=DEV, requires_grad=True)
+    ss = ops.SceneSet(table, DEV)
+    d_set, i_set = ss.query(xyz1.detach(), slot)
+    d_ref, i_ref, _, _ = ops.chamfer_forward_raw(xyz1.detach(), table[slot.long()].contiguous(), both=False)
+    assert torch.equal(d_set, d_ref) and torch.equal(i_set, i_ref)
+    g = torch.tensor(rs.randn(B, n).astype(np.float32), device=DEV)
+    (ops.chamfer_to_scenes(xyz1, ss, slot) * g).sum().backward()
+    ga = xyz1.grad.clone()
+    xyz1.grad = None
+    (ops.chamferDist(one_sided=True)(xyz1, table[slot.long()].contiguous())[0] * g).sum().backward()
+    assert torch.equal(ga, xyz1.grad)
