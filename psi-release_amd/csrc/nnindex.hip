@@ -7,7 +7,8 @@
 //
 //   build (host, once per scene): balanced kd-tree (median split on the widest axis) collapsed three levels at a time into
 //     8-wide nodes; leaves of <= 8 points (padded to 8 records); every internal node stores the exact AABBs of its 8 children; points are re-ordered by leaf and stored as float4 {x, y, z, bitcast(original index)}.
-//   query (one lane per query, per-lane stack in LDS): depth-first, nearer child first.  A node is skipped when
+//   query (EIGHT lanes per query — one per child box of a node / per point of a leaf; the traversal state is replicated in
+//     the 8 lanes, the stack is shared in LDS): depth-first, nearer child first.  A node is skipped when
 //       d2box * 0.999999f > best,  d2box = squared distance from the query to the node's AABB evaluated in fp32.
 //     Safety: for any point p in the box, d_hat(p) >= true(p) (1 - 3e-7) >= trueBox (1 - 3e-7) >= d2box_hat (1 - 3e-7)^2,
 //     so the test implies d_hat(p) > best strictly — p is neither the minimum nor a tie.
@@ -28,24 +29,23 @@
 namespace {
 
 constexpr int LEAF = 8;             // points per leaf; leaves are PADDED to exactly 8 records (copies of the last point)
-                                    // so the scan is a fixed, fully unrolled batch of 8 independent 16-byte loads
-constexpr int WIDE = 8;             // children per internal node
-constexpr int MAXSTACK = 48;        // <= 7 pushes per level, ~5 levels for 2^24 points at fan-out 8
-constexpr int QBLK = 64;            // one wave per workgroup: per-lane stacks live in LDS [MAXSTACK][QPW]
-constexpr int QPW = 64;             // queries per wave.  The search is latency-bound (a chain of dependent node loads) and a
-                                    // batch has only B*n_c = 65536 queries: measured: 16 active lanes per wave (4096 waves) is SLOWER
-                                    // (72 vs 61 us): the kernel is bound by the summed per-lane traversal work, not by load latency.
+constexpr int WIDE = 8;             // children per internal node == lanes per query
+constexpr int MAXSTACK = 72;        // <= 7 pushes per level; 9 levels of fan-out 8 cover 2^24 points
+constexpr int QBLK = 256;           // threads per workgroup
+constexpr int QPB = QBLK / WIDE;    // queries per workgroup (32)
 constexpr int EMPTY = (int)0x80000000;
 
-// 8-wide node (256 bytes): the exact AABBs of all 8 children, structure-of-arrays, plus the 8 child references.
-// The tree is only ~log8(m/8) levels deep (4 for m = 32768): the per-query dependent-load chain is 4 node records and a
-// leaf instead of 12+ binary levels; the 14 16-byte loads of one record are independent and issued together.
+// 8-wide node (256 bytes): per child its exact AABB and its reference, 32 bytes each, so lane c of a query's 8-lane group
+// reads child c with two 16-byte loads and the group reads the 256-byte record contiguously.
 // Child reference: >= 0 internal node index;  < 0 leaf number L encoded -(L) - 1 (records pts[8L .. 8L+7]);  EMPTY = none
 // (its box is [+inf, -inf], i.e. infinitely far).
+struct KdChild {
+    float mn[3], mx[3];
+    int ref;
+    int pad;
+};
 struct KdNode {
-    float mn[3][WIDE], mx[3][WIDE];
-    int child[WIDE];
-    int pad[8];
+    KdChild c[WIDE];
 };
 static_assert(sizeof(KdNode) == 256, "node record is 256 bytes");
 
@@ -55,142 +55,162 @@ struct KdDev {
     const float4 *opts;             // original order {x,y,z,bitcast(index)}: warm-start lookups
     int root;                       // child-reference of the root (a leaf when m <= LEAF)
     int m;
+    int rows;                       // traversal stack rows this tree needs: 7 pushes per level + slack
 };
 
-#ifdef PSI_KD_STATS
-__device__ unsigned long long g_kd_stats[4];     // development build only: node visits, leaf visits, wave iterations
-#endif
+// lane permutations inside an 8-lane group as DPP modifiers (no LDS traffic)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // row_half_mirror: lane i <-> 7 - i inside each 8 lanes
+
+// lexicographic minimum of (d, i) over the 8 lanes of a group, result in every lane
+__device__ __forceinline__ void group_argmin(float &d, int &i)
+{
+#define PSI_STEP(CTRL)                                         \
+    {                                                          \
+        float d2 = dpp_f<CTRL>(d);                             \
+        int i2 = dpp_i<CTRL>(i);                               \
+        bool take = d2 < d || (d2 == d && i2 < i);             \
+        d = take ? d2 : d;                                     \
+        i = take ? i2 : i;                                     \
+    }
+    PSI_STEP(DPP_XOR1)
+    PSI_STEP(DPP_XOR2)
+    PSI_STEP(DPP_HALF_MIRROR)
+#undef PSI_STEP
+}
 
 // CONTACT: fused contact-loss epilogue, identical to nn_resolve_kernel<true> in chamfer.hip
 // MULTI: body b is searched in tab[slot[b]] (a set of scenes, one launch) instead of the single tree T0
+//
+// Why 8 lanes per query: a batch has only B*n_c = 65536 queries.  One lane per query is 1024 waves — one per SIMD, no
+// latency hiding at all — each running ~8000 dependent instructions (measured: 15 cycles per instruction, 41-57 us).
+// With a lane per child box / leaf point the per-wave instruction stream shrinks ~8x in the box and leaf arithmetic,
+// there are 8192 waves (8 per SIMD) to overlap the dependent node loads, and a wave diverges over 8 queries, not 64.
 template <bool CONTACT, bool MULTI = false>
 __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *__restrict__ xyz1, const int *__restrict__ qidx,
                                                         long qstride, int n, float *__restrict__ dist, int *__restrict__ idx,
                                                         float cconst, float gscale, float *__restrict__ gq, float *__restrict__ fpart,
-                                                        int *__restrict__ hint, const KdDev *__restrict__ tab = nullptr,
+                                                        int *__restrict__ hint, int rows, const KdDev *__restrict__ tab = nullptr,
                                                         const int *__restrict__ slot = nullptr)
 {
-    __shared__ int stk_n[MAXSTACK][QPW];
-    __shared__ float stk_d[MAXSTACK][QPW];
-    const int lane = threadIdx.x;
+    extern __shared__ int smem_i[];
+    const int tid = threadIdx.x;
+    const int c = tid & 7;                                    // my child / leaf slot
+    const int g = tid >> 3;                                   // query group inside the workgroup
+    int *stk_n = smem_i + (size_t)g * rows * 2;               // [rows] child references
+    float *stk_d = (float *)(stk_n + rows);                   // [rows] box distances
     const int b = blockIdx.y;
     const KdDev T = MULTI ? tab[slot[b]] : T0;
-    const int j = blockIdx.x * QPW + lane;
-    float fval = 0.0f;
-    if (lane < QPW && j < n) {
+    const int j = blockIdx.x * QPB + g;
+    const bool active = j < n;
+    const size_t o = (size_t)b * n + (active ? j : 0);
+    float qx = 0, qy = 0, qz = 0;
+    if (active) {
         const size_t qrow = qidx ? (size_t)qidx[j] : (size_t)j;
         const float *qp = xyz1 + (size_t)b * qstride + qrow * 3;
-        const float qx = qp[0], qy = qp[1], qz = qp[2];
-        float best = INFINITY;
-        int besti = 0x7fffffff;
-        float bx = 0, by = 0, bz = 0;
-        const size_t o = (size_t)b * n + j;
-        if (hint) {
-            // warm start: the target that won for this query last time is evaluated first (an ordinary candidate, so
-            // the result is unchanged); a good initial `best` prunes almost every sibling on the way down
-            int h = hint[o];
-            if (h >= 0 && h < T.m) {
-                const float4 p = T.opts[h];
-                float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
-                best = x2 * x2 + y2 * y2 + z2 * z2;
-                besti = h;
-                bx = p.x; by = p.y; bz = p.z;
-            }
+        qx = qp[0]; qy = qp[1]; qz = qp[2];
+    }
+    float best = INFINITY;
+    int besti = 0x7fffffff;
+    if (active && hint) {
+        // warm start: the target that won for this query last time is evaluated first (an ordinary candidate, so the
+        // result is unchanged); a good initial `best` prunes almost every sibling on the way down
+        int h = hint[o];
+        if (h >= 0 && h < T.m) {
+            const float4 p = T.opts[h];
+            float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
+            best = x2 * x2 + y2 * y2 + z2 * z2;
+            besti = h;
         }
-        int sp = 0;
-        int cur = T.root;
-        float curd = 0.0f;
-        bool have = true;
-        while (true) {
-#ifdef PSI_KD_STATS
-            if (lane == __builtin_ffsll(__ballot(1)) - 1) atomicAdd(&g_kd_stats[2], 1ull);
-#endif
-            if (!have) {
-                if (sp == 0) break;
-                --sp;
-                cur = stk_n[sp][lane];
-                curd = stk_d[sp][lane];
+    }
+    int sp = 0;
+    int cur = T.root;
+    float curd = 0.0f;
+    bool have = active;
+    const int gshift = (tid & 63) & 56;                       // bit position of my group inside the wave's ballot
+    while (true) {
+        while (!have && sp > 0) {                             // pop until something survives the current bound (group-uniform)
+            --sp;
+            cur = stk_n[sp];
+            curd = stk_d[sp];
+            have = !(curd * 0.999999f > best);
+        }
+        if (!have) break;
+        if (cur >= 0) {
+            const float4 *cp = (const float4 *)(T.nodes + cur) + 2 * c;
+            const float4 lo = cp[0], hi = cp[1];              // {mnx,mny,mnz,mxx} {mxy,mxz,ref,-}
+            float dx = fmaxf(fmaxf(lo.x - qx, qx - lo.w), 0.0f);
+            float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.x), 0.0f);
+            float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.y), 0.0f);
+            const float dc = dx * dx + dy * dy + dz * dz;     // +inf for EMPTY children
+            const int ref = __float_as_int(hi.z);
+            float dmin = dc;
+            int cmin = c;
+            group_argmin(dmin, cmin);
+            // push the other children that can still matter; descend into the nearest without a stack round trip
+            const bool push = c != cmin && dc * 0.999999f <= best;
+            const unsigned gm = (unsigned)(__ballot(push) >> gshift) & 0xffu;
+            if (push) {
+                const int pos = sp + __popc(gm & ((1u << c) - 1u));
+                stk_n[pos] = ref;
+                stk_d[pos] = dc;
+            }
+            sp += __popc(gm);
+            cur = __shfl(ref, (tid & 56) | cmin, 64);
+            curd = dmin;
+            have = dmin < INFINITY && !(dmin * 0.999999f > best);
+        }
+        if (have && cur < 0) {                                // leaf — possibly the one just stepped into
+            const float4 p = T.pts[(size_t)(-cur - 1) * LEAF + c];
+            float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
+            float d = x2 * x2 + y2 * y2 + z2 * z2;
+            int pi = __float_as_int(p.w);
+            group_argmin(d, pi);
+            if (d < best || (d == best && pi < besti)) {
+                best = d;
+                besti = pi;
             }
             have = false;
-            if (curd * 0.999999f > best) continue;
-#ifdef PSI_KD_STATS
-            atomicAdd(&g_kd_stats[cur < 0 ? 1 : 0], 1ull);
-#endif
-            if (cur < 0) {
-                const float4 *lp = T.pts + (size_t)(-cur - 1) * LEAF;
-                float4 pp[LEAF];
-#pragma unroll
-                for (int k = 0; k < LEAF; k++) pp[k] = lp[k];
-#pragma unroll
-                for (int k = 0; k < LEAF; k++) {
-                    const float4 p = pp[k];
-                    float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
-                    float d = x2 * x2 + y2 * y2 + z2 * z2;
-                    int pi = __float_as_int(p.w);
-                    if (d < best || (d == best && pi < besti)) {
-                        best = d;
-                        besti = pi;
-                        bx = p.x; by = p.y; bz = p.z;
-                    }
-                }
-            } else {
-                const float4 *np = (const float4 *)(T.nodes + cur);
-                float4 r[14];
-#pragma unroll
-                for (int k = 0; k < 14; k++) r[k] = np[k];                 // 6 x 8 box floats + 8 child refs, all independent
-                const float *f = (const float *)r;
-                float dc[WIDE];
-#pragma unroll
-                for (int c = 0; c < WIDE; c++) {
-                    float dx = fmaxf(fmaxf(f[0 * 8 + c] - qx, qx - f[24 + 0 * 8 + c]), 0.0f);
-                    float dy = fmaxf(fmaxf(f[1 * 8 + c] - qy, qy - f[24 + 1 * 8 + c]), 0.0f);
-                    float dz = fmaxf(fmaxf(f[2 * 8 + c] - qz, qz - f[24 + 2 * 8 + c]), 0.0f);
-                    dc[c] = dx * dx + dy * dy + dz * dz;                   // +inf for EMPTY children
-                }
-                float dmin = dc[0];
-                int cmin = 0;
-#pragma unroll
-                for (int c = 1; c < WIDE; c++)
-                    if (dc[c] < dmin) { dmin = dc[c]; cmin = c; }
-                // push the other children that can still matter; descend into the nearest without an LDS round trip
-#pragma unroll
-                for (int c = 0; c < WIDE; c++) {
-                    if (c != cmin && dc[c] * 0.999999f <= best) {
-                        stk_n[sp][lane] = __float_as_int(f[48 + c]);
-                        stk_d[sp][lane] = dc[c];
-                        sp++;
-                    }
-                }
-                int cref = __float_as_int(f[48]);
-#pragma unroll
-                for (int c = 1; c < WIDE; c++) cref = (c == cmin) ? __float_as_int(f[48 + c]) : cref;
-                if (dmin < INFINITY) {
-                    cur = cref;
-                    curd = dmin;
-                    have = true;
-                }
-            }
         }
+    }
+    float fval = 0.0f;
+    if (active && c == 0) {
         if (dist) dist[o] = best;
         if (idx) idx[o] = besti;
         if (hint) hint[o] = besti;
         if (CONTACT) {
+            const float4 w = T.opts[besti];                   // the winner's coordinates (same values the scan used)
             float sq = sqrtf(best + 1e-4f);
             float den = sq + cconst;
             fval = sq / den;
-            float g = gscale * (cconst / (2.0f * sq * den * den)) * 2.0f;
-            gq[o * 3 + 0] = g * (qx - bx);
-            gq[o * 3 + 1] = g * (qy - by);
-            gq[o * 3 + 2] = g * (qz - bz);
+            float gg = gscale * (cconst / (2.0f * sq * den * den)) * 2.0f;
+            gq[o * 3 + 0] = gg * (qx - w.x);
+            gq[o * 3 + 1] = gg * (qy - w.y);
+            gq[o * 3 + 2] = gg * (qz - w.z);
         }
     }
     if (CONTACT) {
+        __shared__ float wsum[QBLK / 64];
         float v = fval;
 #pragma unroll
         for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_down(v, o2, 64);
-        if (lane == 0) fpart[(size_t)b * gridDim.x + blockIdx.x] = v;
+        if ((tid & 63) == 0) wsum[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.0f;
+#pragma unroll
+            for (int w = 0; w < QBLK / 64; w++) t += wsum[w];
+            fpart[(size_t)b * gridDim.x + blockIdx.x] = t;
+        }
     }
 }
+
+static inline size_t kd_lds_bytes(int rows) { return (size_t)QPB * rows * 8; }
 
 struct Builder {
     const float *p;
@@ -254,14 +274,14 @@ struct Builder {
         KdNode nd;
         memset(&nd, 0, sizeof(nd));
         for (int c = 0; c < WIDE; c++) {
-            nd.child[c] = EMPTY;
-            for (int a = 0; a < 3; a++) { nd.mn[a][c] = INFINITY; nd.mx[a][c] = -INFINITY; }
+            nd.c[c].ref = EMPTY;
+            for (int a = 0; a < 3; a++) { nd.c[c].mn[a] = INFINITY; nd.c[c].mx[a] = -INFINITY; }
         }
         for (size_t c = 0; c < rg.size(); c++) {
             float mn[3], mx[3];
             bounds(rg[c].first, rg[c].second, mn, mx);
-            for (int a = 0; a < 3; a++) { nd.mn[a][c] = mn[a]; nd.mx[a][c] = mx[a]; }
-            nd.child[c] = build(rg[c].first, rg[c].second, depth + 1);
+            for (int a = 0; a < 3; a++) { nd.c[c].mn[a] = mn[a]; nd.c[c].mx[a] = mx[a]; }
+            nd.c[c].ref = build(rg[c].first, rg[c].second, depth + 1);
         }
         nodes[me] = nd;
         return me;
@@ -284,7 +304,8 @@ extern "C" int psi_nn_index_create(psi_nn_index **out, const float *h_points, in
     for (int i = 0; i < m; i++) bd.order[i] = i;
     bd.nodes.reserve((size_t)2 * (m / LEAF + 2));
     int root = bd.build(0, m, 0);
-    PSI_REQUIRE(7 * (bd.depth_max + 1) + 2 < MAXSTACK, "tree too deep for the traversal stack");
+    const int rows = 7 * (bd.depth_max + 1) + 2;
+    PSI_REQUIRE(rows <= MAXSTACK, "tree too deep for the traversal stack");
     auto rec = [&](int oi) {
         float4 r;
         r.x = h_points[(size_t)oi * 3 + 0];
@@ -321,6 +342,7 @@ extern "C" int psi_nn_index_create(psi_nn_index **out, const float *h_points, in
     ix->d.opts = (const float4 *)(blob + off_opts);
     ix->d.root = root;
     ix->d.m = m;
+    ix->d.rows = rows;
     *out = ix;
     return 0;
 }
@@ -339,8 +361,9 @@ extern "C" int psi_nn_index_query(const psi_nn_index *ix, const float *xyz1, int
     if (B == 0 || n == 0) return 0;
     PSI_REQUIRE(xyz1 && dist1 && idx1, "null pointer");
     PSI_REQUIRE(B <= 65535, "B exceeds grid.y");
-    hipLaunchKernelGGL(kd_query_kernel<false>, dim3(psi_cdiv(n, QPW), B), dim3(QBLK), 0, (hipStream_t)stream, ix->d, xyz1,
-                       (const int *)nullptr, (long)n * 3, n, dist1, idx1, 0.0f, 0.0f, (float *)nullptr, (float *)nullptr, hint);
+    hipLaunchKernelGGL(kd_query_kernel<false>, dim3(psi_cdiv(n, QPB), B), dim3(QBLK), kd_lds_bytes(ix->d.rows), (hipStream_t)stream,
+                       ix->d, xyz1, (const int *)nullptr, (long)n * 3, n, dist1, idx1, 0.0f, 0.0f, (float *)nullptr, (float *)nullptr,
+                       hint, ix->d.rows);
     PSI_CHECK_LAUNCH("kd_query_kernel");
     psi_mark("kd_query_kernel", (hipStream_t)stream);
     return 0;
@@ -349,6 +372,7 @@ extern "C" int psi_nn_index_query(const psi_nn_index *ix, const float *xyz1, int
 struct psi_nn_index_set {
     KdDev *tab;             // device [S]
     int S;
+    int rows;               // max stack rows over the set
 };
 
 extern "C" int psi_nn_index_set_create(psi_nn_index_set **out, const psi_nn_index *const *indices, int S)
@@ -359,6 +383,8 @@ extern "C" int psi_nn_index_set_create(psi_nn_index_set **out, const psi_nn_inde
         PSI_REQUIRE(indices[s], "null index in set");
         h[s] = indices[s]->d;
     }
+    int rows = 0;
+    for (int s = 0; s < S; s++) rows = std::max(rows, h[s].rows);
     KdDev *tab = nullptr;
     PSI_CHECK_HIP(hipMalloc((void **)&tab, sizeof(KdDev) * S));
     hipError_t e = hipMemcpy(tab, h.data(), sizeof(KdDev) * S, hipMemcpyHostToDevice);
@@ -370,6 +396,7 @@ extern "C" int psi_nn_index_set_create(psi_nn_index_set **out, const psi_nn_inde
     psi_nn_index_set *st = new psi_nn_index_set;
     st->tab = tab;
     st->S = S;
+    st->rows = rows;
     *out = st;
     return 0;
 }
@@ -388,9 +415,9 @@ extern "C" int psi_nn_index_set_query(const psi_nn_index_set *set, const int32_t
     if (B == 0 || n == 0) return 0;
     PSI_REQUIRE(slot && xyz1 && dist1 && idx1, "null pointer");
     PSI_REQUIRE(B <= 65535, "B exceeds grid.y");
-    hipLaunchKernelGGL((kd_query_kernel<false, true>), dim3(psi_cdiv(n, QPW), B), dim3(QBLK), 0, (hipStream_t)stream, KdDev(), xyz1,
-                       (const int *)nullptr, (long)n * 3, n, dist1, idx1, 0.0f, 0.0f, (float *)nullptr, (float *)nullptr,
-                       (int *)nullptr, (const KdDev *)set->tab, (const int *)slot);
+    hipLaunchKernelGGL((kd_query_kernel<false, true>), dim3(psi_cdiv(n, QPB), B), dim3(QBLK), kd_lds_bytes(set->rows),
+                       (hipStream_t)stream, KdDev(), xyz1, (const int *)nullptr, (long)n * 3, n, dist1, idx1, 0.0f, 0.0f,
+                       (float *)nullptr, (float *)nullptr, (int *)nullptr, set->rows, (const KdDev *)set->tab, (const int *)slot);
     PSI_CHECK_LAUNCH("kd_query_kernel<multi>");
     psi_mark("kd_query_kernel", (hipStream_t)stream);
     return 0;
@@ -400,17 +427,10 @@ extern "C" int psi_nn_index_set_query(const psi_nn_index_set *set, const int32_t
 int psi_nn_index_contact(const psi_nn_index *ix, const float *verts, long vstride, const int *vid, int B, int n, float cconst,
                          float gscale, float *gq, float *fpart, int *hint, hipStream_t st)
 {
-    hipLaunchKernelGGL(kd_query_kernel<true>, dim3(psi_cdiv(n, QPW), B), dim3(QBLK), 0, st, ix->d, verts, vid, vstride, n,
-                       (float *)nullptr, (int *)nullptr, cconst, gscale, gq, fpart, hint);
+    hipLaunchKernelGGL(kd_query_kernel<true>, dim3(psi_cdiv(n, QPB), B), dim3(QBLK), kd_lds_bytes(ix->d.rows), st, ix->d, verts, vid,
+                       vstride, n, (float *)nullptr, (int *)nullptr, cconst, gscale, gq, fpart, hint, ix->d.rows);
     PSI_CHECK_LAUNCH("kd_query_kernel<contact>");
     psi_mark("kd_query_kernel", st);
     return 0;
 }
-int psi_nn_index_fparts(int n) { return psi_cdiv(n, QPW); }
-#ifdef PSI_KD_STATS
-extern "C" int psi_kd_stats(unsigned long long *h4, int reset)
-{
-    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_kd_stats), z, 32); }
-    return (int)hipMemcpyFromSymbol(h4, HIP_SYMBOL(g_kd_stats), 32);
-}
-#endif
+int psi_nn_index_fparts(int n) { return psi_cdiv(n, QPB); }

@@ -54,7 +54,8 @@ class _TrainBase:
         n_dim_body = 72 + 3 if self.use_cont_rot else 72
         self.model_h_latentD = 256
         self.model_h = self._make_model(n_dim_body)
-        self.optimizer_h = optim.Adam(self.model_h.parameters(), lr=self.init_lr_h)
+        # train_s1.py:229 optim.Adam defaults; fused=True is the same update as ONE multi-tensor kernel instead of ~10 per step
+        self.optimizer_h = optim.Adam(self.model_h.parameters(), lr=self.init_lr_h, fused=bool(getattr(self, 'fused_adam', True)))
         vposer_src = getattr(self, 'vposer_state', None) or self.vposer_ckpt_path
         self.vposer, _ = load_vposer(vposer_src, vp_model='snapshot')
         self.vposer.to(self.device)
