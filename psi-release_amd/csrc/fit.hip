@@ -19,6 +19,7 @@
 // the backward uses that R' == R on SO(3) and that Gram-Schmidt only moves along SO(3), so J_GS^T dL/dR' is the exact
 // gradient (requires pose_mean == 0 for global_orient/body joints, which holds for SMPL-X; checked at creation).
 #include "psi_internal.h"
+#include "lbs_device.h"
 #include "sdf_device.h"
 #include <math.h>
 #include <string.h>
@@ -152,7 +153,9 @@ __device__ __forceinline__ float block_sum(float v, float *sh)
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f)
+// ... followed, in the same workgroup, by the LBS pose stage of this body (Rodrigues, joints, kinematic chain): one launch
+// and one round of dependent loads less than a separate 1-wave-per-body kernel.
+__global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
 {
     const int b = blockIdx.x, t = threadIdx.x;
     __shared__ float sx[XD + 5], sh1[NH], sh2[NH], so6[128], red[HB / 64];
@@ -246,6 +249,8 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f)
     }
     if (t < f.NB) f.betas20[(size_t)b * f.NB + t] = t < 10 ? sx[9 + t] : 0.0f;
     if (t < 3) f.transl[(size_t)b * 3 + t] = sx[t];
+    __syncthreads();                                         // pose / betas20 of this body are visible to the workgroup
+    psi_pose_fwd_body(lv.m, f.betas20, f.pose, f.transl, f.B, b, lv.feat, lv.R, lv.Jl, lv.G, lv.A, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -332,11 +337,57 @@ __global__ __launch_bounds__(256) void grad_verts_kernel(FitDev f, const float *
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f)
+// One workgroup per body: (1) sums this body's split-contraction partials (gA over vertex slices, g_feat over column
+// slices, g_transl over vertex blocks) straight into LDS, (2) runs the LBS pose-backward stage on them, (3) back-propagates
+// through the 6D rotations / hand PCA / VPoser decoder and (4) applies the Adam update.  Formerly three launches
+// (reduce_partials, pose_bwd, head_bwd_adam) with global round trips in between.
+constexpr int KPAD_MAX = 512;
+__global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView lv)
 {
     const int b = blockIdx.x, t = threadIdx.x;
     __shared__ float sx[XD + 5], sg6[128], sga2[NH], sga1[NH], sgx[XD + 5];
     __shared__ f4 part4[4][128], part1[64][8];
+    __shared__ __attribute__((aligned(16))) float s_gA[PSI_JP * 16];
+    __shared__ float s_gfeat[KPAD_MAX], s_gt[4];
+    {
+        const size_t nA = (size_t)f.B * PSI_JP * 16, nF = (size_t)f.B * lv.m.Kpad;
+        for (int i = t; i < PSI_JP * 16; i += HB) {
+            const float *p = lv.gA_part + (size_t)b * PSI_JP * 16 + i;
+            float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            int sl = 0;
+#pragma unroll 4
+            for (; sl + 4 <= lv.nsv; sl += 4) {              // independent loads in flight
+                a0 += p[(size_t)(sl + 0) * nA];
+                a1 += p[(size_t)(sl + 1) * nA];
+                a2 += p[(size_t)(sl + 2) * nA];
+                a3 += p[(size_t)(sl + 3) * nA];
+            }
+            for (; sl < lv.nsv; sl++) a0 += p[(size_t)sl * nA];
+            s_gA[i] = (a0 + a1) + (a2 + a3);
+        }
+        for (int k = t; k < lv.m.Kpad; k += HB) {
+            const float *p = lv.gfeat_part + (size_t)b * lv.m.Kpad + k;
+            float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            int sl = 0;
+#pragma unroll 4
+            for (; sl + 4 <= lv.nsn; sl += 4) {
+                a0 += p[(size_t)(sl + 0) * nF];
+                a1 += p[(size_t)(sl + 1) * nF];
+                a2 += p[(size_t)(sl + 2) * nF];
+                a3 += p[(size_t)(sl + 3) * nF];
+            }
+            for (; sl < lv.nsn; sl++) a0 += p[(size_t)sl * nF];
+            s_gfeat[k] = (a0 + a1) + (a2 + a3);
+        }
+        if (t < 3) {
+            float a = 0;
+            for (int vb = 0; vb < lv.nvb; vb++) a += lv.gt_part[((size_t)vb * f.B + b) * 4 + t];
+            s_gt[t] = a;
+        }
+    }
+    __syncthreads();
+    psi_pose_bwd_body(lv.m, f.betas20, f.pose, lv.R, lv.Jl, lv.G, s_gA, s_gfeat, b, f.g_betas, f.g_pose, f.g_rot);
+    __syncthreads();                                         // g_betas / g_pose / g_rot of this body are visible to the workgroup
     const float *x = f.x + (size_t)b * XD;
     if (t < XD) { sx[t] = x[t]; sgx[t] = 0.0f; }
     if (t < 128) sg6[t] = 0.0f;
@@ -360,7 +411,7 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f)
         for (int c = 0; c < 45; c++) a += comp[ii * 45 + c] * gp[c];
         sgx[(i < f.ncomp ? 51 : 63) + ii] = a;
     } else if (t >= 128 && t < 128 + 3) {
-        sgx[t - 128] = f.g_transl[(size_t)b * 3 + (t - 128)];
+        sgx[t - 128] = s_gt[t - 128];
     } else if (t >= 160 && t < 160 + 10) {
         sgx[9 + (t - 160)] = f.g_betas[(size_t)b * f.NB + (t - 160)];
     }
@@ -451,6 +502,7 @@ struct psi_fit_engine {
     const psi_lbs_model *lbs;
     psi_nn_index *nn_index;
     float *lbs_ws;
+    PsiLbsView lv;                // pointers into lbs_ws for the pose stages fused into the head / tail kernels
     void *nn_ws;
     char *blob;
     float *stats_local;           // engine-owned stats buffer (single-GPU path)
@@ -467,10 +519,10 @@ struct psi_fit_engine {
 static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st)
 {
     FitDev &f = e->d;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(f.B), dim3(HB), 0, st, f);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(f.B), dim3(HB), 0, st, f, e->lv);
     PSI_CHECK_LAUNCH("head_fwd_kernel");
     psi_mark("head_fwd_kernel", st);
-    int rc = psi_lbs_forward(e->lbs, f.betas20, f.pose, f.transl, f.cam, f.B, f.verts, nullptr, e->lbs_ws, st);
+    int rc = psi_lbs_forward_from_pose(e->lbs, f.transl, f.cam, f.B, f.verts, e->lbs_ws, st);
     if (rc) return rc;
     hipLaunchKernelGGL(sdf_pen_kernel, dim3(f.nsdfblk, f.B), dim3(256), 0, st, f);
     PSI_CHECK_LAUNCH("sdf_pen_kernel");
@@ -493,10 +545,9 @@ static int fit_backward(psi_fit_engine *e, const float *stats, hipStream_t st)
     hipLaunchKernelGGL(grad_verts_kernel, dim3(f.nsdfblk, f.B), dim3(256), 0, st, f, stats);
     PSI_CHECK_LAUNCH("grad_verts_kernel");
     psi_mark("grad_verts_kernel", st);
-    PsiLbsGradOut out = {f.g_betas, f.g_pose, f.g_transl, f.g_rot};
-    int rc = psi_lbs_backward_ex(e->lbs, f.g_verts, f.betas20, f.pose, f.cam, f.B, e->lbs_ws, out, st);
+    int rc = psi_lbs_backward_to_partials(e->lbs, f.g_verts, f.cam, f.B, e->lbs_ws, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(head_bwd_adam_kernel, dim3(f.B), dim3(HB), 0, st, f);
+    hipLaunchKernelGGL(head_bwd_adam_kernel, dim3(f.B), dim3(HB), 0, st, f, e->lv);
     PSI_CHECK_LAUNCH("head_bwd_adam_kernel");
     psi_mark("head_bwd_adam_kernel", st);
     return 0;
@@ -594,6 +645,11 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.nn_hint = (int *)(bl + o_hint);
     e->stats_local = F(o_stats);
     e->lbs_ws = F(o_lws);
+    {
+        int rcv = psi_lbs_view(lbs, B, e->lbs_ws, &e->lv);
+        if (rcv) { (void)hipFree(e->blob); delete e; return rcv; }
+        if (e->lv.m.Kpad > KPAD_MAX) { (void)hipFree(e->blob); delete e; psi_set_error("psi_fit_create: feature width %d exceeds %d", e->lv.m.Kpad, KPAD_MAX); return -1; }
+    }
     e->nn_ws = bl + o_nws;
     if (cfg->nn_mode == 1) {
         std::vector<float> hs((size_t)f.m * 3);

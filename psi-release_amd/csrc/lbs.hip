@@ -24,6 +24,7 @@
 //   pose_bwd   (1 wave per body)   chain reverse sweep, Rodrigues derivative, joint/shape gradients
 // The f32 MFMA (v_mfma_f32_16x16x4_f32) is bit-identical to an fmaf chain, so these are exact-f32 GEMMs.
 #include "psi_internal.h"
+#include "lbs_device.h"
 #include <math.h>
 #include <vector>
 #include <string.h>
@@ -33,15 +34,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int JP = 64;          // padded joint count (one wave)
+constexpr int JP = PSI_JP;      // padded joint count (one wave)
 constexpr int SKIN_BT = 1;      // bodies per skinning workgroup (measured: 1 -> 12.4 us, 2 -> 13.4, 4 -> 21.7, 8 -> 60 at B=32)
 constexpr int SKIN_BLK = 256;
-
-struct LbsDev {
-    int V, J, NB, P, K, Kpad, N, Npad, Vpad, maxlevel;
-    const float *dirs, *v_template, *WT, *J_t, *J_s;
-    const int *parents, *level, *child_ptr, *child_idx;
-};
 
 }  // namespace
 
@@ -71,7 +66,7 @@ WsLayout ws_layout(const LbsDev &m, int B)
     if (w.nsn > m.Npad / 16) w.nsn = m.Npad / 16;
     w.nvb = m.Vpad / SKIN_BLK;
     w.feat = take((size_t)((B + 15) & ~15) * m.Kpad);        // k-quad layout [Kpad/4][Bpad][4]
-    w.R = take((size_t)B * m.J * 9);
+    w.R = take((size_t)B * m.J * 12);           // rows padded to 4 floats
     w.Jl = take((size_t)B * m.J * 3);
     w.G = take((size_t)B * m.J * 12);
     w.A = take((size_t)B * m.J * 12);
@@ -90,96 +85,12 @@ WsLayout ws_layout(const LbsDev &m, int B)
 // ------------------------------------------------------------------------------------------------
 // pose forward: one wave per body
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rodrigues(const float *aa, float *R)
-{
-    // lbs.py:177-191: angle = ||aa + 1e-8||, dir = aa / angle, R = I + sin K + (1 - cos) K K
-    float x = aa[0] + 1e-8f, y = aa[1] + 1e-8f, z = aa[2] + 1e-8f;
-    float angle = sqrtf(x * x + y * y + z * z);
-    float rx = aa[0] / angle, ry = aa[1] / angle, rz = aa[2] / angle;
-    float s = sinf(angle), c1 = 1.0f - cosf(angle);
-    R[0] = 1.0f + c1 * (-(ry * ry + rz * rz));
-    R[1] = s * (-rz) + c1 * (rx * ry);
-    R[2] = s * ry + c1 * (rx * rz);
-    R[3] = s * rz + c1 * (rx * ry);
-    R[4] = 1.0f + c1 * (-(rx * rx + rz * rz));
-    R[5] = s * (-rx) + c1 * (ry * rz);
-    R[6] = s * (-ry) + c1 * (rx * rz);
-    R[7] = s * rx + c1 * (ry * rz);
-    R[8] = 1.0f + c1 * (-(rx * rx + ry * ry));
-}
-
 __global__ __launch_bounds__(64) void pose_fwd_kernel(LbsDev m, const float *__restrict__ betas, const float *__restrict__ pose,
                                                       const float *__restrict__ transl, int B, float *__restrict__ feat,
                                                       float *__restrict__ Rs, float *__restrict__ Jls, float *__restrict__ Gs,
                                                       float *__restrict__ As, float *__restrict__ joints)
 {
-    const int b = blockIdx.x, j = threadIdx.x;
-    const int Bpad = (B + 15) & ~15;
-    __shared__ float sJ[JP][3];
-    __shared__ float sG[JP][12];
-    const bool act = j < m.J;
-    float R[9], Jl[3] = {0, 0, 0};
-    if (act) {
-        rodrigues(pose + ((size_t)b * m.J + j) * 3, R);
-        for (int c = 0; c < 3; c++) {
-            float a = m.J_t[j * 3 + c];
-            for (int l = 0; l < m.NB; l++) a += m.J_s[(j * 3 + c) * m.NB + l] * betas[(size_t)b * m.NB + l];
-            Jl[c] = a;
-            sJ[j][c] = a;
-        }
-        for (int e = 0; e < 9; e++) Rs[((size_t)b * m.J + j) * 9 + e] = R[e];
-        for (int c = 0; c < 3; c++) Jls[((size_t)b * m.J + j) * 3 + c] = Jl[c];
-        if (j >= 1)
-            for (int e = 0; e < 9; e++) {
-                int k = m.NB + (j - 1) * 9 + e;
-                feat[((size_t)(k >> 2) * Bpad + b) * 4 + (k & 3)] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
-            }
-    }
-    {   // betas and the zero tail of the feature row (feat is stored as k-quads: [Kpad/4][Bpad][4])
-        for (int l = j; l < m.NB; l += 64) feat[((size_t)(l >> 2) * Bpad + b) * 4 + (l & 3)] = betas[(size_t)b * m.NB + l];
-        for (int l = m.K + j; l < m.Kpad; l += 64) feat[((size_t)(l >> 2) * Bpad + b) * 4 + (l & 3)] = 0.0f;
-    }
-    __syncthreads();
-    const int par = act ? m.parents[j] : -1;
-    const int lvl = act ? m.level[j] : -1;
-    float rel[3] = {Jl[0], Jl[1], Jl[2]};
-    if (act && par >= 0)
-        for (int c = 0; c < 3; c++) rel[c] = Jl[c] - sJ[par][c];
-    float G[12];   // row-major 3x4: [R | t]
-    if (act && lvl == 0) {
-        for (int r = 0; r < 3; r++) {
-            for (int c = 0; c < 3; c++) G[r * 4 + c] = R[r * 3 + c];
-            G[r * 4 + 3] = rel[r];
-        }
-        for (int e = 0; e < 12; e++) sG[j][e] = G[e];
-    }
-    for (int L = 1; L <= m.maxlevel; L++) {
-        __syncthreads();
-        if (act && lvl == L) {
-            float P[12];
-            for (int e = 0; e < 12; e++) P[e] = sG[par][e];
-            for (int r = 0; r < 3; r++) {
-                for (int c = 0; c < 3; c++)
-                    G[r * 4 + c] = P[r * 4 + 0] * R[0 * 3 + c] + P[r * 4 + 1] * R[1 * 3 + c] + P[r * 4 + 2] * R[2 * 3 + c];
-                G[r * 4 + 3] = P[r * 4 + 0] * rel[0] + P[r * 4 + 1] * rel[1] + P[r * 4 + 2] * rel[2] + P[r * 4 + 3];
-            }
-            for (int e = 0; e < 12; e++) sG[j][e] = G[e];
-        }
-    }
-    if (act) {
-        float *Go = Gs + ((size_t)b * m.J + j) * 12, *Ao = As + ((size_t)b * m.J + j) * 12;
-        for (int r = 0; r < 3; r++) {
-            for (int c = 0; c < 3; c++) {
-                Go[r * 4 + c] = G[r * 4 + c];
-                Ao[r * 4 + c] = G[r * 4 + c];
-            }
-            Go[r * 4 + 3] = G[r * 4 + 3];
-            // lbs.py:258-260: A = G - pad(G [J;0])
-            Ao[r * 4 + 3] = G[r * 4 + 3] - (G[r * 4 + 0] * Jl[0] + G[r * 4 + 1] * Jl[1] + G[r * 4 + 2] * Jl[2]);
-        }
-        if (joints)
-            for (int r = 0; r < 3; r++) joints[((size_t)b * m.J + j) * 3 + r] = G[r * 4 + 3] + (transl ? transl[(size_t)b * 3 + r] : 0.0f);
-    }
+    psi_pose_fwd_body(m, betas, pose, transl, B, blockIdx.x, feat, Rs, Jls, Gs, As, joints);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -612,126 +523,8 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(LbsDev m, const float *__r
                                                       const float *__restrict__ gfeat, int B,
                                                       float *__restrict__ g_betas, float *__restrict__ g_pose, float *__restrict__ g_rot)
 {
-    const int b = blockIdx.x, j = threadIdx.x;
-    const bool act = j < m.J;
-    __shared__ float sgG[JP][12];    // gradient wrt G_j (3x4)
-    __shared__ float sgJ[JP][3];     // gradient wrt the rest joint location J_j
-    __shared__ float sgrel[JP][3];
-    __shared__ float sRel[JP][3];
-    __shared__ float sR[JP][9];
-    __shared__ float sJ[JP][3];
-    float R[9], Jl[3], G[12], gG[12], gJ[3] = {0, 0, 0};
-    for (int e = 0; e < 12; e++) gG[e] = 0.0f;
-    if (act) {
-        for (int e = 0; e < 9; e++) { R[e] = Rs[((size_t)b * m.J + j) * 9 + e]; sR[j][e] = R[e]; }
-        for (int c = 0; c < 3; c++) { Jl[c] = Jls[((size_t)b * m.J + j) * 3 + c]; sJ[j][c] = Jl[c]; }
-        for (int e = 0; e < 12; e++) G[e] = Gs[((size_t)b * m.J + j) * 12 + e];
-        float gA[12];
-        for (int e = 0; e < 12; e++) gA[e] = gAr[((size_t)b * JP + j) * 16 + e];
-        // A = [G_R | G_t - G_R J]
-        for (int r = 0; r < 3; r++) {
-            float gt = gA[r * 4 + 3];
-            for (int c = 0; c < 3; c++) gG[r * 4 + c] = gA[r * 4 + c] - gt * Jl[c];
-            gG[r * 4 + 3] = gt;
-        }
-        for (int c = 0; c < 3; c++)
-            gJ[c] = -(G[0 * 4 + c] * gA[0 * 4 + 3] + G[1 * 4 + c] * gA[1 * 4 + 3] + G[2 * 4 + c] * gA[2 * 4 + 3]);
-        for (int e = 0; e < 12; e++) sgG[j][e] = gG[e];
-    }
-    __syncthreads();
-    const int par = act ? m.parents[j] : -1;
-    const int lvl = act ? m.level[j] : -1;
-    if (act) {
-        for (int c = 0; c < 3; c++) sRel[j][c] = (par >= 0) ? Jl[c] - sJ[par][c] : Jl[c];
-    }
-    __syncthreads();
-    // reverse sweep over levels: a joint first gathers from its children (whose gG are final), then publishes its own
-    for (int L = m.maxlevel - 1; L >= 0; L--) {
-        if (act && lvl == L) {
-            for (int ci = m.child_ptr[j]; ci < m.child_ptr[j + 1]; ci++) {
-                int ch = m.child_idx[ci];
-                // G_ch.R = G_j.R R_ch ; G_ch.t = G_j.R rel_ch + G_j.t
-                for (int r = 0; r < 3; r++) {
-                    for (int c = 0; c < 3; c++) {
-                        float a = 0;
-                        for (int k = 0; k < 3; k++) a += sgG[ch][r * 4 + k] * sR[ch][c * 3 + k];   // gG_ch.R R_ch^T
-                        gG[r * 4 + c] += a + sgG[ch][r * 4 + 3] * sRel[ch][c];
-                    }
-                    gG[r * 4 + 3] += sgG[ch][r * 4 + 3];
-                }
-            }
-            for (int e = 0; e < 12; e++) sgG[j][e] = gG[e];
-        }
-        __syncthreads();
-    }
-    // local gradients: gR_j = P_R^T gG_j.R, grel_j = P_R^T gG_j.t  (P = parent's G; root: identity)
-    float gR[9], grel[3] = {0, 0, 0};
-    for (int e = 0; e < 9; e++) gR[e] = 0.0f;
-    if (act) {
-        if (par >= 0) {
-            const float *P = Gs + ((size_t)b * m.J + par) * 12;
-            for (int r = 0; r < 3; r++) {
-                for (int c = 0; c < 3; c++) gR[r * 3 + c] = P[0 * 4 + r] * gG[0 * 4 + c] + P[1 * 4 + r] * gG[1 * 4 + c] + P[2 * 4 + r] * gG[2 * 4 + c];
-                grel[r] = P[0 * 4 + r] * gG[0 * 4 + 3] + P[1 * 4 + r] * gG[1 * 4 + 3] + P[2 * 4 + r] * gG[2 * 4 + 3];
-            }
-        } else {
-            for (int r = 0; r < 3; r++) {
-                for (int c = 0; c < 3; c++) gR[r * 3 + c] = gG[r * 4 + c];
-                grel[r] = gG[r * 4 + 3];
-            }
-        }
-        for (int c = 0; c < 3; c++) sgrel[j][c] = grel[c];
-    }
-    __syncthreads();
-    if (act) {
-        // rel_j = J_j - J_parent: own +grel, minus the children's
-        for (int c = 0; c < 3; c++) gJ[c] += grel[c];
-        for (int ci = m.child_ptr[j]; ci < m.child_ptr[j + 1]; ci++)
-            for (int c = 0; c < 3; c++) gJ[c] -= sgrel[m.child_idx[ci]][c];
-        for (int c = 0; c < 3; c++) sgJ[j][c] = gJ[c];
-    }
-    __syncthreads();
-    // feature gradient (reduced over n-slices): betas part and pose-feature part
-    if (g_betas) {
-        for (int l = j; l < m.NB; l += 64) {
-            float a = gfeat[(size_t)b * m.Kpad + l];
-            for (int jj = 0; jj < m.J; jj++)
-                for (int c = 0; c < 3; c++) a += sgJ[jj][c] * m.J_s[(jj * 3 + c) * m.NB + l];
-            g_betas[(size_t)b * m.NB + l] = a;
-        }
-    }
-    if (act && (g_pose || g_rot)) {
-        if (j >= 1)
-            for (int e = 0; e < 9; e++) gR[e] += gfeat[(size_t)b * m.Kpad + m.NB + (j - 1) * 9 + e];
-        if (g_rot)
-            for (int e = 0; e < 9; e++) g_rot[((size_t)b * m.J + j) * 9 + e] = gR[e];
-    }
-    if (act && g_pose) {
-        // Rodrigues backward (lbs.py:177-191)
-        const float *aa = pose + ((size_t)b * m.J + j) * 3;
-        float x = aa[0] + 1e-8f, y = aa[1] + 1e-8f, z = aa[2] + 1e-8f;
-        float th = sqrtf(x * x + y * y + z * z);
-        float d[3] = {aa[0] / th, aa[1] / th, aa[2] / th};
-        float s = sinf(th), c = cosf(th), c1 = 1.0f - c;
-        float K[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
-        float KK[9];
-        for (int r = 0; r < 3; r++)
-            for (int q = 0; q < 3; q++) KK[r * 3 + q] = K[r * 3 + 0] * K[0 * 3 + q] + K[r * 3 + 1] * K[1 * 3 + q] + K[r * 3 + 2] * K[2 * 3 + q];
-        float gs = 0, gc1 = 0;
-        for (int e = 0; e < 9; e++) { gs += gR[e] * K[e]; gc1 += gR[e] * KK[e]; }
-        float gK[9];
-        for (int r = 0; r < 3; r++)
-            for (int q = 0; q < 3; q++) {
-                float a = 0;
-                for (int k = 0; k < 3; k++) a += gR[r * 3 + k] * K[q * 3 + k] + K[k * 3 + r] * gR[k * 3 + q];   // gR K^T + K^T gR
-                gK[r * 3 + q] = s * gR[r * 3 + q] + c1 * a;
-            }
-        float gd[3] = {gK[7] - gK[5], gK[2] - gK[6], gK[3] - gK[1]};
-        float gth = gs * c + gc1 * s;                      // d sin = cos, d(1-cos) = sin
-        gth -= (gd[0] * aa[0] + gd[1] * aa[1] + gd[2] * aa[2]) / (th * th);
-        float ga[3] = {gd[0] / th + gth * x / th, gd[1] / th + gth * y / th, gd[2] / th + gth * z / th};
-        for (int q = 0; q < 3; q++) g_pose[((size_t)b * m.J + j) * 3 + q] = ga[q];
-    }
+    const int b = blockIdx.x;
+    psi_pose_bwd_body(m, betas, pose, Rs, Jls, Gs, gAr + (size_t)b * JP * 16, gfeat + (size_t)b * m.Kpad, b, g_betas, g_pose, g_rot);
 }
 
 }  // namespace
@@ -847,18 +640,9 @@ extern "C" size_t psi_lbs_workspace_floats(const psi_lbs_model *m, int B)
     return ws_layout(m->d, B).total;
 }
 
-extern "C" int psi_lbs_forward(const psi_lbs_model *mdl, const float *betas, const float *pose, const float *transl,
-                               const float *cam_ext, int B, float *verts, float *joints, float *ws, void *stream)
+static int lbs_launch_blend_skin(const LbsDev &m, const WsLayout &L, const float *transl, const float *cam_ext, int B, float *verts,
+                                 float *ws, hipStream_t st)
 {
-    PSI_REQUIRE(mdl && betas && pose && verts && ws, "null pointer");
-    PSI_REQUIRE(B > 0 && B <= 16384, "batch size out of range");
-    const LbsDev &m = mdl->d;
-    WsLayout L = ws_layout(m, B);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pose_fwd_kernel, dim3(B), dim3(64), 0, st, m, betas, pose, transl, B, ws + L.feat, ws + L.R, ws + L.Jl,
-                       ws + L.G, ws + L.A, joints);
-    PSI_CHECK_LAUNCH("pose_fwd_kernel");
-    psi_mark("pose_fwd_kernel", st);
     {
         const int ntiles = m.Npad / 64;
         const int bgroups = B > 32 ? psi_cdiv(B, 64) : 1;
@@ -881,13 +665,44 @@ extern "C" int psi_lbs_forward(const psi_lbs_model *mdl, const float *betas, con
     return 0;
 }
 
-int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const float *betas, const float *pose,
-                        const float *cam_ext, int B, float *ws, PsiLbsGradOut out, hipStream_t st)
+extern "C" int psi_lbs_forward(const psi_lbs_model *mdl, const float *betas, const float *pose, const float *transl,
+                               const float *cam_ext, int B, float *verts, float *joints, float *ws, void *stream)
 {
-    PSI_REQUIRE(mdl && grad_verts && betas && pose && ws, "null pointer");
+    PSI_REQUIRE(mdl && betas && pose && verts && ws, "null pointer");
     PSI_REQUIRE(B > 0 && B <= 16384, "batch size out of range");
     const LbsDev &m = mdl->d;
     WsLayout L = ws_layout(m, B);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(B), dim3(64), 0, st, m, betas, pose, transl, B, ws + L.feat, ws + L.R, ws + L.Jl,
+                       ws + L.G, ws + L.A, joints);
+    PSI_CHECK_LAUNCH("pose_fwd_kernel");
+    psi_mark("pose_fwd_kernel", st);
+    return lbs_launch_blend_skin(m, L, transl, cam_ext, B, verts, ws, st);
+}
+
+// ---- entry points of the fused fitting engine (psi_internal.h): the pose stages run inside its own head / tail kernels
+int psi_lbs_view(const psi_lbs_model *mdl, int B, float *ws, PsiLbsView *out)
+{
+    PSI_REQUIRE(mdl && ws && out && B > 0, "bad arguments");
+    const LbsDev &m = mdl->d;
+    WsLayout L = ws_layout(m, B);
+    out->m = m;
+    out->feat = ws + L.feat; out->R = ws + L.R; out->Jl = ws + L.Jl; out->G = ws + L.G; out->A = ws + L.A;
+    out->gA_part = ws + L.gA_part; out->gfeat_part = ws + L.gfeat_part; out->gt_part = ws + L.gt_part;
+    out->nsv = L.nsv; out->nsn = L.nsn; out->nvb = L.nvb;
+    return 0;
+}
+
+int psi_lbs_forward_from_pose(const psi_lbs_model *mdl, const float *transl, const float *cam_ext, int B, float *verts, float *ws,
+                              hipStream_t st)
+{
+    const LbsDev &m = mdl->d;
+    return lbs_launch_blend_skin(m, ws_layout(m, B), transl, cam_ext, B, verts, ws, st);
+}
+
+static int lbs_launch_bwd_partials(const LbsDev &m, const WsLayout &L, const float *grad_verts, const float *cam_ext, int B, float *ws,
+                                   hipStream_t st)
+{
     hipLaunchKernelGGL(skin_bwd_v_kernel, dim3(m.Vpad / SKIN_BLK, psi_cdiv(B, SKIN_BT)), dim3(SKIN_BLK), 0, st, m, ws + L.A, grad_verts,
                        cam_ext, B, ws + L.gl, ws + L.g_vp, ws + L.gt_part);
     PSI_CHECK_LAUNCH("skin_bwd_v_kernel");
@@ -907,6 +722,24 @@ int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const
     }
     PSI_CHECK_LAUNCH("blend_bwd_kernel");
     psi_mark("blend_bwd_kernel", st);
+    return 0;
+}
+
+int psi_lbs_backward_to_partials(const psi_lbs_model *mdl, const float *grad_verts, const float *cam_ext, int B, float *ws, hipStream_t st)
+{
+    const LbsDev &m = mdl->d;
+    return lbs_launch_bwd_partials(m, ws_layout(m, B), grad_verts, cam_ext, B, ws, st);
+}
+
+int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const float *betas, const float *pose,
+                        const float *cam_ext, int B, float *ws, PsiLbsGradOut out, hipStream_t st)
+{
+    PSI_REQUIRE(mdl && grad_verts && betas && pose && ws, "null pointer");
+    PSI_REQUIRE(B > 0 && B <= 16384, "batch size out of range");
+    const LbsDev &m = mdl->d;
+    WsLayout L = ws_layout(m, B);
+    int rc = lbs_launch_bwd_partials(m, L, grad_verts, cam_ext, B, ws, st);
+    if (rc) return rc;
     long nred = (long)B * JP * 16 + (long)B * m.Kpad + (long)B * 4;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(psi_cdiv(nred, 256)), dim3(256), 0, st, B, m.Kpad, ws + L.gA_part, L.nsv,
                        ws + L.gfeat_part, L.nsn, ws + L.gt_part, L.nvb, ws + L.gA, ws + L.gfeat, out.g_transl);
