@@ -49,7 +49,7 @@ struct FitDev {
     float *x, *xhr, *cam, *adam_m, *adam_v;
     int *step;
     // per-iteration buffers
-    float *h1, *h2, *o6, *betas20, *pose, *transl, *verts, *og, *g_verts, *gq, *fpart, *penpart, *recpart, *vppart;
+    float *h1, *h2, *o6, *betas20, *pose, *transl, *verts, *og, *gq, *fpart, *penpart, *recpart, *vppart;
     float *g_betas, *g_pose, *g_transl, *g_rot;
     int *nn_hint;        // [B,n_c] previous nearest-neighbour indices (warm start of the kd-tree search), -1 = none
     float *history;      // [max_hist][4] loss values per iteration
@@ -254,31 +254,39 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sdf_pen_kernel(FitDev f)
-{
-    const int b = blockIdx.y;
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    float val = 0.0f, g[3] = {0, 0, 0};
-    if (v < f.V) {
-        const float *p = f.verts + ((size_t)b * f.V + v) * 3;
-        val = psi_trilinear(f.sdf, f.gmin, f.gmax, p[0], p[1], p[2], f.D, f.align_corners, g);
+// Epilogue of the skinning kernel (lbs_device.h): the trilinear SDF lookup (fitting_proxe.py:144-158) happens while the
+// vertex is still in registers; per workgroup it leaves sum(-sdf) and the count over penetrating vertices, per vertex
+// the SDF gradient masked to sdf < 0.
+struct SdfPenEpilogue {
+    FitDev f;
+    float s, c;
+    __device__ __forceinline__ void vertex(int b, int v, float x, float y, float z, bool live)
+    {
+        float g[3] = {0, 0, 0};
+        float val = 0.0f;
+        if (live) val = psi_trilinear(f.sdf, f.gmin, f.gmax, x, y, z, f.D, f.align_corners, g);
+        const bool neg = live && val < 0.0f;
+        if (live) {
+            float *o = f.og + ((size_t)b * f.V + v) * 3;
+            o[0] = neg ? g[0] : 0.0f;
+            o[1] = neg ? g[1] : 0.0f;
+            o[2] = neg ? g[2] : 0.0f;
+        }
+        s = neg ? -val : 0.0f;
+        c = neg ? 1.0f : 0.0f;
     }
-    const bool neg = (v < f.V) && (val < 0.0f);
-    if (v < f.V) {
-        float *o = f.og + ((size_t)b * f.V + v) * 3;
-        o[0] = neg ? g[0] : 0.0f;
-        o[1] = neg ? g[1] : 0.0f;
-        o[2] = neg ? g[2] : 0.0f;
+    __device__ __forceinline__ void finish(int b)
+    {
+        __shared__ float red[4];
+        float ss = block_sum(s, red);
+        float cc = block_sum(c, red);
+        if (threadIdx.x == 0) {
+            size_t o = ((size_t)b * gridDim.x + blockIdx.x) * 2;
+            f.penpart[o] = ss;
+            f.penpart[o + 1] = cc;
+        }
     }
-    __shared__ float red[4];
-    float s = block_sum(neg ? -val : 0.0f, red);
-    float c = block_sum(neg ? 1.0f : 0.0f, red);
-    if (threadIdx.x == 0) {
-        size_t o = ((size_t)b * gridDim.x + blockIdx.x) * 2;
-        f.penpart[o] = s;
-        f.penpart[o + 1] = c;
-    }
-}
+};
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void loss_finalize_kernel(FitDev f, float *stats)
@@ -308,34 +316,75 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(FitDev f, float *sta
     }
 }
 
-// g_verts = penetration part (global count) + contact part (vertex -> contact slots); block 0 records the loss values
-__global__ __launch_bounds__(256) void grad_verts_kernel(FitDev f, const float *__restrict__ stats)
-{
-    const int b = blockIdx.y;
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    const float Bg = (float)f.B * (float)f.world;
-    const float N = stats[4];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        int it = *f.step - 1;
-        if (it >= 0) {
-            float *h = f.history + (size_t)(it % f.max_hist) * 4;     // ring buffer
-            h[0] = f.w_rec * stats[0] / (Bg * XD);
-            h[1] = f.w_vp * stats[1] / (Bg * NZ);
-            h[2] = f.w_contact * stats[2] / (Bg * f.n_c);
-            h[3] = N > 0.0f ? f.w_col * stats[3] / N : 0.0f;
+// Gradient source of the skinning backward (lbs_device.h): dL/dverts[b][v] = penetration part (global count) + contact
+// part (vertex -> contact slots, CSR), assembled on the fly; workgroup (0,0) records the loss values of the iteration.
+// LOCAL (single process): every workgroup re-derives the global penetration count from the per-workgroup partials (a
+// 10 KB L2-resident read) and workgroup (0,0) also produces the iteration's statistics — there is no separate
+// loss_finalize launch.  Data-parallel runs (!LOCAL) read the all-reduced statistics instead.
+template <bool LOCAL>
+struct FitGradSource {
+    FitDev f;
+    float *stats;
+    float N;
+    __device__ __forceinline__ void prepare()
+    {
+        const int t = threadIdx.x;
+        const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+        float st[5];
+        if (LOCAL) {
+            __shared__ float red[4];
+            float a = 0, c = 0;
+            for (int i = t; i < f.B * f.nsdfblk; i += PSI_SKIN_BLK) {
+                a += f.penpart[2 * i];
+                c += f.penpart[2 * i + 1];
+            }
+            st[3] = block_sum(a, red);
+            st[4] = block_sum(c, red);
+            if (first) {                                        // same reductions as loss_finalize_kernel
+                a = 0;
+                for (int i = t; i < f.B; i += PSI_SKIN_BLK) a += f.recpart[i];
+                st[0] = block_sum(a, red);
+                a = 0;
+                for (int i = t; i < f.B; i += PSI_SKIN_BLK) a += f.vppart[i];
+                st[1] = block_sum(a, red);
+                a = 0;
+                for (int i = t; i < f.B * f.nfp; i += PSI_SKIN_BLK) a += f.fpart[i];
+                st[2] = block_sum(a, red);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 5; i++) st[i] = stats[i];
+        }
+        N = st[4];
+        if (first && t == 0) {
+            if (LOCAL) {
+                stats[0] = st[0]; stats[1] = st[1]; stats[2] = st[2]; stats[3] = st[3]; stats[4] = st[4]; stats[5] = 0.0f;
+                *f.step += 1;
+            }
+            const float Bg = (float)f.B * (float)f.world;
+            int it = *f.step - 1;
+            if (it >= 0) {
+                float *h = f.history + (size_t)(it % f.max_hist) * 4;     // ring buffer
+                h[0] = f.w_rec * st[0] / (Bg * XD);
+                h[1] = f.w_vp * st[1] / (Bg * NZ);
+                h[2] = f.w_contact * st[2] / (Bg * f.n_c);
+                h[3] = N > 0.0f ? f.w_col * st[3] / N : 0.0f;
+            }
         }
     }
-    if (v >= f.V) return;
-    const float sp = N > 0.0f ? -f.w_col / N : 0.0f;       // d/d sdf_k of w * sum(-sdf)/N on the penetrating entries
-    const size_t o = ((size_t)b * f.V + v) * 3;
-    float gx = sp * f.og[o + 0], gy = sp * f.og[o + 1], gz = sp * f.og[o + 2];
-    for (int ci = f.cs_ptr[v]; ci < f.cs_ptr[v + 1]; ci++) {
-        const float *q = f.gq + ((size_t)b * f.n_c + f.cs_idx[ci]) * 3;
-        gx += q[0]; gy += q[1]; gz += q[2];
+    __device__ __forceinline__ void load(int b, int v, float &gx, float &gy, float &gz) const
+    {
+        const float sp = N > 0.0f ? -f.w_col / N : 0.0f;       // d/d sdf_k of w * sum(-sdf)/N on the penetrating entries
+        const size_t o = ((size_t)b * f.V + v) * 3;
+        gx = sp * f.og[o + 0]; gy = sp * f.og[o + 1]; gz = sp * f.og[o + 2];
+        for (int ci = f.cs_ptr[v]; ci < f.cs_ptr[v + 1]; ci++) {
+            const float *q = f.gq + ((size_t)b * f.n_c + f.cs_idx[ci]) * 3;
+            gx += q[0]; gy += q[1]; gz += q[2];
+        }
     }
-    f.g_verts[o + 0] = gx; f.g_verts[o + 1] = gy; f.g_verts[o + 2] = gz;
-}
+};
 
+// ------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------
 // One workgroup per body: (1) sums this body's split-contraction partials (gA over vertex slices, g_feat over column
 // slices, g_transl over vertex blocks) straight into LDS, (2) runs the LBS pose-backward stage on them, (3) back-propagates
@@ -516,36 +565,44 @@ struct psi_fit_engine {
     const float *half_stats[2];
 };
 
-static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st)
+// local: single-process iteration — the statistics are produced inside the backward's first kernel (no loss_finalize launch)
+static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool local = false)
 {
     FitDev &f = e->d;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(f.B), dim3(HB), 0, st, f, e->lv);
     PSI_CHECK_LAUNCH("head_fwd_kernel");
     psi_mark("head_fwd_kernel", st);
-    int rc = psi_lbs_forward_from_pose(e->lbs, f.transl, f.cam, f.B, f.verts, e->lbs_ws, st);
+    int rc = psi_lbs_blend_forward(e->lbs, f.B, e->lbs_ws, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(sdf_pen_kernel, dim3(f.nsdfblk, f.B), dim3(256), 0, st, f);
-    PSI_CHECK_LAUNCH("sdf_pen_kernel");
-    psi_mark("sdf_pen_kernel", st);
+    hipLaunchKernelGGL(psi_skin_fwd_kernel<SdfPenEpilogue>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A, e->lv.v_posed,
+                       f.transl, f.cam, f.B, f.verts, SdfPenEpilogue{f, 0.0f, 0.0f});
+    PSI_CHECK_LAUNCH("skin_fwd_sdf_kernel");
+    psi_mark("skin_fwd_sdf_kernel", st);
     float gscale = f.w_contact / ((float)f.B * (float)f.world * (float)f.n_c);
     if (e->nn_index)
         rc = psi_nn_index_contact(e->nn_index, f.verts, (long)f.V * 3, f.vid, f.B, f.n_c, f.cconst, gscale, f.gq, f.fpart, f.nn_hint, st);
     else
         rc = psi_nn_contact(f.verts, (long)f.V * 3, f.vid, f.scene, f.B, f.n_c, f.m, e->nn_ws, f.cconst, gscale, f.gq, f.fpart, nullptr, st);
     if (rc) return rc;
+    if (local) return 0;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, f, stats);
     PSI_CHECK_LAUNCH("loss_finalize_kernel");
     psi_mark("loss_finalize_kernel", st);
     return 0;
 }
 
-static int fit_backward(psi_fit_engine *e, const float *stats, hipStream_t st)
+static int fit_backward(psi_fit_engine *e, float *stats, hipStream_t st, bool local = false)
 {
     FitDev &f = e->d;
-    hipLaunchKernelGGL(grad_verts_kernel, dim3(f.nsdfblk, f.B), dim3(256), 0, st, f, stats);
-    PSI_CHECK_LAUNCH("grad_verts_kernel");
-    psi_mark("grad_verts_kernel", st);
-    int rc = psi_lbs_backward_to_partials(e->lbs, f.g_verts, f.cam, f.B, e->lbs_ws, st);
+    if (local)
+        hipLaunchKernelGGL(psi_skin_bwd_v_kernel<FitGradSource<true>>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
+                           FitGradSource<true>{f, stats, 0.0f}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
+    else
+        hipLaunchKernelGGL(psi_skin_bwd_v_kernel<FitGradSource<false>>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
+                           FitGradSource<false>{f, stats, 0.0f}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
+    PSI_CHECK_LAUNCH("skin_bwd_v_grad_kernel");
+    psi_mark("skin_bwd_v_grad_kernel", st);
+    int rc = psi_lbs_backward_joint_parts(e->lbs, f.B, e->lbs_ws, st);
     if (rc) return rc;
     hipLaunchKernelGGL(head_bwd_adam_kernel, dim3(f.B), dim3(HB), 0, st, f, e->lv);
     PSI_CHECK_LAUNCH("head_bwd_adam_kernel");
@@ -609,7 +666,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     size_t o_x = take((size_t)B * XD * 4), o_xhr = take((size_t)B * XD * 4), o_cam = take((size_t)B * 16 * 4), o_am = take((size_t)B * XD * 4),
            o_av = take((size_t)B * XD * 4), o_step = take(256), o_h1 = take((size_t)B * NH * 4), o_h2 = take((size_t)B * NH * 4),
            o_o6 = take((size_t)B * 128 * 4), o_b20 = take((size_t)B * NB * 4), o_pose = take((size_t)B * J * 3 * 4), o_tr = take((size_t)B * 3 * 4),
-           o_verts = take((size_t)B * V * 3 * 4), o_og = take((size_t)B * V * 3 * 4), o_gv = take((size_t)B * V * 3 * 4),
+           o_verts = take((size_t)B * V * 3 * 4), o_og = take((size_t)B * V * 3 * 4),
            o_gq = take((size_t)B * f.n_c * 3 * 4), o_fp = take((size_t)B * f.nfp * 4), o_pp = take((size_t)B * f.nsdfblk * 2 * 4),
            o_rp = take((size_t)B * 4), o_vp = take((size_t)B * 4), o_gb = take((size_t)B * NB * 4), o_gp = take((size_t)B * J * 3 * 4),
            o_gt = take((size_t)B * 3 * 4), o_gr = take((size_t)B * J * 9 * 4), o_hist = take((size_t)f.max_hist * 4 * 4), o_stats = take(256), o_hint = take((size_t)B * f.n_c * 4);
@@ -639,7 +696,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.gmin = F(o_gmin); f.gmax = F(o_gmax);
     f.x = F(o_x); f.xhr = F(o_xhr); f.cam = F(o_cam); f.adam_m = F(o_am); f.adam_v = F(o_av); f.step = (int *)(bl + o_step);
     f.h1 = F(o_h1); f.h2 = F(o_h2); f.o6 = F(o_o6); f.betas20 = F(o_b20); f.pose = F(o_pose); f.transl = F(o_tr);
-    f.verts = F(o_verts); f.og = F(o_og); f.g_verts = F(o_gv); f.gq = F(o_gq); f.fpart = F(o_fp); f.penpart = F(o_pp);
+    f.verts = F(o_verts); f.og = F(o_og); f.gq = F(o_gq); f.fpart = F(o_fp); f.penpart = F(o_pp);
     f.recpart = F(o_rp); f.vppart = F(o_vp); f.g_betas = F(o_gb); f.g_pose = F(o_gp); f.g_transl = F(o_gt); f.g_rot = F(o_gr);
     f.history = F(o_hist);
     f.nn_hint = (int *)(bl + o_hint);
@@ -743,9 +800,9 @@ extern "C" int psi_fit_iterate(psi_fit_engine *e, int n_iter, int use_graph, voi
     hipStream_t st = (hipStream_t)stream;
     if (!use_graph) {
         for (int i = 0; i < n_iter; i++) {
-            int rc = fit_forward(e, e->stats_local, st);
+            int rc = fit_forward(e, e->stats_local, st, true);
             if (rc) return rc;
-            rc = fit_backward(e, e->stats_local, st);
+            rc = fit_backward(e, e->stats_local, st, true);
             if (rc) return rc;
         }
         return 0;
@@ -753,8 +810,8 @@ extern "C" int psi_fit_iterate(psi_fit_engine *e, int n_iter, int use_graph, voi
     if (!e->graph_ready) {
         PSI_REQUIRE(st != nullptr, "graph capture needs a non-default stream");
         PSI_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        int rc = fit_forward(e, e->stats_local, st);
-        if (!rc) rc = fit_backward(e, e->stats_local, st);
+        int rc = fit_forward(e, e->stats_local, st, true);
+        if (!rc) rc = fit_backward(e, e->stats_local, st, true);
         hipError_t ce = hipStreamEndCapture(st, &e->graph);
         if (rc) return rc;
         PSI_CHECK_HIP(ce);
@@ -784,8 +841,8 @@ extern "C" int psi_fit_profile(psi_fit_engine *e, int n_rep, char *h_names, int 
         tm.name[0] = "start";
         tm.n = 1;
         g_psi_timer = &tm;
-        rc = fit_forward(e, e->stats_local, st);
-        if (!rc) rc = fit_backward(e, e->stats_local, st);
+        rc = fit_forward(e, e->stats_local, st, true);
+        if (!rc) rc = fit_backward(e, e->stats_local, st, true);
         g_psi_timer = nullptr;
         if (rc) break;
         PSI_CHECK_HIP(hipStreamSynchronize(st));
@@ -832,7 +889,6 @@ extern "C" int psi_fit_copy_buffer(psi_fit_engine *e, const char *name, float *d
     const float *src = nullptr;
     long cap = 0;
     if (!strcmp(name, "verts")) { src = f.verts; cap = (long)f.B * f.V * 3; }
-    else if (!strcmp(name, "g_verts")) { src = f.g_verts; cap = (long)f.B * f.V * 3; }
     else if (!strcmp(name, "pose")) { src = f.pose; cap = (long)f.B * f.J * 3; }
     else if (!strcmp(name, "g_pose")) { src = f.g_pose; cap = (long)f.B * f.J * 3; }
     else if (!strcmp(name, "g_rot")) { src = f.g_rot; cap = (long)f.B * f.J * 9; }

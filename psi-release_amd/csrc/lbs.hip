@@ -35,8 +35,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int JP = PSI_JP;      // padded joint count (one wave)
-constexpr int SKIN_BT = 1;      // bodies per skinning workgroup (measured: 1 -> 12.4 us, 2 -> 13.4, 4 -> 21.7, 8 -> 60 at B=32)
-constexpr int SKIN_BLK = 256;
+constexpr int SKIN_BLK = PSI_SKIN_BLK;
 
 }  // namespace
 
@@ -185,163 +184,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(qB, aB);
             finish_tile(it + 1);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// skinning forward
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SKIN_BLK) void skin_fwd_kernel(LbsDev m, const float *__restrict__ As, const float *__restrict__ v_posed,
-                                                            const float *__restrict__ transl, const float *__restrict__ cam_ext,
-                                                            int B, float *__restrict__ verts)
-{
-    const int v = blockIdx.x * SKIN_BLK + threadIdx.x;
-    const int b0 = blockIdx.y * SKIN_BT;
-    // The joint transforms of the workgroup's SKIN_BT bodies are staged in LDS once (10.5 KB); the j loop then has no
-    // scalar-load round trip per joint, the per-lane weights w_j are prefetched 11 joints ahead (unroll 11 of J = 55), and
-    // the accumulation is packed: v_pk_fma_f32 issues two FMAs per slot.  (Profile before: 28 us, >80% of it waiting on
-    // one dependent weight load + one scalar-load batch per joint with ~1.3 waves per SIMD to hide them.)
-    __shared__ f2 sA[SKIN_BT][JP][6];
-    for (int idx = threadIdx.x; idx < SKIN_BT * m.J * 6; idx += SKIN_BLK) {
-        int i = idx / (m.J * 6), rem = idx - i * (m.J * 6);
-        sA[i][rem / 6][rem % 6] = *(const f2 *)(As + ((size_t)min(b0 + i, B - 1) * m.J) * 12 + rem * 2);
-    }
-    __syncthreads();
-    f2 T2[SKIN_BT][6];
-#pragma unroll
-    for (int i = 0; i < SKIN_BT; i++)
-#pragma unroll
-        for (int e = 0; e < 6; e++) T2[i][e] = (f2){0.0f, 0.0f};
-#pragma unroll 11
-    for (int j = 0; j < m.J; j++) {
-        float wj = m.WT[(size_t)j * m.Vpad + v];
-        f2 w2 = {wj, wj};
-#pragma unroll
-        for (int i = 0; i < SKIN_BT; i++)
-#pragma unroll
-            for (int e = 0; e < 6; e++) T2[i][e] = __builtin_elementwise_fma(w2, sA[i][j][e], T2[i][e]);
-    }
-    float T[SKIN_BT][12];
-#pragma unroll
-    for (int i = 0; i < SKIN_BT; i++)
-#pragma unroll
-        for (int e = 0; e < 6; e++) {
-            T[i][2 * e] = T2[i][e].x;
-            T[i][2 * e + 1] = T2[i][e].y;
-        }
-    if (v >= m.V) return;
-#pragma unroll
-    for (int i = 0; i < SKIN_BT; i++) {
-        int b = b0 + i;
-        if (b >= B) break;
-        const float *vp = v_posed + (size_t)b * m.Npad + (size_t)v * 3;
-        float px = vp[0], py = vp[1], pz = vp[2];
-        float x = T[i][0] * px + T[i][1] * py + T[i][2] * pz + T[i][3];
-        float y = T[i][4] * px + T[i][5] * py + T[i][6] * pz + T[i][7];
-        float z = T[i][8] * px + T[i][9] * py + T[i][10] * pz + T[i][11];
-        if (transl) {
-            x += transl[(size_t)b * 3 + 0];
-            y += transl[(size_t)b * 3 + 1];
-            z += transl[(size_t)b * 3 + 2];
-        }
-        if (cam_ext) {   // cvae.py:141-149: [v,1] @ cam_ext^T, drop w
-            const float *C = cam_ext + (size_t)b * 16;
-            float X = C[0] * x + C[1] * y + C[2] * z + C[3];
-            float Y = C[4] * x + C[5] * y + C[6] * z + C[7];
-            float Z = C[8] * x + C[9] * y + C[10] * z + C[11];
-            x = X; y = Y; z = Z;
-        }
-        float *o = verts + ((size_t)b * m.V + v) * 3;
-        o[0] = x; o[1] = y; o[2] = z;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// skinning backward, per-vertex part: g_local, g_vposed, partial g_transl
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float x)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-    return x;
-}
-
-__global__ __launch_bounds__(SKIN_BLK) void skin_bwd_v_kernel(LbsDev m, const float *__restrict__ As, const float *__restrict__ g_verts,
-                                                              const float *__restrict__ cam_ext, int B, float *__restrict__ gl,
-                                                              float *__restrict__ g_vp, float *__restrict__ gt_part)
-{
-    const int v = blockIdx.x * SKIN_BLK + threadIdx.x;
-    const int b0 = blockIdx.y * SKIN_BT;
-    __shared__ f2 sA[SKIN_BT][JP][6];            // same staging / prefetch scheme as skin_fwd_kernel
-    for (int idx = threadIdx.x; idx < SKIN_BT * m.J * 6; idx += SKIN_BLK) {
-        int i = idx / (m.J * 6), rem = idx - i * (m.J * 6);
-        sA[i][rem / 6][rem % 6] = *(const f2 *)(As + ((size_t)min(b0 + i, B - 1) * m.J) * 12 + rem * 2);
-    }
-    __syncthreads();
-    f2 T2[SKIN_BT][6];
-#pragma unroll
-    for (int i = 0; i < SKIN_BT; i++)
-#pragma unroll
-        for (int e = 0; e < 6; e++) T2[i][e] = (f2){0.0f, 0.0f};
-#pragma unroll 11
-    for (int j = 0; j < m.J; j++) {
-        float wj = m.WT[(size_t)j * m.Vpad + v];
-        f2 w2 = {wj, wj};
-#pragma unroll
-        for (int i = 0; i < SKIN_BT; i++)
-#pragma unroll
-            for (int e = 0; e < 6; e++) T2[i][e] = __builtin_elementwise_fma(w2, sA[i][j][e], T2[i][e]);
-    }
-    float T[SKIN_BT][9];     // rotation part, row-major 3x3
-#pragma unroll
-    for (int i = 0; i < SKIN_BT; i++)
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            T[i][r * 3 + 0] = T2[i][2 * r].x;
-            T[i][r * 3 + 1] = T2[i][2 * r].y;
-            T[i][r * 3 + 2] = T2[i][2 * r + 1].x;
-        }
-    __shared__ float sh[SKIN_BLK / 64][SKIN_BT][3];
-    const bool live = v < m.V;
-#pragma unroll
-    for (int i = 0; i < SKIN_BT; i++) {
-        int b = b0 + i;
-        float lx = 0, ly = 0, lz = 0;
-        if (b < B && live) {
-            const float *g = g_verts + ((size_t)b * m.V + v) * 3;
-            float gx = g[0], gy = g[1], gz = g[2];
-            if (cam_ext) {   // g_local = R_c^T g
-                const float *C = cam_ext + (size_t)b * 16;
-                lx = C[0] * gx + C[4] * gy + C[8] * gz;
-                ly = C[1] * gx + C[5] * gy + C[9] * gz;
-                lz = C[2] * gx + C[6] * gy + C[10] * gz;
-            } else {
-                lx = gx; ly = gy; lz = gz;
-            }
-        }
-        if (b < B) {
-            float *o = gl + (size_t)b * m.Npad + (size_t)v * 3;
-            o[0] = lx; o[1] = ly; o[2] = lz;
-            float *p = g_vp + (size_t)b * m.Npad + (size_t)v * 3;   // T_R^T g_local
-            p[0] = T[i][0] * lx + T[i][3] * ly + T[i][6] * lz;
-            p[1] = T[i][1] * lx + T[i][4] * ly + T[i][7] * lz;
-            p[2] = T[i][2] * lx + T[i][5] * ly + T[i][8] * lz;
-        }
-        float sx = wave_sum(lx), sy = wave_sum(ly), sz = wave_sum(lz);
-        if ((threadIdx.x & 63) == 0) {
-            sh[threadIdx.x >> 6][i][0] = sx;
-            sh[threadIdx.x >> 6][i][1] = sy;
-            sh[threadIdx.x >> 6][i][2] = sz;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < SKIN_BT * 3) {
-        int i = threadIdx.x / 3, c = threadIdx.x % 3, b = b0 + i;
-        if (b < B) {
-            float s = 0;
-            for (int ww = 0; ww < SKIN_BLK / 64; ww++) s += sh[ww][i][c];
-            gt_part[((size_t)blockIdx.x * B + b) * 4 + c] = s;
         }
     }
 }
@@ -640,8 +482,7 @@ extern "C" size_t psi_lbs_workspace_floats(const psi_lbs_model *m, int B)
     return ws_layout(m->d, B).total;
 }
 
-static int lbs_launch_blend_skin(const LbsDev &m, const WsLayout &L, const float *transl, const float *cam_ext, int B, float *verts,
-                                 float *ws, hipStream_t st)
+static int lbs_launch_blend(const LbsDev &m, const WsLayout &L, int B, float *ws, hipStream_t st)
 {
     {
         const int ntiles = m.Npad / 64;
@@ -658,8 +499,16 @@ static int lbs_launch_blend_skin(const LbsDev &m, const WsLayout &L, const float
     }
     PSI_CHECK_LAUNCH("blend_fwd_kernel");
     psi_mark("blend_fwd_kernel", st);
-    hipLaunchKernelGGL(skin_fwd_kernel, dim3(m.Vpad / SKIN_BLK, psi_cdiv(B, SKIN_BT)), dim3(SKIN_BLK), 0, st, m, ws + L.A,
-                       ws + L.v_posed, transl, cam_ext, B, verts);
+    return 0;
+}
+
+static int lbs_launch_blend_skin(const LbsDev &m, const WsLayout &L, const float *transl, const float *cam_ext, int B, float *verts,
+                                 float *ws, hipStream_t st)
+{
+    int rc = lbs_launch_blend(m, L, B, ws, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(psi_skin_fwd_kernel<PsiSkinNoEpilogue>, dim3(m.Vpad / SKIN_BLK, B), dim3(SKIN_BLK), 0, st, m, ws + L.A,
+                       ws + L.v_posed, transl, cam_ext, B, verts, PsiSkinNoEpilogue());
     PSI_CHECK_LAUNCH("skin_fwd_kernel");
     psi_mark("skin_fwd_kernel", st);
     return 0;
@@ -688,25 +537,32 @@ int psi_lbs_view(const psi_lbs_model *mdl, int B, float *ws, PsiLbsView *out)
     WsLayout L = ws_layout(m, B);
     out->m = m;
     out->feat = ws + L.feat; out->R = ws + L.R; out->Jl = ws + L.Jl; out->G = ws + L.G; out->A = ws + L.A;
+    out->v_posed = ws + L.v_posed; out->gl = ws + L.gl; out->g_vp = ws + L.g_vp; out->gt_part_w = ws + L.gt_part;
     out->gA_part = ws + L.gA_part; out->gfeat_part = ws + L.gfeat_part; out->gt_part = ws + L.gt_part;
     out->nsv = L.nsv; out->nsn = L.nsn; out->nvb = L.nvb;
     return 0;
 }
 
-int psi_lbs_forward_from_pose(const psi_lbs_model *mdl, const float *transl, const float *cam_ext, int B, float *verts, float *ws,
-                              hipStream_t st)
+int psi_lbs_blend_forward(const psi_lbs_model *mdl, int B, float *ws, hipStream_t st)
 {
     const LbsDev &m = mdl->d;
-    return lbs_launch_blend_skin(m, ws_layout(m, B), transl, cam_ext, B, verts, ws, st);
+    return lbs_launch_blend(m, ws_layout(m, B), B, ws, st);
 }
+
+static int lbs_launch_bwd_joint_parts(const LbsDev &m, const WsLayout &L, int B, float *ws, hipStream_t st);
 
 static int lbs_launch_bwd_partials(const LbsDev &m, const WsLayout &L, const float *grad_verts, const float *cam_ext, int B, float *ws,
                                    hipStream_t st)
 {
-    hipLaunchKernelGGL(skin_bwd_v_kernel, dim3(m.Vpad / SKIN_BLK, psi_cdiv(B, SKIN_BT)), dim3(SKIN_BLK), 0, st, m, ws + L.A, grad_verts,
-                       cam_ext, B, ws + L.gl, ws + L.g_vp, ws + L.gt_part);
+    hipLaunchKernelGGL(psi_skin_bwd_v_kernel<PsiGradFromMemory>, dim3(m.Vpad / SKIN_BLK, B), dim3(SKIN_BLK), 0, st, m, ws + L.A,
+                       PsiGradFromMemory{grad_verts, m.V}, cam_ext, B, ws + L.gl, ws + L.g_vp, ws + L.gt_part);
     PSI_CHECK_LAUNCH("skin_bwd_v_kernel");
     psi_mark("skin_bwd_v_kernel", st);
+    return lbs_launch_bwd_joint_parts(m, L, B, ws, st);
+}
+
+static int lbs_launch_bwd_joint_parts(const LbsDev &m, const WsLayout &L, int B, float *ws, hipStream_t st)
+{
     hipLaunchKernelGGL(skin_bwd_A_kernel, dim3(L.nsv, B), dim3(256), 0, st, m, ws + L.gl, ws + L.v_posed, B, ws + L.gA_part);
     PSI_CHECK_LAUNCH("skin_bwd_A_kernel");
     psi_mark("skin_bwd_A_kernel", st);
@@ -725,10 +581,10 @@ static int lbs_launch_bwd_partials(const LbsDev &m, const WsLayout &L, const flo
     return 0;
 }
 
-int psi_lbs_backward_to_partials(const psi_lbs_model *mdl, const float *grad_verts, const float *cam_ext, int B, float *ws, hipStream_t st)
+int psi_lbs_backward_joint_parts(const psi_lbs_model *mdl, int B, float *ws, hipStream_t st)
 {
     const LbsDev &m = mdl->d;
-    return lbs_launch_bwd_partials(m, ws_layout(m, B), grad_verts, cam_ext, B, ws, st);
+    return lbs_launch_bwd_joint_parts(m, ws_layout(m, B), B, ws, st);
 }
 
 int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const float *betas, const float *pose,

@@ -47,7 +47,5 @@ void psi_lbs_dims(const psi_lbs_model *mdl, int *V, int *J, int *NB);
 // the fused fitting engine runs the per-body pose stages inside its own kernels (lbs_device.h) and calls these for the rest
 struct PsiLbsView;
 int psi_lbs_view(const psi_lbs_model *mdl, int B, float *ws, PsiLbsView *out);
-int psi_lbs_forward_from_pose(const psi_lbs_model *mdl, const float *transl, const float *cam_ext, int B, float *verts, float *ws,
-                              hipStream_t st);     // blend_fwd + skin_fwd (feat / A already in the workspace)
-int psi_lbs_backward_to_partials(const psi_lbs_model *mdl, const float *grad_verts, const float *cam_ext, int B, float *ws,
-                                 hipStream_t st);  // skin_bwd_v + skin_bwd_A + blend_bwd (partials left in the workspace)
+int psi_lbs_blend_forward(const psi_lbs_model *mdl, int B, float *ws, hipStream_t st);          // v_posed = v_t + feat @ dirs
+int psi_lbs_backward_joint_parts(const psi_lbs_model *mdl, int B, float *ws, hipStream_t st);   // skin_bwd_A + blend_bwd partials
