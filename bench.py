@@ -105,13 +105,17 @@ def kernel_work(args, op):
         'kd_query_kernel': ('byte', B * nc * (12 + 12 + 8) + m * 16.0,
                             'exact kd-tree NN (latency-bound pointer chase): queries in, gradients + hints out, scene once'),
         'blend_fwd_kernel': ('byte', dirs + B * Npad * 4.0 + B * Kpad * 4.0, 'v_posed = v_t + feat @ dirs: dirs (64.5 MB) streamed once + output'),
-        'blend_bwd_kernel': ('byte', dirs + B * Npad * 4.0 + 41 * B * Kpad * 4.0, 'g_feat = g_vposed @ dirs^T: dirs streamed once + input + partials'),
+        'blend_bwd_kernel': ('byte', dirs + B * Npad * 4.0 + 32 * B * Kpad * 4.0, 'g_feat = g_vposed @ dirs^T: dirs streamed once + input + 32 column-slice partials'),
         'skin_fwd_kernel': ('byte', 55 * Vpad * 4.0 + B * Npad * 4.0 + B * V * 12.0, 'weights + v_posed in, vertices out (660 FMA per vertex: VALU-heavy)'),
+        'skin_fwd_sdf_kernel': ('byte', 55 * Vpad * 4.0 + B * Npad * 4.0 + B * V * (12.0 + 32 + 12),
+                                'skinning + SDF lookup fused: weights + v_posed in, vertices out, 8 gathers + 12 B masked gradient per vertex'),
         'skin_bwd_v_kernel': ('byte', 55 * Vpad * 4.0 + B * V * 12.0 + 2 * B * Npad * 4.0, 'weights + grad in, g_local + g_vposed out'),
+        'skin_bwd_v_grad_kernel': ('byte', 55 * Vpad * 4.0 + B * V * 12.0 + B * nc * 12.0 + 2 * B * Npad * 4.0,
+                                   'loss-gradient assembly + skinning backward fused: weights + SDF gradient + contact gradients in, g_local + g_vposed out'),
         'skin_bwd_A_kernel': ('byte', 64 * Vpad * 4.0 + 2 * B * Npad * 4.0 + 41 * B * 1024 * 4.0, 'weights + g_local + v_posed in, partials out'),
-        'sdf_pen_kernel': ('byte', B * V * (12 + 32 + 12.0), '12 B vertex + 8 gathers + 12 B gradient per vertex'),
-        'head_fwd_kernel': ('byte', 1.4e6 + B * 4000.0, 'VPoser decoder weights (L2 resident) + per-body state'),
-        'head_bwd_adam_kernel': ('byte', 1.4e6 + B * 4000.0, 'VPoser decoder weights (L2 resident) + per-body state'),
+        'head_fwd_kernel': ('byte', 1.4e6 + B * 12000.0, 'VPoser decoder weights (L2 resident) + per-body state + LBS pose stage'),
+        'head_bwd_adam_kernel': ('byte', 1.4e6 + B * (41 * 4096 + 32 * 2048 + 12000.0),
+                                 'partials reduction + LBS pose backward + VPoser decoder backward (weights L2 resident) + Adam'),
     }
 
 

@@ -386,56 +386,16 @@ struct FitGradSource {
 
 // ------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------
-// One workgroup per body: (1) sums this body's split-contraction partials (gA over vertex slices, g_feat over column
-// slices, g_transl over vertex blocks) straight into LDS, (2) runs the LBS pose-backward stage on them, (3) back-propagates
-// through the 6D rotations / hand PCA / VPoser decoder and (4) applies the Adam update.  Formerly three launches
-// (reduce_partials, pose_bwd, head_bwd_adam) with global round trips in between.
-constexpr int KPAD_MAX = 512;
+// One workgroup per body: (1) the LBS pose-backward stage on this body's reduced gradients, (2) back-propagation through
+// the 6D rotations / hand PCA / VPoser decoder, (3) the Adam update.  (The split-contraction partials are summed by a
+// separate all-CU kernel: 32 workgroups pulling 7.5 MB of freshly written partials through 32 CUs took 15 us.)
 __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView lv)
 {
     const int b = blockIdx.x, t = threadIdx.x;
     __shared__ float sx[XD + 5], sg6[128], sga2[NH], sga1[NH], sgx[XD + 5];
     __shared__ f4 part4[4][128], part1[64][8];
-    __shared__ __attribute__((aligned(16))) float s_gA[PSI_JP * 16];
-    __shared__ float s_gfeat[KPAD_MAX], s_gt[4];
-    {
-        const size_t nA = (size_t)f.B * PSI_JP * 16, nF = (size_t)f.B * lv.m.Kpad;
-        for (int i = t; i < PSI_JP * 16; i += HB) {
-            const float *p = lv.gA_part + (size_t)b * PSI_JP * 16 + i;
-            float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            int sl = 0;
-#pragma unroll 4
-            for (; sl + 4 <= lv.nsv; sl += 4) {              // independent loads in flight
-                a0 += p[(size_t)(sl + 0) * nA];
-                a1 += p[(size_t)(sl + 1) * nA];
-                a2 += p[(size_t)(sl + 2) * nA];
-                a3 += p[(size_t)(sl + 3) * nA];
-            }
-            for (; sl < lv.nsv; sl++) a0 += p[(size_t)sl * nA];
-            s_gA[i] = (a0 + a1) + (a2 + a3);
-        }
-        for (int k = t; k < lv.m.Kpad; k += HB) {
-            const float *p = lv.gfeat_part + (size_t)b * lv.m.Kpad + k;
-            float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            int sl = 0;
-#pragma unroll 4
-            for (; sl + 4 <= lv.nsn; sl += 4) {
-                a0 += p[(size_t)(sl + 0) * nF];
-                a1 += p[(size_t)(sl + 1) * nF];
-                a2 += p[(size_t)(sl + 2) * nF];
-                a3 += p[(size_t)(sl + 3) * nF];
-            }
-            for (; sl < lv.nsn; sl++) a0 += p[(size_t)sl * nF];
-            s_gfeat[k] = (a0 + a1) + (a2 + a3);
-        }
-        if (t < 3) {
-            float a = 0;
-            for (int vb = 0; vb < lv.nvb; vb++) a += lv.gt_part[((size_t)vb * f.B + b) * 4 + t];
-            s_gt[t] = a;
-        }
-    }
-    __syncthreads();
-    psi_pose_bwd_body(lv.m, f.betas20, f.pose, lv.R, lv.Jl, lv.G, s_gA, s_gfeat, b, f.g_betas, f.g_pose, f.g_rot);
+    psi_pose_bwd_body(lv.m, f.betas20, f.pose, lv.R, lv.Jl, lv.G, lv.gA + (size_t)b * PSI_JP * 16, lv.gfeat + (size_t)b * lv.m.Kpad, b,
+                      f.g_betas, f.g_pose, f.g_rot);
     __syncthreads();                                         // g_betas / g_pose / g_rot of this body are visible to the workgroup
     const float *x = f.x + (size_t)b * XD;
     if (t < XD) { sx[t] = x[t]; sgx[t] = 0.0f; }
@@ -460,7 +420,7 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         for (int c = 0; c < 45; c++) a += comp[ii * 45 + c] * gp[c];
         sgx[(i < f.ncomp ? 51 : 63) + ii] = a;
     } else if (t >= 128 && t < 128 + 3) {
-        sgx[t - 128] = s_gt[t - 128];
+        sgx[t - 128] = f.g_transl[(size_t)b * 3 + (t - 128)];
     } else if (t >= 160 && t < 160 + 10) {
         sgx[9 + (t - 160)] = f.g_betas[(size_t)b * f.NB + (t - 160)];
     }
@@ -602,7 +562,7 @@ static int fit_backward(psi_fit_engine *e, float *stats, hipStream_t st, bool lo
                            FitGradSource<false>{f, stats, 0.0f}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
     PSI_CHECK_LAUNCH("skin_bwd_v_grad_kernel");
     psi_mark("skin_bwd_v_grad_kernel", st);
-    int rc = psi_lbs_backward_joint_parts(e->lbs, f.B, e->lbs_ws, st);
+    int rc = psi_lbs_backward_joint_parts(e->lbs, f.B, e->lbs_ws, f.g_transl, st);
     if (rc) return rc;
     hipLaunchKernelGGL(head_bwd_adam_kernel, dim3(f.B), dim3(HB), 0, st, f, e->lv);
     PSI_CHECK_LAUNCH("head_bwd_adam_kernel");
@@ -705,7 +665,6 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     {
         int rcv = psi_lbs_view(lbs, B, e->lbs_ws, &e->lv);
         if (rcv) { (void)hipFree(e->blob); delete e; return rcv; }
-        if (e->lv.m.Kpad > KPAD_MAX) { (void)hipFree(e->blob); delete e; psi_set_error("psi_fit_create: feature width %d exceeds %d", e->lv.m.Kpad, KPAD_MAX); return -1; }
     }
     e->nn_ws = bl + o_nws;
     if (cfg->nn_mode == 1) {

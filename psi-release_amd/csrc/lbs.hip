@@ -317,6 +317,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // pose backward: one wave per body
 // ------------------------------------------------------------------------------------------------
 // sum the split-contraction partials: gA[b][j][16] over v-slices, g_feat[b][k] over n-slices, g_transl over vertex blocks
+// One output per thread, ALL of its slices requested before the first add (the partials were just written by other XCDs'
+// workgroups: every dependent round of loads is a ~2 us trip to memory; measured 10 us with 4 loads in flight, and 15 us
+// when 32 workgroups did the whole 7.5 MB themselves).
+template <int MAXS>
+__device__ __forceinline__ float sum_slices(const float *__restrict__ p, size_t stride, int n)
+{
+    float v[MAXS];
+#pragma unroll
+    for (int sl = 0; sl < MAXS; sl++) v[sl] = sl < n ? p[(size_t)sl * stride] : 0.0f;
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int sl = 0; sl < MAXS; sl += 4) { a0 += v[sl]; a1 += v[sl + 1]; a2 += v[sl + 2]; a3 += v[sl + 3]; }
+    float r = (a0 + a1) + (a2 + a3);
+    for (int sl = MAXS; sl < n; sl++) r += p[(size_t)sl * stride];
+    return r;
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int Kpad, const float *__restrict__ gA_part, int nsv,
                                                               const float *__restrict__ gfeat_part, int nsn,
                                                               const float *__restrict__ gt_part, int nvb,
@@ -326,36 +343,14 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int Kpad, c
     const long nA = (long)B * JP * 16, nF = (long)B * Kpad, nT = (long)B * 4;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < nA) {
-        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        int sl = 0;
-        for (; sl + 4 <= nsv; sl += 4) {       // 4 independent loads in flight
-            a0 += gA_part[(size_t)(sl + 0) * nA + i];
-            a1 += gA_part[(size_t)(sl + 1) * nA + i];
-            a2 += gA_part[(size_t)(sl + 2) * nA + i];
-            a3 += gA_part[(size_t)(sl + 3) * nA + i];
-        }
-        for (; sl < nsv; sl++) a0 += gA_part[(size_t)sl * nA + i];
-        gA[i] = (a0 + a1) + (a2 + a3);
+        gA[i] = sum_slices<48>(gA_part + i, (size_t)nA, nsv);
     } else if (i < nA + nF) {
         long k = i - nA;
-        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        int sl = 0;
-        for (; sl + 4 <= nsn; sl += 4) {
-            a0 += gfeat_part[(size_t)(sl + 0) * nF + k];
-            a1 += gfeat_part[(size_t)(sl + 1) * nF + k];
-            a2 += gfeat_part[(size_t)(sl + 2) * nF + k];
-            a3 += gfeat_part[(size_t)(sl + 3) * nF + k];
-        }
-        for (; sl < nsn; sl++) a0 += gfeat_part[(size_t)sl * nF + k];
-        gfeat[k] = (a0 + a1) + (a2 + a3);
+        gfeat[k] = sum_slices<32>(gfeat_part + k, (size_t)nF, nsn);
     } else if (i < nA + nF + nT) {
         long k = i - nA - nF;
         int b = (int)(k >> 2), c = (int)(k & 3);
-        if (c < 3 && g_transl) {
-            float a = 0;
-            for (int vb = 0; vb < nvb; vb++) a += gt_part[((size_t)vb * B + b) * 4 + c];
-            g_transl[(size_t)b * 3 + c] = a;
-        }
+        if (c < 3 && g_transl) g_transl[(size_t)b * 3 + c] = sum_slices<48>(gt_part + (size_t)b * 4 + c, (size_t)B * 4, nvb);
     }
 }
 
@@ -539,6 +534,7 @@ int psi_lbs_view(const psi_lbs_model *mdl, int B, float *ws, PsiLbsView *out)
     out->feat = ws + L.feat; out->R = ws + L.R; out->Jl = ws + L.Jl; out->G = ws + L.G; out->A = ws + L.A;
     out->v_posed = ws + L.v_posed; out->gl = ws + L.gl; out->g_vp = ws + L.g_vp; out->gt_part_w = ws + L.gt_part;
     out->gA_part = ws + L.gA_part; out->gfeat_part = ws + L.gfeat_part; out->gt_part = ws + L.gt_part;
+    out->gA = ws + L.gA; out->gfeat = ws + L.gfeat;
     out->nsv = L.nsv; out->nsn = L.nsn; out->nvb = L.nvb;
     return 0;
 }
@@ -581,10 +577,23 @@ static int lbs_launch_bwd_joint_parts(const LbsDev &m, const WsLayout &L, int B,
     return 0;
 }
 
-int psi_lbs_backward_joint_parts(const psi_lbs_model *mdl, int B, float *ws, hipStream_t st)
+static int lbs_launch_reduce(const LbsDev &m, const WsLayout &L, int B, float *ws, float *g_transl, hipStream_t st)
+{
+    long nred = (long)B * JP * 16 + (long)B * m.Kpad + (long)B * 4;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(psi_cdiv(nred, 256)), dim3(256), 0, st, B, m.Kpad, ws + L.gA_part, L.nsv,
+                       ws + L.gfeat_part, L.nsn, ws + L.gt_part, L.nvb, ws + L.gA, ws + L.gfeat, g_transl);
+    PSI_CHECK_LAUNCH("reduce_partials_kernel");
+    psi_mark("reduce_partials_kernel", st);
+    return 0;
+}
+
+int psi_lbs_backward_joint_parts(const psi_lbs_model *mdl, int B, float *ws, float *g_transl, hipStream_t st)
 {
     const LbsDev &m = mdl->d;
-    return lbs_launch_bwd_joint_parts(m, ws_layout(m, B), B, ws, st);
+    WsLayout L = ws_layout(m, B);
+    int rc = lbs_launch_bwd_joint_parts(m, L, B, ws, st);
+    if (rc) return rc;
+    return lbs_launch_reduce(m, L, B, ws, g_transl, st);
 }
 
 int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const float *betas, const float *pose,
@@ -596,11 +605,8 @@ int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const
     WsLayout L = ws_layout(m, B);
     int rc = lbs_launch_bwd_partials(m, L, grad_verts, cam_ext, B, ws, st);
     if (rc) return rc;
-    long nred = (long)B * JP * 16 + (long)B * m.Kpad + (long)B * 4;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(psi_cdiv(nred, 256)), dim3(256), 0, st, B, m.Kpad, ws + L.gA_part, L.nsv,
-                       ws + L.gfeat_part, L.nsn, ws + L.gt_part, L.nvb, ws + L.gA, ws + L.gfeat, out.g_transl);
-    PSI_CHECK_LAUNCH("reduce_partials_kernel");
-    psi_mark("reduce_partials_kernel", st);
+    rc = lbs_launch_reduce(m, L, B, ws, out.g_transl, st);
+    if (rc) return rc;
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(64), 0, st, m, betas, pose, ws + L.R, ws + L.Jl, ws + L.G, ws + L.gA,
                        ws + L.gfeat, B, out.g_betas, out.g_pose, out.g_rot);
     PSI_CHECK_LAUNCH("pose_bwd_kernel");

@@ -19,6 +19,7 @@ struct PsiLbsView {
     LbsDev m;
     float *feat, *R, *Jl, *G, *A, *v_posed, *gl, *g_vp, *gt_part_w;
     const float *gA_part, *gfeat_part, *gt_part;     // split-contraction partials written by skin_bwd_A / blend_bwd / skin_bwd_v
+    const float *gA, *gfeat;                         // their sums (reduce_partials_kernel): [B][JP][16], [B][Kpad]
     int nsv, nsn, nvb;                               // their slice counts
 };
 
@@ -221,21 +222,26 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
     __syncthreads();
     // feature gradient (reduced over n-slices): betas part and pose-feature part
     if (g_betas) {
-        // g_betas[l] = g_feat[l] + sum_q gJ[q] J_s[q][l]: the (joint, axis) range is cut into 8 parts summed through LDS
-        __shared__ float sgb[8][32];
-        const int nq = m.J * 3, per = (nq + 7) / 8;
-        for (int i = j; i < 8 * m.NB && m.NB <= 32; i += nthr) {
+        // g_betas[l] = g_feat[l] + sum_q gJ[q] J_s[q][l]: the (joint, axis) range is cut into nthr/NB parts summed through LDS,
+        // so a thread has only a handful of independent loads (they were 165 dependent rounds for NB threads before)
+        __shared__ float sgb[32][32];
+        const int nq = m.J * 3;
+        const int npart = m.NB > 0 ? min(32, max(1, nthr / m.NB)) : 1;
+        const int per = (nq + npart - 1) / npart;
+        const bool par_ok = m.NB <= 32;
+        for (int i = j; i < npart * m.NB && par_ok; i += nthr) {
             const int part = i / m.NB, l = i - part * m.NB;
             const int q1 = min(nq, (part + 1) * per);
             float a = 0.0f;
+#pragma unroll 8
             for (int q = part * per; q < q1; q++) a += (&sgJ[0][0])[q] * m.J_s[(size_t)q * m.NB + l];
             sgb[part][l] = a;
         }
         __syncthreads();
         for (int l = j; l < m.NB; l += nthr) {
             float a = gfeat_b[l];
-            if (m.NB <= 32) {
-                for (int part = 0; part < 8; part++) a += sgb[part][l];
+            if (par_ok) {
+                for (int part = 0; part < npart; part++) a += sgb[part][l];
             } else {
                 for (int q = 0; q < nq; q++) a += (&sgJ[0][0])[q] * m.J_s[(size_t)q * m.NB + l];
             }

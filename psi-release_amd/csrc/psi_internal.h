@@ -48,4 +48,5 @@ void psi_lbs_dims(const psi_lbs_model *mdl, int *V, int *J, int *NB);
 struct PsiLbsView;
 int psi_lbs_view(const psi_lbs_model *mdl, int B, float *ws, PsiLbsView *out);
 int psi_lbs_blend_forward(const psi_lbs_model *mdl, int B, float *ws, hipStream_t st);          // v_posed = v_t + feat @ dirs
-int psi_lbs_backward_joint_parts(const psi_lbs_model *mdl, int B, float *ws, hipStream_t st);   // skin_bwd_A + blend_bwd partials
+int psi_lbs_backward_joint_parts(const psi_lbs_model *mdl, int B, float *ws, float *g_transl,
+                                 hipStream_t st);   // skin_bwd_A + blend_bwd partials + their reduction (gA, gfeat in the workspace)
