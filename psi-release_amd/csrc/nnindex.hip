@@ -67,21 +67,27 @@ constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141;  // row_half_mirror: lane i <-> 7 - i inside each 8 lanes
 
-// lexicographic minimum of (d, i) over the 8 lanes of a group, result in every lane
-__device__ __forceinline__ void group_argmin(float &d, int &i)
+// (d, i) packed into one 64-bit key: d >= +0 always (a sum of squares), so its IEEE-754 bit pattern orders like an
+// unsigned integer and  key = bits(d) << 32 | i  orders lexicographically by (d, i) — the lowest-index-among-minima
+// rule is a single unsigned 64-bit minimum, with no branches.
+typedef unsigned long long kd_key;
+__device__ __forceinline__ kd_key kd_pack(float d, int i) { return ((kd_key)(unsigned)__float_as_int(d) << 32) | (unsigned)i; }
+__device__ __forceinline__ float kd_key_d(kd_key k) { return __int_as_float((int)(k >> 32)); }
+__device__ __forceinline__ int kd_key_i(kd_key k) { return (int)(unsigned)k; }
+
+// minimum of the key over the 8 lanes of a group, result in every lane
+__device__ __forceinline__ kd_key group_min(kd_key k)
 {
-#define PSI_STEP(CTRL)                                         \
-    {                                                          \
-        float d2 = dpp_f<CTRL>(d);                             \
-        int i2 = dpp_i<CTRL>(i);                               \
-        bool take = d2 < d || (d2 == d && i2 < i);             \
-        d = take ? d2 : d;                                     \
-        i = take ? i2 : i;                                     \
+#define PSI_STEP(CTRL)                                                                              \
+    {                                                                                               \
+        kd_key k2 = ((kd_key)(unsigned)dpp_i<CTRL>((int)(k >> 32)) << 32) | (unsigned)dpp_i<CTRL>((int)(unsigned)k); \
+        k = k2 < k ? k2 : k;                                                                        \
     }
     PSI_STEP(DPP_XOR1)
     PSI_STEP(DPP_XOR2)
     PSI_STEP(DPP_HALF_MIRROR)
 #undef PSI_STEP
+    return k;
 }
 
 // CONTACT: fused contact-loss epilogue, identical to nn_resolve_kernel<true> in chamfer.hip
@@ -115,8 +121,8 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *_
         const float *qp = xyz1 + (size_t)b * qstride + qrow * 3;
         qx = qp[0]; qy = qp[1]; qz = qp[2];
     }
-    float best = INFINITY;
-    int besti = 0x7fffffff;
+    kd_key bestk = kd_pack(INFINITY, 0x7fffffff);
+    float best = INFINITY;                                    // == kd_key_d(bestk)
     if (active && hint) {
         // warm start: the target that won for this query last time is evaluated first (an ordinary candidate, so the
         // result is unchanged); a good initial `best` prunes almost every sibling on the way down
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *_
             const float4 p = T.opts[h];
             float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
             best = x2 * x2 + y2 * y2 + z2 * z2;
-            besti = h;
+            bestk = kd_pack(best, h);
         }
     }
     int sp = 0;
@@ -149,9 +155,9 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *_
             float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.y), 0.0f);
             const float dc = dx * dx + dy * dy + dz * dz;     // +inf for EMPTY children
             const int ref = __float_as_int(hi.z);
-            float dmin = dc;
-            int cmin = c;
-            group_argmin(dmin, cmin);
+            const kd_key km = group_min(kd_pack(dc, c));
+            const float dmin = kd_key_d(km);
+            const int cmin = kd_key_i(km);
             // push the other children that can still matter; descend into the nearest without a stack round trip
             const bool push = c != cmin && dc * 0.999999f <= best;
             const unsigned gm = (unsigned)(__ballot(push) >> gshift) & 0xffu;
@@ -168,18 +174,16 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *_
         if (have && cur < 0) {                                // leaf — possibly the one just stepped into
             const float4 p = T.pts[(size_t)(-cur - 1) * LEAF + c];
             float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
-            float d = x2 * x2 + y2 * y2 + z2 * z2;
-            int pi = __float_as_int(p.w);
-            group_argmin(d, pi);
-            if (d < best || (d == best && pi < besti)) {
-                best = d;
-                besti = pi;
-            }
+            const float d = x2 * x2 + y2 * y2 + z2 * z2;
+            const kd_key k = group_min(kd_pack(d, __float_as_int(p.w)));
+            bestk = k < bestk ? k : bestk;
+            best = kd_key_d(bestk);
             have = false;
         }
     }
     float fval = 0.0f;
     if (active && c == 0) {
+        const int besti = kd_key_i(bestk);
         if (dist) dist[o] = best;
         if (idx) idx[o] = besti;
         if (hint) hint[o] = besti;

@@ -21,9 +21,8 @@ s = after("        for (int c = 0; c < 4; c++) sh2[t * 4 + c] = leaky(a[c], 0.2f
 s = after("        for (int c = 0; c < 4; c++) so6[t * 4 + c] = a[c];\n    }\n    __syncthreads();", 4, s)
 s = after("    if (t < 3) f.transl[(size_t)b * 3 + t] = sx[t];\n    __syncthreads();                                         // pose / betas20 of this body are visible to the workgroup", 5, s)
 s = after("    psi_pose_fwd_body(lv.m, f.betas20, f.pose, f.transl, f.B, b, lv.feat, lv.R, lv.Jl, lv.G, lv.A, nullptr);", 6, s)
-s = s.replace("    __shared__ __attribute__((aligned(16))) float s_gA[PSI_JP * 16];", "    PHASE(16);\n    __shared__ __attribute__((aligned(16))) float s_gA[PSI_JP * 16];")
-s = s.replace("    __syncthreads();\n    psi_pose_bwd_body(lv.m,", "    PHASE(17);\n    psi_pose_bwd_body(lv.m,")
-s = after("    psi_pose_bwd_body(lv.m, f.betas20, f.pose, lv.R, lv.Jl, lv.G, s_gA, s_gfeat, b, f.g_betas, f.g_pose, f.g_rot);", 18, s)
+s = s.replace("    psi_pose_bwd_body(lv.m, f.betas20, f.pose, lv.R, lv.Jl, lv.G, lv.gA +", "    PHASE(16);\n    PHASE(17);\n    psi_pose_bwd_body(lv.m, f.betas20, f.pose, lv.R, lv.Jl, lv.G, lv.gA +")
+s = after("                      f.g_betas, f.g_pose, f.g_rot);", 18, s)
 s = after("        sgx[9 + (t - 160)] = f.g_betas[(size_t)b * f.NB + (t - 160)];\n    }\n    __syncthreads();", 19, s)
 s = after("        for (int c = 0; c < 4; c++) sga2[t * 4 + c] = a[c] * (h2[t * 4 + c] > 0.0f ? 1.0f : 0.2f);\n    }\n    __syncthreads();", 20, s)
 s = after("        for (int c = 0; c < 4; c++) sga1[t * 4 + c] = a[c] * (h1[t * 4 + c] > 0.0f ? 1.0f : 0.2f);\n    }\n    __syncthreads();", 21, s)
