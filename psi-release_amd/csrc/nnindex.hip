@@ -7,8 +7,8 @@
 //
 //   build (host, once per scene): balanced kd-tree (median split on the widest axis) collapsed three levels at a time into
 //     8-wide nodes; leaves of <= 8 points (padded to 8 records); every internal node stores the exact AABBs of its 8 children; points are re-ordered by leaf and stored as float4 {x, y, z, bitcast(original index)}.
-//   query (EIGHT lanes per query — one per child box of a node / per point of a leaf; the traversal state is replicated in
-//     the 8 lanes, the stack is shared in LDS): depth-first, nearer child first.  A node is skipped when
+//   query (a GROUP of 4 lanes per query — each takes two child boxes of a node / two points of a leaf; the traversal state is
+//     replicated in the group's lanes, the stack is shared in LDS): depth-first, nearer child first.  A node is skipped when
 //       d2box * 0.999999f > best,  d2box = squared distance from the query to the node's AABB evaluated in fp32.
 //     Safety: for any point p in the box, d_hat(p) >= true(p) (1 - 3e-7) >= trueBox (1 - 3e-7) >= d2box_hat (1 - 3e-7)^2,
 //     so the test implies d_hat(p) > best strictly — p is neither the minimum nor a tie.
@@ -32,7 +32,13 @@ constexpr int LEAF = 8;             // points per leaf; leaves are PADDED to exa
 constexpr int WIDE = 8;             // children per internal node == lanes per query
 constexpr int MAXSTACK = 72;        // <= 7 pushes per level; 9 levels of fan-out 8 cover 2^24 points
 constexpr int QBLK = 256;           // threads per workgroup
-constexpr int QPB = QBLK / WIDE;    // queries per workgroup (32)
+#ifndef PSI_KD_LPQ
+#define PSI_KD_LPQ 4
+#endif
+constexpr int LPQ = PSI_KD_LPQ;     // lanes per query (8: one child box / leaf point per lane; 4: two).  Measured at B*n_c = 65536:
+                                    // 4 lanes 28.8 us cold / 23.2 warm, 8 lanes 31.4 / 22.5; the fused iteration is 1.3 us faster with 4
+constexpr int CPL = WIDE / LPQ;     // children (leaf points) per lane
+constexpr int QPB = QBLK / LPQ;     // queries per workgroup
 constexpr int EMPTY = (int)0x80000000;
 
 // 8-wide node (256 bytes): per child its exact AABB and its reference, 32 bytes each, so lane c of a query's 8-lane group
@@ -75,7 +81,8 @@ __device__ __forceinline__ kd_key kd_pack(float d, int i) { return ((kd_key)(uns
 __device__ __forceinline__ float kd_key_d(kd_key k) { return __int_as_float((int)(k >> 32)); }
 __device__ __forceinline__ int kd_key_i(kd_key k) { return (int)(unsigned)k; }
 
-// minimum of the key over the 8 lanes of a group, result in every lane
+// minimum of the key over the LPQ (4 or 8) lanes of a group, result in every lane
+template <int LPQ>
 __device__ __forceinline__ kd_key group_min(kd_key k)
 {
 #define PSI_STEP(CTRL)                                                                              \
@@ -85,7 +92,7 @@ __device__ __forceinline__ kd_key group_min(kd_key k)
     }
     PSI_STEP(DPP_XOR1)
     PSI_STEP(DPP_XOR2)
-    PSI_STEP(DPP_HALF_MIRROR)
+    if (LPQ == 8) PSI_STEP(DPP_HALF_MIRROR)
 #undef PSI_STEP
     return k;
 }
@@ -93,10 +100,11 @@ __device__ __forceinline__ kd_key group_min(kd_key k)
 // CONTACT: fused contact-loss epilogue, identical to nn_resolve_kernel<true> in chamfer.hip
 // MULTI: body b is searched in tab[slot[b]] (a set of scenes, one launch) instead of the single tree T0
 //
-// Why 8 lanes per query: a batch has only B*n_c = 65536 queries.  One lane per query is 1024 waves — one per SIMD, no
+// Why a lane group per query: a batch has only B*n_c = 65536 queries.  One lane per query is 1024 waves — one per SIMD, no
 // latency hiding at all — each running ~8000 dependent instructions (measured: 15 cycles per instruction, 41-57 us).
-// With a lane per child box / leaf point the per-wave instruction stream shrinks ~8x in the box and leaf arithmetic,
-// there are 8192 waves (8 per SIMD) to overlap the dependent node loads, and a wave diverges over 8 queries, not 64.
+// With the child boxes / leaf points of a visit spread over the group's lanes the per-wave instruction stream shrinks several
+// fold in the box and leaf arithmetic, there are 4096-8192 waves to overlap the dependent node loads, and a wave diverges
+// over 16 (8) queries, not 64.
 template <bool CONTACT, bool MULTI = false>
 __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *__restrict__ xyz1, const int *__restrict__ qidx,
                                                         long qstride, int n, float *__restrict__ dist, int *__restrict__ idx,
@@ -106,8 +114,8 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *_
 {
     extern __shared__ int smem_i[];
     const int tid = threadIdx.x;
-    const int c = tid & 7;                                    // my child / leaf slot
-    const int g = tid >> 3;                                   // query group inside the workgroup
+    const int c = tid & (LPQ - 1);                            // my first child / leaf slot (the others: c + LPQ, ...)
+    const int g = tid / LPQ;                                  // query group inside the workgroup
     int *stk_n = smem_i + (size_t)g * rows * 2;               // [rows] child references
     float *stk_d = (float *)(stk_n + rows);                   // [rows] box distances
     const int b = blockIdx.y;
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *_
     int cur = T.root;
     float curd = 0.0f;
     bool have = active;
-    const int gshift = (tid & 63) & 56;                       // bit position of my group inside the wave's ballot
+    const int gshift = (tid & 63) & ~(LPQ - 1);               // bit position of my group inside the wave's ballot
     while (true) {
         while (!have && sp > 0) {                             // pop until something survives the current bound (group-uniform)
             --sp;
@@ -148,34 +156,54 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *_
         }
         if (!have) break;
         if (cur >= 0) {
-            const float4 *cp = (const float4 *)(T.nodes + cur) + 2 * c;
-            const float4 lo = cp[0], hi = cp[1];              // {mnx,mny,mnz,mxx} {mxy,mxz,ref,-}
-            float dx = fmaxf(fmaxf(lo.x - qx, qx - lo.w), 0.0f);
-            float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.x), 0.0f);
-            float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.y), 0.0f);
-            const float dc = dx * dx + dy * dy + dz * dz;     // +inf for EMPTY children
-            const int ref = __float_as_int(hi.z);
-            const kd_key km = group_min(kd_pack(dc, c));
+            float dc[CPL];
+            int ref[CPL];
+            kd_key km = ~0ull;
+#pragma unroll
+            for (int u = 0; u < CPL; u++) {
+                const float4 *cp = (const float4 *)(T.nodes + cur) + 2 * (c + u * LPQ);
+                const float4 lo = cp[0], hi = cp[1];          // {mnx,mny,mnz,mxx} {mxy,mxz,ref,-}
+                float dx = fmaxf(fmaxf(lo.x - qx, qx - lo.w), 0.0f);
+                float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.x), 0.0f);
+                float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.y), 0.0f);
+                dc[u] = dx * dx + dy * dy + dz * dz;          // +inf for EMPTY children
+                ref[u] = __float_as_int(hi.z);
+                const kd_key k = kd_pack(dc[u], c + u * LPQ);
+                km = k < km ? k : km;
+            }
+            km = group_min<LPQ>(km);
             const float dmin = kd_key_d(km);
             const int cmin = kd_key_i(km);
             // push the other children that can still matter; descend into the nearest without a stack round trip
-            const bool push = c != cmin && dc * 0.999999f <= best;
-            const unsigned gm = (unsigned)(__ballot(push) >> gshift) & 0xffu;
-            if (push) {
-                const int pos = sp + __popc(gm & ((1u << c) - 1u));
-                stk_n[pos] = ref;
-                stk_d[pos] = dc;
+#pragma unroll
+            for (int u = 0; u < CPL; u++) {
+                const bool push = (c + u * LPQ) != cmin && dc[u] * 0.999999f <= best;
+                const unsigned gm = (unsigned)(__ballot(push) >> gshift) & ((1u << LPQ) - 1u);
+                if (push) {
+                    const int pos = sp + __popc(gm & ((1u << c) - 1u));
+                    stk_n[pos] = ref[u];
+                    stk_d[pos] = dc[u];
+                }
+                sp += __popc(gm);
             }
-            sp += __popc(gm);
-            cur = __shfl(ref, (tid & 56) | cmin, 64);
+            int rsel = ref[0];
+#pragma unroll
+            for (int u = 1; u < CPL; u++) rsel = (cmin / LPQ == u) ? ref[u] : rsel;
+            cur = __shfl(rsel, (tid & 63 & ~(LPQ - 1)) | (cmin & (LPQ - 1)), 64);
             curd = dmin;
             have = dmin < INFINITY && !(dmin * 0.999999f > best);
         }
         if (have && cur < 0) {                                // leaf — possibly the one just stepped into
-            const float4 p = T.pts[(size_t)(-cur - 1) * LEAF + c];
-            float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
-            const float d = x2 * x2 + y2 * y2 + z2 * z2;
-            const kd_key k = group_min(kd_pack(d, __float_as_int(p.w)));
+            kd_key k = ~0ull;
+#pragma unroll
+            for (int u = 0; u < CPL; u++) {
+                const float4 p = T.pts[(size_t)(-cur - 1) * LEAF + c + u * LPQ];
+                float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
+                const float d = x2 * x2 + y2 * y2 + z2 * z2;
+                const kd_key ku = kd_pack(d, __float_as_int(p.w));
+                k = ku < k ? ku : k;
+            }
+            k = group_min<LPQ>(k);
             bestk = k < bestk ? k : bestk;
             best = kd_key_d(bestk);
             have = false;
