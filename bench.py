@@ -114,8 +114,10 @@ def kernel_work(args, op):
                                    'loss-gradient assembly + skinning backward fused: weights + SDF gradient + contact gradients in, g_local + g_vposed out'),
         'skin_bwd_A_kernel': ('byte', 64 * Vpad * 4.0 + 2 * B * Npad * 4.0 + 41 * B * 1024 * 4.0, 'weights + g_local + v_posed in, partials out'),
         'head_fwd_kernel': ('byte', 1.4e6 + B * 12000.0, 'VPoser decoder weights (L2 resident) + per-body state + LBS pose stage'),
-        'head_bwd_adam_kernel': ('byte', 1.4e6 + B * (41 * 4096 + 32 * 2048 + 12000.0),
-                                 'partials reduction + LBS pose backward + VPoser decoder backward (weights L2 resident) + Adam'),
+        'head_bwd_adam_kernel': ('byte', 1.4e6 + B * 20000.0,
+                                 'LBS pose backward + VPoser decoder backward (1.3 MB of weights, L2 resident, re-read by each of the B workgroups) + Adam: '
+                                 'a per-body latency chain, not a bandwidth kernel'),
+        'reduce_partials_kernel': ('byte', B * (41 * 4096 + 32 * 2048 + 41 * 16.0) + B * (4096 + 2048.0), 'split-contraction partials in, sums out'),
     }
 
 

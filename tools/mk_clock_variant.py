@@ -49,6 +49,10 @@ rep("    if (act && (g_pose || g_rot)) {", "    PHASE(35);\n    if (act && (g_po
 rep("    __syncthreads();\n    const int par = act ? m.parents[j] : -1;\n    const int lvl = act ? m.level[j] : -1;\n    if (act)\n        for (int c = 0; c < 3; c++) Jl[c] = sJ[j][c];",
     "    PHASE(40);\n    const int par = act ? m.parents[j] : -1;\n    const int lvl = act ? m.level[j] : -1;\n    if (act)\n        for (int c = 0; c < 3; c++) Jl[c] = sJ[j][c];")
 rep("    if (act) {\n        psi_f4 *Go = (psi_f4 *)(Gs +", "    PHASE(41);\n    if (act) {\n        psi_f4 *Go = (psi_f4 *)(Gs +")
+# skinning forward + SDF epilogue (block (0,0) only)
+d = d.replace("#define PHASE(i)\n#endif", "#define PHASE(i)\n#endif\n#ifdef PSI_PHASE_CLOCK\n#define PHASE2(i) do { __syncthreads(); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_dbg[i] = wall_clock64(); } while (0)\n#else\n#define PHASE2(i)\n#endif", 1)
+rep("    const int b = blockIdx.y;\n    psi_f2 T2[6];\n    psi_blend_transforms(m, As, b, v, T2);\n    const bool live = v < m.V;", "    const int b = blockIdx.y;\n    PHASE2(48);\n    psi_f2 T2[6];\n    psi_blend_transforms(m, As, b, v, T2);\n    PHASE2(49);\n    const bool live = v < m.V;")
+rep("    epi.vertex(b, v, x, y, z, live);\n    epi.finish(b);", "    PHASE2(50);\n    epi.vertex(b, v, x, y, z, live);\n    PHASE2(51);\n    epi.finish(b);\n    PHASE2(52);")
 os.makedirs('/tmp/clk_inc', exist_ok=True)
 open('/tmp/clk_inc/lbs_device.h', 'w').write(d)
 print(subprocess.run([R + '/tools/mkvariant.sh', 'clock', '/tmp/fit_clock.hip', 'fit.hip', '-DPSI_PHASE_CLOCK'], capture_output=True, text=True).stdout[-200:])

@@ -18,6 +18,8 @@ doc = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-t
        "uncalibrated.  bytes = (fetch_kb * (2 if fetch_x2 else 1) + write_kb) * 1024.")
 d = {'_doc': doc}
 for k in sorted(f):
+    if k.startswith('at::') or k.startswith('__amd'):
+        continue
     x2 = k in X2
     d[k] = {'fetch_kb': f[k], 'write_kb': w.get(k, 0.0), 'fetch_x2': x2, 'bytes': int((f[k] * (2 if x2 else 1) + w.get(k, 0.0)) * 1024)}
 json.dump(d, open('profiles/%s_pmc_traffic.json' % rnd, 'w'), indent=1)

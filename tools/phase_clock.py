@@ -18,7 +18,9 @@ names = {0: 'head start', 1: 'x + loss partials', 2: 'fc1', 3: 'fc2', 4: 'fc3', 
          16: 'tail start', 17: 'reduce partials', 32: '  pose_bwd: loads', 33: '  pose_bwd: level sweep', 34: '  pose_bwd: local grads + gJ',
          35: '  pose_bwd: g_betas', 18: '  pose_bwd: rest (rodrigues bwd, stores)', 19: 'gs_backward/pca bwd', 20: 'W3^T', 21: 'W2^T', 22: 'W1^T', 23: 'adam'}
 order = [0, 1, 2, 3, 4, 5, 40, 41, 6, 16, 17, 32, 33, 34, 35, 18, 19, 20, 21, 22, 23]
+names.update({48: 'skin_fwd_sdf start', 49: 'blend transforms (55 weights)', 50: 'v_posed, transl, cam, store', 51: 'sdf trilinear + og', 52: 'block sums'})
+order += [48, 49, 50, 51, 52]
 prev = None
 for i in order:
-    if i in (0, 16): prev = v[i]; print(names[i]); continue
+    if i in (0, 16, 48): prev = v[i]; print(names[i]); continue
     print('%-44s %6.2f us' % (names[i], v[i] - prev)); prev = v[i]
