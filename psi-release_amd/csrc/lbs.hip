@@ -192,14 +192,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // skinning backward, joint part (MFMA): gA[b][j][r*4+s] = sum_v W[v][j] * g_local[b][v][r] * [v_posed;1][s]
 // wave = one body x one 256-vertex slice x all 64 padded joints (4 accumulators).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void skin_bwd_A_kernel(LbsDev m, const float *__restrict__ gl, const float *__restrict__ v_posed,
-                                                         int B, float *__restrict__ part)
+__device__ __forceinline__ void skin_bwd_A_body(const LbsDev &m, const float *__restrict__ gl, const float *__restrict__ v_posed,
+                                                int B, float *__restrict__ part, int vslice, int b, f4 *smem)
 {
     // workgroup = one body x one 256-vertex slice; wave w contracts vertices [64w, 64w+64) of the slice (4 MFMA steps,
     // all operand loads issued up front); the four waves are summed through LDS -> one partial per workgroup.
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = blockIdx.y;
-    const int vs = blockIdx.x * 256 + w * 64;
+    const int vs = vslice * 256 + w * 64;
     const int li = lane & 15, lk = lane >> 4;
     const int r = li >> 2, s = li & 3;
     const float *glb = gl + (size_t)b * m.Npad;
@@ -228,13 +227,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         for (int t = 0; t < 4; t++)
 #pragma unroll
             for (int jt = 0; jt < 4; jt++) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[st][jt][t], bop[st][t], acc[jt], 0, 0, 0);
-    __shared__ f4 red[4][4][64];
+    f4 (*red)[4][64] = (f4 (*)[4][64])smem;      // [4][4][64]
 #pragma unroll
     for (int jt = 0; jt < 4; jt++) red[w][jt][lane] = acc[jt];
     __syncthreads();
     // wave w finishes joint tile w: D[row = lk*4+e -> joint][col = li -> r*4+s]
     f4 o4 = red[0][w][lane] + red[1][w][lane] + red[2][w][lane] + red[3][w][lane];
-    float *o = part + ((size_t)blockIdx.x * B + b) * JP * 16;
+    float *o = part + ((size_t)vslice * B + b) * JP * 16;
 #pragma unroll
     for (int e = 0; e < 4; e++) o[(w * 16 + lk * 4 + e) * 16 + li] = o4[e];
 }
@@ -244,15 +243,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 // workgroup = 4 waves sharing a 64-row k group and an n-slice; wave w takes n-steps w, w+4, ...; LDS reduce.
 // ------------------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void blend_bwd_kernel(LbsDev m, const float *__restrict__ g_vp, int B, int steps_per_slice,
-                                                        float *__restrict__ part)
+__device__ __forceinline__ void blend_bwd_body(const LbsDev &m, const float *__restrict__ g_vp, int B, int steps_per_slice,
+                                               float *__restrict__ part, int kgroup, int slice, int bgroup, f4 *smem)
 {
     constexpr int KT = 4;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int k0 = blockIdx.x * 16 * KT;
-    const int slice = blockIdx.y;
-    const int b0 = blockIdx.z * 16 * MT;
+    const int k0 = kgroup * 16 * KT;
+    const int b0 = bgroup * 16 * MT;
     const int total_steps = m.Npad / 16;
     const int s_begin = slice * steps_per_slice;
     const int s_end = min(s_begin + steps_per_slice, total_steps);
@@ -295,7 +293,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     }
-    __shared__ f4 red[4][KT][MT][64];
+    f4 (*red)[KT][MT][64] = (f4 (*)[KT][MT][64])smem;      // [4][KT][MT][64]
 #pragma unroll
     for (int kt = 0; kt < KT; kt++)
 #pragma unroll
@@ -310,6 +308,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             int b = b0 + t * 16 + lk * 4 + e;
             if (b < B) part[((size_t)slice * B + b) * m.Kpad + k0 + w * 16 + li] = o[e];
         }
+    }
+}
+
+// The two joint-side halves of the LBS backward in ONE launch.  Both depend only on skin_bwd_v; blend_bwd is a 64.5 MB
+// stream with 256 long-lived workgroups, skin_bwd_A is 1312 short L2-latency-bound workgroups.  As separate launches they
+// ran back to back (22 + 19 us); as one grid — blend workgroups first, so every CU picks one up, then the skin_bwd_A
+// workgroups fill the remaining slots — the short ones run in the shadow of the stream.
+template <int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void bwd_joint_kernel(
+    LbsDev m, const float *__restrict__ g_vp, const float *__restrict__ gl, const float *__restrict__ v_posed, int B, int steps_per_slice,
+    float *__restrict__ gfeat_part, float *__restrict__ gA_part, int n_blend, int kgroups, int nslices, int nsv)
+{
+    __shared__ f4 smem[4 * 4 * MT * 64 > 4 * 4 * 64 ? 4 * 4 * MT * 64 : 4 * 4 * 64];
+    // all stream workgroups first: they must START at once (interleaving them one-per-five through the grid delayed the last
+    // of them behind ~1500 dispatches and doubled the kernel: 73 vs 39 us)
+    const int bid = blockIdx.x;
+    if (bid < n_blend) {
+        const int kg = bid % kgroups, rest = bid / kgroups;
+        blend_bwd_body<MT>(m, g_vp, B, steps_per_slice, gfeat_part, kg, rest % nslices, rest / nslices, smem);
+    } else {
+        const int i = bid - n_blend;
+        skin_bwd_A_body(m, gl, v_posed, B, gA_part, i % nsv, i / nsv, smem);
     }
 }
 
@@ -559,21 +579,21 @@ static int lbs_launch_bwd_partials(const LbsDev &m, const WsLayout &L, const flo
 
 static int lbs_launch_bwd_joint_parts(const LbsDev &m, const WsLayout &L, int B, float *ws, hipStream_t st)
 {
-    hipLaunchKernelGGL(skin_bwd_A_kernel, dim3(L.nsv, B), dim3(256), 0, st, m, ws + L.gl, ws + L.v_posed, B, ws + L.gA_part);
-    PSI_CHECK_LAUNCH("skin_bwd_A_kernel");
-    psi_mark("skin_bwd_A_kernel", st);
     const int steps = psi_cdiv(m.Npad / 16, L.nsn);
-    dim3 g(m.Kpad / 64, L.nsn, 1);
-    if (B > 32) {
-        g.z = psi_cdiv(B, 64);
-        hipLaunchKernelGGL(blend_bwd_kernel<4>, g, dim3(256), 0, st, m, ws + L.g_vp, B, steps, ws + L.gfeat_part);
-    } else if (B > 16) {
-        hipLaunchKernelGGL(blend_bwd_kernel<2>, g, dim3(256), 0, st, m, ws + L.g_vp, B, steps, ws + L.gfeat_part);
-    } else {
-        hipLaunchKernelGGL(blend_bwd_kernel<1>, g, dim3(256), 0, st, m, ws + L.g_vp, B, steps, ws + L.gfeat_part);
-    }
-    PSI_CHECK_LAUNCH("blend_bwd_kernel");
-    psi_mark("blend_bwd_kernel", st);
+    const int kgroups = m.Kpad / 64;
+    const int mt = B > 32 ? 4 : (B > 16 ? 2 : 1);
+    const int bgroups = psi_cdiv(B, 16 * mt);
+    const int n_blend = kgroups * L.nsn * bgroups;
+    const int grid = n_blend + L.nsv * B;
+#define PSI_LAUNCH_JOINT(MT_)                                                                                                      \
+    hipLaunchKernelGGL(bwd_joint_kernel<MT_>, dim3(grid), dim3(256), 0, st, m, ws + L.g_vp, ws + L.gl, ws + L.v_posed, B, steps,     \
+                       ws + L.gfeat_part, ws + L.gA_part, n_blend, kgroups, L.nsn, L.nsv)
+    if (mt == 4) PSI_LAUNCH_JOINT(4);
+    else if (mt == 2) PSI_LAUNCH_JOINT(2);
+    else PSI_LAUNCH_JOINT(1);
+#undef PSI_LAUNCH_JOINT
+    PSI_CHECK_LAUNCH("bwd_joint_kernel");
+    psi_mark("bwd_joint_kernel", st);
     return 0;
 }
 
