@@ -174,6 +174,16 @@ int psi_fit_iterate(psi_fit_engine *engine, int n_iter, int use_graph, void *str
  * (l_rec, l_vposer, l_contact, l_collision as printed by fitting_proxe.py:184-186) to device buffers;
  * h_step (host, nullable) receives the Adam step count and forces a stream sync. */
 int psi_fit_read(psi_fit_engine *engine, float *d_x_out, float *d_history_out, int n_hist, int *h_step, void *stream);
+/* Differentiable body decode of the CVAE training losses: x75 [B,75] = [transl | 6D global rot | betas 10 | VPoser latent 32 |
+ * hand PCA 12+12] -> camera-frame vertices [B,V,3].  One call replaces the reference's chain
+ *   convert_to_3D_rot (cvae.py:117-139) -> body_params_encapsulate_batch (cvae.py:221-251) -> vposer.decode(..., 'aa')
+ *   (vposer_smpl.py:156-167) -> body_mesh_model(...) (train_s1.py:143-150) -> verts_transform (cvae.py:141-149),
+ * train_s1.py:136-157, with the engine's own head / LBS kernels (B = the engine's batch size).  The forward leaves its
+ * activations in the engine; psi_fit_decode_backward must follow it (before the next forward) and returns dL/dx75.
+ * The engine's fitting state (x, Adam moments) is overwritten: use a dedicated engine. */
+int psi_fit_decode_forward(psi_fit_engine *engine, const float *d_x75, const float *d_cam_ext, float *d_verts, void *stream);
+int psi_fit_decode_backward(psi_fit_engine *engine, const float *d_grad_verts, float *d_grad_x75, void *stream);
+
 /* Per-kernel timing of one fitting iteration with HIP events on the launch stream (an event is recorded right after
  * every kernel launch of the sequence psi_fit_iterate runs; ungraphed), averaged over n_rep iterations.  Advances the
  * optimisation by n_rep steps.  h_names: [max_stages][name_stride] chars, h_ms: [max_stages] milliseconds. */

@@ -389,7 +389,10 @@ struct FitGradSource {
 // One workgroup per body: (1) the LBS pose-backward stage on this body's reduced gradients, (2) back-propagation through
 // the 6D rotations / hand PCA / VPoser decoder, (3) the Adam update.  (The split-contraction partials are summed by a
 // separate all-CU kernel: 32 workgroups pulling 7.5 MB of freshly written partials through 32 CUs took 15 us.)
-__global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView lv)
+// ADAM = false (psi_fit_decode_backward): the chain-rule gradient wrt the 75-D body vector is written to g_out instead of
+// being combined with the fitting losses' own terms and applied.
+template <bool ADAM>
+__global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView lv, float *__restrict__ g_out)
 {
     const int b = blockIdx.x, t = threadIdx.x;
     __shared__ float sx[XD + 5], sg6[128], sga2[NH], sga1[NH], sgx[XD + 5];
@@ -473,6 +476,10 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         for (int c = 0; c < 4; c++) sgx[19 + t * 4 + c] = a[c];
     }
     __syncthreads();
+    if (!ADAM) {
+        if (t < XD) g_out[(size_t)b * XD + t] = sgx[t];
+        return;
+    }
     if (t < XD) {
         const float Bg = (float)f.B * (float)f.world;
         float g = sgx[t];
@@ -564,7 +571,7 @@ static int fit_backward(psi_fit_engine *e, float *stats, hipStream_t st, bool lo
     psi_mark("skin_bwd_v_grad_kernel", st);
     int rc = psi_lbs_backward_joint_parts(e->lbs, f.B, e->lbs_ws, f.g_transl, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(head_bwd_adam_kernel, dim3(f.B), dim3(HB), 0, st, f, e->lv);
+    hipLaunchKernelGGL(head_bwd_adam_kernel<true>, dim3(f.B), dim3(HB), 0, st, f, e->lv, (float *)nullptr);
     PSI_CHECK_LAUNCH("head_bwd_adam_kernel");
     psi_mark("head_bwd_adam_kernel", st);
     return 0;
@@ -778,6 +785,40 @@ extern "C" int psi_fit_iterate(psi_fit_engine *e, int n_iter, int use_graph, voi
         e->graph_ready = true;
     }
     for (int i = 0; i < n_iter; i++) PSI_CHECK_HIP(hipGraphLaunch(e->graph_exec, st));
+    return 0;
+}
+
+// ---- differentiable body decode for the CVAE training losses (train_s1.py:136-170): the same head / LBS kernels, driven
+// from outside; forward state (activations, rotations, transforms) stays in the engine for the matching backward
+extern "C" int psi_fit_decode_forward(psi_fit_engine *e, const float *d_x75, const float *d_cam_ext, float *d_verts, void *stream)
+{
+    PSI_REQUIRE(e && d_x75 && d_cam_ext && d_verts, "null pointer");
+    FitDev &f = e->d;
+    hipStream_t st = (hipStream_t)stream;
+    PSI_CHECK_HIP(hipMemcpyAsync(f.x, d_x75, (size_t)f.B * XD * 4, hipMemcpyDeviceToDevice, st));
+    PSI_CHECK_HIP(hipMemcpyAsync(f.cam, d_cam_ext, (size_t)f.B * 16 * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(f.B), dim3(HB), 0, st, f, e->lv);
+    PSI_CHECK_LAUNCH("head_fwd_kernel");
+    int rc = psi_lbs_blend_forward(e->lbs, f.B, e->lbs_ws, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(psi_skin_fwd_kernel<PsiSkinNoEpilogue>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
+                       e->lv.v_posed, f.transl, f.cam, f.B, d_verts, PsiSkinNoEpilogue());
+    PSI_CHECK_LAUNCH("skin_fwd_kernel");
+    return 0;
+}
+
+extern "C" int psi_fit_decode_backward(psi_fit_engine *e, const float *d_grad_verts, float *d_grad_x75, void *stream)
+{
+    PSI_REQUIRE(e && d_grad_verts && d_grad_x75, "null pointer");
+    FitDev &f = e->d;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(psi_skin_bwd_v_kernel<PsiGradFromMemory>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
+                       PsiGradFromMemory{d_grad_verts, f.V}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
+    PSI_CHECK_LAUNCH("skin_bwd_v_kernel");
+    int rc = psi_lbs_backward_joint_parts(e->lbs, f.B, e->lbs_ws, f.g_transl, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_bwd_adam_kernel<false>, dim3(f.B), dim3(HB), 0, st, f, e->lv, d_grad_x75);
+    PSI_CHECK_LAUNCH("head_bwd_kernel");
     return 0;
 }
 

@@ -336,3 +336,55 @@ class FittingOPHabitat(FittingOP):
     """fitting_habitat.py: contact constant 1.0 (:141), camera flipped to the Habitat convention (:179-184)."""
     contact_const = 1.0
     flip_camera_yz = True
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Differentiable body decode for the CVAE training losses
+# ------------------------------------------------------------------------------------------------------------------
+class BodyDecoder:
+    """x75 [B,75] = [transl | 6D global rot | betas | VPoser latent | hand PCA] -> camera-frame SMPL-X vertices [B,V,3] with
+    a hand-derived backward (psi_fit_decode_forward / _backward): ONE op instead of the reference's
+    ``convert_to_3D_rot -> body_params_encapsulate_batch -> vposer.decode -> body_mesh_model -> verts_transform`` chain
+    (train_s1.py:136-157) and the ~1000 elementwise launches autograd spends on it per step.  It is a fused engine used
+    only for its head / LBS kernels; the engine's scene-side inputs are one-voxel placeholders that are never evaluated."""
+
+    def __init__(self, vposer, body_mesh_model, batch_size, device):
+        import types
+        dev = torch.device(device)
+        shim = types.SimpleNamespace(
+            device=dev, vposer=vposer, body_mesh_model=body_mesh_model, batch_size=batch_size, align_corners=True, nn_mode='bruteforce',
+            contact_vertex_ids=lambda: torch.zeros(1, dtype=torch.int64), s_verts=torch.zeros(1, 8, 3, device=dev),
+            s_sdf=torch.ones(1, 2, 2, 2, device=dev), s_grid_min_batch=torch.full((1, 3), -1.0), s_grid_max_batch=torch.full((1, 3), 1.0),
+            weight_loss_rec=0.0, weight_loss_vposer=0.0, weight_contact=0.0, weight_collision=0.0, contact_const=1.0, init_lr_h=0.0)
+        self.engine = FusedEngine(shim)
+        self.batch_size = batch_size
+        self.V = int(body_mesh_model.lbs_model.V) if hasattr(body_mesh_model.lbs_model, 'V') else 10475
+        self.version = 0
+
+    def __call__(self, x75, cam_ext):
+        return _BodyDecodeFn.apply(x75, cam_ext, self)
+
+
+class _BodyDecodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x75, cam_ext, dec):
+        if x75.shape != (dec.batch_size, 75):
+            raise ValueError('BodyDecoder was built for x75 of shape (%d, 75), got %s' % (dec.batch_size, tuple(x75.shape)))
+        x = x75.detach().contiguous().float()
+        cam = cam_ext.detach().contiguous().float()
+        verts = torch.empty(dec.batch_size, dec.V, 3, device=x.device)
+        hip.check(hip.lib().psi_fit_decode_forward(dec.engine.handle, hip.ptr(x), hip.ptr(cam), hip.ptr(verts), hip.stream()),
+                  'psi_fit_decode_forward')
+        dec.version += 1
+        ctx.dec, ctx.version = dec, dec.version
+        return verts
+
+    @staticmethod
+    def backward(ctx, gverts):
+        dec = ctx.dec
+        if dec.version != ctx.version:
+            raise RuntimeError('BodyDecoder: another forward ran before this backward (the activations live in the engine)')
+        g = gverts.contiguous().float()
+        gx = torch.empty(dec.batch_size, 75, device=g.device)
+        hip.check(hip.lib().psi_fit_decode_backward(dec.engine.handle, hip.ptr(g), hip.ptr(gx), hip.stream()), 'psi_fit_decode_backward')
+        return gx, None, None

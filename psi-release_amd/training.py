@@ -39,6 +39,7 @@ class _TrainBase:
         self.use_cont_rot = True
         self.verbose = False
         self.scene_model_ckpt = None
+        self.fused_decode = True        # body decode (6D rot -> VPoser -> SMPL-X -> camera frame) as ONE HIP op (fitting.BodyDecoder)
         self.use_graph = False          # capture the whole optimiser step (forward, backward, Adam) in one HIP graph
         self._graphs = {}
         self._fca_t = None
@@ -63,6 +64,7 @@ class _TrainBase:
         self.body_mesh_model = body_model.create(smplx_src, model_type='smplx', gender='neutral', ext='npz', num_pca_comps=12,
                                                  batch_size=self.batch_size, device=self.device)
         self._vid = None
+        self._decoder = None
         self._contact_parts = getattr(self, 'contact_parts_data', None)
         self._chamfer = ops.chamferDist(one_sided=True)
         print('--[INFO] device: ' + str(torch.cuda.get_device_name(self.device)))
@@ -80,16 +82,24 @@ class _TrainBase:
 
     def _scene_losses(self, xh_rec, cam_ext, scene_verts, s_grid_min_batch, s_grid_max_batch, s_grid_sdf_batch, ep):
         """Shared tail of cal_loss: VPoser prior, contact (const 1.0) and penetration terms (train_s1.py:136-205)."""
-        loss_vposer = self.weight_loss_vposer * torch.mean(xh_rec[:, 16:48] ** 2)
+        fused = xh_rec.shape[1] == 75                                            # 75-D: 6D global rotation, decoded by the fused op
+        latent = xh_rec[:, 19:51] if fused else xh_rec[:, 16:48]
+        loss_vposer = self.weight_loss_vposer * torch.mean(latent ** 2)
         if not ep > 0.75 * self.epoch and getattr(self, 'skip_gated_losses', True):
             # train_s1.py:171-173,197-199 multiply both scene terms by 0 for the first 75% of the epochs; their value and
             # gradient are exactly 0 there, so the body mesh, NN search and SDF lookup are not evaluated at all.
             zero = xh_rec.new_zeros(())
             return zero, loss_vposer, zero
-        body_param_rec = BodyParamParser.body_params_encapsulate_batch(xh_rec)
-        joint_rot_batch = self.vposer.decode(body_param_rec['body_pose_vp'], output_type='aa').view(xh_rec.shape[0], -1)
-        body_param_ = {k: v for k, v in body_param_rec.items() if k != 'body_pose_vp'}
-        body_verts_batch = self.body_mesh_model(return_verts=True, body_pose=joint_rot_batch, cam_ext=cam_ext, **body_param_).vertices
+        if fused:
+            if self._decoder is None or self._decoder.batch_size != xh_rec.shape[0]:
+                from .fitting import BodyDecoder
+                self._decoder = BodyDecoder(self.vposer, self.body_mesh_model, xh_rec.shape[0], self.device)
+            body_verts_batch = self._decoder(xh_rec, cam_ext)
+        else:
+            body_param_rec = BodyParamParser.body_params_encapsulate_batch(xh_rec)
+            joint_rot_batch = self.vposer.decode(body_param_rec['body_pose_vp'], output_type='aa').view(xh_rec.shape[0], -1)
+            body_param_ = {k: v for k, v in body_param_rec.items() if k != 'body_pose_vp'}
+            body_verts_batch = self.body_mesh_model(return_verts=True, body_pose=joint_rot_batch, cam_ext=cam_ext, **body_param_).vertices
         body_verts_contact_batch = body_verts_batch[:, self._contact_ids(), :]
         if isinstance(s_grid_sdf_batch, tuple) and len(s_grid_sdf_batch) == 5 and getattr(self, 'use_scene_index', True):
             contact_dist = ops.chamfer_to_scenes(body_verts_contact_batch.contiguous(), s_grid_sdf_batch[4], s_grid_sdf_batch[1])
@@ -288,8 +298,11 @@ class TrainOP(_TrainBase):
         xhn = GeometryTransformer.normalize_global_T(xh, cam_int, max_d)
         xhnr = GeometryTransformer.convert_to_6D_rot(xhn)
         xhnr_rec, mu, logsigma2 = self.model_h(xhnr, xs, eps=eps)
-        xhn_rec = GeometryTransformer.convert_to_3D_rot(xhnr_rec)
-        xh_rec = GeometryTransformer.recover_global_T(xhn_rec, cam_int, max_d)
+        if self.fused_decode and self.use_cont_rot:
+            xh_rec = GeometryTransformer.recover_global_T(xhnr_rec, cam_int, max_d)     # stays 75-D; only the translation changes
+        else:
+            xhn_rec = GeometryTransformer.convert_to_3D_rot(xhnr_rec)
+            xh_rec = GeometryTransformer.recover_global_T(xhn_rec, cam_int, max_d)
         loss_rec_t = self.weight_loss_rec_h * (0.5 * F.l1_loss(xhnr_rec[:, :3], xhnr[:, :3]) + 0.5 * F.l1_loss(xh_rec[:, :3], xh[:, :3]))
         loss_rec_p = self.weight_loss_rec_h * F.l1_loss(xhnr_rec[:, 3:], xhnr[:, 3:])
         loss_KL = self._kl(mu, logsigma2, ep)
@@ -320,8 +333,11 @@ class TrainOPS2(_TrainBase):
         xhn = GeometryTransformer.normalize_global_T(xh, cam_int, max_d)
         xhnr = GeometryTransformer.convert_to_6D_rot(xhn)
         xhnr_rec, mu_g, lv_g, mu_l, lv_l = self.model_h(xhnr, eps_g, eps_l, xs, use_eps=use_eps)
-        xhn_rec = GeometryTransformer.convert_to_3D_rot(xhnr_rec)
-        xh_rec = GeometryTransformer.recover_global_T(xhn_rec, cam_int, max_d)
+        if self.fused_decode and self.use_cont_rot:
+            xh_rec = GeometryTransformer.recover_global_T(xhnr_rec, cam_int, max_d)     # stays 75-D; only the translation changes
+        else:
+            xhn_rec = GeometryTransformer.convert_to_3D_rot(xhnr_rec)
+            xh_rec = GeometryTransformer.recover_global_T(xhn_rec, cam_int, max_d)
         loss_rec_t = self.weight_loss_rec_h * (0.5 * F.l1_loss(xhnr_rec[:, :3], xhnr[:, :3]) + 0.5 * F.l1_loss(xh_rec[:, :3], xh[:, :3]))
         loss_rec_p = self.weight_loss_rec_h * F.l1_loss(xhnr_rec[:, 3:], xhnr[:, 3:])
         loss_KL_g, loss_KL_l = self._kl(mu_g, lv_g, ep), self._kl(mu_l, lv_l, ep)

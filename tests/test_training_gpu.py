@@ -197,3 +197,36 @@ def test_graph_step_equals_eager_step(tmp_path, smplx_data, vposer_sd, monkeypat
         out[use_graph] = torch.stack(hist)
     assert float(out[True][1][4]) > 0 and float(out[True][0][4]) == 0      # contact term: off, then live
     assert torch.allclose(out[True], out[False], rtol=2e-3, atol=1e-6), (out[True], out[False])
+
+
+def test_body_decoder_equals_modular_chain(tmp_path, smplx_data, vposer_sd):
+    """fitting.BodyDecoder (one HIP op, hand-derived backward) == convert_to_3D_rot -> vposer.decode -> SMPL-X layer -> cam_ext
+    with autograd: vertices and the gradient wrt the 75-D body vector."""
+    from psi_release_amd.geometry import BodyParamParser, GeometryTransformer
+    scene = synth.make_scene(2, 500, 8, 64)
+    B = 5
+    op = training.TrainOP(make_cfg(tmp_path, smplx_data, vposer_sd, scene, B), dict(LW))
+    rs = np.random.RandomState(3)
+    body = synth.body_vector_72(synth.make_bodies(4, B))
+    x72 = T(body)
+    x75 = GeometryTransformer.convert_to_6D_rot(x72).detach().clone().requires_grad_(True)
+    cam = T(synth.make_cam_ext(4, B))
+    gv = T(rs.randn(B, 10475, 3))
+    # modular chain (what the reference's cal_loss does)
+    xa = GeometryTransformer.convert_to_3D_rot(x75)
+    bp = BodyParamParser.body_params_encapsulate_batch(xa)
+    jr = op.vposer.decode(bp['body_pose_vp'], output_type='aa').view(B, -1)
+    v_ref = op.body_mesh_model(return_verts=True, body_pose=jr, cam_ext=cam, **{k: v for k, v in bp.items() if k != 'body_pose_vp'}).vertices
+    (v_ref * gv).sum().backward()
+    g_ref = x75.grad.clone()
+    x75.grad = None
+    from psi_release_amd.fitting import BodyDecoder
+    dec = BodyDecoder(op.vposer, op.body_mesh_model, B, DEV)
+    v = dec(x75, cam)
+    (v * gv).sum().backward()
+    assert rel_err(v.detach().cpu(), v_ref.detach().cpu()) < 1e-5
+    assert rel_err(x75.grad.cpu(), g_ref.cpu()) < 1e-4
+    with pytest.raises(RuntimeError):                      # a second forward invalidates the first one's saved activations
+        v1 = dec(x75, cam)
+        dec(x75, cam)
+        v1.sum().backward()
