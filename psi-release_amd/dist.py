@@ -34,7 +34,7 @@ def rank():
 def init_from_env(backend=None):
     """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); no-op for one process."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
-    if ws <= 1:
+    if ws <= 1 and os.environ.get('PSI_FORCE_DP_PATH') != '1':    # (forced: a 1-rank group, to exercise the RCCL leg on one GPU)
         return 0, 0, 1
     rk = int(os.environ.get('RANK', '0'))
     lrk = int(os.environ.get('LOCAL_RANK', str(rk)))

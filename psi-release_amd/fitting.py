@@ -253,7 +253,9 @@ class FusedEngine:
 
     def iterate(self, n, use_graph=True):
         L = hip.lib()
-        if self.world == 1:
+        # PSI_FORCE_DP_PATH=1 runs the data-parallel sequence (forward half, all-reduce, backward half) even at world size 1:
+        # the way to exercise the RCCL leg on a single-GPU box
+        if self.world == 1 and not (os.environ.get('PSI_FORCE_DP_PATH') == '1' and torch.distributed.is_initialized()):
             hip.check(L.psi_fit_iterate(self.handle, n, int(bool(use_graph)), self.stream.cuda_stream), 'psi_fit_iterate')
             return
         import torch.distributed as tdist
