@@ -93,3 +93,23 @@ def test_training_gradient_allreduce_equals_full_batch(tmp_path):
     for k in full:
         scale = float(full[k].abs().max()) + 1e-12
         assert float((dp[k] - full[k]).abs().max()) / scale < 1e-3, k
+
+
+def test_rccl_leg_at_world_size_one():
+    """The data-parallel sequence (forward half-graph -> RCCL all-reduce of stats[6] -> backward half-graph) over a 1-rank
+    nccl group (PSI_FORCE_DP_PATH=1) reproduces the single-process result: the collective leg the multi-GPU bench relies on,
+    exercised on the one GPU this box has."""
+    import subprocess
+    out = {}
+    for force in ('0', '1'):
+        env = dict(os.environ, PSI_FORCE_DP_PATH=force, GRAFT_REPO_ROOT=ROOT)
+        port = 29800 + (os.getpid() % 500) + int(force)
+        r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                            '--master-port', str(port), os.path.join(ROOT, 'tools', 'dp_check.py')], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = {l.split()[0]: l for l in r.stdout.splitlines() if l.startswith(('checksum', 'stats', 'backend'))}
+        out[force] = lines
+    assert 'backend' not in out['0'] or 'nccl' in out['1'].get('backend', 'nccl')
+    assert 'nccl' in out['1']['backend']
+    assert out['0']['checksum'] == out['1']['checksum'], (out['0'], out['1'])
+    assert out['1']['stats'] != out['0']['stats']            # the all-reduced statistics buffer was actually used
