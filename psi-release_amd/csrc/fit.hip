@@ -3,17 +3,24 @@
 //                                                                                        source/fitting_proxe.py:101-162,177-189
 // as a fixed sequence of HIP kernels with a hand-derived backward, replayable as a hipGraph (no host sync, no autograd).
 //
+// Eight launches per iteration (single process):
 //   head_fwd          per body: L1 / latent-prior partial sums (fitting_proxe.py:105-110); convert_to_3D_rot (cvae.py:128-137);
 //                     VPoser.decode 32->512->512->126 -> 21 x (6D -> R -> angle-axis) (vposer_smpl.py:107-121,152-161);
-//                     SMPL-X hand PCA + pose_mean (smplx 0.1.13 forward)
-//   lbs forward       pose_fwd, blend_fwd (MFMA), skin_fwd incl. cam_ext                  (lbs.hip)
-//   sdf_pen           trilinear SDF + analytic gradient + penetration partial sums       (fitting_proxe.py:144-158)
-//   nn_contact        Chamfer NN of the gathered contact vertices + contact-loss epilogue (chamfer.hip; fitting_proxe.py:131-139)
-//   loss_finalize     deterministic reduction of all partial sums -> stats[6] = [sum|dx|, sum z^2, sum f, sum|sdf-|, N, 0]
-//   --- data-parallel runs all-reduce `stats` here (one 6-float RCCL all-reduce per iteration) ---
-//   grad_verts        d loss / d verts = penetration part (needs the GLOBAL count N) + contact part
-//   lbs backward      skin_bwd_v, skin_bwd_A (MFMA), blend_bwd (MFMA), reduce, pose_bwd      (lbs.hip)
-//   head_bwd_adam     Gram-Schmidt / VPoser-MLP / hand-PCA backward, + L1 and prior gradients, Adam update (torch.optim.Adam defaults)
+//                     SMPL-X hand PCA + pose_mean (smplx 0.1.13 forward); then the LBS pose stage of the
+//                     body (Rodrigues, joints, kinematic chain: lbs_device.h)
+//   blend_fwd         v_posed = v_t + feat @ dirs (MFMA)                                  (lbs.hip)
+//   skin_fwd<SdfPen>  skinning incl. cam_ext, with the trilinear SDF lookup + analytic gradient + penetration partial sums
+//                     as its per-vertex epilogue (fitting_proxe.py:144-158)               (lbs_device.h template)
+//   kd_query<CONTACT> exact NN of the gathered contact vertices + contact-loss epilogue   (nnindex.hip; fitting_proxe.py:131-139;
+//                     nn_mode 0: the brute-force kernels of chamfer.hip)
+//   skin_bwd_v<Grad>  prologue: statistics stats[6] = [sum|dx|, sum z^2, sum f, sum|sdf-|, N, 0] and d loss / d verts =
+//                     penetration part (needs the GLOBAL count N) + contact part, built on the fly; then the skinning backward
+//   bwd_joint         skin_bwd_A and blend_bwd (both MFMA) as one heterogeneous grid       (lbs.hip)
+//   reduce_partials   sums of the split-contraction partials                               (lbs.hip)
+//   head_bwd_adam     per body: LBS pose backward, Gram-Schmidt / VPoser-MLP / hand-PCA backward, + L1 and prior gradients,
+//                     Adam update (torch.optim.Adam defaults)
+// Data-parallel runs add loss_finalize after kd_query, all-reduce `stats` there (one 6-float RCCL all-reduce per iteration)
+// and skin_bwd_v reads the reduced values.  psi_fit_decode_forward/backward drive the head / LBS kernels alone (training).
 //
 // Gradient through "6D -> R -> angle-axis -> Rodrigues -> R'": the forward evaluates the reference's chain literally;
 // the backward uses that R' == R on SO(3) and that Gram-Schmidt only moves along SO(3), so J_GS^T dL/dR' is the exact

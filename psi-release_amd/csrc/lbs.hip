@@ -15,13 +15,17 @@
 //   J_t [J][3], J_s [J][3][NB]   joint regressor pre-contracted with v_template / shapedirs (fp64 on the host):
 //                        J = J_t + J_s @ betas, algebraically lbs.py:85 without the V-long reduction per call.
 // Kernels:
-//   pose_fwd   (1 wave per body)   Rodrigues (lbs.py:165-192), joints, level-parallel kinematic chain (lbs.py:207-262)
-//   blend_fwd  (MFMA f32 16x16x4)  v_posed = v_template + feat @ dirs       — HBM-bound on dirs (64 MB)
-//   skin_fwd                       verts = cam_ext * (sum_j W_j A_j [v_posed;1] + transl)  (lbs.py:108-116, cvae.py:141-149)
-//   skin_bwd_v                     g_local = R_c^T g_verts;  g_vposed = T_R^T g_local;  partial g_transl
-//   skin_bwd_A (MFMA)              gA[b][j] = sum_v W[v][j] * g_local (x) [v_posed;1]   (contraction over V)
-//   blend_bwd  (MFMA)              g_feat = g_vposed @ dirs^T                (contraction over N, dirs streamed again)
-//   pose_bwd   (1 wave per body)   chain reverse sweep, Rodrigues derivative, joint/shape gradients
+//   pose_fwd   (1 wave per body)   Rodrigues (lbs.py:165-192), joints, level-parallel kinematic chain (lbs.py:207-262)   [lbs_device.h]
+//   blend_fwd  (MFMA f32 16x16x4)  v_posed = v_template + feat @ dirs       — a 64 MB stream + 6.5 us of MFMA
+//   skin_fwd                       verts = cam_ext * (sum_j W_j A_j [v_posed;1] + transl)  (lbs.py:108-116, cvae.py:141-149) [lbs_device.h]
+//   skin_bwd_v                     g_local = R_c^T g_verts;  g_vposed = T_R^T g_local;  partial g_transl                    [lbs_device.h]
+//   bwd_joint  (MFMA)              one grid, two kinds of workgroup:
+//       skin_bwd_A                 gA[b][j] = sum_v W[v][j] * g_local (x) [v_posed;1]   (contraction over V)
+//       blend_bwd                  g_feat = g_vposed @ dirs^T                (contraction over N, dirs streamed again)
+//   reduce_partials                sums the 41 vertex-slice and 32 column-slice partials
+//   pose_bwd   (1 wave per body)   chain reverse sweep, Rodrigues derivative, joint/shape gradients                          [lbs_device.h]
+// The per-body pose stages and the skinning kernels live in lbs_device.h because the fused fitting engine (fit.hip) inlines /
+// re-instantiates them with its own hooks.
 // The f32 MFMA (v_mfma_f32_16x16x4_f32) is bit-identical to an fmaf chain, so these are exact-f32 GEMMs.
 #include "psi_internal.h"
 #include "lbs_device.h"
