@@ -54,7 +54,10 @@ def _worker(rank, world, port, tmp):
 
 
 def test_loss_reduce_world2(tmp_path):
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / 'ok0').read() == '1' and open(tmp_path / 'ok1').read() == '1'
 

@@ -12,6 +12,13 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
 LOSS = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1, 'weight_collision': 0.5}
 
 
@@ -55,7 +62,7 @@ def test_two_ranks_equal_full_batch(tmp_path, engine):
     full = op.xhr_rec.detach().cpu().numpy()
     del op
     torch.cuda.synchronize()
-    port = 29600 + (os.getpid() % 1000) + (0 if engine == 'fused' else 1)
+    port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path), engine), nprocs=2, join=True)
     got = np.concatenate([np.load(tmp_path / 'x0.npy'), np.load(tmp_path / 'x1.npy')])
     assert np.abs(got - full).max() < 5e-5
@@ -86,7 +93,7 @@ def test_training_gradient_allreduce_equals_full_batch(tmp_path):
     full = {k: v.grad.detach().cpu() for k, v in op.model_h.named_parameters()}
     del op
     torch.cuda.synchronize()
-    port = 29700 + (os.getpid() % 1000)
+    port = _free_port()
     mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     dp = torch.load(tmp_path / 'dp.pt')
     # gradients (after the all-reduce) rather than parameters: Adam's first step is +-lr for any non-tiny gradient
@@ -103,7 +110,7 @@ def test_rccl_leg_at_world_size_one():
     out = {}
     for force in ('0', '1'):
         env = dict(os.environ, PSI_FORCE_DP_PATH=force, GRAFT_REPO_ROOT=ROOT)
-        port = 29800 + (os.getpid() % 500) + int(force)
+        port = _free_port()
         r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
                             '--master-port', str(port), os.path.join(ROOT, 'tools', 'dp_check.py')], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
