@@ -1,7 +1,7 @@
 """dev: gpurun_out/pmc_<tag>_{FETCH_SIZE,WRITE_SIZE}.txt (tools/pmc.sh) -> profiles/<round>_pmc_{fetch_size,write_size}.csv + _pmc_traffic.json"""
 import json, sys, shutil
 tag, rnd = sys.argv[1], sys.argv[2]
-X2 = ('blend_bwd_kernel', 'blend_fwd_kernel', 'head_bwd_adam_kernel', 'head_fwd_kernel', 'skin_bwd_A_kernel')   # 16 B/lane streams
+X2 = ('bwd_joint_kernel', 'blend_bwd_kernel', 'blend_fwd_kernel', 'head_bwd_adam_kernel', 'head_fwd_kernel', 'skin_bwd_A_kernel')   # 16 B/lane streams
 def rd(c):
     out = {}
     for l in open('gpurun_out/pmc_%s_%s.txt' % (tag, c)).read().splitlines()[1:]:
