@@ -114,6 +114,24 @@ def test_fused_matches_modular(smplx_data, vposer_sd, B, cls, lr, graph):
     assert np.abs(res['fused'][0] - res['modular'][0]).max() < 1e-3
 
 
+@pytest.mark.parametrize('B', [40, 64])
+def test_fused_gradient_matches_modular_large_batch(smplx_data, vposer_sd, B):
+    """B > 32 selects the 4-row-tile MFMA variants (blend_fwd<4>, bwd_joint<4>).  Compared on the FIRST-iteration gradient
+    (Adam's first moment after one step = 0.1 * gradient in both engines): with 1/B normalisers some elements have
+    |g| < 1e-8 ~ Adam's eps, so trajectories differ by the eps-sensitivity of those elements even for gradients that
+    agree to 1e-7."""
+    scene = synth.make_scene(3, 3000, 24, 300)
+    bodies = synth.make_bodies(21, B)
+    bodies['cam_ext'] = synth.make_cam_ext(7, B)
+    g = {}
+    for engine in ('modular', 'fused'):
+        op = make_op(smplx_data, vposer_sd, scene, B, engine, num_iter=1, lr=0.05)
+        op.fitting(dict(bodies))
+        g[engine] = (op._fused.buffer('adam_m', (B, 75)) if engine == 'fused' else op.optimizer.state[op.xhr_rec]['exp_avg']).detach().cpu().numpy() * 10
+    d = np.abs(g['fused'] - g['modular'])
+    assert d.max() < 2e-6 and d.max() < 1e-4 * np.abs(g['modular']).max(), (d.max(), np.abs(g['modular']).max())
+
+
 def test_nn_modes_agree(smplx_data, vposer_sd):
     """kd-tree index and brute-force Chamfer give the same fitting step in both engines (they are bit-identical ops)."""
     scene = synth.make_scene(3, 3000, 16, 300)

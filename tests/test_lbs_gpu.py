@@ -48,7 +48,7 @@ def test_lbs_forward_batch_sizes(layer, oracle_model, B):
     assert rel_err(v.cpu(), vo) < 1e-4
 
 
-@pytest.mark.parametrize('B,use_cam', [(2, True), (5, False), (32, True)])
+@pytest.mark.parametrize('B,use_cam', [(2, True), (5, False), (32, True), (40, True), (70, False)])   # > 32: the 4-tile MFMA variants
 def test_lbs_backward_vs_autograd(layer, oracle_model, B, use_cam):
     rs = np.random.RandomState(100 + B)
     betas = rs.standard_normal((B, 20)).astype(np.float32)
