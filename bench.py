@@ -239,12 +239,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        runner.step()
+    # steps(n) = n fitting iterations, exactly what FittingOP.fitting runs for num_iter = n (the fused engine replays them as
+    # device-resident graphs of 10 iterations + single-iteration graphs for the remainder)
+    runner.steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.step()
+    runner.steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

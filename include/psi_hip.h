@@ -167,8 +167,9 @@ int psi_fit_set_problem(psi_fit_engine *engine, const float *d_xhr, const float 
 /* use_graph != 0: each half is captured once into its own hipGraph (stats pointer baked in) and replayed. */
 int psi_fit_forward(psi_fit_engine *engine, float *d_stats, int use_graph, void *stream);
 int psi_fit_backward_step(psi_fit_engine *engine, const float *d_stats, int use_graph, void *stream);
-/* n_iter full iterations on one GPU; use_graph != 0 captures one iteration once (stream must not be the
- * NULL stream) and replays it with hipGraphLaunch. */
+/* n_iter full iterations on one GPU; use_graph != 0 captures the iteration once (stream must not be the NULL stream)
+ * and replays it with hipGraphLaunch — a 10-iteration graph for every full ten, a single-iteration graph for the rest
+ * (the iteration keeps no host-side state, so the result does not depend on how n_iter is split into calls). */
 int psi_fit_iterate(psi_fit_engine *engine, int n_iter, int use_graph, void *stream);
 /* Copies x [B,75] and the first n_hist rows of the loss-history RING [max_history,4] (row = (adam_step-1) % max_history) =
  * (l_rec, l_vposer, l_contact, l_collision as printed by fitting_proxe.py:184-186) to device buffers;

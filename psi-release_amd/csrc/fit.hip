@@ -520,6 +520,8 @@ __global__ void adam_reset_kernel(float *m, float *v, int *step, int n)
 
 }  // namespace
 
+constexpr int GRAPH_UNROLL = 10;
+
 struct psi_fit_engine {
     FitDev d;
     const psi_lbs_model *lbs;
@@ -529,9 +531,9 @@ struct psi_fit_engine {
     void *nn_ws;
     char *blob;
     float *stats_local;           // engine-owned stats buffer (single-GPU path)
-    hipGraph_t graph;
-    hipGraphExec_t graph_exec;
-    bool graph_ready;
+    hipGraph_t graph, graphN;     // one iteration / GRAPH_UNROLL iterations
+    hipGraphExec_t graph_exec, graphN_exec;
+    bool graph_ready, graphN_ready;
     // data-parallel path: forward and backward halves captured separately (the all-reduce sits between them)
     hipGraph_t g_half[2];
     hipGraphExec_t ge_half[2];
@@ -703,6 +705,10 @@ extern "C" void psi_fit_destroy(psi_fit_engine *e)
         (void)hipGraphExecDestroy(e->graph_exec);
         (void)hipGraphDestroy(e->graph);
     }
+    if (e->graphN_ready) {
+        (void)hipGraphExecDestroy(e->graphN_exec);
+        (void)hipGraphDestroy(e->graphN);
+    }
     for (int i = 0; i < 2; i++)
         if (e->half_ready[i]) {
             (void)hipGraphExecDestroy(e->ge_half[i]);
@@ -780,18 +786,39 @@ extern "C" int psi_fit_iterate(psi_fit_engine *e, int n_iter, int use_graph, voi
         }
         return 0;
     }
-    if (!e->graph_ready) {
+    // Two graphs: one iteration, and GRAPH_UNROLL iterations back to back.  Launching a graph costs ~8 us on this stack
+    // (tools/ubench_graph.hip: 9.8 us for a 1-kernel graph, +1.5-2.7 us per further kernel), i.e. 4 % of an iteration when every
+    // iteration is its own launch; the iteration has no host-side state (step count, history and statistics live on the
+    // device), so a 100-iteration fit is 10 launches of the long graph.
+    auto capture = [&](int iters, hipGraph_t *g, hipGraphExec_t *ge) -> int {
         PSI_REQUIRE(st != nullptr, "graph capture needs a non-default stream");
         PSI_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        int rc = fit_forward(e, e->stats_local, st, true);
-        if (!rc) rc = fit_backward(e, e->stats_local, st, true);
-        hipError_t ce = hipStreamEndCapture(st, &e->graph);
+        int rc = 0;
+        for (int i = 0; i < iters && !rc; i++) {
+            rc = fit_forward(e, e->stats_local, st, true);
+            if (!rc) rc = fit_backward(e, e->stats_local, st, true);
+        }
+        hipError_t ce = hipStreamEndCapture(st, g);
         if (rc) return rc;
         PSI_CHECK_HIP(ce);
-        PSI_CHECK_HIP(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+        PSI_CHECK_HIP(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+        return 0;
+    };
+    int done = 0;
+    if (n_iter >= GRAPH_UNROLL) {
+        if (!e->graphN_ready) {
+            int rc = capture(GRAPH_UNROLL, &e->graphN, &e->graphN_exec);
+            if (rc) return rc;
+            e->graphN_ready = true;
+        }
+        for (; done + GRAPH_UNROLL <= n_iter; done += GRAPH_UNROLL) PSI_CHECK_HIP(hipGraphLaunch(e->graphN_exec, st));
+    }
+    if (done < n_iter && !e->graph_ready) {
+        int rc = capture(1, &e->graph, &e->graph_exec);
+        if (rc) return rc;
         e->graph_ready = true;
     }
-    for (int i = 0; i < n_iter; i++) PSI_CHECK_HIP(hipGraphLaunch(e->graph_exec, st));
+    for (; done < n_iter; done++) PSI_CHECK_HIP(hipGraphLaunch(e->graph_exec, st));
     return 0;
 }
 

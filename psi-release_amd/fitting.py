@@ -160,12 +160,13 @@ class FittingOP:
     def fitting(self, input_data_file):
         """fitting_proxe.py:167-195; ``input_data_file`` is a pkl path or the already-loaded dict."""
         runner = self.make_step_runner(input_data_file)
-        for ii in range(self.num_iter):
+        if not self.verbose:
+            runner.steps(self.num_iter)                 # fused engine: the loop is device-resident, 10 iterations per graph launch
+        for ii in range(self.num_iter if self.verbose else 0):
             runner.step()
-            if self.verbose:
-                l = runner.last_losses()
-                print('[INFO][fitting] iter={:d}, l_rec={:f}, l_vposer={:f}, l_contact={:f}, l_collision={:f}'.format(
-                    ii, l[0], l[1], l[2], l[3]))
+            l = runner.last_losses()
+            print('[INFO][fitting] iter={:d}, l_rec={:f}, l_vposer={:f}, l_contact={:f}, l_collision={:f}'.format(
+                ii, l[0], l[1], l[2], l[3]))
         runner.finish()
         print('[INFO][fitting] fitting finish, returning optimal value')
         return GeometryTransformer.convert_to_3D_rot(self.xhr_rec)
@@ -198,6 +199,10 @@ class _ModularRunner:
         self._losses = [l.detach() for l in losses]
         (losses[0] + losses[1] + losses[2] + losses[3]).backward()
         op.optimizer.step()
+
+    def steps(self, n):
+        for _ in range(n):
+            self.step()
 
     def last_losses(self):
         """Loss values evaluated at the START of the last step (what the reference prints), as Python floats."""
@@ -323,6 +328,10 @@ class _FusedRunner:
     def step(self):
         self.eng.iterate(1, self.op.use_graph)
         self.n += 1
+
+    def steps(self, n):
+        self.eng.iterate(n, self.op.use_graph)
+        self.n += n
 
     def last_losses(self):
         idx = self.step0 + self.n                       # Adam step count after the last step

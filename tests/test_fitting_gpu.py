@@ -194,3 +194,26 @@ def test_full_baseline_size_properties(smplx_data, vposer_sd):
     l0, l19 = res[('kdtree', True)][2], res[('kdtree', True)][3]
     assert abs(sum(l0) - sum(rm.last_losses())) < 1e-5
     assert l19[2] + l19[3] < l0[2] + l0[3]                      # contact + collision terms go down
+
+
+def test_long_graph_equals_single_iteration_graphs(smplx_data, vposer_sd):
+    """psi_fit_iterate(23) = 2 replays of the 10-iteration graph + 3 single-iteration replays; bit-identical to 23 calls of
+    psi_fit_iterate(1) (the iteration has no host-side state), including the recorded loss history."""
+    scene = synth.make_scene(3, 3000, 24, 300)
+    B = 3
+    bodies = synth.make_bodies(21, B)
+    bodies['cam_ext'] = synth.make_cam_ext(7, B)
+    res = {}
+    for mode in ('one_call', 'per_iteration'):
+        op = make_op(smplx_data, vposer_sd, scene, B, 'fused', num_iter=23, lr=0.05)
+        runner = op.make_step_runner(dict(bodies))
+        if mode == 'one_call':
+            runner.steps(23)
+        else:
+            for _ in range(23):
+                runner.step()
+        losses = runner.last_losses()
+        runner.finish()
+        res[mode] = (op.xhr_rec.detach().cpu().numpy().copy(), np.array(losses))
+    assert np.array_equal(res['one_call'][0], res['per_iteration'][0])
+    assert np.array_equal(res['one_call'][1], res['per_iteration'][1])
