@@ -44,7 +44,7 @@ def _worker(rank, world, port, tmp, engine):
     bodies = synth.make_bodies(51, 4)
     bodies['cam_ext'] = synth.make_cam_ext(4, 4)
     op = fitting.FittingOP(_cfg(2, engine), dict(LOSS))
-    op.use_graph = (rank == 0)            # one rank replays the two half-graphs, the other launches eagerly: same numbers
+    op.dp_use_graph = (rank == 0)         # one rank replays the two half-graphs, the other launches eagerly: same numbers
     op.fitting(_rows(bodies, 2 * rank, 2 * rank + 2))
     np.save(os.path.join(tmp, 'x%d.npy' % rank), op.xhr_rec.detach().cpu().numpy())
     dist.barrier()
