@@ -217,7 +217,14 @@ def bench_train_s2(args):
 def main():
     args = parse()
     if args.workload == 'train_s2':
-        return bench_train_s2(args)
+        import contextlib, io
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):                 # the trainer's [INFO] lines go to stderr: stdout carries ONE JSON line
+            bench_train_s2(args)
+        lines = buf.getvalue().splitlines()
+        sys.stderr.write('\n'.join(lines[:-1]) + '\n')
+        print(lines[-1])
+        return
     from psi_release_amd import dist as pd
     # RCCL (backend 'nccl') over xGMI; PSI_DIST_BACKEND=gloo lets a single-GPU box exercise the N>1 code path
     rank, local_rank, world = pd.init_from_env(os.environ.get('PSI_DIST_BACKEND', 'nccl'))
