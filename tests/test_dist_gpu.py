@@ -113,7 +113,7 @@ def test_rccl_leg_at_world_size_one():
         for attempt in range(2):                               # one retry: a failed rendezvous is not what this test is about
             port = _free_port()
             r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
-                                '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'tools', 'dp_check.py')], env=env,
+                                '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'tests', 'dp_check_worker.py')], env=env,
                                capture_output=True, text=True, timeout=600)
             if r.returncode == 0:
                 break
