@@ -29,7 +29,9 @@
 // The f32 MFMA (v_mfma_f32_16x16x4_f32) is bit-identical to an fmaf chain, so these are exact-f32 GEMMs.
 #include "psi_internal.h"
 #include "lbs_device.h"
+#include <algorithm>
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 #include <string.h>
 
@@ -452,19 +454,45 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
             }
         }
     }
+    // compressed skinning rows: used by the skinning kernels when no vertex has more than PSI_WNZ non-zero weights
+    // (PSI_LBS_DENSE=1 keeps the dense loop, for A/B tests)
+    std::vector<float> Wc;
+    std::vector<int> Wj;
+    {
+        int nnz_max = 0;
+        for (int v = 0; v < V; v++) {
+            int c = 0;
+            for (int j = 0; j < J; j++) c += h_weights[(size_t)v * J + j] != 0.0f;
+            nnz_max = std::max(nnz_max, c);
+        }
+        const char *dense = getenv("PSI_LBS_DENSE");
+        if (nnz_max <= PSI_WNZ && !(dense && dense[0] == '1')) {
+            Wc.assign((size_t)PSI_WNZ * d.Vpad, 0.0f);
+            Wj.assign((size_t)PSI_WNZ * d.Vpad, 0);
+            for (int v = 0; v < V; v++) {
+                int k = 0;
+                for (int j = 0; j < J; j++) {
+                    float w = h_weights[(size_t)v * J + j];
+                    if (w != 0.0f) { Wc[(size_t)k * d.Vpad + v] = w; Wj[(size_t)k * d.Vpad + v] = j; k++; }
+                }
+            }
+        }
+    }
     // one device blob
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     size_t o_dirs = take(dirs.size() * 4), o_vt = take(vt.size() * 4), o_wt = take(WT.size() * 4), o_jt = take(Jt.size() * 4),
-           o_js = take(Js.size() * 4), o_par = take(J * 4), o_lvl = take(J * 4), o_cp = take((J + 1) * 4), o_ci = take(cidx.size() * 4);
+           o_js = take(Js.size() * 4), o_wc = take(Wc.size() * 4 + 4), o_wj = take(Wj.size() * 4 + 4), o_par = take(J * 4), o_lvl = take(J * 4), o_cp = take((J + 1) * 4), o_ci = take(cidx.size() * 4);
     char *blob = nullptr;
     PSI_CHECK_HIP(hipMalloc((void **)&blob, o));
     std::vector<int> par(h_parents, h_parents + J);
     struct { size_t off; const void *src; size_t bytes; } cp[] = {
         {o_dirs, dirs.data(), dirs.size() * 4}, {o_vt, vt.data(), vt.size() * 4}, {o_wt, WT.data(), WT.size() * 4},
-        {o_jt, Jt.data(), Jt.size() * 4}, {o_js, Js.data(), Js.size() * 4}, {o_par, par.data(), (size_t)J * 4},
+        {o_jt, Jt.data(), Jt.size() * 4}, {o_js, Js.data(), Js.size() * 4}, {o_wc, Wc.data(), Wc.size() * 4}, {o_wj, Wj.data(), Wj.size() * 4},
+        {o_par, par.data(), (size_t)J * 4},
         {o_lvl, level.data(), (size_t)J * 4}, {o_cp, cptr.data(), (size_t)(J + 1) * 4}, {o_ci, cidx.data(), cidx.size() * 4}};
     for (auto &c : cp) {
+        if (!c.bytes) continue;
         hipError_t e = hipMemcpy(blob + c.off, c.src, c.bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             (void)hipFree(blob);
@@ -475,6 +503,8 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     d.dirs = (const float *)(blob + o_dirs);
     d.v_template = (const float *)(blob + o_vt);
     d.WT = (const float *)(blob + o_wt);
+    d.Wc = Wc.empty() ? nullptr : (const float *)(blob + o_wc);
+    d.Wj = Wj.empty() ? nullptr : (const int *)(blob + o_wj);
     d.J_t = (const float *)(blob + o_jt);
     d.J_s = (const float *)(blob + o_js);
     d.parents = (const int *)(blob + o_par);

@@ -117,3 +117,34 @@ def test_lbs_generic_tree_and_small_model():
     (vo * C(w)).sum().backward()
     assert rel_err(v.detach().cpu(), vo.detach()) < 1e-4
     assert rel_err(bt.grad.cpu(), bo.grad) < 1e-4 and rel_err(pt.grad.cpu(), po.grad) < 1e-4
+
+
+def test_compressed_skinning_rows_bit_identical(monkeypatch):
+    """Weight rows with <= 8 non-zeros (what real SMPL-X rows look like) take the compressed-row skinning path; it skips
+    exact zeros in ascending joint order, so vertices and gradients equal the dense loop's bit for bit."""
+    data = synth.make_smplx(seed=7)
+    W = np.array(data.weights, dtype=np.float32)
+    keep = np.argsort(-W, axis=1)[:, :5]                       # 5 strongest joints per vertex, renormalised
+    Ws = np.zeros_like(W)
+    np.put_along_axis(Ws, keep, np.take_along_axis(W, keep, axis=1), axis=1)
+    Ws /= Ws.sum(axis=1, keepdims=True)
+    parents = data.kintree_table[0].copy()
+    parents[0] = -1
+    posedirs = data.posedirs.reshape(-1, data.posedirs.shape[-1]).T.copy()
+    rs = np.random.RandomState(11)
+    B = 4
+    betas, pose = rs.standard_normal((B, 20)).astype(np.float32), (rs.standard_normal((B, 165)) * 0.4).astype(np.float32)
+    transl, cam, w = rs.standard_normal((B, 3)).astype(np.float32), synth.make_cam_ext(3, B), rs.standard_normal((B, 10475, 3)).astype(np.float32)
+    out = {}
+    for mode in ('compressed', 'dense'):
+        monkeypatch.setenv('PSI_LBS_DENSE', '1' if mode == 'dense' else '0')
+        mdl = body_model.LbsModel(data.v_template, data.shapedirs, posedirs, data.J_regressor, Ws, parents, DEV)
+        bt, pt, tt = T(betas).requires_grad_(), T(pose).requires_grad_(), T(transl).requires_grad_()
+        v = body_model.lbs(mdl, bt, pt, transl=tt, cam_ext=T(cam))
+        (v * T(w)).sum().backward()
+        out[mode] = [v.detach().clone(), bt.grad.clone(), pt.grad.clone(), tt.grad.clone()]
+    for a, b in zip(out['compressed'], out['dense']):
+        assert torch.equal(a, b)
+    # and the path is actually different from the dense model's (the sparsified weights changed the mesh)
+    dense_model = body_model.LbsModel(data.v_template, data.shapedirs, posedirs, data.J_regressor, W, parents, DEV)
+    assert not torch.equal(body_model.lbs(dense_model, T(betas), T(pose), transl=T(transl), cam_ext=T(cam)), out['dense'][0])
