@@ -43,14 +43,33 @@ def build_c_oracle(force: bool = False) -> str:
     os.makedirs(_BUILD, exist_ok=True)
     src = os.path.join(_HERE, 'chamfer_oracle.c')
     out = os.path.join(_BUILD, 'libpsi_oracle.so')
-    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+    # -march=native code must not travel to a different CPU (the prebuilt .so ships to the GPU box with the snapshot): the
+    # build records the host's ISA flags and is redone when they differ
+    stamp, here = os.path.join(_BUILD, 'cpu.stamp'), _cpu_flags()
+    try:
+        same_cpu = open(stamp).read() == here
+    except OSError:
+        same_cpu = False
+    if force or not same_cpu or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
         cmd = ['gcc', '-O3', '-march=native', '-ffp-contract=off', '-fno-fast-math', '-fopenmp', '-shared', '-fPIC',
                src, '-o', out]
         try:
             subprocess.run(cmd, check=True, capture_output=True)
         except subprocess.CalledProcessError as e:  # pragma: no cover
             raise RuntimeError('oracle build failed: ' + e.stderr.decode())
+        with open(stamp, 'w') as f:
+            f.write(here)
     return out
+
+
+def _cpu_flags() -> str:
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('flags'):
+                return ' '.join(sorted(line.split(':', 1)[1].split()))
+    except OSError:
+        pass
+    return 'unknown'
 
 
 def c_oracle():
