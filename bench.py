@@ -1,19 +1,31 @@
 #!/usr/bin/env python
 """bench.py — fitting iterations/sec of the PSI hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE fitting iteration (fitting_proxe.py:177-189: zero_grad, cal_loss, backward, Adam step) over a
-batch of 32 bodies per GPU on synthetic PROX-E-shaped inputs (configs[1] of BASELINE.json: V=10475 SMPL-X-shaped
-model, VPoser(512,32,[1,21,3]), n_c=2048 contact vertices, m=32768 scene points, 256^3 SDF; all inputs resident in
-HBM before the timed region).  Weak scaling: every rank fits its own 32 bodies; the only data-path collective is
-the one 6-float all-reduce per iteration of the loss normalisers (psi-release_amd/dist.py).
-value = (N * K) / max-over-ranks wall time of the K timed steps  [batch-32 fitting iterations per second].
+N > 1: one rank per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE are read from the environment) or, when no
+torchrun environment is present, bench.py starts them ITSELF by re-executing under torch.distributed.run on 127.0.0.1.
+
+A "step" is ONE fitting iteration (fitting_proxe.py:177-189: zero_grad, cal_loss, backward, Adam step) over a batch of
+32 bodies per GPU on synthetic PROX-E-shaped inputs (configs[1] of BASELINE.json: V=10475 SMPL-X-shaped model,
+VPoser(512,32,[1,21,3]), n_c=2048 contact vertices, m=32768 scene points, 256^3 SDF; all inputs resident in HBM before the
+timed region).  Weak scaling: every rank fits its own 32 bodies; the only data-path collective is the one 6-float
+all-reduce per iteration of the loss normalisers (psi-release_amd/dist.py).
+
+Protocol: W untimed warm-up steps plus an untimed clock-ramp warm-up (>= 0.3 s of iterations), then
+R >= 5 timed blocks of EXACTLY K steps each, every block bracketed by a barrier + torch.cuda.synchronize() on both sides
+and timed as the MAX over ranks; R is raised so that the timed GPU time is >= 0.5 s whatever K is.  `ms_per_step` is the
+MEDIAN block (min / max are reported next to it) and value = N / median seconds per step  [batch-32 iterations / s].
+
+Workloads:  --workload fitting (default, configs[1]; configs[3] at --gpus 8) | fitting_habitat (configs[4]: contact
+constant 1.0, Habitat camera flip, 64 bodies per GPU, a sweep over 7 synthetic rooms) | train_s2 (configs[2]).
+The default line also carries `secondary.train_s2` (a bounded train_s2 measurement, N=1 only) so configs[2] is measured
+by the same run.
 
 The JSON line also carries
-  roofline     — the dominant kernel (brute-force Chamfer NN, fp32-VALU bound): algorithmic flops per launch
-                 (8 flop per query/target pair) / its average launch duration measured with
-                 HIP events on the launch stream; peak = 157.3 TFLOP/s (fp32 vector = fp32 MFMA peak, MI355X guide);
+  roofline     — the dominant kernel of the iteration: algorithmic bytes per launch / its average
+                 launch duration measured with HIP events on the launch stream; peak = 8 TB/s HBM3E (MI355X guide);
   cpu_baseline — the oracle (oracle/psi_oracle.py + oracle/chamfer_oracle.c, a CPU port of the reference path,
                  validated against the reference's golden vectors) timed on this box's host cores on a bounded
                  sample of the same workload (rank 0, N=1 only).
@@ -22,57 +34,136 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
+ROOMS = 7                     # fitting_habitat.py:238-241: seven MP3D-R rooms
+PMC_FILES = ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='bodies per GPU (BASELINE: 32)')
+    ap.add_argument('--batch', type=int, default=None, help='bodies per GPU (fitting: 32 = BASELINE; fitting_habitat: 64)')
     ap.add_argument('--m', type=int, default=32768, help='scene points')
     ap.add_argument('--nc', type=int, default=2048, help='contact vertices')
     ap.add_argument('--D', type=int, default=256, help='SDF grid dimension')
     ap.add_argument('--engine', default=os.environ.get('PSI_ENGINE', 'auto'), choices=['auto', 'fused', 'modular'])
-    ap.add_argument('--workload', default='fitting', choices=['fitting', 'train_s2'],
-                    help="'fitting' = BASELINE metric (configs[1]); 'train_s2' = secondary line for configs[2] (train_s2 step, batch 128)")
+    ap.add_argument('--workload', default='fitting', choices=['fitting', 'fitting_habitat', 'train_s2'],
+                    help="'fitting' = BASELINE metric (configs[1]/[3]); 'fitting_habitat' = configs[4]; 'train_s2' = configs[2]")
+    ap.add_argument('--repeats', type=int, default=5, help='minimum number of timed K-step blocks (the median is reported)')
+    ap.add_argument('--min-timed-s', type=float, default=0.5, help='timed GPU time is kept above this by adding blocks')
     ap.add_argument('--graph', type=int, default=1, help='train_s2: replay the whole optimiser step as one HIP graph')
     ap.add_argument('--bf16', type=int, default=1, help='train_s2: bf16 autocast for the CVAE trunk')
+    ap.add_argument('--secondary', type=int, default=1, help='attach the bounded train_s2 measurement (configs[2]) to the default line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='time budget of the CPU baseline sample')
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.batch is None:
+        args.batch = 64 if args.workload == 'fitting_habitat' else (128 if args.workload == 'train_s2' else 32)
+    return args
 
 
-def make_op(args, rank, device):
+# ----------------------------------------------------------------------------------------------------------------------
+# multi-GPU launch
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one per GPU, RCCL)."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1) // 2)))
+    env['PSI_BENCH_SPAWNED'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# timing protocol
+# ----------------------------------------------------------------------------------------------------------------------
+def timed_blocks(run_steps, barrier, K, W, world, device, min_repeats=5, min_total_s=0.5, ramp_s=0.3, max_repeats=400):
+    """run_steps(n) enqueues n steps.  Returns the per-block wall times (max over ranks) of R blocks of exactly K steps."""
+    import torch
+    run_steps(max(W, 0))
+    barrier()
+    # clock ramp: the first milliseconds after idle run at a lower clock (measured: 10 % on a 4 ms region)
+    t0 = time.perf_counter()
+    n_ramp = 0
+    while time.perf_counter() - t0 < ramp_s and n_ramp < 10000:
+        run_steps(K)
+        torch.cuda.synchronize()
+        n_ramp += K
+    est = (time.perf_counter() - t0) / max(n_ramp, 1)       # seconds per step, this rank
+    R = max(min_repeats, int(math.ceil(min_total_s / max(est * K, 1e-9))))
+    R = min(R, max_repeats)
+    if world > 1:                                            # every rank must run the same number of blocks
+        t = torch.tensor([R], device=device, dtype=torch.int64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        R = int(t.item())
+    times = []
+    for _ in range(R):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(K)
+        barrier()
+        times.append(time.perf_counter() - t0)
+    if world > 1:
+        t = torch.tensor(times, device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        times = [float(x) for x in t.tolist()]
+    return times
+
+
+def summarize(times, K):
+    med = statistics.median(times)
+    return {'ms_per_step': round(med / K * 1e3, 4), 'ms_per_step_min': round(min(times) / K * 1e3, 4),
+            'ms_per_step_max': round(max(times) / K * 1e3, 4), 'repeats': len(times), 'timed_s': round(sum(times), 4)}, med
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fitting workloads
+# ----------------------------------------------------------------------------------------------------------------------
+LOSS = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1, 'weight_collision': 0.5}
+
+
+def make_op(args, rank, device, scene_seed=0, habitat=False, assets=None):
     from psi_release_amd import fitting, synth
-    smplx = synth.make_smplx(7)
-    vposer = synth.make_vposer_state(3)
-    scene = synth.make_scene(0, args.m, args.D, args.nc)
+    smplx, vposer = assets if assets else (synth.make_smplx(7), synth.make_vposer_state(3))
+    scene = synth.make_scene(scene_seed, args.m, args.D, args.nc)
     cfg = {'scene_verts_path': None, 'scene_sdf_path': None, 'human_model_path': None, 'vposer_ckpt_path': None,
            'init_lr_h': 0.1, 'num_iter': 1, 'batch_size': args.batch, 'device': device,
            'contact_part': synth.CONTACT_PARTS, 'contact_id_folder': None, 'verbose': False,
            'smplx_data': smplx, 'vposer_state': vposer, 'scene': scene, 'engine': args.engine_resolved}
-    loss = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1, 'weight_collision': 0.5}
-    op = fitting.FittingOP(cfg, loss)
-    bodies = synth.make_bodies(11 + rank, args.batch)
+    op = (fitting.FittingOPHabitat if habitat else fitting.FittingOP)(cfg, dict(LOSS))
+    bodies = synth.make_bodies(11 + rank + 1000 * scene_seed, args.batch)
+    if habitat:
+        bodies['cam_ext'] = synth.make_cam_ext(5 + scene_seed, args.batch)[:1].repeat(args.batch, 0)   # one camera per room view
     return op, bodies, (smplx, vposer, scene)
 
 
 def time_chamfer_kernel(op, args, reps=20):
-    """Average duration of one Chamfer NN launch (body->scene direction, the one PSI consumes) with HIP events on the
-    stream the kernel is launched on, on the live contact vertices of the bench state."""
+    """Average duration of one brute-force Chamfer NN launch (body->scene direction, the one PSI consumes) with HIP events on
+    the stream the kernel is launched on."""
+    import torch
     from psi_release_amd import hip
     B, n, m = args.batch, args.nc, args.m
     x = torch.randn(B, n, 3, device=op.device) * 0.5
@@ -84,7 +175,7 @@ def time_chamfer_kernel(op, args, reps=20):
     st = torch.cuda.current_stream()
     call = lambda: L.psi_chamfer_forward(x.data_ptr(), y.data_ptr(), B, n, m, d.data_ptr(), i.data_ptr(), None, None,
                                          ws.data_ptr(), st.cuda_stream)
-    for _ in range(3):
+    for _ in range(10):
         call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
@@ -95,44 +186,82 @@ def time_chamfer_kernel(op, args, reps=20):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-def kernel_work(args, op):
+def kernel_work(args):
     """Algorithmic work per launch of the kernels of one fitting iteration: ('flop'|'byte', amount, note)."""
     B, V, nc, m = args.batch, 10475, args.nc, args.m
     Kpad, Npad, Vpad = 512, 31488, 10496
     dirs = Kpad * Npad * 4
-    return {
+    w = {
         'nn_partial_kernel': ('flop', 8.0 * B * nc * m, 'brute-force NN: 8 flop per query/target pair, fp32 VALU (no FMA contraction)'),
         'kd_query_kernel': ('byte', B * nc * (12 + 12 + 8) + m * 16.0,
                             'exact kd-tree NN (latency-bound pointer chase): queries in, gradients + hints out, scene once'),
         'blend_fwd_kernel': ('byte', dirs + B * Npad * 4.0 + B * Kpad * 4.0, 'v_posed = v_t + feat @ dirs: dirs (64.5 MB) streamed once + output'),
-        'bwd_joint_kernel': ('byte', dirs + B * Npad * 4.0 + 32 * B * Kpad * 4.0 + 64 * Vpad * 4.0 + 2 * B * Npad * 4.0 + 41 * B * 1024 * 4.0,
-                             'blend_bwd (dirs streamed once + g_vposed in + 32 column-slice partials out) and skin_bwd_A (weights + g_local + v_posed in, '
-                             '41 vertex-slice partials out) as one heterogeneous grid'),
-        'blend_bwd_kernel': ('byte', dirs + B * Npad * 4.0 + 32 * B * Kpad * 4.0, 'g_feat = g_vposed @ dirs^T: dirs streamed once + input + 32 column-slice partials'),
+        'bwd_joint_kernel': ('byte', dirs + B * Npad * 4.0 + 55 * Vpad * 4.0 + 2 * B * Npad * 4.0,
+                             'blend_bwd (dirs streamed once + g_vposed in) and skin_bwd_A (weights + g_local + v_posed in) as one '
+                             'heterogeneous grid; split-contraction partials are implementation traffic, not counted'),
         'skin_fwd_kernel': ('byte', 55 * Vpad * 4.0 + B * Npad * 4.0 + B * V * 12.0, 'weights + v_posed in, vertices out (660 FMA per vertex: VALU-heavy)'),
         'skin_fwd_sdf_kernel': ('byte', 55 * Vpad * 4.0 + B * Npad * 4.0 + B * V * (12.0 + 32 + 12),
                                 'skinning + SDF lookup fused: weights + v_posed in, vertices out, 8 gathers + 12 B masked gradient per vertex'),
         'skin_bwd_v_kernel': ('byte', 55 * Vpad * 4.0 + B * V * 12.0 + 2 * B * Npad * 4.0, 'weights + grad in, g_local + g_vposed out'),
         'skin_bwd_v_grad_kernel': ('byte', 55 * Vpad * 4.0 + B * V * 12.0 + B * nc * 12.0 + 2 * B * Npad * 4.0,
                                    'loss-gradient assembly + skinning backward fused: weights + SDF gradient + contact gradients in, g_local + g_vposed out'),
-        'skin_bwd_A_kernel': ('byte', 64 * Vpad * 4.0 + 2 * B * Npad * 4.0 + 41 * B * 1024 * 4.0, 'weights + g_local + v_posed in, partials out'),
         'head_fwd_kernel': ('byte', 1.4e6 + B * 12000.0, 'VPoser decoder weights (L2 resident) + per-body state + LBS pose stage'),
-        'head_bwd_adam_kernel': ('byte', 1.4e6 + B * 20000.0,
-                                 'LBS pose backward + VPoser decoder backward (1.3 MB of weights, L2 resident, re-read by each of the B workgroups) + Adam: '
-                                 'a per-body latency chain, not a bandwidth kernel'),
+        'head_bwd_adam_kernel': ('byte', 1.4e6 + B * 20000.0, 'LBS pose backward + VPoser decoder backward + Adam: a per-body latency chain'),
         'reduce_partials_kernel': ('byte', B * (41 * 4096 + 32 * 2048 + 41 * 16.0) + B * (4096 + 2048.0), 'split-contraction partials in, sums out'),
     }
+    return w
 
 
-def cpu_baseline(args, assets, budget_s):
+def load_pmc():
+    for f in PMC_FILES:
+        p = os.path.join(ROOT, 'profiles', f)
+        if os.path.exists(p):
+            return json.load(open(p)), 'profiles/' + f
+    return None, None
+
+
+def roofline_from_kernels(args, agg, work):
+    """Roofline entry of the DOMINANT kernel of the iteration (largest HIP-event time) + the same for every kernel."""
+    per = {}
+    for k, ms in agg.items():
+        w = work.get(k)
+        if w is None or w[0] != 'byte':
+            continue
+        gbs = w[1] / (ms * 1e-3) * 1e-9
+        per[k] = {'us': round(ms * 1e3, 2), 'GB/s': round(gbs, 1), 'frac_hbm': round(gbs / PEAK_HBM_GBS, 4)}
+    dom = max(agg, key=agg.get)
+    w = work.get(dom)
+    roof = None
+    if w is not None:
+        t_dom = agg[dom] * 1e-3
+        if w[0] == 'flop':
+            ach = w[1] / t_dom * 1e-12
+            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_FP32_TFLOPS, 4), 'traffic': None, 'avg_launch_ms': round(agg[dom], 4),
+                    'flops_per_launch': w[1], 'note': w[2]}
+        else:
+            ach = w[1] / t_dom * 1e-9
+            roof = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None, 'avg_launch_ms': round(agg[dom], 4),
+                    'bytes_per_launch': w[1], 'note': w[2]}
+        pmc, src = load_pmc()
+        if pmc and (args.batch, args.nc, args.m, args.D) == (32, 2048, 32768, 256) and dom in pmc:
+            roof['traffic'] = pmc[dom]['bytes']
+            roof['traffic_source'] = '%s (FETCH_SIZE%s + WRITE_SIZE, separate rocprofv3 --pmc passes)' % (
+                src, ' x2 (gfx950 wide-load correction)' if pmc[dom].get('fetch_x2') else '')
+    return roof, per
+
+
+def cpu_baseline(args, assets, budget_s, habitat=False):
     """Oracle fitting iterations on the host cores: bounded sample of the SAME workload (same B, m, n_c, D)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import psi_oracle as O
     from psi_release_amd import synth
     smplx, vposer, scene = assets
     ncpu = os.cpu_count() or 1
+    kw = {'contact_const': 1.0} if habitat else {}
     fo = O.FittingOracle(O.SMPLXOracle(smplx), vposer, scene.verts, scene.sdf, scene.grid_min, scene.grid_max,
-                         synth.contact_ids_from_parts(scene.contact_parts), args.batch)
+                         synth.contact_ids_from_parts(scene.contact_parts), args.batch, **kw)
     bodies = synth.make_bodies(11, args.batch)
     xh = synth.body_vector_72(bodies)
     # the oracle is memory/NUMA sensitive: all cores of a 256-thread host are ~200x SLOWER than 16 threads.  Report the
@@ -164,13 +293,155 @@ def cpu_baseline(args, assets, budget_s):
                       % (n, args.batch, args.nc, args.m, args.D, el, cands, ncpu)}
 
 
+def bench_fitting(args):
+    import torch
+    from psi_release_amd import dist as pd
+    habitat = args.workload == 'fitting_habitat'
+    # RCCL (backend 'nccl') over xGMI; PSI_DIST_BACKEND=gloo lets a single-GPU box exercise the N>1 code path
+    backend = os.environ.get('PSI_DIST_BACKEND', 'nccl')
+    rank, local_rank, world = pd.init_from_env(backend)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path is the only implementation')
+    ndev = torch.cuda.device_count()
+    if world > ndev and backend == 'nccl':
+        raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible (one rank per GPU over RCCL)' % (world, ndev))
+    local_rank = local_rank % ndev
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    from psi_release_amd import fitting
+    args.engine_resolved = ('fused' if getattr(fitting, 'HAS_FUSED_ENGINE', False) else 'modular') if args.engine == 'auto' else args.engine
+
+    if habitat:
+        ops, runners = [], []
+        assets0 = None
+        for r in range(ROOMS):
+            op, bodies, assets = make_op(args, rank, device, scene_seed=r, habitat=True, assets=assets0[:2] if assets0 else None)
+            assets0 = assets0 or assets
+            ops.append(op)
+            runners.append(op.make_step_runner(bodies))
+        op, runner, assets = ops[0], runners[0], assets0
+
+        def run_steps(n):                                     # K steps of the sweep: the rooms take turns, K/7 iterations each
+            base, extra = divmod(n, ROOMS)
+            for r in range(ROOMS):
+                k = base + (1 if r < extra else 0)
+                if k:
+                    runners[r].steps(k)
+    else:
+        op, bodies, assets = make_op(args, rank, device)
+        runner = op.make_step_runner(bodies)                  # everything resident in HBM from here on
+        runners = [runner]
+        # steps(n) = n fitting iterations, exactly what FittingOP.fitting runs for num_iter = n (single process: device-resident
+        # graphs of 10 iterations + single-iteration graphs for the remainder; data parallel: forward / all-reduce / backward)
+        run_steps = runner.steps
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    times = timed_blocks(run_steps, barrier, args.steps, args.warmup, world, device, args.repeats, args.min_timed_s)
+    summ, med = summarize(times, args.steps)
+    losses = runners[-1].last_losses() if habitat else runner.last_losses()
+    rccl_world = torch.distributed.get_world_size() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+    per_rank_ms = None
+    if world > 1:                                             # per-rank local view of the median block (no max-reduction)
+        t = torch.zeros(world, device=device, dtype=torch.float64)
+        t[rank] = med / args.steps * 1e3
+        torch.distributed.all_reduce(t)
+        per_rank_ms = [round(float(x), 4) for x in t.tolist()]
+
+    out = None
+    if rank == 0:
+        if habitat:
+            metric = 'fitting iters/sec (SMPL-X+SDF+Chamfer), MP3D-R 7-room sweep batch=%d per GPU' % args.batch
+            wl = ('fitting_habitat sweep over %d synthetic rooms (contact constant 1.0, Habitat camera flip): one Adam fitting iteration per step, '
+                  'batch=%d bodies per GPU, V=10475, n_c=%d, m=%d, SDF %d^3 per room (BASELINE configs[4])' % (ROOMS, args.batch, args.nc, args.m, args.D))
+        else:
+            metric = 'fitting iters/sec (SMPL-X+SDF+Chamfer), PROX-E batch=32'
+            wl = ('fitting_proxe 100-iter loop: one Adam fitting iteration per step, batch=%d bodies per GPU, V=10475, n_c=%d, m=%d, SDF %d^3, '
+                  'synthetic SMPL-X/VPoser/scene (BASELINE configs[%d])' % (args.batch, args.nc, args.m, args.D, 3 if world >= 8 else 1))
+        out = {
+            'metric': metric, 'value': round(world / (med / args.steps), 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': wl, 'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'engine': args.engine_resolved,
+                       'nn': op.nn_mode, 'parallelism': 'dp%d (rows sharded, one 6-float all-reduce per iteration)' % world,
+                       'rccl_world_size': rccl_world, 'backend': backend if world > 1 else 'none (single process)',
+                       'launcher': 'bench.py self-spawn' if os.environ.get('PSI_BENCH_SPAWNED') == '1' else ('torchrun' if world > 1 else 'direct'),
+                       'protocol': 'median of %d blocks of %d steps (barrier + synchronize around each, max over ranks)' % (summ['repeats'], args.steps),
+                       'final_losses': [round(float(x), 6) for x in losses]},
+        }
+        out.update(summ)
+        if per_rank_ms:
+            out['per_rank_ms_per_step'] = per_rank_ms
+        # ---- per-kernel times of one iteration: HIP events recorded on the launch stream after every kernel launch
+        work = kernel_work(args)
+        roof = None
+        if args.engine_resolved == 'fused' and world == 1:
+            kernels = runner.eng.profile(30)
+            agg = {}
+            for nm, ms in kernels:
+                agg[nm] = agg.get(nm, 0.0) + ms
+            out['kernels_us'] = {k: round(v * 1e3, 2) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])}
+            roof, per = roofline_from_kernels(args, agg, work)
+            out['kernel_bandwidth'] = per
+            alg = 131.7e6 + args.batch * 1.76e6                    # algorithmic bytes of the whole iteration
+            out['iteration_roofline'] = {'bound': 'hbm', 'algorithmic_bytes': alg, 'achieved': round(alg / (med / args.steps) * 1e-9, 1),
+                                         'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(alg / (med / args.steps) * 1e-9 / PEAK_HBM_GBS, 4)}
+        if world == 1 and not habitat:
+            t_ch = time_chamfer_kernel(op, args)
+            flops = 8.0 * args.batch * args.nc * args.m
+            out['roofline_bruteforce_nn'] = {
+                'bound': 'mfma', 'kernel': 'nn_partial_kernel + nn_resolve_kernel (brute-force Chamfer NN op, fp32 VALU)',
+                'achieved': round(flops / t_ch * 1e-12, 2), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(flops / t_ch * 1e-12 / PEAK_FP32_TFLOPS, 4), 'avg_launch_ms': round(t_ch * 1e3, 4), 'flops_per_launch': flops,
+                'note': 'fp32 vector peak == fp32 MFMA peak on gfx950; 8 flop/pair without FMA contraction caps the fraction near 8/18'}
+            if roof is None:
+                roof = dict(out['roofline_bruteforce_nn'], traffic=None)
+        if roof is not None:
+            out['roofline'] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(args, assets, args.cpu_seconds, habitat)
+            except Exception as e:  # the oracle needs gcc; report rather than fail the GPU number
+                out['cpu_baseline'] = {'value': None, 'unit': 'iters/s', 'cores': os.cpu_count(), 'kind': 'port',
+                                       'sample': 'failed: %r' % (e,)}
+    # free the fitting state before the secondary measurement
+    del runners, runner, op
+    if habitat:
+        del ops
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if world == 1 and not habitat and args.secondary and (args.batch, args.nc, args.m, args.D) == (32, 2048, 32768, 256):
+            try:
+                import contextlib
+                import io
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    sec = bench_train_s2(argparse.Namespace(**dict(vars(args), batch=128, steps=10, warmup=3, repeats=5, min_timed_s=0.3)))
+                sys.stderr.write(buf.getvalue())
+                out['secondary'] = {'train_s2': sec}
+            except Exception as e:
+                out['secondary'] = {'train_s2': {'error': repr(e)}}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# train_s2 (BASELINE configs[2])
+# ----------------------------------------------------------------------------------------------------------------------
 def bench_train_s2(args):
-    """Secondary workload (BASELINE configs[2]): train_s2.py optimiser steps at batch 128 on synthetic PROX-shaped data
-    (two scenes with 256^3 SDFs held once in HBM, indirect scene ids), CVAE trunk on the matrix cores via MIOpen/hipBLASLt."""
+    """train_s2.py optimiser steps at batch 128 on synthetic PROX-shaped data (two scenes with 256^3 SDFs held once in HBM,
+    indirect scene ids), CVAE trunk on the matrix cores.  Returns the result dict (same keys as the main line)."""
     import tempfile
+    import numpy as np
+    import torch
     from psi_release_amd import batch_gen, synth, training
-    dev = torch.device('cuda', 0)
-    B = 128 if args.batch == 32 else args.batch
+    dev = torch.device('cuda', torch.cuda.current_device())
+    B = args.batch
     names = ['SynA', 'SynB']
     sd = {n: synth.make_scene(i, args.m, args.D, args.nc) for i, n in enumerate(names)}
     scenes = {n: {'verts': s.verts, 'sdf': s.sdf, 'grid_min': s.grid_min, 'grid_max': s.grid_max, 'grid_dim': s.grid_dim} for n, s in sd.items()}
@@ -197,150 +468,58 @@ def bench_train_s2(args):
             d = bg.next_batch(B)
             if d is not None:
                 batches.append(d)
-        step = lambda i: op.train_step(batches[i % len(batches)], ep=9)       # ep > 0.75*epoch: scene losses active
-        for i in range(args.warmup):
-            step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    print(json.dumps({'metric': 'train_s2 optimiser steps/sec (HumanCVAES2 + SMPL-X + Chamfer + SDF), batch=%d' % B,
-                      'value': round(args.steps / dt, 3), 'unit': 'steps/s', 'samples_per_s': round(args.steps * B / dt, 1), 'n_gpus': 1,
-                      'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-                      'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 trunk / f32 losses' if args.bf16 else 'f32', 'data': 'synthetic',
-                      'config': {'workload': 'train_s2.py step, batch=%d, 2 scenes (m=%d, SDF %d^3, indirect scene ids), n_c=%d (BASELINE configs[2])'
-                                             % (B, args.m, args.D, args.nc), 'hip_graph': bool(args.graph)}}))
+        # matrix-core flops of one step (forward + backward of the PyTorch trunk; the HIP body/scene operators are not GEMMs)
+        flops = None
+        try:
+            from torch.utils.flop_counter import FlopCounterMode
+            with FlopCounterMode(display=False) as fc:
+                op.optimizer_h.zero_grad(set_to_none=True)
+                sum(op._losses_from_batch(batches[0], 9)).backward()
+            flops = float(fc.get_total_flops())
+            op.optimizer_h.zero_grad(set_to_none=True)
+        except Exception:
+            pass
+        cnt = [0]
+
+        def run_steps(k):
+            for _ in range(k):
+                op.train_step(batches[cnt[0] % len(batches)], ep=9)       # ep > 0.75*epoch: scene losses active
+                cnt[0] += 1
+
+        times = timed_blocks(run_steps, torch.cuda.synchronize, args.steps, args.warmup, 1, dev, args.repeats, args.min_timed_s, ramp_s=0.2)
+        summ, med = summarize(times, args.steps)
+    spp = med / args.steps
+    res = {'metric': 'train_s2 optimiser steps/sec (HumanCVAES2 + SMPL-X + Chamfer + SDF), batch=%d' % B,
+           'value': round(1.0 / spp, 3), 'unit': 'steps/s', 'samples_per_s': round(B / spp, 1), 'n_gpus': 1,
+           'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 trunk / f32 losses' if args.bf16 else 'f32', 'data': 'synthetic',
+           'config': {'workload': 'train_s2.py step, batch=%d, 2 scenes (m=%d, SDF %d^3, indirect scene ids), n_c=%d (BASELINE configs[2])'
+                                  % (B, args.m, args.D, args.nc), 'hip_graph': bool(args.graph)}}
+    res.update(summ)
+    if flops:
+        ach = flops / spp * 1e-12
+        res['roofline'] = {'bound': 'mfma', 'kernel': 'whole optimiser step (CVAE trunk GEMMs/convs, forward + backward)', 'achieved': round(ach, 2),
+                           'peak': PEAK_BF16_TFLOPS if args.bf16 else PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': round(ach / (PEAK_BF16_TFLOPS if args.bf16 else PEAK_FP32_TFLOPS), 5), 'flops_per_step': flops, 'traffic': None,
+                           'note': 'matrix-core flops counted by torch.utils.flop_counter over one forward+backward; a step is a chain of small '
+                                   '(128-row) GEMMs/convs and elementwise glue, bound by launch count and activation traffic, not by the MFMA pipe'}
+    return res
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        sys.exit(spawn_ranks(args))
     if args.workload == 'train_s2':
-        import contextlib, io
+        import contextlib
+        import io
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):                 # the trainer's [INFO] lines go to stderr: stdout carries ONE JSON line
-            bench_train_s2(args)
-        lines = buf.getvalue().splitlines()
-        sys.stderr.write('\n'.join(lines[:-1]) + '\n')
-        print(lines[-1])
+            res = bench_train_s2(args)
+        sys.stderr.write(buf.getvalue())
+        print(json.dumps(res))
         return
-    from psi_release_amd import dist as pd
-    # RCCL (backend 'nccl') over xGMI; PSI_DIST_BACKEND=gloo lets a single-GPU box exercise the N>1 code path
-    rank, local_rank, world = pd.init_from_env(os.environ.get('PSI_DIST_BACKEND', 'nccl'))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the HIP path is the only implementation')
-    local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
-    from psi_release_amd import fitting
-    args.engine_resolved = ('fused' if getattr(fitting, 'HAS_FUSED_ENGINE', False) else 'modular') if args.engine == 'auto' else args.engine
-
-    op, bodies, assets = make_op(args, rank, device)
-    runner = op.make_step_runner(bodies)          # everything resident in HBM from here on
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    # steps(n) = n fitting iterations, exactly what FittingOP.fitting runs for num_iter = n (the fused engine replays them as
-    # device-resident graphs of 10 iterations + single-iteration graphs for the remainder)
-    runner.steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    runner.steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    losses = runner.last_losses()
-
-    out = None
-    if rank == 0:
-        # ---- per-kernel times of one iteration: HIP events recorded on the launch stream after every kernel launch
-        kernels = None
-        if args.engine_resolved == 'fused' and world == 1:
-            kernels = runner.eng.profile(20)
-        work = kernel_work(args, op)
-        t_ch = time_chamfer_kernel(op, args)
-        flops = 8.0 * args.batch * args.nc * args.m
-        bf = {'bound': 'mfma', 'kernel': 'nn_partial_kernel + nn_resolve_kernel (brute-force Chamfer NN op, fp32 VALU)',
-              'achieved': round(flops / t_ch * 1e-12, 2), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-              'frac': round(flops / t_ch * 1e-12 / PEAK_FP32_TFLOPS, 4), 'avg_launch_ms': round(t_ch * 1e3, 4), 'flops_per_launch': flops,
-              'note': 'fp32 vector peak == fp32 MFMA peak on gfx950; 8 flop/pair without FMA contraction caps the fraction near 8/18'}
-        roof = dict(bf, traffic=None)
-        kernels_us = None
-        if kernels:
-            agg = {}
-            for nm, ms in kernels:
-                agg[nm] = agg.get(nm, 0.0) + ms
-            kernels_us = {k: round(v * 1e3, 2) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])}
-            dom = max(agg, key=agg.get)
-            w = work.get(dom)
-            if w is not None:
-                t_dom = agg[dom] * 1e-3
-                if w[0] == 'flop':
-                    ach = w[1] / t_dom * 1e-12
-                    roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': round(ach / PEAK_FP32_TFLOPS, 4), 'traffic': None, 'avg_launch_ms': round(agg[dom], 4),
-                            'flops_per_launch': w[1], 'note': w[2]}
-                else:
-                    ach = w[1] / t_dom * 1e-9
-                    roof = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                            'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None, 'avg_launch_ms': round(agg[dom], 4),
-                            'bytes_per_launch': w[1], 'note': w[2]}
-        # HBM traffic per launch from the committed PMC collection (profiles/r01_pmc_traffic.json; rocprofv3 --pmc cannot run
-        # inside this process).  Only attached for the default shape the counters were collected on.
-        pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(pmc_path) and (args.batch, args.nc, args.m, args.D) == (32, 2048, 32768, 256):
-            pmc = json.load(open(pmc_path))
-            kn = roof.get('kernel', '').split(' ')[0]
-            if kn in pmc:
-                roof['traffic'] = pmc[kn]['bytes']
-                roof['traffic_source'] = 'profiles/r01_pmc_traffic.json (FETCH_SIZE%s + WRITE_SIZE, separate rocprofv3 --pmc passes)' % (
-                    ' x2 (gfx950 wide-load correction)' if pmc[kn]['fetch_x2'] else '')
-        out = {
-            'metric': 'fitting iters/sec (SMPL-X+SDF+Chamfer), PROX-E batch=32',
-            'value': round(world * args.steps / dt, 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'fitting_proxe 100-iter loop: one Adam fitting iteration per step, batch=%d bodies per GPU, '
-                                   'V=10475, n_c=%d, m=%d, SDF %d^3, synthetic SMPL-X/VPoser/scene (BASELINE configs[1])'
-                                   % (args.batch, args.nc, args.m, args.D),
-                       'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'engine': args.engine_resolved,
-                       'nn': op.nn_mode,
-                       'parallelism': 'dp%d (rows sharded, one 6-float all-reduce per iteration)' % world,
-                       'final_losses': [round(float(x), 6) for x in losses]},
-            'roofline': roof,
-        }
-        if kernels_us:
-            out['kernels_us'] = kernels_us
-            out['roofline_bruteforce_nn'] = bf
-            # the largest HBM-streaming kernel, reported next to the dominant one
-            if 'blend_fwd_kernel' in agg and roof.get('kernel') != 'blend_fwd_kernel':
-                w = work['blend_fwd_kernel']
-                ach = w[1] / (agg['blend_fwd_kernel'] * 1e-3) * 1e-9
-                out['roofline_hbm_stream'] = {'bound': 'hbm', 'kernel': 'blend_fwd_kernel', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS,
-                                              'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4), 'bytes_per_launch': w[1],
-                                              'avg_launch_ms': round(agg['blend_fwd_kernel'], 4), 'note': w[2]}
-                if os.path.exists(pmc_path) and (args.batch, args.nc, args.m, args.D) == (32, 2048, 32768, 256):
-                    out['roofline_hbm_stream']['traffic'] = json.load(open(pmc_path))['blend_fwd_kernel']['bytes']
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out['cpu_baseline'] = cpu_baseline(args, assets, args.cpu_seconds)
-            except Exception as e:  # the oracle needs gcc; report rather than fail the GPU number
-                out['cpu_baseline'] = {'value': None, 'unit': 'iters/s', 'cores': os.cpu_count(), 'kind': 'port',
-                                       'sample': 'failed: %r' % (e,)}
-        print(json.dumps(out))
-        sys.stdout.flush()
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+    bench_fitting(args)
 
 
 if __name__ == '__main__':

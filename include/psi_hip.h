@@ -175,6 +175,10 @@ int psi_fit_iterate(psi_fit_engine *engine, int n_iter, int use_graph, void *str
  * (l_rec, l_vposer, l_contact, l_collision as printed by fitting_proxe.py:184-186) to device buffers;
  * h_step (host, nullable) receives the Adam step count and forces a stream sync. */
 int psi_fit_read(psi_fit_engine *engine, float *d_x_out, float *d_history_out, int n_hist, int *h_step, void *stream);
+/* The four loss values recorded by Adam step `adam_step` (1-based; the row (adam_step-1) % max_history of the ring) -> d_out4
+ * (device, 4 floats): what the reference prints per iteration (fitting_proxe.py:184-186) without copying the whole ring.
+ * The caller must not ask for a step more than max_history steps in the past (the ring has wrapped). */
+int psi_fit_read_losses(psi_fit_engine *engine, int adam_step, float *d_out4, void *stream);
 /* Differentiable body decode of the CVAE training losses: x75 [B,75] = [transl | 6D global rot | betas 10 | VPoser latent 32 |
  * hand PCA 12+12] -> camera-frame vertices [B,V,3].  One call replaces the reference's chain
  *   convert_to_3D_rot (cvae.py:117-139) -> body_params_encapsulate_batch (cvae.py:221-251) -> vposer.decode(..., 'aa')

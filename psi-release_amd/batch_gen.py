@@ -48,7 +48,13 @@ def _read_table(path):
 
 class BatchGeneratorWithSceneMesh:
     def __init__(self, dataset_path, device, scene_verts_path, scene_sdf_path, mode='train', read_all_to_ram=True,
-                 indirect_sdf=False, scene_name_list=None, scene_sub_list=None, _tables=None, _scenes=None):
+                 indirect_sdf=False, scene_name_list=None, scene_sub_list=None, _tables=None, _scenes=None,
+                 rank=0, world=1, seed=None):
+        # rank / world / seed (new; the reference is single-process): with world > 1 every rank shuffles the SAME full index list
+        # with a shared seeded generator and keeps the slice [rank::world], truncated to equal length, so all ranks run the same
+        # number of optimiser steps (and of gradient all-reduces) per epoch.
+        self.rank, self.world = int(rank), int(world)
+        self._rng = random.Random(0 if seed is None else seed) if (self.world > 1 or seed is not None) else random
         self.device = torch.device(device)
         self.index_rec = 0
         self.indirect_sdf = indirect_sdf
@@ -66,11 +72,14 @@ class BatchGeneratorWithSceneMesh:
         if mode != 'all':
             sub = scene_sub_list or (PROX_TRAIN if mode == 'train' else PROX_TEST)
             sub_id = [self.scene_name_list.index(x) for x in sub if x in self.scene_name_list]
-            self.index = [i for i in range(n_all) if int(self.sceneid_stream[i]) in sub_id]
-            random.shuffle(self.index)
+            self._full_index = [i for i in range(n_all) if int(self.sceneid_stream[i]) in sub_id]
+            self._rng.shuffle(self._full_index)
+            if 0 in self._full_index:
+                self._full_index.remove(0)        # batch_gen_hdf5.py:121-122: with the placeholder row already stripped (read_all_to_ram /
+                                                  # list-of-files, :58-64,:84-98) this drops the first REAL sample; kept for index parity
         else:
-            self.index = list(range(n_all))
-        self.n_samples = len(self.index)
+            self._full_index = list(range(n_all))
+        self._take_shard()
         print('[INFO][BatchGeneratorWithSceneMesh] n_samples={:d}'.format(self.n_samples))
         # ---- scenes: uploaded once
         if _scenes is None:
@@ -102,10 +111,18 @@ class BatchGeneratorWithSceneMesh:
         return cls(None, device, None, None, mode=mode, _tables=[table], _scenes=scenes,
                    scene_name_list=kw.pop('scene_name_list', list(scenes.keys())), **kw)
 
+    def _take_shard(self):
+        if self.world > 1:
+            per = len(self._full_index) // self.world
+            self.index = self._full_index[self.rank::self.world][:per]
+        else:
+            self.index = self._full_index
+        self.n_samples = len(self.index)
+
     def reset(self):
         self.index_rec = 0
-        random.shuffle(self.index)
-        self.n_samples = len(self.index)
+        self._rng.shuffle(self._full_index)
+        self._take_shard()
         print('[INFO][BatchGeneratorWithSceneMesh] reset dataset')
 
     def has_next_batch(self):

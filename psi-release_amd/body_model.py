@@ -68,6 +68,14 @@ class _LbsFn(Function):
         betas = betas.contiguous().float()
         pose = pose.contiguous().float()
         B = betas.shape[0]
+        if tuple(betas.shape) != (B, model.NB) or tuple(pose.shape) != (B, model.J * 3):
+            raise ValueError('lbs: betas must be [B,%d] and pose [B,%d], got %s / %s' % (model.NB, model.J * 3, tuple(betas.shape), tuple(pose.shape)))
+        if transl is not None and tuple(transl.shape) != (B, 3):
+            raise ValueError('lbs: transl must be [%d,3], got %s' % (B, tuple(transl.shape)))
+        if cam_ext is not None:
+            if cam_ext.dim() != 3 or tuple(cam_ext.shape[1:]) != (4, 4) or cam_ext.shape[0] not in (1, B):
+                raise ValueError('lbs: cam_ext must be [%d,4,4] or [1,4,4], got %s' % (B, tuple(cam_ext.shape)))
+            cam_ext = cam_ext.expand(B, 4, 4)
         transl_c = transl.contiguous().float() if transl is not None else None
         cam_c = cam_ext.contiguous().float() if cam_ext is not None else None
         verts = torch.empty(B, model.V, 3, device=betas.device)

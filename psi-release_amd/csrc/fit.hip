@@ -916,6 +916,14 @@ extern "C" int psi_fit_read(psi_fit_engine *e, float *d_x_out, float *d_history_
     return 0;
 }
 
+extern "C" int psi_fit_read_losses(psi_fit_engine *e, int adam_step, float *d_out4, void *stream)
+{
+    PSI_REQUIRE(e && d_out4 && adam_step >= 1, "bad arguments");
+    FitDev &f = e->d;
+    PSI_CHECK_HIP(hipMemcpyAsync(d_out4, f.history + (size_t)((adam_step - 1) % f.max_hist) * 4, 16, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int psi_fit_copy_buffer(psi_fit_engine *e, const char *name, float *d_out, long n_floats, void *stream)
 {
     PSI_REQUIRE(e && name && d_out && n_floats >= 0, "bad arguments");

@@ -49,6 +49,26 @@ def init_from_env(backend=None):
     return rk, lrk, ws
 
 
+def assert_equal_across_ranks(value, what='value'):
+    """The global-batch normalisers are B * world: every rank must hold the same number of rows."""
+    if not is_dist():
+        return
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor([float(value), -float(value)], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if float(t[0]) != float(value) or -float(t[1]) != float(value):
+        raise ValueError('%s differs across ranks (this rank: %s, max %s, min %s): shard the rows evenly' % (what, value, float(t[0]), -float(t[1])))
+
+
+def gather_rows(x):
+    """[b,...] per rank -> [b*world,...] on every rank, rank order (rows were sharded contiguously by shard_rows)."""
+    if not is_dist():
+        return x
+    parts = [torch.empty_like(x) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, x.contiguous())
+    return torch.cat(parts, dim=0)
+
+
 def shard_rows(n_rows, r=None, w=None):
     """Contiguous row range of rank r: rows [lo, hi)."""
     r = rank() if r is None else r

@@ -36,6 +36,14 @@ from .vposer import load_vposer
 HAS_FUSED_ENGINE = True
 
 
+def expand_cam_ext(cam_ext, B):
+    """cam_ext as [B,4,4]: the reference's PROX-E pkls carry ONE camera [1,4,4] that broadcasts over the batch
+    (verts_transform, cvae.py:141-149); anything else must already have B rows."""
+    if cam_ext.dim() != 3 or tuple(cam_ext.shape[1:]) != (4, 4) or cam_ext.shape[0] not in (1, B):
+        raise ValueError('cam_ext must be [%d,4,4] or [1,4,4], got %s' % (B, tuple(cam_ext.shape)))
+    return cam_ext.expand(B, 4, 4).contiguous() if cam_ext.shape[0] != B else cam_ext
+
+
 class FittingOP:
     contact_const = 0.01            # fitting_proxe.py:139; fitting_habitat.py:141 uses 1.0
     flip_camera_yz = False          # fitting_habitat.py:179-184
@@ -47,6 +55,8 @@ class FittingOP:
         self.dp_use_graph = False       # data-parallel sequence: half-graphs around the all-reduce instead of plain launches
         self.nn_mode = 'kdtree'          # 'kdtree' (exact index over the static scene cloud) | 'bruteforce'
         self.reset_optimizer = False
+        self.data_parallel = None        # None: rows are sharded over the ranks whenever torch.distributed runs with > 1 rank;
+                                         # False: this instance fits its own independent batch (file-sharded scripts)
         for key, val in fittingconfig.items():
             setattr(self, key, val)
         for key, val in lossconfig.items():
@@ -89,6 +99,12 @@ class FittingOP:
         self._chamfer = ops.chamferDist(one_sided=True)
 
     # ---------------------------------------------------------------------------------------
+    def dp_world(self):
+        """Number of ranks that share this batch's loss normalisers (1 = an independent batch)."""
+        if self.data_parallel is False:
+            return 1
+        return psi_dist.world_size()
+
     def contact_vertex_ids(self):
         if self._vid is None:
             if self._contact_parts is not None:
@@ -126,7 +142,7 @@ class FittingOP:
 
         body_sdf_batch = ops.sdf_sample(body_verts_batch, self.s_sdf, self.s_grid_min_batch, self.s_grid_max_batch,
                                         scene_id=None, align_corners=self.align_corners)
-        if psi_dist.is_dist():
+        if self.dp_world() > 1:
             # data-parallel batch: global-batch normalisers through ONE all-reduce (dist.py)
             loss_rec, loss_vposer, loss_contact, pen = psi_dist.fitting_loss_reduce(loss_rec, loss_vposer, loss_contact,
                                                                                   body_sdf_batch)
@@ -190,7 +206,10 @@ class _ModularRunner:
     """One fitting iteration = zero_grad, cal_loss, backward, Adam step (autograd over the HIP operators)."""
 
     def __init__(self, op, xhr, cam):
-        self.op, self.xhr, self.cam = op, xhr, cam
+        if tuple(xhr.shape) != (op.batch_size, 75):
+            raise ValueError('FittingOP was built for batch_size=%d: expected body vectors of shape (%d, 75), got %s'
+                             % (op.batch_size, op.batch_size, tuple(xhr.shape)))
+        self.op, self.xhr, self.cam = op, xhr, expand_cam_ext(cam, op.batch_size)
         self._losses = None
 
     def step(self):
@@ -231,8 +250,10 @@ class FusedEngine:
         pm = f32(bm.pose_mean.cpu().numpy())
         vid = np.ascontiguousarray(op.contact_vertex_ids().cpu().numpy(), dtype=np.int32)
         gmin, gmax = f32(op.s_grid_min_batch.cpu().numpy().reshape(3)), f32(op.s_grid_max_batch.cpu().numpy().reshape(3))
-        world = psi_dist.world_size()
+        world = op.dp_world() if hasattr(op, 'dp_world') else 1
         self.world = world
+        if world > 1:
+            psi_dist.assert_equal_across_ranks(op.batch_size, 'per-rank batch size')   # the normalisers are B * world
         cfg = hip.FitConfig(B=op.batch_size, n_contact=len(vid), m_scene=op.s_verts.shape[1], D=op.s_sdf.shape[1],
                             align_corners=int(bool(op.align_corners)), world_size=world, num_pca_comps=lhc.shape[0],
                             max_history=4096, nn_mode=1 if op.nn_mode == 'kdtree' else 0, w_rec=op.weight_loss_rec, w_vposer=op.weight_loss_vposer,
@@ -251,6 +272,11 @@ class FusedEngine:
         self.max_history = 4096
 
     def set_problem(self, xhr, x_init, cam, reset):
+        B = self.op.batch_size
+        if tuple(xhr.shape) != (B, 75) or tuple(x_init.shape) != (B, 75):
+            raise ValueError('FusedEngine was built for batch_size=%d: expected body vectors of shape (%d, 75), got %s / %s (a generated-body '
+                             'pkl must hold batch_size rows)' % (B, B, tuple(xhr.shape), tuple(x_init.shape)))
+        cam = expand_cam_ext(cam, B)
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
         self._args = (xhr.contiguous(), x_init.contiguous(), cam.contiguous())
@@ -284,6 +310,13 @@ class FusedEngine:
                   'psi_fit_read')
         torch.cuda.current_stream().wait_stream(self.stream)
         return x, hist[:n_hist], step.value
+
+    def read_losses(self, adam_step):
+        """The four loss values of Adam step ``adam_step`` (one 16-byte copy, not the whole history ring)."""
+        out = torch.empty(4, device=self.op.device)
+        hip.check(hip.lib().psi_fit_read_losses(self.handle, int(adam_step), hip.ptr(out), self.stream.cuda_stream), 'psi_fit_read_losses')
+        self.stream.synchronize()
+        return out
 
     def profile(self, n_rep=20):
         """{kernel name: average ms} of one iteration, HIP events on the launch stream (psi_fit_profile)."""
@@ -340,8 +373,9 @@ class _FusedRunner:
 
     def last_losses(self):
         idx = self.step0 + self.n                       # Adam step count after the last step
-        _, hist, _ = self.eng.read(self.eng.max_history)
-        return [float(v) for v in hist[(idx - 1) % self.eng.max_history].cpu()]
+        if idx < 1:
+            return [float('nan')] * 4
+        return [float(v) for v in self.eng.read_losses(idx).cpu()]
 
     def finish(self):
         x, _, _ = self.eng.read(0)
@@ -371,7 +405,8 @@ class BodyDecoder:
             device=dev, vposer=vposer, body_mesh_model=body_mesh_model, batch_size=batch_size, align_corners=True, nn_mode='bruteforce',
             contact_vertex_ids=lambda: torch.zeros(1, dtype=torch.int64), s_verts=torch.zeros(1, 8, 3, device=dev),
             s_sdf=torch.ones(1, 2, 2, 2, device=dev), s_grid_min_batch=torch.full((1, 3), -1.0), s_grid_max_batch=torch.full((1, 3), 1.0),
-            weight_loss_rec=0.0, weight_loss_vposer=0.0, weight_contact=0.0, weight_collision=0.0, contact_const=1.0, init_lr_h=0.0)
+            weight_loss_rec=0.0, weight_loss_vposer=0.0, weight_contact=0.0, weight_collision=0.0, contact_const=1.0, init_lr_h=0.0,
+            dp_world=lambda: 1)
         self.engine = FusedEngine(shim)
         self.batch_size = batch_size
         self.V = int(body_mesh_model.lbs_model.V) if hasattr(body_mesh_model.lbs_model, 'V') else 10475
@@ -387,7 +422,7 @@ class _BodyDecodeFn(torch.autograd.Function):
         if x75.shape != (dec.batch_size, 75):
             raise ValueError('BodyDecoder was built for x75 of shape (%d, 75), got %s' % (dec.batch_size, tuple(x75.shape)))
         x = x75.detach().contiguous().float()
-        cam = cam_ext.detach().contiguous().float()
+        cam = expand_cam_ext(cam_ext.detach(), dec.batch_size).contiguous().float()
         verts = torch.empty(dec.batch_size, dec.V, 3, device=x.device)
         hip.check(hip.lib().psi_fit_decode_forward(dec.engine.handle, hip.ptr(x), hip.ptr(cam), hip.ptr(verts), hip.stream()),
                   'psi_fit_decode_forward')

@@ -46,6 +46,7 @@ SIGNATURES = {
     'psi_fit_backward_step': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'psi_fit_iterate': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'psi_fit_read': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'psi_fit_read_losses': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     'psi_fit_decode_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'psi_fit_decode_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'psi_fit_profile': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),

@@ -64,6 +64,6 @@ def main(stage, argv=None):
         bg = batch_gen.BatchGeneratorWithSceneMesh(dataset_path=files, scene_verts_path=os.path.join(a.dataset_path, 'scenes_downsampled'),
                                                    scene_sdf_path=os.path.join(a.dataset_path, 'scenes_sdf'),
                                                    mode='all' if a.use_all == 1 else 'train', device=device, read_all_to_ram=True,
-                                                   indirect_sdf=True)
+                                                   indirect_sdf=True, rank=psi_dist.rank(), world=psi_dist.world_size(), seed=0)
     cls = training.TrainOP if stage == 's1' else training.TrainOPS2
     cls(trainconfig, lossconfig).train(bg)

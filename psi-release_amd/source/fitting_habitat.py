@@ -26,30 +26,34 @@ def main(argv=None):
     ap.add_argument('--engine', default='fused', choices=['fused', 'modular'])
     ap.add_argument('--verbose', action='store_true')
     ap.add_argument('--synthetic', default=None)
+    ap.add_argument('--batch_size', type=int, default=1, help='bodies per pkl (reference: 1; BASELINE configs[4]: 512 over 8 GPUs)')
+    ap.add_argument('--shard', default='files', choices=['files', 'rows'], help='under torchrun: shard the pkl files or the rows of every batch')
     a = ap.parse_args(argv)
+    rank, world = _common.dist_setup()
     extra = {}
     if a.synthetic:
-        root, a.gen_path, extra['smplx_data'], extra['vposer_state'] = _common.synthetic_prox_tree(a.synthetic, a.scenes, batch=1)
+        if rank == 0:
+            _common.synthetic_prox_tree(a.synthetic, a.scenes, batch=a.batch_size)
+        if world > 1:
+            torch.distributed.barrier()
+        root, a.gen_path, extra['smplx_data'], extra['vposer_state'] = _common.synthetic_prox_tree(a.synthetic, a.scenes, batch=a.batch_size, write=False)
         sdf_dir, ply_dir, a.contact_id_folder = os.path.join(root, 'scenes_sdf'), os.path.join(root, 'scenes_downsampled'), os.path.join(root, 'body_segments')
     else:
         sdf_dir, ply_dir = os.path.join(a.mp3dr_path, 'sdf'), os.path.join(a.mp3dr_path, 'mesh')
     for scenename in a.scenes:
         cfg = {'scene_verts_path': os.path.join(ply_dir, scenename + '.ply'), 'scene_sdf_path': os.path.join(sdf_dir, scenename),
                'human_model_path': a.human_model_path, 'vposer_ckpt_path': a.vposer_ckpt_path, 'init_lr_h': 0.1,
-               'num_iter': a.num_iter, 'batch_size': 1, 'device': torch.device('cuda' if torch.cuda.is_available() else 'cpu'),
+               'num_iter': a.num_iter, 'batch_size': a.batch_size,
+               'device': torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu'),
                'contact_part': ['back', 'butt', 'L_Hand', 'R_Hand', 'L_Leg', 'R_Leg', 'thighs'],
                'contact_id_folder': a.contact_id_folder, 'verbose': a.verbose, 'engine': a.engine}
         cfg.update(extra)
         lossconfig = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1, 'weight_collision': 0.5}
-        fop = FittingOPHabitat(cfg, lossconfig)
-        for ii in range(a.max_files):
-            inp = os.path.join(a.gen_path, scenename + '/body_gen_{:06d}.pkl'.format(ii))
-            if not os.path.exists(inp):
-                continue
-            outp = os.path.join(a.fit_path, scenename + '/body_gen_{:06d}.pkl'.format(ii))
-            if os.path.exists(outp):
-                continue
-            fop.save_result(fop.fitting(inp), outp)
+        _common.fit_files(FittingOPHabitat, cfg, lossconfig, os.path.join(a.gen_path, scenename), os.path.join(a.fit_path, scenename),
+                          a.max_files, a.shard, rank, world)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -30,33 +30,36 @@ def main(argv=None):
     ap.add_argument('--align_corners', type=int, default=1, help='1 = torch 1.2.0 (pinned) semantics of the SDF lookup')
     ap.add_argument('--verbose', action='store_true')
     ap.add_argument('--synthetic', default=None, help='directory to create synthetic stand-in assets in')
+    ap.add_argument('--shard', default='files', choices=['files', 'rows'],
+                    help="under torchrun: 'files' = every rank fits its own pkl files (independent problems); 'rows' = every file's batch is "
+                         "split over the ranks with one all-reduce of the loss normalisers per iteration (BASELINE configs[3])")
     a = ap.parse_args(argv)
+    rank, world = _common.dist_setup()
     extra = {}
     if a.synthetic:
+        if rank == 0:
+            _common.synthetic_prox_tree(a.synthetic, a.scenes, batch=a.batch_size)
+        if world > 1:
+            torch.distributed.barrier()
         a.proxe_path, a.gen_path, extra['smplx_data'], extra['vposer_state'] = _common.synthetic_prox_tree(
-            a.synthetic, a.scenes, batch=a.batch_size)
+            a.synthetic, a.scenes, batch=a.batch_size, write=False)
     for scenename in a.scenes:
         fittingconfig = {
             'scene_verts_path': os.path.join(a.proxe_path, 'scenes_downsampled/' + scenename + '.ply'),
             'scene_sdf_path': os.path.join(a.proxe_path, 'scenes_sdf/' + scenename),
             'human_model_path': a.human_model_path, 'vposer_ckpt_path': a.vposer_ckpt_path,
             'init_lr_h': a.init_lr_h, 'num_iter': a.num_iter, 'batch_size': a.batch_size,
-            'device': torch.device('cuda' if torch.cuda.is_available() else 'cpu'),
+            'device': torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu'),
             'contact_part': ['back', 'butt', 'L_Hand', 'R_Hand', 'L_Leg', 'R_Leg', 'thighs'],
             'contact_id_folder': os.path.join(a.proxe_path, 'body_segments'), 'verbose': a.verbose,
             'engine': a.engine, 'align_corners': bool(a.align_corners)}
         fittingconfig.update(extra)
         lossconfig = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1, 'weight_collision': 0.5}
-        fop = FittingOP(fittingconfig, lossconfig)
-        for ii in range(a.max_files):
-            input_data_file = os.path.join(a.gen_path, scenename + '/body_gen_{:06d}.pkl'.format(ii))
-            if not os.path.exists(input_data_file):
-                continue
-            output_data_file = os.path.join(a.fit_path, scenename + '/body_gen_{:06d}.pkl'.format(ii))
-            if os.path.exists(output_data_file):
-                continue
-            xh_rec = fop.fitting(input_data_file)
-            fop.save_result(xh_rec, output_data_file)
+        _common.fit_files(FittingOP, fittingconfig, lossconfig, os.path.join(a.gen_path, scenename), os.path.join(a.fit_path, scenename),
+                          a.max_files, a.shard, rank, world)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -259,6 +259,17 @@ class _TrainBase:
         self.optimizer_h.step()
         return losses
 
+    def _all_ranks_have(self, train_data):
+        """Skip decision of the batch loop (batch_gen_hdf5.py:198-199,211-214 return None).  It must be COLLECTIVE: train_step
+        issues a gradient all-reduce, so a rank that skipped alone would leave the others waiting in it."""
+        ok = train_data is not None
+        if not psi_dist.is_dist():
+            return ok
+        import torch.distributed as tdist
+        flag = torch.tensor([1.0 if ok else 0.0], device=self.device if tdist.get_backend() == 'nccl' else 'cpu')
+        tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
+
     def train(self, batch_gen):
         self.model_h.train()
         self.model_h.to(self.device)
@@ -269,7 +280,7 @@ class _TrainBase:
         for ep in range(starting_ep, self.epoch):
             while batch_gen.has_next_batch():
                 train_data = batch_gen.next_batch(self.batch_size)
-                if train_data is None:
+                if not self._all_ranks_have(train_data):
                     continue
                 losses = self.train_step(train_data, ep)
                 if self.verbose:
