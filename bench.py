@@ -196,9 +196,12 @@ def kernel_work(args):
         'kd_query_kernel': ('byte', B * nc * (12 + 12 + 8) + m * 16.0,
                             'exact kd-tree NN (latency-bound pointer chase): queries in, gradients + hints out, scene once'),
         'blend_fwd_kernel': ('byte', dirs + B * Npad * 4.0 + B * Kpad * 4.0, 'v_posed = v_t + feat @ dirs: dirs (64.5 MB) streamed once + output'),
-        'bwd_joint_kernel': ('byte', dirs + B * Npad * 4.0 + 55 * Vpad * 4.0 + 2 * B * Npad * 4.0,
-                             'blend_bwd (dirs streamed once + g_vposed in) and skin_bwd_A (weights + g_local + v_posed in) as one '
-                             'heterogeneous grid; split-contraction partials are implementation traffic, not counted'),
+        'bwd_joint_kernel': ('byte', dirs + B * Npad * 4.0 + B * Kpad * 4.0 + 55 * Vpad * 4.0 + 2 * B * Npad * 4.0 + B * 64 * 16 * 4.0,
+                             'blend_bwd (dirs streamed once + g_vposed in + g_feat out) and skin_bwd_A (weights + g_local + v_posed in, joint-transform '
+                             'gradients out) as one heterogeneous grid; split-contraction partials are implementation traffic, not counted'),
+        'blend_bwd_kernel': ('byte', dirs + B * Npad * 4.0 + B * Kpad * 4.0,
+                             'g_feat = g_vposed @ dirs^T: dirs (64.5 MB) streamed once + g_vposed in + g_feat out; the 32 column-slice partials '
+                             'are implementation traffic, not counted'),
         'skin_fwd_kernel': ('byte', 55 * Vpad * 4.0 + B * Npad * 4.0 + B * V * 12.0, 'weights + v_posed in, vertices out (660 FMA per vertex: VALU-heavy)'),
         'skin_fwd_sdf_kernel': ('byte', 55 * Vpad * 4.0 + B * Npad * 4.0 + B * V * (12.0 + 32 + 12),
                                 'skinning + SDF lookup fused: weights + v_posed in, vertices out, 8 gathers + 12 B masked gradient per vertex'),

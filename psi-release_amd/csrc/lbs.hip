@@ -198,50 +198,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // skinning backward, joint part (MFMA): gA[b][j][r*4+s] = sum_v W[v][j] * g_local[b][v][r] * [v_posed;1][s]
 // wave = one body x one 256-vertex slice x all 64 padded joints (4 accumulators).
 // ------------------------------------------------------------------------------------------------
+// NBODY bodies per workgroup: the weight tile of the slice (64 joints x 256 vertices = 64 KB, 16 registers x 16 B per lane) is
+// loaded ONCE and reused for every body (it was re-read from L2 per body: 86 MB per launch at B = 32), the next body's
+// operands are requested before the current body's MFMAs issue, and there are Vpad/256 * ceil(B/NBODY) workgroups (164 at
+// B = 32) instead of 1312 — few enough to be resident all at once beside the blend_bwd stream workgroups.
+constexpr int SKA_NBODY = 8;
+
 __device__ __forceinline__ void skin_bwd_A_body(const LbsDev &m, const float *__restrict__ gl, const float *__restrict__ v_posed,
-                                                int B, float *__restrict__ part, int vslice, int b, f4 *smem)
+                                                int B, float *__restrict__ part, int vslice, int b0, int nbody, f4 *smem)
 {
-    // workgroup = one body x one 256-vertex slice; wave w contracts vertices [64w, 64w+64) of the slice (4 MFMA steps,
-    // all operand loads issued up front); the four waves are summed through LDS -> one partial per workgroup.
+    // workgroup = NBODY bodies x one 256-vertex slice; wave w contracts vertices [64w, 64w+64) of the slice (4 MFMA steps);
+    // the four waves are summed through LDS -> one partial per (slice, body).
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int vs = vslice * 256 + w * 64;
     const int li = lane & 15, lk = lane >> 4;
     const int r = li >> 2, s = li & 3;
-    const float *glb = gl + (size_t)b * m.Npad;
-    const float *vpb = v_posed + (size_t)b * m.Npad;
     f4 wa[4][4];
-    float bop[4][4];
-#pragma unroll
-    for (int st = 0; st < 4; st++) {
-        const int v0 = vs + st * 16 + 4 * lk;
-#pragma unroll
-        for (int jt = 0; jt < 4; jt++) wa[st][jt] = *(const f4 *)(m.WT + (size_t)(jt * 16 + li) * m.Vpad + v0);
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            float g = (r < 3) ? glb[(size_t)(v0 + t) * 3 + r] : 0.0f;
-            float p = (s < 3) ? vpb[(size_t)(v0 + t) * 3 + s] : 1.0f;
-            bop[st][t] = g * p;
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);           // all operand loads of the 4 steps are issued before the first MFMA waits
-    f4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = (f4){0, 0, 0, 0};
 #pragma unroll
     for (int st = 0; st < 4; st++)
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int jt = 0; jt < 4; jt++) wa[st][jt] = *(const f4 *)(m.WT + (size_t)(jt * 16 + li) * m.Vpad + vs + st * 16 + 4 * lk);
+    const int nb = min(nbody, B - b0);
+    auto load_ops = [&](int b, float (&g)[4][4], float (&p)[4][4]) {
+        const float *glb = gl + (size_t)b * m.Npad, *vpb = v_posed + (size_t)b * m.Npad;
 #pragma unroll
-            for (int jt = 0; jt < 4; jt++) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[st][jt][t], bop[st][t], acc[jt], 0, 0, 0);
+        for (int st = 0; st < 4; st++) {
+            const int v0 = vs + st * 16 + 4 * lk;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                g[st][t] = (r < 3) ? glb[(size_t)(v0 + t) * 3 + r] : 0.0f;
+                p[st][t] = (s < 3) ? vpb[(size_t)(v0 + t) * 3 + s] : 1.0f;
+            }
+        }
+    };
     f4 (*red)[4][64] = (f4 (*)[4][64])smem;      // [4][4][64]
+    float gA_[4][4], pA_[4][4], gB_[4][4], pB_[4][4];
+    load_ops(b0, gA_, pA_);
+    auto body = [&](int bb, const float (&g)[4][4], const float (&p)[4][4]) {
+        f4 acc[4];
 #pragma unroll
-    for (int jt = 0; jt < 4; jt++) red[w][jt][lane] = acc[jt];
-    __syncthreads();
-    // wave w finishes joint tile w: D[row = lk*4+e -> joint][col = li -> r*4+s]
-    f4 o4 = red[0][w][lane] + red[1][w][lane] + red[2][w][lane] + red[3][w][lane];
-    float *o = part + ((size_t)vslice * B + b) * JP * 16;
+        for (int t = 0; t < 4; t++) acc[t] = (f4){0, 0, 0, 0};
 #pragma unroll
-    for (int e = 0; e < 4; e++) o[(w * 16 + lk * 4 + e) * 16 + li] = o4[e];
+        for (int st = 0; st < 4; st++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float bop = g[st][t] * p[st][t];
+#pragma unroll
+                for (int jt = 0; jt < 4; jt++) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[st][jt][t], bop, acc[jt], 0, 0, 0);
+            }
+        if (bb > 0) __syncthreads();             // the previous body's reduction has been read
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++) red[w][jt][lane] = acc[jt];
+        __syncthreads();
+        // wave w finishes joint tile w: D[row = lk*4+e -> joint][col = li -> r*4+s]
+        f4 o4 = red[0][w][lane] + red[1][w][lane] + red[2][w][lane] + red[3][w][lane];
+        float *o = part + ((size_t)vslice * B + b0 + bb) * JP * 16;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[(w * 16 + lk * 4 + e) * 16 + li] = o4[e];
+    };
+    for (int bb = 0; bb < nb; bb += 2) {
+        if (bb + 1 < nb) load_ops(b0 + bb + 1, gB_, pB_);
+        __builtin_amdgcn_sched_barrier(0);       // the next body's operand loads are issued before this body's MFMAs wait
+        body(bb, gA_, pA_);
+        if (bb + 1 < nb) {
+            if (bb + 2 < nb) load_ops(b0 + bb + 2, gA_, pA_);
+            __builtin_amdgcn_sched_barrier(0);
+            body(bb + 1, gB_, pB_);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -318,24 +342,37 @@ __device__ __forceinline__ void blend_bwd_body(const LbsDev &m, const float *__r
 }
 
 // The two joint-side halves of the LBS backward in ONE launch.  Both depend only on skin_bwd_v; blend_bwd is a 64.5 MB
-// stream with 256 long-lived workgroups, skin_bwd_A is 1312 short L2-latency-bound workgroups.  As separate launches they
-// ran back to back (22 + 19 us); as one grid — blend workgroups first, so every CU picks one up, then the skin_bwd_A
-// workgroups fill the remaining slots — the short ones run in the shadow of the stream.
+// stream with 256 long-lived workgroups (one per CU, one wave per SIMD), skin_bwd_A is a short L2-latency-bound contraction.
+// Block ids [0, n_blend) are the stream workgroups, so every CU picks one up at once; the skin_bwd_A workgroups behind them
+// (Vpad/256 x ceil(B/8): 164 at B = 32) are all resident at the same time and finish inside the stream's shadow.
+// XCD-aware mapping of the stream part: workgroup `bid` runs on XCD bid % 8 (observed dispatch order) and every XCD has its
+// own L2, so the k-groups that share an n-slice — and therefore read the same g_vposed columns — are placed on ONE XCD: that
+// slice of g_vposed is fetched from memory once and served to the other k-groups from L2 (it used to be fetched by all 8 XCDs).
 template <int MT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void bwd_joint_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void bwd_joint_kernel(
     LbsDev m, const float *__restrict__ g_vp, const float *__restrict__ gl, const float *__restrict__ v_posed, int B, int steps_per_slice,
-    float *__restrict__ gfeat_part, float *__restrict__ gA_part, int n_blend, int kgroups, int nslices, int nsv)
+    float *__restrict__ gfeat_part, float *__restrict__ gA_part, int n_blend, int kgroups, int nslices, int nsv, int nbody)
 {
     __shared__ f4 smem[4 * 4 * MT * 64 > 4 * 4 * 64 ? 4 * 4 * MT * 64 : 4 * 4 * 64];
-    // all stream workgroups first: they must START at once (interleaving them one-per-five through the grid delayed the last
-    // of them behind ~1500 dispatches and doubled the kernel: 73 vs 39 us)
     const int bid = blockIdx.x;
     if (bid < n_blend) {
-        const int kg = bid % kgroups, rest = bid / kgroups;
-        blend_bwd_body<MT>(m, g_vp, B, steps_per_slice, gfeat_part, kg, rest % nslices, rest / nslices, smem);
+        int kg, slice, bg;
+        if ((nslices & 7) == 0) {
+            const int xcd = bid & 7, idx = bid >> 3, spx = nslices >> 3;
+            kg = idx % kgroups;
+            const int t = idx / kgroups;
+            slice = xcd + 8 * (t % spx);
+            bg = t / spx;
+        } else {
+            kg = bid % kgroups;
+            const int rest = bid / kgroups;
+            slice = rest % nslices;
+            bg = rest / nslices;
+        }
+        blend_bwd_body<MT>(m, g_vp, B, steps_per_slice, gfeat_part, kg, slice, bg, smem);
     } else {
         const int i = bid - n_blend;
-        skin_bwd_A_body(m, gl, v_posed, B, gA_part, i % nsv, i / nsv, smem);
+        skin_bwd_A_body(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem);
     }
 }
 
@@ -618,10 +655,14 @@ static int lbs_launch_bwd_joint_parts(const LbsDev &m, const WsLayout &L, int B,
     const int mt = B > 32 ? 4 : (B > 16 ? 2 : 1);
     const int bgroups = psi_cdiv(B, 16 * mt);
     const int n_blend = kgroups * L.nsn * bgroups;
-    const int grid = n_blend + L.nsv * B;
+    // bodies per skin_bwd_A workgroup: about one such workgroup per CU beside its stream workgroup
+    int nbody = psi_cdiv(B, 256 / L.nsv > 0 ? 256 / L.nsv : 1);
+    if (nbody > SKA_NBODY) nbody = SKA_NBODY;
+    if (const char *ev = getenv("PSI_SKA_NBODY")) { int v = atoi(ev); if (v >= 1 && v <= SKA_NBODY) nbody = v; }
+    const int grid = n_blend + L.nsv * psi_cdiv(B, nbody);
 #define PSI_LAUNCH_JOINT(MT_)                                                                                                      \
     hipLaunchKernelGGL(bwd_joint_kernel<MT_>, dim3(grid), dim3(256), 0, st, m, ws + L.g_vp, ws + L.gl, ws + L.v_posed, B, steps,     \
-                       ws + L.gfeat_part, ws + L.gA_part, n_blend, kgroups, L.nsn, L.nsv)
+                       ws + L.gfeat_part, ws + L.gA_part, n_blend, kgroups, L.nsn, L.nsv, nbody)
     if (mt == 4) PSI_LAUNCH_JOINT(4);
     else if (mt == 2) PSI_LAUNCH_JOINT(2);
     else PSI_LAUNCH_JOINT(1);
