@@ -41,9 +41,15 @@ int psi_device_info(int *cu_count, int *wave_size, int *clock_khz, int *is_gfx95
  * contraction; idx = lowest k attaining it (first-minimum rule of chamfer.cu:46,126).
  * dist2/idx2 may both be NULL: PSI discards that direction (fitting_proxe.py:136) and it is skipped.
  * `workspace` (device, >= psi_chamfer_workspace_bytes) holds per-slice partial minima; NULL lets the
- * library use an internal per-device buffer that grows on demand (not capturable in a hipGraph the
- * first time it grows).
+ * library use an internal buffer owned by (device, stream) that grows on demand — calls on different
+ * streams never share it; growth is refused (PSI_ENOMEM) while the stream is being captured into a
+ * hipGraph, so captured callers pass their own workspace.
  * ------------------------------------------------------------------------------------------- */
+/* Arithmetic mode of the distance expression this library was built with: 0 = three products and two sums, each rounded
+ * (the CUDA source as written, nvcc --fmad=false) — libpsi_hip.so; 1 = mul, fma, fma (nvcc's default --fmad=true contraction
+ * of chamfer.cu:32-35) — libpsi_hip_fma.so, selected by PSI_CHAMFER_FMA=1.  Indices can differ between the two only where two
+ * targets are within an ulp of the same distance. */
+int psi_chamfer_arith_mode(void);
 size_t psi_chamfer_workspace_bytes(int B, int n, int m);
 int psi_chamfer_forward(const float *xyz1, const float *xyz2, int B, int n, int m,
                         float *dist1, int32_t *idx1, float *dist2, int32_t *idx2,

@@ -22,6 +22,7 @@
  * Parity pin: chamfer_pytorch/test_chamfer.py:35-54 (expanded-form brute force, sum of squared
  * differences < 1e-8 on rand(4,100,3)) is reproduced in tests/test_oracle_cpu.py.
  */
+#include <math.h>
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>
@@ -39,6 +40,15 @@ void psi_oracle_set_threads(int n)
     (void)n;
 #endif
 }
+
+/* The distance expression in the two arithmetic modes of the build (psi-release_amd/csrc/psi_common.h has the same macro):
+ * default = the CUDA source as written with every product and sum rounded (nvcc --fmad=false); -DPSI_CHAMFER_FMA = mul, fma, fma,
+ * what nvcc's default --fmad=true makes of chamfer.cu:32-35 (each `product + sum` pair contracted, left to right). */
+#ifdef PSI_CHAMFER_FMA
+#define PSI_SQ3(x, y, z) fmaf((z), (z), fmaf((y), (y), (x) * (x)))
+#else
+#define PSI_SQ3(x, y, z) ((x) * (x) + (y) * (y) + (z) * (z))
+#endif
 
 #define QB 16 /* queries per SIMD block: the inner loop over queries vectorises (fair CPU baseline) */
 
@@ -70,7 +80,7 @@ void psi_oracle_nm_distance(int b, int n, const float *xyz, int m, const float *
                     float x2 = tx - qx[q];
                     float y2 = ty - qy[q];
                     float z2 = tz - qz[q];
-                    float d = x2 * x2 + y2 * y2 + z2 * z2;
+                    float d = PSI_SQ3(x2, y2, z2);
                     int take = (k == 0) | (d < best[q]);
                     best[q] = take ? d : best[q];
                     besti[q] = take ? k : besti[q];
@@ -103,7 +113,7 @@ void psi_oracle_nm_distance_chunked(int b, int n, const float *xyz, int m, const
                     float x2 = buf[k * 3 + 0] - x1;
                     float y2 = buf[k * 3 + 1] - y1;
                     float z2 = buf[k * 3 + 2] - z1;
-                    float d = x2 * x2 + y2 * y2 + z2 * z2;
+                    float d = PSI_SQ3(x2, y2, z2);
                     if (k == 0 || d < best) {
                         best = d;
                         best_i = k + k2;

@@ -38,21 +38,28 @@ _LIB = None
 # --------------------------------------------------------------------------------------------
 # C oracle (Chamfer NN + scalar trilinear) build/load
 # --------------------------------------------------------------------------------------------
-def build_c_oracle(force: bool = False) -> str:
-    """gcc -O3 -ffp-contract=off -fopenmp: IEEE fp32, no FMA contraction."""
+def fma_mode() -> bool:
+    """PSI_CHAMFER_FMA=1: the Chamfer distance in nvcc --fmad=true form (mul, fma, fma), matching libpsi_hip_fma.so."""
+    return os.environ.get('PSI_CHAMFER_FMA') == '1'
+
+
+def build_c_oracle(force: bool = False, fma: bool = None) -> str:
+    """gcc -O3 -ffp-contract=off -fopenmp: IEEE fp32, no compiler-chosen FMA contraction.  fma=True builds the
+    second arithmetic mode, in which the distance is spelled with explicit fmaf calls (-DPSI_CHAMFER_FMA)."""
+    fma = fma_mode() if fma is None else fma
     os.makedirs(_BUILD, exist_ok=True)
     src = os.path.join(_HERE, 'chamfer_oracle.c')
-    out = os.path.join(_BUILD, 'libpsi_oracle.so')
+    out = os.path.join(_BUILD, 'libpsi_oracle_fma.so' if fma else 'libpsi_oracle.so')
     # -march=native code must not travel to a different CPU (the prebuilt .so ships to the GPU box with the snapshot): the
     # build records the host's ISA flags and is redone when they differ
-    stamp, here = os.path.join(_BUILD, 'cpu.stamp'), _cpu_flags()
+    stamp, here = os.path.join(_BUILD, 'cpu_fma.stamp' if fma else 'cpu.stamp'), _cpu_flags()
     try:
         same_cpu = open(stamp).read() == here
     except OSError:
         same_cpu = False
     if force or not same_cpu or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
         cmd = ['gcc', '-O3', '-march=native', '-ffp-contract=off', '-fno-fast-math', '-fopenmp', '-shared', '-fPIC',
-               src, '-o', out]
+               src, '-o', out, '-lm'] + (['-DPSI_CHAMFER_FMA'] if fma else [])
         try:
             subprocess.run(cmd, check=True, capture_output=True)
         except subprocess.CalledProcessError as e:  # pragma: no cover
@@ -72,11 +79,14 @@ def _cpu_flags() -> str:
     return 'unknown'
 
 
-def c_oracle():
-    global _LIB
-    if _LIB is None:
-        _LIB = ctypes.CDLL(build_c_oracle())
-    return _LIB
+_LIBS = {}
+
+
+def c_oracle(fma: bool = None):
+    fma = fma_mode() if fma is None else bool(fma)
+    if fma not in _LIBS:
+        _LIBS[fma] = ctypes.CDLL(build_c_oracle(fma=fma))
+    return _LIBS[fma]
 
 
 def set_threads(n: int):
@@ -89,9 +99,9 @@ def _fp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def chamfer_nn_np(xyz1: np.ndarray, xyz2: np.ndarray, both: bool = True, chunked: bool = False):
+def chamfer_nn_np(xyz1: np.ndarray, xyz2: np.ndarray, both: bool = True, chunked: bool = False, fma: bool = None):
     """chamfer.cu:12-154.  Returns dist1[B,n], idx1[B,n] (int32), dist2[B,m], idx2[B,m]."""
-    lib = c_oracle()
+    lib = c_oracle(fma)
     xyz1 = np.ascontiguousarray(xyz1, np.float32)
     xyz2 = np.ascontiguousarray(xyz2, np.float32)
     B, n, _ = xyz1.shape

@@ -18,6 +18,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIBDIR = os.path.join(PKG, 'lib')
 LIB = os.path.join(LIBDIR, 'libpsi_hip.so')
+LIB_FMA = os.path.join(LIBDIR, 'libpsi_hip_fma.so')     # same library with the Chamfer distance in nvcc --fmad=true form (-DPSI_CHAMFER_FMA)
+FMA_FILES = ('chamfer.hip', 'nnindex.hip')
 ARCH = 'gfx950'
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 COMMON = ['-O3', '-std=c++17', '--offload-arch=' + ARCH, '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
@@ -44,12 +46,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     headers.append(os.path.join(os.path.dirname(PKG), 'include', 'psi_hip.h'))
     jobs = []
     objs = []
+    objs_fma = []
     for f in sources():
         src = os.path.join(CSRC, f)
         obj = os.path.join(LIBDIR, 'obj', f[:-4] + '.o')
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
             jobs.append([HIPCC] + COMMON + PER_FILE.get(f, []) + ['-c', src, '-o', obj])
+        if f in FMA_FILES:
+            obj2 = os.path.join(LIBDIR, 'obj', f[:-4] + '_fma.o')
+            if force or _stale(obj2, [src] + headers):
+                jobs.append([HIPCC] + COMMON + PER_FILE.get(f, []) + ['-DPSI_CHAMFER_FMA', '-c', src, '-o', obj2])
+            objs_fma.append(obj2)
+        else:
+            objs_fma.append(obj)
 
     def run(cmd):
         if verbose:
@@ -65,6 +75,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print(warn)
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs)
+    if force or jobs or _stale(LIB_FMA, objs_fma):
+        run([HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB_FMA] + objs_fma)
     return LIB
 
 

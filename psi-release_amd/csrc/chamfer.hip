@@ -19,9 +19,16 @@
 #include "psi_internal.h"
 #include <math.h>
 
-#ifndef PSI_CHAMFER_ALLOW_FMA   // development A/B only; the shipped library never defines it
-#pragma clang fp contract(off)
+#pragma clang fp contract(off)    // the distance expression is spelled out by PSI_SQ3 (psi_common.h) in both arithmetic modes
+
+extern "C" int psi_chamfer_arith_mode(void)
+{
+#ifdef PSI_CHAMFER_FMA
+    return 1;
+#else
+    return 0;
 #endif
+}
 
 namespace {
 
@@ -33,7 +40,7 @@ __device__ __forceinline__ float sqdist(float tx, float ty, float tz, float qx, 
     float x2 = tx - qx;
     float y2 = ty - qy;
     float z2 = tz - qz;
-    return x2 * x2 + y2 * y2 + z2 * z2;   // ((x2*x2 + y2*y2) + z2*z2), contraction off for this file
+    return PSI_SQ3(x2, y2, z2);
 }
 
 template <int Q>
@@ -286,7 +293,7 @@ extern "C" int psi_chamfer_forward(const float *xyz1, const float *xyz2, int B, 
     hipStream_t st = (hipStream_t)stream;
     void *ws = workspace;
     if (!ws) {
-        ws = psi_scratch(psi_chamfer_workspace_bytes(B, n, m));
+        ws = psi_scratch(psi_chamfer_workspace_bytes(B, n, m), st);
         if (!ws) return PSI_ENOMEM;
     }
     int rc = launch_nn(xyz1, xyz2, B, n, m, dist1, idx1, ws, st);

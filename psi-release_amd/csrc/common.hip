@@ -1,7 +1,9 @@
 // libpsi_hip.so: error reporting, device facts, growable scratch.
 #include "psi_internal.h"
 #include <stdarg.h>
+#include <map>
 #include <mutex>
+#include <utility>
 
 static thread_local char g_err[512] = "ok";
 
@@ -32,30 +34,41 @@ extern "C" int psi_device_info(int *cu_count, int *wave_size, int *clock_khz, in
     return 0;
 }
 
+// Internal scratch for entry points called with workspace = NULL: ONE buffer per (device, stream), so calls enqueued on different
+// streams never share partial-result storage (a single per-device buffer raced between streams).  Growing a stream's buffer
+// waits for THAT stream only before freeing the old one, and is refused while the stream is being captured into a hipGraph
+// (allocation is illegal there): captured callers pass their own workspace.
 static std::mutex g_scratch_mu;
-static void *g_scratch[16] = {0};
-static size_t g_scratch_sz[16] = {0};
+struct PsiScratchEntry { void *ptr; size_t size; };
+static std::map<std::pair<int, hipStream_t>, PsiScratchEntry> g_scratch;
 
-void *psi_scratch(size_t bytes)
+void *psi_scratch(size_t bytes, hipStream_t stream)
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    if (g_scratch_sz[dev] < bytes) {
-        if (g_scratch[dev]) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(g_scratch[dev]);
-            g_scratch[dev] = nullptr;
-            g_scratch_sz[dev] = 0;
-        }
-        size_t want = bytes + bytes / 4 + (1 << 20);
-        if (hipMalloc(&g_scratch[dev], want) != hipSuccess) {
-            psi_set_error("scratch hipMalloc(%zu) failed", want);
+    PsiScratchEntry &e = g_scratch[std::make_pair(dev, stream)];
+    if (e.size < bytes) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            psi_set_error("internal scratch cannot grow while the stream is being captured: pass a workspace");
             return nullptr;
         }
-        g_scratch_sz[dev] = want;
+        if (e.ptr) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(e.ptr);
+            e.ptr = nullptr;
+            e.size = 0;
+        }
+        size_t want = bytes + bytes / 4 + (1 << 20);
+        if (hipMalloc(&e.ptr, want) != hipSuccess) {
+            psi_set_error("scratch hipMalloc(%zu) failed", want);
+            e.ptr = nullptr;
+            return nullptr;
+        }
+        e.size = want;
     }
-    return g_scratch[dev];
+    return e.ptr;
 }
 
 thread_local PsiStageTimer *g_psi_timer = nullptr;

@@ -22,9 +22,7 @@
 #include <string.h>
 #include <vector>
 
-#ifndef PSI_CHAMFER_ALLOW_FMA
-#pragma clang fp contract(off)
-#endif
+#pragma clang fp contract(off)    // the distance expression is spelled out by PSI_SQ3 (psi_common.h) in both arithmetic modes
 
 namespace {
 
@@ -138,7 +136,7 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *_
         if (h >= 0 && h < T.m) {
             const float4 p = T.opts[h];
             float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
-            best = x2 * x2 + y2 * y2 + z2 * z2;
+            best = PSI_SQ3(x2, y2, z2);
             bestk = kd_pack(best, h);
         }
     }
@@ -199,7 +197,7 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *_
             for (int u = 0; u < CPL; u++) {
                 const float4 p = T.pts[(size_t)(-cur - 1) * LEAF + c + u * LPQ];
                 float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
-                const float d = x2 * x2 + y2 * y2 + z2 * z2;
+                const float d = PSI_SQ3(x2, y2, z2);
                 const kd_key ku = kd_pack(d, __float_as_int(p.w));
                 k = ku < k ? ku : k;
             }

@@ -24,6 +24,8 @@ class PlausibilityEvaluator:
 
     @torch.no_grad()
     def scores(self, body_param_input):
+        """(non-collision score, contact score) of one pkl.  The reference scores ONE body per file (batch_size 1,
+        utils_eval_collision_habitat.py:145-175); a pkl that holds B > 1 bodies gives two lists with one entry per body."""
         op = self.op
         xh, cam_ext, _ = BodyParamParser.body_params_parse_fitting(body_param_input)
         B = xh.shape[0]
@@ -35,10 +37,17 @@ class PlausibilityEvaluator:
         verts = op.body_verts(xh_rec, cam)
         sdf = ops.sdf_sample(verts, op.s_sdf, op.s_grid_min_batch, op.s_grid_max_batch, align_corners=op.align_corners)
         V = verts.shape[1]
-        n_neg = (sdf < 0).sum()
-        if int(n_neg) < 1:                                  # utils_eval_collision_habitat.py:131-135
-            return 1.0, 0.0
-        return float((sdf > 0).sum()) / float(V * B), 1.0
+        n_neg = (sdf < 0).sum(dim=1).cpu().tolist()
+        n_pos = (sdf > 0).sum(dim=1).cpu().tolist()
+        coll, cont = [], []
+        for neg, pos in zip(n_neg, n_pos):
+            if neg < 1:                                     # utils_eval_collision_habitat.py:131-135: nothing penetrates
+                coll.append(10475.0 / 10475.0)
+                cont.append(0.0)
+            else:
+                coll.append(float(pos) / 10475.0)           # :137,139 (the reference hard-codes the SMPL-X vertex count)
+                cont.append(1.0)
+        return (coll[0], cont[0]) if B == 1 else (coll, cont)
 
     def eval_folder(self, folder, max_files=8000):
         coll, cont = [], []
@@ -48,8 +57,8 @@ class PlausibilityEvaluator:
                 continue
             with open(fn, 'rb') as f:
                 c, k = self.scores(pickle.load(f))
-            coll.append(c)
-            cont.append(k)
+            coll.extend(c if isinstance(c, list) else [c])
+            cont.extend(k if isinstance(k, list) else [k])
         return coll, cont
 
 

@@ -78,6 +78,10 @@ class TestOP:
                                        test=True, autocast_bf16=self.autocast_bf16)
         self.model_h.eval().to(self.device)
         self._loaded = False
+        # optional: callable(view_index, n_samples) -> (eps_g [n,32], eps_l [n,32]) (S2) or eps [n,32] (S1).  The reference draws the
+        # latent with the global CPU generator inside the model (net_layers.py:97-98,197-198); injecting it makes a run reproducible
+        # and lets the tests replay the exact latents a reference run consumed.
+        self.latent_source = getattr(self, 'latent_source', None)
 
     def load(self, state_dict=None):
         if state_dict is None:
@@ -88,18 +92,25 @@ class TestOP:
         self._loaded = True
 
     @torch.no_grad()
-    def sample_view(self, depth, seg, cam_int, cam_ext, max_d, n_samples=None):
-        """depth/seg [1,1,128,128] (preprocessed), cam_int [1,3,3], cam_ext [1,4,4], max_d [1] -> list of pkl dicts."""
+    def sample_view(self, depth, seg, cam_int, cam_ext, max_d, n_samples=None, latents=None, repeat_cams=True):
+        """depth/seg [1,1,128,128] (preprocessed), cam_int [1,3,3], cam_ext [1,4,4], max_d [1] -> list of pkl dicts.
+        ``repeat_cams``: the Habitat drivers store the cameras repeated to [n,...] in every pkl (test_habitat_s2.py:216-217), the
+        PROX-E drivers store the single [1,4,4] / [1,3,3] (test_proxe_s1.py:120-128)."""
         n = n_samples or self.n_samples
         xs_n = torch.cat([depth, seg], dim=1).repeat(n, 1, 1, 1)
         cam_int_b, cam_ext_b, max_d_b = cam_int.repeat(n, 1, 1), cam_ext.repeat(n, 1, 1), max_d.view(1).repeat(n)
-        xhnr_gen = self.model_h.sample(xs_n)
+        if latents is None:
+            xhnr_gen = self.model_h.sample(xs_n)
+        elif self.stage == 's1':
+            xhnr_gen = self.model_h.sample(xs_n, eps=latents)
+        else:
+            xhnr_gen = self.model_h.sample(xs_n, eps_g=latents[0], eps_l=latents[1], use_eps=True)
         xhn_gen = GeometryTransformer.convert_to_3D_rot(xhnr_gen)
         xh_gen = GeometryTransformer.recover_global_T(xhn_gen, cam_int_b, max_d_b)
         body_param_list = BodyParamParser.body_params_encapsulate(xh_gen)
         for body_param in body_param_list:
-            body_param['cam_ext'] = cam_ext_b.detach().cpu().numpy()
-            body_param['cam_int'] = cam_int_b.detach().cpu().numpy()
+            body_param['cam_ext'] = (cam_ext_b if repeat_cams else cam_ext).detach().cpu().numpy()
+            body_param['cam_int'] = (cam_int_b if repeat_cams else cam_int).detach().cpu().numpy()
         return body_param_list
 
     @staticmethod
@@ -121,7 +132,8 @@ class TestOP:
             depth0, seg0 = t(np.load(cam_file.replace('cam', 'depth'))), t(np.load(cam_file.replace('cam', 'seg')))
             depth, _, max_d = data_preprocessing(depth0, 'depth', [128, 128])
             seg, _, _ = data_preprocessing(seg0, 'depth', [128, 128])          # sic: 'depth' (see module docstring)
-            bodies = self.sample_view(depth, seg, t(cam_params['cam_int']).unsqueeze(0), t(cam_params['cam_ext']).unsqueeze(0), max_d)
+            lat = self.latent_source(ii, self.n_samples) if self.latent_source is not None else None
+            bodies = self.sample_view(depth, seg, t(cam_params['cam_int']).unsqueeze(0), t(cam_params['cam_ext']).unsqueeze(0), max_d, latents=lat)
             self.write(bodies, self.outdir, self.n_samples * ii)
 
     def test_proxe(self, test_data, scene_name):
@@ -129,5 +141,6 @@ class TestOP:
         if not self._loaded:
             self.load()
         depth, seg, max_d, cam_int, cam_ext = test_data[:5]
-        bodies = self.sample_view(depth, seg, cam_int, cam_ext, max_d)
+        lat = self.latent_source(0, self.n_samples) if self.latent_source is not None else None
+        bodies = self.sample_view(depth, seg, cam_int, cam_ext, max_d, latents=lat, repeat_cams=False)
         self.write(bodies, os.path.join(self.output_dir, scene_name), 900)

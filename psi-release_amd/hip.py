@@ -11,7 +11,10 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('PSI_HIP_LIB') or os.path.join(_PKG, 'lib', 'libpsi_hip.so')   # PSI_HIP_LIB: development A/B builds
+# PSI_CHAMFER_FMA=1 selects the build whose Chamfer distance is contracted the way nvcc's default --fmad=true contracts the
+# reference's expression (include/psi_hip.h: psi_chamfer_arith_mode); PSI_HIP_LIB: development A/B builds
+LIB_PATH = os.environ.get('PSI_HIP_LIB') or os.path.join(
+    _PKG, 'lib', 'libpsi_hip_fma.so' if os.environ.get('PSI_CHAMFER_FMA') == '1' else 'libpsi_hip.so')
 _lib = None
 
 c_void_p, c_int, c_long, c_size_t, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_float
@@ -21,6 +24,7 @@ SIGNATURES = {
     'psi_last_error': (ctypes.c_char_p, []),
     'psi_version': (c_int, []),
     'psi_device_info': (c_int, [c_void_p] * 4),
+    'psi_chamfer_arith_mode': (c_int, []),
     'psi_chamfer_workspace_bytes': (c_size_t, [c_int] * 3),
     'psi_chamfer_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),

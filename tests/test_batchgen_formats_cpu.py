@@ -1,0 +1,169 @@
+"""Data feed and on-disk formats on the CPU:
+  * ``BatchGeneratorWithSceneMesh`` reading the reference's file layout against the batches the REFERENCE's own generator produced on
+    the same files (tests/golden/batchgen.npz, made by oracle/make_golden_f.py through an array-backed h5py stand-in);
+  * the PLY variants open3d writes (float / double coordinates, normals, colours, faces; binary and ASCII);
+  * a VPoser experiment directory in the reference layout (``snapshots/*.pt`` + ``*.ini``) loaded by path."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+import fixture_inputs as FI
+from psi_release_amd import batch_gen, scene_io, synth
+from psi_release_amd.vposer import load_vposer
+
+
+def _write_dataset(tmp):
+    files = []
+    for t, tab in enumerate(FI.bg_tables()):
+        fn = os.path.join(tmp, 'cams_%d.npz' % t)
+        np.savez(fn, **tab)
+        files.append(fn)
+    for name, s in FI.bg_scenes().items():
+        s.write_prox_layout(tmp, name)
+    return files, os.path.join(tmp, 'scenes_downsampled'), os.path.join(tmp, 'scenes_sdf')
+
+
+@pytest.mark.parametrize('tag,which,mode', [('train_list', 'list', 'train'), ('all_single', 'single', 'all'), ('test_single_ram', 'single', 'test')])
+def test_batch_generator_equals_reference_generator(tmp_path, tag, which, mode):
+    """Same files, same `random.seed` -> the same index lists (selection by scene split, shuffle, the remove(0) quirk), the same
+    sequence of batches over two epochs including the dropped short batch and the skipped |z| > max_d batch, and the same 12
+    tensors (s_faces excepted: no loss reads it, this build returns it empty)."""
+    g = golden('batchgen')
+    files, vdir, sdir = _write_dataset(str(tmp_path))
+    random.seed(77)
+    bg = batch_gen.BatchGeneratorWithSceneMesh(dataset_path=files if which == 'list' else files[0], device='cpu', scene_verts_path=vdir,
+                                               scene_sdf_path=sdir, mode=mode, read_all_to_ram=True)
+    assert bg.n_samples == int(g[tag + '_n_samples'])
+    assert np.array_equal(np.array(bg.index), g[tag + '_index0'])
+    seq = []
+    for epoch in range(2):
+        while bg.has_next_batch():
+            seq.append(bg.next_batch(3))
+        bg.reset()
+        assert np.array_equal(np.array(bg.index), g['%s_index_after_reset%d' % (tag, epoch)])
+    assert len(seq) == int(g[tag + '_n_calls'])
+    assert [b is None for b in seq] == list(g[tag + '_none'])
+    assert any(b is None for b in seq)
+    for i, b in enumerate(seq):
+        if b is None:
+            continue
+        d = FI.batch_digest(b)
+        for k, v in d.items():
+            ref = g['%s_b%d_%s' % (tag, i, k)]
+            if k == 'shapes':
+                keep = [j for j in range(12) if j != 7]                     # 7 = s_faces
+                assert np.array_equal(v[keep], ref[keep]), (tag, i)
+            else:
+                assert np.array_equal(v, ref), (tag, i, k)
+        assert list(b[2][:, 0].numpy()) == sorted(b[2][:, 0].numpy())       # batch_gen_hdf5.py:201: sorted indices inside a batch
+
+
+def test_sharded_generator_same_step_count_and_disjoint_rows(tmp_path):
+    """world > 1: every rank shuffles the same full list with the shared seed and keeps [rank::world] truncated to equal length."""
+    files, vdir, sdir = _write_dataset(str(tmp_path))
+    gens = [batch_gen.BatchGeneratorWithSceneMesh(dataset_path=files, device='cpu', scene_verts_path=vdir, scene_sdf_path=sdir, mode='train',
+                                                  rank=r, world=2, seed=5) for r in range(2)]
+    for epoch in range(2):
+        assert gens[0].n_samples == gens[1].n_samples
+        assert not set(gens[0].index) & set(gens[1].index)
+        n = [0, 0]
+        for r, bg in enumerate(gens):
+            while bg.has_next_batch():
+                bg.next_batch(3)
+                n[r] += 1
+            bg.reset()
+        assert n[0] == n[1] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _write_open3d_style_ply(path, verts, coord='double', ascii_=False, normals=True, colors=True, faces=True):
+    """A triangle mesh as open3d's write_triangle_mesh lays it out: x y z [nx ny nz] [red green blue] per vertex, then
+    `property list uchar uint vertex_indices` faces."""
+    n = len(verts)
+    rs = np.random.RandomState(1)
+    nrm = rs.standard_normal((n, 3))
+    col = rs.randint(0, 255, (n, 3)).astype(np.uint8)
+    tri = rs.randint(0, n, (5, 3)).astype(np.uint32)
+    ct = 'double' if coord == 'double' else 'float'
+    hdr = ['ply', 'format %s 1.0' % ('ascii' if ascii_ else 'binary_little_endian'), 'comment Created by Open3D', 'element vertex %d' % n]
+    hdr += ['property %s %s' % (ct, c) for c in 'xyz']
+    if normals:
+        hdr += ['property %s %s' % (ct, c) for c in ('nx', 'ny', 'nz')]
+    if colors:
+        hdr += ['property uchar %s' % c for c in ('red', 'green', 'blue')]
+    if faces:
+        hdr += ['element face %d' % len(tri), 'property list uchar uint vertex_indices']
+    hdr += ['end_header']
+    with open(path, 'wb') as f:
+        f.write(('\n'.join(hdr) + '\n').encode())
+        dt = np.float64 if coord == 'double' else np.float32
+        if ascii_:
+            for i in range(n):
+                row = ['%.9g' % x for x in verts[i]]
+                if normals:
+                    row += ['%.9g' % x for x in nrm[i]]
+                if colors:
+                    row += [str(int(x)) for x in col[i]]
+                f.write((' '.join(row) + '\n').encode())
+            if faces:
+                for t in tri:
+                    f.write(('3 %d %d %d\n' % tuple(t)).encode())
+        else:
+            for i in range(n):
+                f.write(verts[i].astype(dt).tobytes())
+                if normals:
+                    f.write(nrm[i].astype(dt).tobytes())
+                if colors:
+                    f.write(col[i].tobytes())
+            if faces:
+                for t in tri:
+                    f.write(np.uint8(3).tobytes() + t.tobytes())
+
+
+@pytest.mark.parametrize('coord', ['double', 'float'])
+@pytest.mark.parametrize('ascii_', [False, True])
+def test_ply_reader_open3d_layouts(tmp_path, coord, ascii_):
+    verts = np.random.RandomState(0).standard_normal((37, 3)).astype(np.float32)
+    for normals, colors, faces in ((True, True, True), (False, True, True), (False, False, False)):
+        p = str(tmp_path / ('m_%d%d%d.ply' % (normals, colors, faces)))
+        _write_open3d_style_ply(p, verts, coord, ascii_, normals, colors, faces)
+        got = scene_io.read_ply_vertices(p)
+        assert got.dtype == np.float32 and got.shape == (37, 3)
+        assert np.array_equal(got, verts) if not ascii_ else np.allclose(got, verts, rtol=0, atol=1e-7)
+
+
+def test_sdf_reader_layout(tmp_path):
+    s = synth.make_scene(3, 64, 6, 14)
+    paths = s.write_prox_layout(str(tmp_path), 'X')
+    sdf, gmin, gmax, dim = scene_io.read_sdf(paths['scene_sdf_path'])
+    assert dim == 6 and np.array_equal(sdf, s.sdf) and np.array_equal(gmin, s.grid_min) and np.array_equal(gmax, s.grid_max)
+    assert np.array_equal(scene_io.read_ply_vertices(paths['scene_verts_path']), s.verts)
+
+
+def test_vposer_experiment_dir_loaded_by_path(tmp_path, vposer_sd):
+    """model_loader.py:25-72: ``{expr_dir}/snapshots/*.pt`` (newest by mtime) + hyper-parameters from ``{expr_dir}/*.ini``."""
+    expr = tmp_path / 'vposer_v1_0'
+    (expr / 'snapshots').mkdir(parents=True)
+    sd = {k: torch.tensor(np.asarray(v)) for k, v in vposer_sd.items()}
+    stale = {k: torch.zeros_like(v) for k, v in sd.items()}
+    torch.save(stale, str(expr / 'snapshots' / 'TR00_E001.pt'))
+    os.utime(str(expr / 'snapshots' / 'TR00_E001.pt'), (1, 1))                 # older snapshot: must NOT be the one picked
+    torch.save(sd, str(expr / 'snapshots' / 'TR00_E096.pt'))
+    (expr / 'TR00_vposer_v1_0.ini').write_text(
+        '[general]\nverbosity : 0\nwork_dir : None\nbm_path: None # path to the body model\n[training]\nnum_epochs: 100\n'
+        '[network]\nnum_neurons : 512\ndata_shape : [1, 21, 3]\nlatentD : 32\n')
+    vp, ps = load_vposer(str(expr), vp_model='snapshot')
+    assert ps['num_neurons'] == 512 and ps['latentD'] == 32 and list(ps['data_shape']) == [1, 21, 3]
+    assert not vp.training
+    ref, _ = load_vposer(vposer_sd)
+    z = torch.tensor(golden('vposer_decode')['z'])
+    with torch.no_grad():
+        a, b = vp.decode(z, output_type='aa'), ref.decode(z, output_type='aa')
+    assert torch.equal(a, b)
+    assert np.abs(a.view(z.shape[0], -1).numpy() - golden('vposer_decode')['aa']).max() < 1e-4
+    with pytest.raises(ValueError):
+        load_vposer(str(tmp_path / 'nope'))

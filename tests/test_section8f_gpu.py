@@ -1,0 +1,161 @@
+"""SURVEY section 8(f) rows and the body-model seam (b2) on the GPU, against fixtures produced by the REFERENCE's own drivers
+(oracle/make_golden_f.py):
+  f1  generation driver: TestOP.test of test_habitat_s2.py (preprocess -> sample -> recover_global_T -> pkl) end to end, then the
+      generated pkls through FittingOPHabitat.fitting (generate -> fit pipeline);
+  f2  plausibility metrics of utils_eval_collision_habitat.py on a reference-scored pkl set;
+  b2  SMPLX_NEUTRAL.npz in its real layout loaded by path (folder and file), extra keys and 45x45 hand components included."""
+import glob
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import psi_oracle as O
+from conftest import golden, rel_err
+import fixture_inputs as FI
+from psi_release_amd import body_model, evaluation, fitting, generation, synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=DEV)
+KEYS = ['transl', 'global_orient', 'betas', 'body_pose', 'left_hand_pose', 'right_hand_pose', 'cam_ext', 'cam_int']
+
+
+def _sensor_dir(tmp):
+    d = os.path.join(tmp, 'room-sensor')
+    os.makedirs(d)
+    for i, v in enumerate(FI.gen_views()):
+        np.save(os.path.join(d, 'cam_%03d.npy' % i), {'cam_ext': v['cam_ext'], 'cam_int': v['cam_int']}, allow_pickle=True)
+        np.save(os.path.join(d, 'depth_%03d.npy' % i), v['depth'])
+        np.save(os.path.join(d, 'seg_%03d.npy' % i), v['seg'])
+    return d
+
+
+def _generate(tmp, g):
+    ckpt = os.path.join(tmp, 'ckpt')
+    os.makedirs(ckpt)
+    out = os.path.join(tmp, 'gen')
+    n = int(g['n_samples'])
+    op = generation.TestOP({'outdir': out, 'ckpt_dir': ckpt, 'human_model_path': '', 'vposer_ckpt_path': '', 'device': torch.device(DEV),
+                            'test_data_path': _sensor_dir(tmp), 'n_samples': n, 'use_cont_rot': True, 'stage': 's2'})
+    shapes = {k: tuple(v.shape) for k, v in op.model_h.state_dict().items()}
+    torch.save({'epoch': 1, 'model_h_state_dict': {k: torch.tensor(v) for k, v in synth.make_state_like(shapes, int(g['state_seed'])).items()}},
+               os.path.join(ckpt, 'epoch-000001.ckp'))
+    op.latent_source = lambda view, n_: (T(g['z_g_%d' % view]), T(g['z_l_%d' % view]))    # the latents the reference run drew
+    op.test_habitat()
+    return out
+
+
+def test_generation_driver_equals_reference_driver(tmp_path):
+    g = golden('generation')
+    out = _generate(str(tmp_path), g)
+    files = sorted(glob.glob(os.path.join(out, 'body_gen_*.pkl')))
+    n = int(g['n_samples']) * int(g['n_views'])
+    assert [os.path.basename(f) for f in files] == ['body_gen_{:06d}.pkl'.format(i) for i in range(n)]   # n_samples*ii+jj numbering
+    for i, fn in enumerate(files):
+        with open(fn, 'rb') as f:
+            b = pickle.load(f)
+        assert list(b.keys()) == KEYS == list(g['pkl_keys'])
+        for k in KEYS:
+            ref = g['pkl_' + k][i]
+            assert b[k].shape == ref.shape and b[k].dtype == ref.dtype, (k, b[k].shape, ref.shape)
+            assert np.abs(b[k] - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), (i, k)
+
+
+def _room():
+    return synth.make_scene(**FI.PLAUS_SCENE)
+
+
+def _habitat_op(smplx_data, vposer_sd, scene, num_iter, engine='fused'):
+    cfg = {'scene_verts_path': None, 'scene_sdf_path': None, 'human_model_path': None, 'vposer_ckpt_path': None, 'init_lr_h': 0.1,
+           'num_iter': num_iter, 'batch_size': 1, 'device': torch.device(DEV), 'contact_part': synth.CONTACT_PARTS, 'contact_id_folder': None,
+           'verbose': False, 'smplx_data': smplx_data, 'vposer_state': vposer_sd, 'scene': scene, 'engine': engine}
+    loss = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1, 'weight_collision': 0.5}
+    return fitting.FittingOPHabitat(cfg, loss)
+
+
+def test_generate_then_fit_pipeline(tmp_path, smplx_data, vposer_sd):
+    """generate (this build's driver) -> pkl -> FittingOPHabitat.fitting, next to the same fit started from the pkl set the
+    REFERENCE driver wrote; one of the fits is also checked against the oracle's fitting loop (Habitat constants)."""
+    g = golden('generation')
+    out = _generate(str(tmp_path), g)
+    scene = _room()
+    op = _habitat_op(smplx_data, vposer_sd, scene, 5)
+    op.reset_optimizer = True                                 # every file is an independent fit in this comparison
+    fits = []
+    files = sorted(glob.glob(os.path.join(out, 'body_gen_*.pkl')))
+    for i, fn in enumerate(files[:4]):
+        a = op.fitting(fn).detach().cpu().numpy()            # from this build's generated pkl (a file path, as the script passes)
+        ref_body = {k: g['pkl_' + k][i] for k in KEYS}
+        b = op.fitting(ref_body).detach().cpu().numpy()       # from the reference-generated pkl contents
+        assert a.shape == (1, 72) and np.isfinite(a).all()
+        assert np.abs(a - b).max() < 2e-3, i                  # inputs agree to 1e-4; five Adam steps of lr 0.1 keep them together
+        fits.append((ref_body, b))
+    body, xh = fits[0]
+    fo = O.FittingOracle(O.SMPLXOracle(smplx_data), vposer_sd, scene.verts, scene.sdf, scene.grid_min, scene.grid_max,
+                         synth.contact_ids_from_parts(scene.contact_parts), 1, contact_const=1.0)
+    x72 = np.concatenate([body[k] for k in KEYS[:6]], -1)
+    cam = body['cam_ext'][:1] @ np.diag([1.0, -1.0, -1.0, 1.0]).astype(np.float32)       # fitting_habitat.py:179-184
+    ref = fo.fitting(x72, cam, 5).detach().numpy()
+    assert np.abs(xh - ref).max() < 1e-4
+    op.save_result(op.fitting(fits[1][0]), str(tmp_path / 'fit' / 'body_gen_000001.pkl'))
+    with open(str(tmp_path / 'fit' / 'body_gen_000001.pkl'), 'rb') as f:
+        assert list(pickle.load(f).keys()) == KEYS
+
+
+@pytest.mark.parametrize('tag', ['ac1', 'ac0'])
+def test_plausibility_scores_equal_reference_script(tmp_path, smplx_data, vposer_sd, tag):
+    """eval_colllision of utils_eval_collision_habitat.py:145-175: per body, non-collision score = #(sdf > 0) / 10475 and contact
+    score = [any sdf < 0], with the all-outside convention; both grid_sample conventions."""
+    g = golden('plausibility')
+    gen = tmp_path / 'gen'
+    gen.mkdir()
+    n = g['in_transl'].shape[0]
+    for i in range(n):
+        with open(str(gen / 'body_gen_{:06d}.pkl'.format(i)), 'wb') as f:
+            pickle.dump({k: g['in_' + k][i] for k in KEYS}, f)
+    op = _habitat_op(smplx_data, vposer_sd, _room(), 1, engine='modular')
+    op.align_corners = (tag == 'ac1')
+    ev = evaluation.PlausibilityEvaluator(op, flip_camera_yz=True)
+    coll, cont = ev.eval_folder(str(gen))
+    assert len(coll) == n and cont == list(g['cont_' + tag])
+    assert 0 < sum(cont) < n
+    # a vertex whose |sdf| is at rounding level may fall on either side: allow 3 of 10475 vertices
+    assert np.abs(np.array(coll) - g['coll_' + tag]).max() <= 3.0 / 10475.0 + 1e-12, (coll, g['coll_' + tag])
+    # batched pkl: the same bodies in ONE file score the same, body by body
+    grp = [i for i in range(n) if np.array_equal(g['in_cam_ext'][i], g['in_cam_ext'][0])]      # the bodies of the first view
+    assert len(grp) >= 2
+    many = {k: np.concatenate([g['in_' + k][i] for i in grp]) for k in KEYS[:6]}
+    many['cam_ext'], many['cam_int'] = g['in_cam_ext'][0], g['in_cam_int'][0]
+    c2, k2 = ev.scores(many)
+    assert k2 == [cont[i] for i in grp] and np.abs(np.array(c2) - np.array([coll[i] for i in grp])).max() < 1e-12
+
+
+def test_smplx_npz_real_layout_loaded_by_path(tmp_path, smplx_data):
+    """body_model.create(folder) finds {folder}/smplx/SMPLX_NEUTRAL.npz (fitting_proxe.py:55-56 / train_s1.py:83-85), reads the keys
+    the vendored loader reads (body_model.py:65-136) — 45x45 hand components of which the first 12 rows are used, >= 20 shape
+    components with the expression block behind the betas, kintree_table, f — and ignores the rest."""
+    d = dict(smplx_data.__dict__)
+    rs = np.random.RandomState(0)
+    d.update(lmk_faces_idx=rs.randint(0, 100, 51), lmk_bary_coords=rs.rand(51, 3), dynamic_lmk_faces_idx=rs.randint(0, 100, (79, 17)),
+             dynamic_lmk_bary_coords=rs.rand(79, 17, 3), allow_pickle_obj=np.array({'note': 'extra keys are ignored'}, dtype=object))
+    folder = tmp_path / 'models'
+    (folder / 'smplx').mkdir(parents=True)
+    np.savez(str(folder / 'smplx' / 'SMPLX_NEUTRAL.npz'), **d)
+    B = 3
+    kw = dict(model_type='smplx', gender='neutral', ext='npz', num_pca_comps=12, create_global_orient=True, create_body_pose=True,
+              create_betas=True, create_left_hand_pose=True, create_right_hand_pose=True, create_expression=True, create_jaw_pose=True,
+              create_leye_pose=True, create_reye_pose=True, create_transl=True, batch_size=B, device=DEV)
+    from_mem = body_model.create(smplx_data, **kw)
+    from_dir = body_model.create(str(folder), **kw)
+    from_file = body_model.create(str(folder / 'smplx' / 'SMPLX_NEUTRAL.npz'), **kw)
+    args = dict(return_verts=True, body_pose=T(rs.standard_normal((B, 63)) * 0.3), transl=T(rs.standard_normal((B, 3))),
+                global_orient=T(rs.standard_normal((B, 3))), betas=T(rs.standard_normal((B, 10))),
+                left_hand_pose=T(rs.standard_normal((B, 12)) * 0.3), right_hand_pose=T(rs.standard_normal((B, 12)) * 0.3))
+    v0 = from_mem(**args).vertices
+    assert torch.equal(from_dir(**args).vertices, v0) and torch.equal(from_file(**args).vertices, v0)
+    assert from_dir.faces_tensor.shape[1] == 3
+    ref = O.SMPLXOracle(smplx_data)(**{k: v.cpu() for k, v in args.items() if k != 'return_verts'}).vertices
+    assert rel_err(v0.cpu(), ref) < 1e-5
