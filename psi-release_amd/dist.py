@@ -40,8 +40,8 @@ def init_from_env(backend=None):
     lrk = int(os.environ.get('LOCAL_RANK', str(rk)))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
-    if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend is None:                           # PSI_DIST_BACKEND=gloo: several ranks on ONE GPU (tests on a single-GPU box)
+        backend = os.environ.get('PSI_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(lrk % max(torch.cuda.device_count(), 1))
     if not dist.is_initialized():
@@ -113,3 +113,31 @@ class _FittingLossReduce(Function):
 
 def fitting_loss_reduce(l_rec, l_vp, l_contact, body_sdf, group=None):
     return _FittingLossReduce.apply(l_rec, l_vp, l_contact, body_sdf, group)
+
+
+class _PenetrationLossGlobal(Function):
+    """Penetration loss of a row-sharded TRAINING batch (train_s1.py:192-202: mean of |sdf| over the penetrating vertices of the
+    whole batch).  Forward: all-reduce [sum_{sdf<0}|sdf|, count(sdf<0)] and return the global mean on every rank.  Backward: the
+    trainer AVERAGES parameter gradients over the W ranks afterwards, so the local entries get -W/N_global: the average of the
+    per-rank gradients is then exactly the gradient of the full-batch loss."""
+
+    @staticmethod
+    def forward(ctx, body_sdf, group):
+        W = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        st = penetration_stats(body_sdf.detach())
+        if W > 1:
+            dist.all_reduce(st, op=dist.ReduceOp.SUM, group=group)
+        n = st[1]
+        ctx.W = W
+        ctx.save_for_backward(body_sdf, n)
+        return torch.where(n > 0, st[0] / n.clamp(min=1.0), torch.zeros_like(n))
+
+    @staticmethod
+    def backward(ctx, g):
+        body_sdf, n = ctx.saved_tensors
+        scale = torch.where(n > 0, -g * ctx.W / n.clamp(min=1.0), torch.zeros_like(n))
+        return (body_sdf < 0).to(body_sdf.dtype) * scale, None
+
+
+def penetration_loss_global(body_sdf, group=None):
+    return _PenetrationLossGlobal.apply(body_sdf, group)

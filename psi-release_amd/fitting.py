@@ -195,6 +195,15 @@ class FittingOP:
             os.makedirs(dirname)
         body_param_list = BodyParamParser.body_params_encapsulate(xh_rec)
         print('[INFO] save results to: ' + output_data_file)
+        if getattr(self, 'save_all_rows', False) and len(body_param_list) > 1:
+            # batched fits: one pkl with ALL rows, in the schema of a generated-body pkl ([B,.] arrays); the reference loop below
+            # rewrites the same file once per row, so with batch_size > 1 only the last body survives
+            out = {k: np.concatenate([bp[k] for bp in body_param_list], axis=0) for k in body_param_list[0]}
+            out['cam_ext'] = self.cam_ext.detach().cpu().numpy()
+            out['cam_int'] = self.cam_int.detach().cpu().numpy()
+            with open(output_data_file, 'wb') as outfile:
+                pickle.dump(out, outfile)
+            return
         for body_param in body_param_list:
             body_param['cam_ext'] = self.cam_ext.detach().cpu().numpy()
             body_param['cam_int'] = self.cam_int.detach().cpu().numpy()

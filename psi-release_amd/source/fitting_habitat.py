@@ -28,6 +28,10 @@ def main(argv=None):
     ap.add_argument('--synthetic', default=None)
     ap.add_argument('--batch_size', type=int, default=1, help='bodies per pkl (reference: 1; BASELINE configs[4]: 512 over 8 GPUs)')
     ap.add_argument('--shard', default='files', choices=['files', 'rows'], help='under torchrun: shard the pkl files or the rows of every batch')
+    ap.add_argument('--reset_optimizer', action='store_true',
+                    help='fresh Adam state for every file (the reference carries one optimizer across the files of a scene, fitting_proxe.py:73-74; '
+                         'with --shard files the carried state depends on which files a rank sees)')
+    ap.add_argument('--save_all_rows', action='store_true', help='batch_size > 1: write every fitted row (the reference keeps the last one)')
     a = ap.parse_args(argv)
     rank, world = _common.dist_setup()
     extra = {}
@@ -46,7 +50,7 @@ def main(argv=None):
                'num_iter': a.num_iter, 'batch_size': a.batch_size,
                'device': torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu'),
                'contact_part': ['back', 'butt', 'L_Hand', 'R_Hand', 'L_Leg', 'R_Leg', 'thighs'],
-               'contact_id_folder': a.contact_id_folder, 'verbose': a.verbose, 'engine': a.engine}
+               'contact_id_folder': a.contact_id_folder, 'verbose': a.verbose, 'engine': a.engine, 'save_all_rows': a.save_all_rows, 'reset_optimizer': a.reset_optimizer}
         cfg.update(extra)
         lossconfig = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1, 'weight_collision': 0.5}
         _common.fit_files(FittingOPHabitat, cfg, lossconfig, os.path.join(a.gen_path, scenename), os.path.join(a.fit_path, scenename),

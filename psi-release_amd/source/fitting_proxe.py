@@ -33,6 +33,10 @@ def main(argv=None):
     ap.add_argument('--shard', default='files', choices=['files', 'rows'],
                     help="under torchrun: 'files' = every rank fits its own pkl files (independent problems); 'rows' = every file's batch is "
                          "split over the ranks with one all-reduce of the loss normalisers per iteration (BASELINE configs[3])")
+    ap.add_argument('--reset_optimizer', action='store_true',
+                    help='fresh Adam state for every file (the reference carries one optimizer across the files of a scene, fitting_proxe.py:73-74; '
+                         'with --shard files the carried state depends on which files a rank sees)')
+    ap.add_argument('--save_all_rows', action='store_true', help='batch_size > 1: write every fitted row (the reference keeps the last one)')
     a = ap.parse_args(argv)
     rank, world = _common.dist_setup()
     extra = {}
@@ -52,7 +56,7 @@ def main(argv=None):
             'device': torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu'),
             'contact_part': ['back', 'butt', 'L_Hand', 'R_Hand', 'L_Leg', 'R_Leg', 'thighs'],
             'contact_id_folder': os.path.join(a.proxe_path, 'body_segments'), 'verbose': a.verbose,
-            'engine': a.engine, 'align_corners': bool(a.align_corners)}
+            'engine': a.engine, 'align_corners': bool(a.align_corners), 'save_all_rows': a.save_all_rows, 'reset_optimizer': a.reset_optimizer}
         fittingconfig.update(extra)
         lossconfig = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1, 'weight_collision': 0.5}
         _common.fit_files(FittingOP, fittingconfig, lossconfig, os.path.join(a.gen_path, scenename), os.path.join(a.fit_path, scenename),

@@ -8,8 +8,9 @@ lines.  The body / Chamfer / SDF sub-stack is the HIP operator set (ops.py, body
 (MIOpen / hipBLASLt matrix-core path, optional bf16 autocast).  GPU only.
 
 Data parallel (new; the reference is single-GPU): wrap-free — gradients of the model parameters are all-reduced
-(averaged) across ranks after ``backward`` in one flattened bucket per dtype; the scene-loss normalisers follow the
-per-rank batch like the reference's single process (documented difference: the penetration mean is per rank).
+(averaged) across ranks after ``backward`` in one flattened bucket per dtype.  Mean-type losses over equal row shards average to the
+full-batch mean; the one data-dependent normaliser, the count of penetrating vertices (train_s1.py:192-202), is made global by a
+2-float all-reduce inside the loss (dist.penetration_loss_global), so sharded training equals the full batch in every loss phase.
 """
 from __future__ import annotations
 
@@ -115,7 +116,9 @@ class _TrainBase:
             sid = torch.arange(s_grid_sdf_batch.shape[0], dtype=torch.int32, device=self.device)
             body_sdf = ops.sdf_sample(body_verts_batch, s_grid_sdf_batch, s_grid_min_batch, s_grid_max_batch, scene_id=sid,
                                       align_corners=self.align_corners)
-        loss_sdf_pene = gate * self.weight_collision * ops.penetration_loss(body_sdf)
+        # data parallel: the mean runs over the penetrating vertices of the GLOBAL batch (one 2-float all-reduce, psi_release_amd/dist.py)
+        pen = psi_dist.penetration_loss_global(body_sdf) if psi_dist.is_dist() else ops.penetration_loss(body_sdf)
+        loss_sdf_pene = gate * self.weight_collision * pen
         return loss_contact, loss_vposer, loss_sdf_pene
 
     def _fca(self, ep):

@@ -70,3 +70,58 @@ def test_shard_rows_covers_everything():
             spans = [pd.shard_rows(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _worker_training_pen(rank, world, port, tmp):
+    """dist.penetration_loss_global + averaged gradients == the full-batch penetration mean and its gradient; gather_rows and
+    assert_equal_across_ranks; the collective skip decision of the training loop."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from psi_release_amd import dist as pd
+    pd.penetration_stats = _torch_pen_stats
+    rs = np.random.RandomState(1)
+    Wt = torch.tensor(rs.standard_normal((3,)), dtype=torch.float32)           # "model parameters" shared by the ranks
+    S = torch.tensor(rs.standard_normal((8, 40)), dtype=torch.float32)
+    S[:4] += 1.5                                                                   # very different penetration counts per rank
+    lo, hi = pd.shard_rows(8, rank, world)
+    w = Wt.clone().requires_grad_()
+    sdf = S[lo:hi] * w[0] + w[1] * 0.1 + w[2] * S[lo:hi] ** 2 * 0.01
+    loss = pd.penetration_loss_global(sdf)
+    loss.backward()
+    g = w.grad.clone()
+    dist.all_reduce(g)
+    g /= world                                                                     # what TrainOP._allreduce_grads does
+    wf = Wt.clone().requires_grad_()
+    sf = S * wf[0] + wf[1] * 0.1 + wf[2] * S ** 2 * 0.01
+    neg = sf < 0
+    lf = sf[neg].abs().mean()
+    lf.backward()
+    ok = abs(float(loss) - float(lf)) < 1e-6 and float((g - wf.grad).abs().max()) < 1e-5
+    # rows come back in rank order
+    rows = pd.gather_rows(torch.arange(lo, hi, dtype=torch.float32).view(-1, 1))
+    ok = ok and rows.view(-1).tolist() == list(range(8))
+    pd.assert_equal_across_ranks(4, 'rows')
+    try:
+        pd.assert_equal_across_ranks(4 + rank, 'rows')
+        ok = False
+    except ValueError:
+        pass
+    # collective skip: a batch that only ONE rank lacks is skipped by both
+    import types
+    from psi_release_amd import training
+    me = types.SimpleNamespace(device=torch.device('cpu'))
+    ok = ok and training._TrainBase._all_ranks_have(me, None if rank == 1 else [1]) is False
+    ok = ok and training._TrainBase._all_ranks_have(me, [1]) is True
+    open(os.path.join(tmp, 'pen%d' % rank), 'w').write('1' if ok else '0')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_penetration_global_and_helpers_world2(tmp_path):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker_training_pen, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / 'pen0').read() == '1' and open(tmp_path / 'pen1').read() == '1'

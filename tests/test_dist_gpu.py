@@ -68,7 +68,7 @@ def test_two_ranks_equal_full_batch(tmp_path, engine):
     assert np.abs(got - full).max() < 5e-5
 
 
-def _train_worker(rank, world, port, tmp):
+def _train_worker(rank, world, port, tmp, ep):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -76,26 +76,34 @@ def _train_worker(rank, world, port, tmp):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from test_training_gpu import _train_setup
     op, batch = _train_setup(tmp, 2, rows=slice(2 * rank, 2 * rank + 2))
-    op.train_step(batch, ep=0)
+    losses = op.train_step(batch, ep=ep)
     if rank == 0:
         torch.save({k: v.grad.detach().cpu() for k, v in op.model_h.named_parameters()}, os.path.join(tmp, 'dp.pt'))
+        torch.save(torch.stack([l.detach().float().cpu() for l in losses]), os.path.join(tmp, 'dp_losses.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_training_gradient_allreduce_equals_full_batch(tmp_path):
-    """TrainOP data parallel: averaged per-rank gradients == full-batch gradient (mean-type losses, equal shards, BN in
-    eval mode so that batch statistics do not differ between the shardings)."""
+@pytest.mark.parametrize('ep', [0, 90])
+def test_training_gradient_allreduce_equals_full_batch(tmp_path, ep):
+    """TrainOP data parallel: averaged per-rank gradients == full-batch gradient (equal shards, BN in eval mode so that batch
+    statistics do not differ between the shardings) — in the first loss phase (ep 0: scene terms gated off) and in the second
+    (ep 90 of 100: contact + penetration live, the penetration mean over the GLOBAL count of penetrating vertices)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from test_training_gpu import _train_setup
     op, batch = _train_setup(str(tmp_path), 4, rows=slice(0, 4))
-    op.train_step(batch, ep=0)
+    losses = op.train_step(batch, ep=ep)
+    full_losses = torch.stack([l.detach().float().cpu() for l in losses])
+    if ep == 90:
+        assert float(full_losses[3]) > 0 and float(full_losses[5]) > 0        # contact and penetration terms are live
     full = {k: v.grad.detach().cpu() for k, v in op.model_h.named_parameters()}
     del op
     torch.cuda.synchronize()
     port = _free_port()
-    mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path), ep), nprocs=2, join=True)
     dp = torch.load(tmp_path / 'dp.pt')
+    dp_losses = torch.load(tmp_path / 'dp_losses.pt')
+    assert abs(float(dp_losses[5]) - float(full_losses[5])) < 1e-6 * max(1.0, abs(float(full_losses[5])))   # global penetration mean on every rank
     # gradients (after the all-reduce) rather than parameters: Adam's first step is +-lr for any non-tiny gradient
     for k in full:
         scale = float(full[k].abs().max()) + 1e-12

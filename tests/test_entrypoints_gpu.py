@@ -52,3 +52,45 @@ def test_train_script_and_generation(tmp_path, stage):
     assert len(ck) == 1
     sd = torch.load(ck[0], map_location='cpu')
     assert sd['epoch'] == 10 and 'model_h_state_dict' in sd and 'optimizer_h_state_dict' in sd
+
+
+def _torchrun(args, nproc, env_extra, timeout=900):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+                        '--master-port', str(port)] + args, capture_output=True, text=True, timeout=timeout, cwd=SRC, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def _load(fn):
+    with open(fn, 'rb') as f:
+        return pickle.load(f)
+
+
+@pytest.mark.parametrize('script', ['fitting_proxe.py', 'fitting_habitat.py'])
+def test_fitting_scripts_rank_sharded(tmp_path, script):
+    """The file loop of the fitting entry points on 2 ranks (gloo, both on the one GPU of the test box):
+    --shard files: rank r fits files r, r+2, ... as independent problems -> identical to the single-process outputs;
+    --shard rows : every file's batch is split over the ranks with the global loss normalisers (one all-reduce per iteration)
+                   -> the gathered rows equal the single-process batch fit."""
+    import numpy as np
+    common = ['--synthetic', str(tmp_path / 'syn'), '--scenes', 'S0', '--num_iter', '4', '--batch_size', '2', '--save_all_rows', '--reset_optimizer']
+    one, files_d, rows_d = str(tmp_path / 'one'), str(tmp_path / 'files'), str(tmp_path / 'rows')
+    run([os.path.join(SRC, script), one] + common)
+    _torchrun([os.path.join(SRC, script), files_d] + common + ['--shard', 'files'], 2, {'PSI_DIST_BACKEND': 'gloo'})
+    _torchrun([os.path.join(SRC, script), rows_d] + common + ['--shard', 'rows'], 2, {'PSI_DIST_BACKEND': 'gloo'})
+    ref = sorted(glob.glob(os.path.join(one, 'S0', 'body_gen_*.pkl')))
+    assert len(ref) == 2
+    for fn in ref:
+        a = _load(fn)
+        assert a['transl'].shape == (2, 3)                     # --save_all_rows: both rows of the batch
+        for other, tol in ((files_d, 0.0), (rows_d, 5e-5)):
+            b = _load(os.path.join(other, 'S0', os.path.basename(fn)))
+            assert list(a.keys()) == list(b.keys())
+            for k in a:
+                assert a[k].shape == b[k].shape, (k, a[k].shape, b[k].shape)
+                assert np.abs(a[k] - b[k]).max() <= tol, (other, k, np.abs(a[k] - b[k]).max())
