@@ -296,27 +296,29 @@ struct SdfPenEpilogue {
 };
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void loss_finalize_kernel(FitDev f, float *stats)
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(FitDev f, float *stats)
 {
-    __shared__ float red[4];
-    const int t = threadIdx.x;
-    float a = 0;
-    for (int i = t; i < f.B; i += 256) a += f.recpart[i];
-    float s_rec = block_sum(a, red);
-    a = 0;
-    for (int i = t; i < f.B; i += 256) a += f.vppart[i];
-    float s_vp = block_sum(a, red);
-    a = 0;
-    for (int i = t; i < f.B * f.nfp; i += 256) a += f.fpart[i];
-    float s_f = block_sum(a, red);
-    a = 0;
-    float c = 0;
-    for (int i = t; i < f.B * f.nsdfblk; i += 256) {
-        a += f.penpart[2 * i];
-        c += f.penpart[2 * i + 1];
-    }
-    float s_pen = block_sum(a, red);
-    float n_pen = block_sum(c, red);
+    // one workgroup of 1024 threads; every thread keeps four independent partial sums per quantity so that its loads are all in
+    // flight together (a 256-thread version with one accumulator took 44 us for the 21k partial pairs of B = 512)
+    __shared__ float red[16];
+    const int t = threadIdx.x, nt = 1024;
+    auto total = [&](const float *p, int n, int stride) {
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int i = t;
+        for (; i + 3 * nt < n; i += 4 * nt) {
+            a0 += p[(size_t)i * stride];
+            a1 += p[(size_t)(i + nt) * stride];
+            a2 += p[(size_t)(i + 2 * nt) * stride];
+            a3 += p[(size_t)(i + 3 * nt) * stride];
+        }
+        for (; i < n; i += nt) a0 += p[(size_t)i * stride];
+        return block_sum((a0 + a1) + (a2 + a3), red);
+    };
+    float s_rec = total(f.recpart, f.B, 1);
+    float s_vp = total(f.vppart, f.B, 1);
+    float s_f = total(f.fpart, f.B * f.nfp, 1);
+    float s_pen = total(f.penpart, f.B * f.nsdfblk, 2);
+    float n_pen = total(f.penpart + 1, f.B * f.nsdfblk, 2);
     if (t == 0) {
         stats[0] = s_rec; stats[1] = s_vp; stats[2] = s_f; stats[3] = s_pen; stats[4] = n_pen; stats[5] = 0.0f;
         *f.step += 1;
@@ -542,16 +544,22 @@ struct psi_fit_engine {
 };
 
 // local: single-process iteration — the statistics are produced inside the backward's first kernel (no loss_finalize launch)
+// Single-process iterations fold the statistics into the first backward kernel (every workgroup re-derives the global
+// penetration count from the per-workgroup partials: no loss_finalize launch).  That re-derivation reads B * 41 partial pairs per
+// workgroup — O(B^2) in total — so from B = 128 on the separate one-workgroup statistics kernel is used instead.
+static inline bool fit_use_local_stats(const FitDev &f, bool local) { return local && f.B < PSI_SKIN_MB_MIN_B; }
+
 static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool local = false)
 {
     FitDev &f = e->d;
+    local = fit_use_local_stats(f, local);
     hipLaunchKernelGGL(head_fwd_kernel, dim3(f.B), dim3(HB), 0, st, f, e->lv);
     PSI_CHECK_LAUNCH("head_fwd_kernel");
     psi_mark("head_fwd_kernel", st);
     int rc = psi_lbs_blend_forward(e->lbs, f.B, e->lbs_ws, st);
     if (rc) return rc;
     hipLaunchKernelGGL(psi_skin_fwd_kernel<SdfPenEpilogue>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A, e->lv.v_posed,
-                       f.transl, f.cam, f.B, f.verts, SdfPenEpilogue{f, 0.0f, 0.0f});
+                           f.transl, f.cam, f.B, f.verts, SdfPenEpilogue{f, 0.0f, 0.0f});
     PSI_CHECK_LAUNCH("skin_fwd_sdf_kernel");
     psi_mark("skin_fwd_sdf_kernel", st);
     float gscale = f.w_contact / ((float)f.B * (float)f.world * (float)f.n_c);
@@ -561,7 +569,7 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
         rc = psi_nn_contact(f.verts, (long)f.V * 3, f.vid, f.scene, f.B, f.n_c, f.m, e->nn_ws, f.cconst, gscale, f.gq, f.fpart, nullptr, st);
     if (rc) return rc;
     if (local) return 0;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, f, stats);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, f, stats);
     PSI_CHECK_LAUNCH("loss_finalize_kernel");
     psi_mark("loss_finalize_kernel", st);
     return 0;
@@ -570,11 +578,18 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
 static int fit_backward(psi_fit_engine *e, float *stats, hipStream_t st, bool local = false)
 {
     FitDev &f = e->d;
-    if (local)
-        hipLaunchKernelGGL(psi_skin_bwd_v_kernel<FitGradSource<true>>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
+    local = fit_use_local_stats(f, local);
+    const bool mb = f.B >= PSI_SKIN_MB_MIN_B;
+    const dim3 bgrid(f.nsdfblk, mb ? psi_cdiv(f.B, PSI_SKIN_MB) : f.B);
+    if (local && mb)
+        psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, FitGradSource<true>{f, stats, 0.0f}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
+    else if (local)
+        hipLaunchKernelGGL(psi_skin_bwd_v_kernel<FitGradSource<true>>, bgrid, dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
                            FitGradSource<true>{f, stats, 0.0f}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
+    else if (mb)
+        psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, FitGradSource<false>{f, stats, 0.0f}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
     else
-        hipLaunchKernelGGL(psi_skin_bwd_v_kernel<FitGradSource<false>>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
+        hipLaunchKernelGGL(psi_skin_bwd_v_kernel<FitGradSource<false>>, bgrid, dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
                            FitGradSource<false>{f, stats, 0.0f}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
     PSI_CHECK_LAUNCH("skin_bwd_v_grad_kernel");
     psi_mark("skin_bwd_v_grad_kernel", st);
@@ -846,8 +861,11 @@ extern "C" int psi_fit_decode_backward(psi_fit_engine *e, const float *d_grad_ve
     PSI_REQUIRE(e && d_grad_verts && d_grad_x75, "null pointer");
     FitDev &f = e->d;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(psi_skin_bwd_v_kernel<PsiGradFromMemory>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
-                       PsiGradFromMemory{d_grad_verts, f.V}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
+    if (f.B >= PSI_SKIN_MB_MIN_B)
+        psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, PsiGradFromMemory{d_grad_verts, f.V}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
+    else
+        hipLaunchKernelGGL(psi_skin_bwd_v_kernel<PsiGradFromMemory>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
+                           PsiGradFromMemory{d_grad_verts, f.V}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
     PSI_CHECK_LAUNCH("skin_bwd_v_kernel");
     int rc = psi_lbs_backward_joint_parts(e->lbs, f.B, e->lbs_ws, f.g_transl, st);
     if (rc) return rc;

@@ -641,8 +641,11 @@ static int lbs_launch_bwd_joint_parts(const LbsDev &m, const WsLayout &L, int B,
 static int lbs_launch_bwd_partials(const LbsDev &m, const WsLayout &L, const float *grad_verts, const float *cam_ext, int B, float *ws,
                                    hipStream_t st)
 {
-    hipLaunchKernelGGL(psi_skin_bwd_v_kernel<PsiGradFromMemory>, dim3(m.Vpad / SKIN_BLK, B), dim3(SKIN_BLK), 0, st, m, ws + L.A,
-                       PsiGradFromMemory{grad_verts, m.V}, cam_ext, B, ws + L.gl, ws + L.g_vp, ws + L.gt_part);
+    if (B >= PSI_SKIN_MB_MIN_B)
+        psi_launch_skin_bwd_v_mb(m, ws + L.A, PsiGradFromMemory{grad_verts, m.V}, cam_ext, B, ws + L.gl, ws + L.g_vp, ws + L.gt_part, st);
+    else
+        hipLaunchKernelGGL(psi_skin_bwd_v_kernel<PsiGradFromMemory>, dim3(m.Vpad / SKIN_BLK, B), dim3(SKIN_BLK), 0, st, m, ws + L.A,
+                           PsiGradFromMemory{grad_verts, m.V}, cam_ext, B, ws + L.gl, ws + L.g_vp, ws + L.gt_part);
     PSI_CHECK_LAUNCH("skin_bwd_v_kernel");
     psi_mark("skin_bwd_v_kernel", st);
     return lbs_launch_bwd_joint_parts(m, L, B, ws, st);

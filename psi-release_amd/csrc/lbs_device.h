@@ -340,6 +340,18 @@ __device__ __forceinline__ void psi_blend_transforms(const LbsDev &m, const floa
     }
 }
 
+// The per-vertex affine maps of the skinning kernels with an EXPLICIT operation order (fma chains), so that every instantiation
+// — one body or several per workgroup, dense or compressed rows — rounds identically (left to the compiler's contraction the
+// kernels differed in the last bit).
+__device__ __forceinline__ float psi_dot3p(float a, float b, float c, float d, float x, float y, float z)
+{
+    return __builtin_fmaf(c, z, __builtin_fmaf(b, y, a * x)) + d;           // ((a x + b y) + c z) + d
+}
+__device__ __forceinline__ float psi_dot3(float a, float b, float c, float x, float y, float z)
+{
+    return __builtin_fmaf(c, z, __builtin_fmaf(b, y, a * x));               // (a x + b y) + c z
+}
+
 // Epilogue hook of skin_fwd: vertex() sees every lane's final world-space vertex (live = false for padding lanes),
 // finish() runs once per workgroup with all threads present.
 struct PsiSkinNoEpilogue {
@@ -349,7 +361,7 @@ struct PsiSkinNoEpilogue {
 
 // verts = cam_ext * (sum_j W_j A_j [v_posed;1] + transl)      (lbs.py:108-116, cvae.py:141-149)
 template <class Epi>
-__global__ __launch_bounds__(PSI_SKIN_BLK) void psi_skin_fwd_kernel(LbsDev m, const float *__restrict__ As, const float *__restrict__ v_posed,
+__global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_fwd_kernel(LbsDev m, const float *__restrict__ As, const float *__restrict__ v_posed,
                                                                      const float *__restrict__ transl, const float *__restrict__ cam_ext,
                                                                      int B, float *__restrict__ verts, Epi epi)
 {
@@ -362,9 +374,9 @@ __global__ __launch_bounds__(PSI_SKIN_BLK) void psi_skin_fwd_kernel(LbsDev m, co
     if (live) {
         const float *vp = v_posed + (size_t)b * m.Npad + (size_t)v * 3;
         float px = vp[0], py = vp[1], pz = vp[2];
-        x = T2[0].x * px + T2[0].y * py + T2[1].x * pz + T2[1].y;
-        y = T2[2].x * px + T2[2].y * py + T2[3].x * pz + T2[3].y;
-        z = T2[4].x * px + T2[4].y * py + T2[5].x * pz + T2[5].y;
+        x = psi_dot3p(T2[0].x, T2[0].y, T2[1].x, T2[1].y, px, py, pz);
+        y = psi_dot3p(T2[2].x, T2[2].y, T2[3].x, T2[3].y, px, py, pz);
+        z = psi_dot3p(T2[4].x, T2[4].y, T2[5].x, T2[5].y, px, py, pz);
         if (transl) {
             x += transl[(size_t)b * 3 + 0];
             y += transl[(size_t)b * 3 + 1];
@@ -372,9 +384,9 @@ __global__ __launch_bounds__(PSI_SKIN_BLK) void psi_skin_fwd_kernel(LbsDev m, co
         }
         if (cam_ext) {   // cvae.py:141-149: [v,1] @ cam_ext^T, drop w
             const float *C = cam_ext + (size_t)b * 16;
-            float X = C[0] * x + C[1] * y + C[2] * z + C[3];
-            float Y = C[4] * x + C[5] * y + C[6] * z + C[7];
-            float Z = C[8] * x + C[9] * y + C[10] * z + C[11];
+            float X = psi_dot3p(C[0], C[1], C[2], C[3], x, y, z);
+            float Y = psi_dot3p(C[4], C[5], C[6], C[7], x, y, z);
+            float Z = psi_dot3p(C[8], C[9], C[10], C[11], x, y, z);
             x = X; y = Y; z = Z;
         }
         float *o = verts + ((size_t)b * m.V + v) * 3;
@@ -398,7 +410,7 @@ struct PsiGradFromMemory {
 
 // per-vertex part of the skinning backward: g_local = R_c^T g_verts;  g_vposed = T_R^T g_local;  partial g_transl
 template <class Src>
-__global__ __launch_bounds__(PSI_SKIN_BLK) void psi_skin_bwd_v_kernel(LbsDev m, const float *__restrict__ As, Src src,
+__global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_bwd_v_kernel(LbsDev m, const float *__restrict__ As, Src src,
                                                                        const float *__restrict__ cam_ext, int B, float *__restrict__ gl,
                                                                        float *__restrict__ g_vp, float *__restrict__ gt_part)
 {
@@ -414,9 +426,9 @@ __global__ __launch_bounds__(PSI_SKIN_BLK) void psi_skin_bwd_v_kernel(LbsDev m, 
         src.load(b, v, gx, gy, gz);
         if (cam_ext) {   // g_local = R_c^T g
             const float *C = cam_ext + (size_t)b * 16;
-            lx = C[0] * gx + C[4] * gy + C[8] * gz;
-            ly = C[1] * gx + C[5] * gy + C[9] * gz;
-            lz = C[2] * gx + C[6] * gy + C[10] * gz;
+            lx = psi_dot3(C[0], C[4], C[8], gx, gy, gz);
+            ly = psi_dot3(C[1], C[5], C[9], gx, gy, gz);
+            lz = psi_dot3(C[2], C[6], C[10], gx, gy, gz);
         } else {
             lx = gx; ly = gy; lz = gz;
         }
@@ -425,9 +437,9 @@ __global__ __launch_bounds__(PSI_SKIN_BLK) void psi_skin_bwd_v_kernel(LbsDev m, 
         float *o = gl + (size_t)b * m.Npad + (size_t)v * 3;
         o[0] = lx; o[1] = ly; o[2] = lz;
         float *p = g_vp + (size_t)b * m.Npad + (size_t)v * 3;   // T_R^T g_local (rotation part of T, row-major 3x3)
-        p[0] = T2[0].x * lx + T2[2].x * ly + T2[4].x * lz;
-        p[1] = T2[0].y * lx + T2[2].y * ly + T2[4].y * lz;
-        p[2] = T2[1].x * lx + T2[3].x * ly + T2[5].x * lz;
+        p[0] = psi_dot3(T2[0].x, T2[2].x, T2[4].x, lx, ly, lz);
+        p[1] = psi_dot3(T2[0].y, T2[2].y, T2[4].y, lx, ly, lz);
+        p[2] = psi_dot3(T2[1].x, T2[3].x, T2[5].x, lx, ly, lz);
     }
     float sx = psi_wave_sum(lx), sy = psi_wave_sum(ly), sz = psi_wave_sum(lz);
     if ((threadIdx.x & 63) == 0) {
@@ -441,4 +453,159 @@ __global__ __launch_bounds__(PSI_SKIN_BLK) void psi_skin_bwd_v_kernel(LbsDev m, 
         for (int ww = 0; ww < PSI_SKIN_BLK / 64; ww++) s += sh[ww][threadIdx.x];
         gt_part[((size_t)blockIdx.x * B + b) * 4 + threadIdx.x] = s;
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Multi-body skinning backward for large batches (B >= PSI_SKIN_MB_MIN_B).  One body per workgroup re-reads the vertex's skinning
+// weights from L2 for every body — 2.3 MB x B, 1.2 GB at B = 512.  Here a lane loads its vertex's weights ONCE into registers and
+// walks PSI_SKIN_MB bodies: per body only the 2.6 KB of joint transforms are staged (double-buffered in LDS, one barrier per
+// body): 349 -> 281 us at B = 512.  At B = 32 this shape is slower (fewer, longer workgroups on a latency-bound launch: measured
+// 1.8x at 4 bodies), so the single-body kernel stays the default for small batches.  The FORWARD kernel keeps one body per
+// workgroup at every batch size: with the SDF lookup fused in it is bound by the eight-corner gathers (272 us multi-body vs 222 us
+// single-body at B = 512: the lower occupancy of the register-resident weights costs more gather latency than the weights save).
+// ------------------------------------------------------------------------------------------------
+constexpr int PSI_SKIN_MB = 8;            // bodies per workgroup
+constexpr int PSI_SKIN_MB_MIN_B = 128;    // batch size from which the multi-body kernels are used
+
+template <bool COMPRESSED>
+struct PsiLaneWeights;
+template <>
+struct PsiLaneWeights<false> {
+    psi_f2 w2[PSI_JP / 2];                // dense row of this lane's vertex, two joints per 64-bit register pair (zero beyond J)
+    __device__ __forceinline__ void load(const LbsDev &m, int v)
+    {
+        // WT is [PSI_JP][Vpad] with zero rows beyond J.  Buffer loads: ONE lane offset register + a scalar row offset per joint.
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)m.WT, 0, PSI_JP * m.Vpad * 4, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < PSI_JP / 2; j++) {
+            w2[j].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, v * 4, (2 * j) * m.Vpad * 4, 0));
+            w2[j].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, v * 4, (2 * j + 1) * m.Vpad * 4, 0));
+        }
+    }
+    // same sum, same order as psi_blend_transforms (ascending joints, packed fma): bit-identical results.  The packed fma takes
+    // the weight of BOTH result lanes from one half of the weight pair (op_sel / op_sel_hi on src0), so a weight costs one
+    // register — the compiler's own form of `{w,w} * A + T` materialises a 2-register broadcast per weight (128 VGPRs for 64
+    // joints, which spilled).
+    __device__ __forceinline__ void blend(const LbsDev &m, const psi_f2 (*sA)[6], psi_f2 (&T2)[6]) const
+    {
+#pragma unroll
+        for (int e = 0; e < 6; e++) T2[e] = (psi_f2){0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < PSI_JP / 8; c++) {
+            if (c * 8 < m.J) {                    // whole groups of 8 joints (padding joints: weight 0, transform 0 -> exact zeros)
+#pragma unroll
+                for (int jj = c * 4; jj < c * 4 + 4; jj++) {
+#pragma unroll
+                    for (int e = 0; e < 6; e++) {
+                        const psi_f2 a = sA[2 * jj][e];
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(T2[e]) : "v"(w2[jj]), "v"(a));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 6; e++) {
+                        const psi_f2 a = sA[2 * jj + 1][e];
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(T2[e]) : "v"(w2[jj]), "v"(a));
+                    }
+                }
+            }
+        }
+    }
+};
+template <>
+struct PsiLaneWeights<true> {
+    float wk[PSI_WNZ];                    // compressed row: the k-th non-zero weight and its joint
+    int jk[PSI_WNZ];
+    __device__ __forceinline__ void load(const LbsDev &m, int v)
+    {
+#pragma unroll
+        for (int k = 0; k < PSI_WNZ; k++) {
+            wk[k] = m.Wc[(size_t)k * m.Vpad + v];
+            jk[k] = m.Wj[(size_t)k * m.Vpad + v];
+        }
+    }
+    __device__ __forceinline__ void blend(const LbsDev &, const psi_f2 (*sA)[6], psi_f2 (&T2)[6]) const
+    {
+#pragma unroll
+        for (int e = 0; e < 6; e++) T2[e] = (psi_f2){0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < PSI_WNZ; k++) {
+            psi_f2 w2 = {wk[k], wk[k]};
+#pragma unroll
+            for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, sA[jk[k]][e], T2[e]);
+        }
+    }
+};
+
+__device__ __forceinline__ void psi_stage_transforms(const LbsDev &m, const float *__restrict__ As, int b, psi_f2 (*sA)[6])
+{
+    for (int idx = threadIdx.x; idx < PSI_JP * 6; idx += PSI_SKIN_BLK)
+        sA[idx / 6][idx % 6] = idx < m.J * 6 ? *(const psi_f2 *)(As + ((size_t)b * m.J) * 12 + idx * 2) : (psi_f2){0.0f, 0.0f};
+}
+
+template <class Src, bool COMPRESSED>
+__global__ __launch_bounds__(PSI_SKIN_BLK, 4) void psi_skin_bwd_v_mb_kernel(LbsDev m, const float *__restrict__ As, Src src,
+                                                                          const float *__restrict__ cam_ext, int B, float *__restrict__ gl,
+                                                                          float *__restrict__ g_vp, float *__restrict__ gt_part)
+{
+    const int v = blockIdx.x * PSI_SKIN_BLK + threadIdx.x;
+    const int b0 = blockIdx.y * PSI_SKIN_MB;
+    src.prepare();
+    __shared__ psi_f2 sA[2][PSI_JP][6];
+    __shared__ float sh[2][PSI_SKIN_BLK / 64][3];
+    PsiLaneWeights<COMPRESSED> lw;
+    lw.load(m, v);
+    const int nb = min(PSI_SKIN_MB, B - b0);
+#pragma nounroll
+    for (int bb = 0; bb < nb; bb++) {
+        const int b = b0 + bb;
+        psi_stage_transforms(m, As, b, sA[bb & 1]);
+        float lx = 0, ly = 0, lz = 0;
+        if (v < m.V) {
+            float gx, gy, gz;
+            src.load(b, v, gx, gy, gz);
+            if (cam_ext) {
+                const float *C = cam_ext + (size_t)b * 16;
+                lx = psi_dot3(C[0], C[4], C[8], gx, gy, gz);
+                ly = psi_dot3(C[1], C[5], C[9], gx, gy, gz);
+                lz = psi_dot3(C[2], C[6], C[10], gx, gy, gz);
+            } else {
+                lx = gx; ly = gy; lz = gz;
+            }
+        }
+        float sx = psi_wave_sum(lx), sy = psi_wave_sum(ly), sz = psi_wave_sum(lz);
+        if ((threadIdx.x & 63) == 0) {
+            sh[bb & 1][threadIdx.x >> 6][0] = sx;
+            sh[bb & 1][threadIdx.x >> 6][1] = sy;
+            sh[bb & 1][threadIdx.x >> 6][2] = sz;
+        }
+        __syncthreads();
+        psi_f2 T2[6];
+        lw.blend(m, sA[bb & 1], T2);
+        {
+            float *o = gl + (size_t)b * m.Npad + (size_t)v * 3;
+            o[0] = lx; o[1] = ly; o[2] = lz;
+            float *p = g_vp + (size_t)b * m.Npad + (size_t)v * 3;
+            p[0] = psi_dot3(T2[0].x, T2[2].x, T2[4].x, lx, ly, lz);
+            p[1] = psi_dot3(T2[0].y, T2[2].y, T2[4].y, lx, ly, lz);
+            p[2] = psi_dot3(T2[1].x, T2[3].x, T2[5].x, lx, ly, lz);
+        }
+        if (threadIdx.x < 3) {
+            float s = 0;
+            for (int ww = 0; ww < PSI_SKIN_BLK / 64; ww++) s += sh[bb & 1][ww][threadIdx.x];
+            gt_part[((size_t)blockIdx.x * B + b) * 4 + threadIdx.x] = s;
+        }
+    }
+}
+
+
+// launch helpers: pick the dense / compressed-row instantiation
+template <class Src>
+static inline void psi_launch_skin_bwd_v_mb(const LbsDev &m, const float *As, Src src, const float *cam_ext, int B, float *gl, float *g_vp,
+                                            float *gt_part, hipStream_t st)
+{
+    const dim3 grid(m.Vpad / PSI_SKIN_BLK, (B + PSI_SKIN_MB - 1) / PSI_SKIN_MB);
+    if (m.Wc)
+        hipLaunchKernelGGL((psi_skin_bwd_v_mb_kernel<Src, true>), grid, dim3(PSI_SKIN_BLK), 0, st, m, As, src, cam_ext, B, gl, g_vp, gt_part);
+    else
+        hipLaunchKernelGGL((psi_skin_bwd_v_mb_kernel<Src, false>), grid, dim3(PSI_SKIN_BLK), 0, st, m, As, src, cam_ext, B, gl, g_vp, gt_part);
 }

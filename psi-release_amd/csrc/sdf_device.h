@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+typedef float psi_f2u __attribute__((ext_vector_type(2), aligned(4)));     // 8-byte load at 4-byte alignment (global_load_dwordx2)
+
 struct PsiAxis {
     int i0, i1;
     float w1, du;   // weight of the upper corner; d(u)/d(vert) (0 when clamped by the border rule)
@@ -42,10 +44,17 @@ __device__ __forceinline__ float psi_trilinear(const float *__restrict__ vol, co
     PsiAxis az = psi_axis_setup(z, gmin[2], gmax[2], D, align_corners);
     const size_t x0 = (size_t)ax.i0 * D, x1 = (size_t)ax.i1 * D;
     const size_t r00 = (x0 + ay.i0) * D, r01 = (x0 + ay.i1) * D, r10 = (x1 + ay.i0) * D, r11 = (x1 + ay.i1) * D;
-    float c000 = vol[r00 + az.i0], c001 = vol[r00 + az.i1];
-    float c010 = vol[r01 + az.i0], c011 = vol[r01 + az.i1];
-    float c100 = vol[r10 + az.i0], c101 = vol[r10 + az.i1];
-    float c110 = vol[r11 + az.i0], c111 = vol[r11 + az.i1];
+    // the two z-neighbours of a corner pair are adjacent in memory ([ix][iy][iz] layout): FOUR 8-byte gathers instead of eight
+    // 4-byte ones (the gathers are what bounds the fused skinning+SDF kernel at large batches).  At the upper border both corners
+    // are the last cell (i0 == i1 == D-1): the pair is read one cell lower and its upper half used for both.
+    const int zb = min(az.i0, D - 2);
+    const bool top = az.i0 > zb;
+    const psi_f2u p00 = *(const psi_f2u *)(vol + r00 + zb), p01 = *(const psi_f2u *)(vol + r01 + zb);
+    const psi_f2u p10 = *(const psi_f2u *)(vol + r10 + zb), p11 = *(const psi_f2u *)(vol + r11 + zb);
+    float c000 = top ? p00.y : p00.x, c001 = p00.y;
+    float c010 = top ? p01.y : p01.x, c011 = p01.y;
+    float c100 = top ? p10.y : p10.x, c101 = p10.y;
+    float c110 = top ? p11.y : p11.x, c111 = p11.y;
     const float wx1 = ax.w1, wx0 = 1.0f - ax.w1;
     const float wy1 = ay.w1, wy0 = 1.0f - ay.w1;
     const float wz1 = az.w1, wz0 = 1.0f - az.w1;

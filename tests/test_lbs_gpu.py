@@ -33,7 +33,7 @@ def test_lbs_forward_golden(layer):
     assert np.abs(v.cpu().numpy() - g['verts']).max() < 2e-5
 
 
-@pytest.mark.parametrize('B', [1, 3, 16, 17, 32, 40, 70])
+@pytest.mark.parametrize('B', [1, 3, 16, 17, 32, 40, 70, 128, 131])          # >= 128: the multi-body skinning kernels
 def test_lbs_forward_batch_sizes(layer, oracle_model, B):
     rs = np.random.RandomState(B)
     betas = rs.standard_normal((B, 20)).astype(np.float32)
@@ -48,7 +48,7 @@ def test_lbs_forward_batch_sizes(layer, oracle_model, B):
     assert rel_err(v.cpu(), vo) < 1e-4
 
 
-@pytest.mark.parametrize('B,use_cam', [(2, True), (5, False), (32, True), (40, True), (70, False)])   # > 32: the 4-tile MFMA variants
+@pytest.mark.parametrize('B,use_cam', [(2, True), (5, False), (32, True), (40, True), (70, False), (131, True)])   # > 32: the 4-tile MFMA variants; >= 128: multi-body skinning
 def test_lbs_backward_vs_autograd(layer, oracle_model, B, use_cam):
     rs = np.random.RandomState(100 + B)
     betas = rs.standard_normal((B, 20)).astype(np.float32)
@@ -148,3 +148,37 @@ def test_compressed_skinning_rows_bit_identical(monkeypatch):
     # and the path is actually different from the dense model's (the sparsified weights changed the mesh)
     dense_model = body_model.LbsModel(data.v_template, data.shapedirs, posedirs, data.J_regressor, W, parents, DEV)
     assert not torch.equal(body_model.lbs(dense_model, T(betas), T(pose), transl=T(transl), cam_ext=T(cam)), out['dense'][0])
+
+
+@pytest.mark.parametrize('compressed', [False, True])
+def test_multi_body_skinning_kernels_bit_identical_to_single_body(compressed):
+    """B >= 128 takes the multi-body skinning kernels (a lane keeps its vertex's weights in registers and walks 8 bodies); they sum
+    the same terms in the same order as the one-body-per-workgroup kernels, so a batch of 136 equals its 32-row chunks bit for bit
+    (forward vertices and all three gradients), dense and compressed weight rows alike."""
+    data = synth.make_smplx(seed=7)
+    W = np.array(data.weights, dtype=np.float32)
+    if compressed:
+        keep = np.argsort(-W, axis=1)[:, :6]
+        Ws = np.zeros_like(W)
+        np.put_along_axis(Ws, keep, np.take_along_axis(W, keep, axis=1), axis=1)
+        W = Ws / Ws.sum(axis=1, keepdims=True)
+    parents = data.kintree_table[0].copy()
+    parents[0] = -1
+    posedirs = data.posedirs.reshape(-1, data.posedirs.shape[-1]).T.copy()
+    mdl = body_model.LbsModel(data.v_template, data.shapedirs, posedirs, data.J_regressor, W, parents, DEV)
+    rs = np.random.RandomState(12)
+    B = 136
+    betas, pose = rs.standard_normal((B, 20)).astype(np.float32), (rs.standard_normal((B, 165)) * 0.4).astype(np.float32)
+    transl, cam, w = rs.standard_normal((B, 3)).astype(np.float32), synth.make_cam_ext(3, B), rs.standard_normal((B, 10475, 3)).astype(np.float32)
+
+    def run(sl):
+        bt, pt, tt = T(betas[sl]).requires_grad_(), T(pose[sl]).requires_grad_(), T(transl[sl]).requires_grad_()
+        v = body_model.lbs(mdl, bt, pt, transl=tt, cam_ext=T(cam[sl]))
+        (v * T(w[sl])).sum().backward()
+        return [v.detach(), bt.grad, pt.grad, tt.grad]
+    whole = run(slice(0, B))
+    parts = [run(slice(i, min(i + 32, B))) for i in range(0, B, 32)]
+    assert torch.equal(whole[0], torch.cat([p[0] for p in parts]))                 # vertices: bit-identical
+    for k in (1, 2, 3):                                                            # gradients: the per-body contractions are the same code,
+        ref = torch.cat([p[k] for p in parts])                                     # only the MFMA row-tile variant differs (B > 32 vs 32)
+        assert rel_err(whole[k].cpu(), ref.cpu()) < 1e-5

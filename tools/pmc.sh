@@ -4,7 +4,7 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --secondary 0 > /tmp/pmc_$c.log 2>&1
   f=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1)
   python - "$f" "$c" > $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$c.txt <<'PY'
 import csv, sys, collections
