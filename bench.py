@@ -224,7 +224,12 @@ def load_pmc():
 
 
 def roofline_from_kernels(args, agg, work):
-    """Roofline entry of the DOMINANT kernel of the iteration (largest HIP-event time) + the same for every kernel."""
+    """Roofline entry of the DOMINANT kernel of the iteration + the achieved bandwidth of every kernel.
+
+    Dominant = the kernel that carries the largest share of the iteration's algorithmic bytes (the big HBM stream: bwd_joint_kernel, 42 %
+    of the 188 MB at the BASELINE shape; the kernel VERDICT r01 names).  After this round's work three kernels are within a few per
+    cent of each other in TIME — the longest one is reported as `longest_kernel` — and the two per-body head kernels among them are
+    latency chains whose byte count is tiny, so "largest time" would flip between runs and say nothing about bandwidth."""
     per = {}
     for k, ms in agg.items():
         w = work.get(k)
@@ -232,7 +237,8 @@ def roofline_from_kernels(args, agg, work):
             continue
         gbs = w[1] / (ms * 1e-3) * 1e-9
         per[k] = {'us': round(ms * 1e3, 2), 'GB/s': round(gbs, 1), 'frac_hbm': round(gbs / PEAK_HBM_GBS, 4)}
-    dom = max(agg, key=agg.get)
+    byte_kernels = {k: work[k][1] for k in agg if k in work and work[k][0] == 'byte'}
+    dom = max(byte_kernels, key=byte_kernels.get) if byte_kernels else max(agg, key=agg.get)
     w = work.get(dom)
     roof = None
     if w is not None:
@@ -247,6 +253,9 @@ def roofline_from_kernels(args, agg, work):
             roof = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None, 'avg_launch_ms': round(agg[dom], 4),
                     'bytes_per_launch': w[1], 'note': w[2]}
+        longest = max(agg, key=agg.get)
+        roof['longest_kernel'] = {'kernel': longest, 'avg_launch_ms': round(agg[longest], 4)}
+        roof['share_of_iteration_bytes'] = round(w[1] / (131.7e6 + args.batch * 1.76e6), 3) if w[0] == 'byte' else None
         pmc, src = load_pmc()
         if pmc and (args.batch, args.nc, args.m, args.D) == (32, 2048, 32768, 256) and dom in pmc:
             roof['traffic'] = pmc[dom]['bytes']

@@ -204,6 +204,27 @@ int psi_fit_profile(psi_fit_engine *engine, int n_rep, char *h_names, int name_s
  * "g_pose", "g_rot" [B,55,9], "stats" [8], "adam_m"/"adam_v" [B,75]) into d_out (device). */
 int psi_fit_copy_buffer(psi_fit_engine *engine, const char *name, float *d_out, long n_floats, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense layers of the CVAEs on the matrix cores — replaces nn.Linear (+ LeakyReLU, + skip connection) of
+ *   ResBlock                 net_layers.py:28-43  (fc1 -> LeakyReLU -> fc2 -> LeakyReLU -> + x0)
+ *   scene feature `fc`       cvae.py:436-440, net_layers.py:66,164  (8192 -> 256, 32768 -> 256)
+ *   linear_in / mu_enc / logvar_enc / linear_latent / linear_out, torso_linear, pose_linear, mean/log_var_linear, decode.*
+ *                            cvae.py:441-452,474-492; net_layers.py:67-86,165-184
+ * y[M,N] = act(x[M,K] W[N,K]^T + bias[N]) (+ residual[M,N]);  W is the nn.Linear weight ([out,in], fp32 master copy).
+ * Arithmetic: x and W are rounded to bf16 (RNE) as they are loaded, products accumulate in fp32 on v_mfma_f32_32x32x16_bf16,
+ * y is fp32 — the precision of the reference trained under bf16 autocast with an fp32 output.  x: fp32 [M,K], or bf16 [M,K]
+ * when x_is_bf16 != 0 (the NHWC bf16 conv feature map flattened).  K % 16 == 0 (forward) and N % 16 == 0 (backward).
+ * act: 0 none, 1 LeakyReLU(slope).  act_out (nullable, [M,N]) receives act(...) BEFORE the residual is added: the backward
+ * needs its sign.  ws: psi_linear_workspace_floats(M,N,K) floats (0 for small layers; split-K partials for large weights).
+ * Backward: gy [M,N] = dL/dy; act_out as saved by the forward (NULL when act == 0); outputs gx [M,K] (dtype of x; nullable),
+ * gW [N,K] fp32 and gbias [N] fp32 (nullable), all OVERWRITTEN.  The residual's gradient is gy itself (caller adds it).
+ * ------------------------------------------------------------------------------------------- */
+size_t psi_linear_workspace_floats(int M, int N, int K);
+int psi_linear_forward(const void *x, int x_is_bf16, const float *W, const float *bias, const float *residual, int M, int N, int K,
+                       int act, float slope, float *y, float *act_out, float *ws, void *stream);
+int psi_linear_backward(const float *gy, const float *act_out, const void *x, int x_is_bf16, const float *W, int M, int N, int K,
+                        float slope, void *gx, float *gW, float *gbias, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,14 @@ class ResBlock(nn.Module):
         self.fc2 = nn.Linear(n_dim, n_dim)
         self.acfun = nn.LeakyReLU()
 
+    hip_linear = False          # set by the owning model: dense layers on the hand-written bf16 MFMA kernels (ops.linear_act)
+
     def forward(self, x0):
+        if _use_hip_linear(self, x0) and self.n_dim % 16 == 0:
+            from .ops import linear_act
+            slope = self.acfun.negative_slope
+            x = linear_act(x0, self.fc1.weight, self.fc1.bias, 'leaky_relu', slope)
+            return linear_act(x, self.fc2.weight, self.fc2.bias, 'leaky_relu', slope, residual=x0)      # fc2 + LeakyReLU + skip: one kernel
         x = self.acfun(self.fc1(x0))
         x = self.acfun(self.fc2(x))
         return x + x0
@@ -78,6 +85,29 @@ def load_pretrained_resnet18(trunk, ckpt_path):
     trunk.load_state_dict(own)
 
 
+def set_hip_linear(model, on=True):
+    """Route the dense layers of ``model`` (ResBlock stacks and the scene-feature ``fc``) through the hand-written bf16 MFMA kernels of
+    libpsi_hip.so (ops.linear_act: Linear + bias + LeakyReLU + skip in one launch, fp32 master weights rounded to bf16 on load).
+    Enabled together with ``autocast_bf16`` (same operand precision as the autocast GEMMs, fp32 output).  Policy (PSI_HIP_LINEAR):
+    unset — used whenever no gradient is recorded (the forward / sampling path: generation drivers, evaluation), while training
+    keeps the library GEMMs (measured on MI355X at batch 128: the fused forward equals the library forward, 12 vs 5-9 us + cast +
+    epilogue kernels, but the backward GEMMs are the library's either way and the extra casts cost 1.8 % of a train_s2 step);
+    '1' — also while training; '0' — never."""
+    for m in model.modules():
+        if isinstance(m, (ResBlock, _SceneCond)):
+            m.hip_linear = bool(on)
+
+
+def _use_hip_linear(module, x):
+    import os
+    if not getattr(module, 'hip_linear', False) or not x.is_cuda:
+        return False
+    mode = os.environ.get('PSI_HIP_LINEAR', '')
+    if mode == '0':
+        return False
+    return mode == '1' or not torch.is_grad_enabled()
+
+
 def _reparam(mu, logvar, eps=None):
     std = torch.exp(0.5 * logvar)
     if eps is None:
@@ -98,6 +128,11 @@ class _SceneCond(nn.Module):
             scene = scene.contiguous(memory_format=torch.channels_last)
             with torch.autocast('cuda', dtype=torch.bfloat16):
                 f = self.conv(self.resnet(scene))
+                if _use_hip_linear(self, scene):
+                    # the 8192 / 32768 -> num_hidden layer: the bf16 feature map goes straight into the MFMA kernel, the fp32 master
+                    # weight (up to 33.5 MB) is read once and rounded on load instead of being cast by a separate kernel every step
+                    from .ops import linear_act
+                    return linear_act(f.reshape(b, -1), self.fc.weight, self.fc.bias)
                 return self.fc(f.reshape(b, -1)).float()
         f = self.conv(self.resnet(scene))
         return self.fc(f.reshape(b, -1))
@@ -173,6 +208,7 @@ class HumanCVAES2(nn.Module):
         self.trans_vae = BodyGlobalPoseVAE(zdim=32, in_dim=2, num_hidden=latentD_g, pretrained_resnet=scene_model_ckpt, test=test)
         self.pose_vae = BodyLocalPoseVAE(zdim=32, in_dim=2, num_hidden=latentD_g, pretrained_resnet=scene_model_ckpt, test=test)
         self.trans_vae.autocast_bf16 = self.pose_vae.autocast_bf16 = autocast_bf16
+        set_hip_linear(self, autocast_bf16)
 
     def forward(self, x_body, eps_g, eps_l, x_s, use_eps=False):
         x_g, x_l = x_body[:, :3], x_body[:, 3:]
@@ -205,6 +241,7 @@ class HumanCVAES1(_SceneCond):
         self.linear_latent = nn.Linear(self.eps_d, latentD)
         self.human_decoder = nn.Sequential(ResBlock(2 * latentD), ResBlock(2 * latentD))
         self.linear_out = nn.Linear(2 * latentD, n_dim_body)
+        set_hip_linear(self, autocast_bf16)
 
     def forward(self, x_body, x_s, eps=None):
         z_s = self._scene_feature(x_s)

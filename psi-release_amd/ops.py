@@ -12,6 +12,8 @@ import torch
 from torch import nn
 from torch.autograd import Function
 
+import os
+
 from . import hip
 
 
@@ -278,3 +280,68 @@ def chamfer_to_scenes(xyz1, scenes: SceneSet, slot):
     """dist1 [B,n] of every body against its own scene.  slot: int32 device [B]."""
     assert slot.dtype == torch.int32 and slot.is_contiguous()
     return _SceneSetChamfer.apply(xyz1, scenes, slot)
+
+
+# ------------------------------------------------------------------------------------------
+# Dense layers on the matrix cores (csrc/linear.hip): y = act(x W^T + b) (+ residual), bf16 MFMA with fp32 accumulation
+# ------------------------------------------------------------------------------------------
+class _LinearAct(Function):
+    """nn.Linear (+ LeakyReLU, + skip connection) as ONE hand-written bf16-MFMA kernel per direction; replaces, on the bf16 path of the
+    CVAEs, the cast / GEMM / bias-activation / add kernels PyTorch launches per layer (net_layers.py:28-43, cvae.py:474-492)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, act, slope):
+        if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1]:
+            raise ValueError('linear_act: x [M,K] and weight [N,K] expected, got %s / %s' % (tuple(x.shape), tuple(weight.shape)))
+        M, K = x.shape
+        N = weight.shape[0]
+        if K % 16 or N % 16:
+            raise ValueError('linear_act: K and N must be multiples of 16 (got K=%d, N=%d)' % (K, N))
+        xb = x.dtype == torch.bfloat16
+        xc = x.detach().contiguous() if xb else x.detach().contiguous().float()
+        w = weight.detach().contiguous().float()
+        b = bias.detach().contiguous().float() if bias is not None else None
+        r = residual.detach().contiguous().float() if residual is not None else None
+        y = torch.empty(M, N, device=x.device)
+        a_out = torch.empty(M, N, device=x.device) if (act and residual is not None) else None
+        L = hip.lib()
+        nws = L.psi_linear_workspace_floats(M, N, K)
+        ws = torch.empty(nws, device=x.device) if nws else None
+        hip.check(L.psi_linear_forward(hip.ptr(xc), int(xb), hip.ptr(w), hip.ptr(b), hip.ptr(r), M, N, K, int(act), float(slope), hip.ptr(y),
+                                       hip.ptr(a_out), hip.ptr(ws), hip.stream()), 'psi_linear_forward')
+        ctx.act, ctx.slope, ctx.xb = int(act), float(slope), xb
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        # without a residual the output itself carries the sign of the pre-activation
+        ctx.save_for_backward(xc, w, (a_out if a_out is not None else y) if act else torch.empty(0, device=x.device))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, w, a_out = ctx.saved_tensors
+        M, K = xc.shape
+        N = w.shape[0]
+        gy = gy.contiguous().float()
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if os.environ.get('PSI_HIP_LINEAR_BWD', '0') != '1':
+            # default: the two backward GEMMs go to the library (hipBLASLt) on the same bf16-rounded operands.  The hand-written
+            # dX / dW kernels (csrc/linear.hip, selected by PSI_HIP_LINEAR_BWD=1) are exact to the same reference but read their
+            # transposed operands lane-per-row and are slower than the library at these shapes (85 vs ~10 us for a 512 x 512 layer)
+            g = gy if not ctx.act else torch.where(a_out > 0, gy, gy * ctx.slope)
+            gb16 = g.to(torch.bfloat16)
+            gx = (gb16 @ w.to(torch.bfloat16)).to(xc.dtype) if need_x else None
+            gw = (gb16.t() @ xc.to(torch.bfloat16)).float() if need_w else None
+            gb = g.sum(0) if need_b else None
+            return gx, gw, gb, gy if (ctx.has_res and ctx.needs_input_grad[3]) else None, None, None
+        gx = torch.empty(M, K, device=gy.device, dtype=torch.bfloat16 if ctx.xb else torch.float32) if need_x else None
+        gw = torch.empty(N, K, device=gy.device) if (need_w or need_b) else None         # gbias is produced by the dW kernel
+        gb = torch.empty(N, device=gy.device) if need_b else None
+        hip.check(hip.lib().psi_linear_backward(hip.ptr(gy), hip.ptr(a_out) if ctx.act else None, hip.ptr(xc), int(ctx.xb), hip.ptr(w), M, N, K,
+                                                ctx.slope, hip.ptr(gx), hip.ptr(gw), hip.ptr(gb), hip.stream()), 'psi_linear_backward')
+        return gx, gw if need_w else None, gb, gy if (ctx.has_res and ctx.needs_input_grad[3]) else None, None, None
+
+
+def linear_act(x, weight, bias=None, act=None, slope=0.01, residual=None):
+    """act(x @ weight.T + bias) (+ residual) on the HIP bf16-MFMA kernels; ``act`` is None or 'leaky_relu'.  x: [M,K] fp32 or bf16."""
+    if act not in (None, 'leaky_relu'):
+        raise ValueError('act must be None or "leaky_relu"')
+    return _LinearAct.apply(x, weight, bias, residual, 1 if act else 0, slope)
