@@ -106,12 +106,22 @@ def timed_blocks(run_steps, barrier, K, W, world, device, min_repeats=5, min_tot
     run_steps(max(W, 0))
     barrier()
     # clock ramp: the first milliseconds after idle run at a lower clock (measured: 10 % on a 4 ms region)
+    # (with more than one rank the steps contain a collective, so the ranks must agree on how many ramp rounds they run: rank 0's
+    # clock decides, the decision is broadcast after every round)
     t0 = time.perf_counter()
     n_ramp = 0
-    while time.perf_counter() - t0 < ramp_s and n_ramp < 10000:
+    go = torch.ones(1, device=device, dtype=torch.int32)
+    while n_ramp < 10000:
         run_steps(K)
         torch.cuda.synchronize()
         n_ramp += K
+        more = time.perf_counter() - t0 < ramp_s
+        if world > 1:
+            go.fill_(1 if more else 0)
+            torch.distributed.broadcast(go, src=0)
+            more = bool(go.item())
+        if not more:
+            break
     est = (time.perf_counter() - t0) / max(n_ramp, 1)       # seconds per step, this rank
     R = max(min_repeats, int(math.ceil(min_total_s / max(est * K, 1e-9))))
     R = min(R, max_repeats)

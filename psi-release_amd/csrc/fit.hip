@@ -29,6 +29,7 @@
 #include "lbs_device.h"
 #include "sdf_device.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -38,7 +39,13 @@ constexpr int NH = 512;        // VPoser hidden width (vposer_smpl.py:75-89 with
 constexpr int NZ = 32;         // VPoser latent
 constexpr int NJ6 = 126;       // 21 joints x 6D
 constexpr int XD = 75;         // body vector with 6D global rotation (cvae.py:117-126)
-constexpr int HB = 512;        // threads per body in the head kernels: 128 output quads x 4 K-quarters
+#ifndef PSI_HEAD_THREADS
+#define PSI_HEAD_THREADS 512
+#endif
+constexpr int HB = PSI_HEAD_THREADS;   // threads per body in the head kernels: 128 output quads x KQ K-splits
+constexpr int KQ = HB / 128;            // K-splits of the 512-wide layers
+constexpr int KS3 = HB / 32;            // K-slices of fc3 (32 output quads)
+constexpr int OS1 = HB / 8;             // output slices of W1^T (8 latent quads)
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct FitDev {
@@ -52,6 +59,7 @@ struct FitDev {
     const int *vid;                                   // [n_c] contact vertex ids
     const int *cs_ptr, *cs_idx;                       // vertex -> contact slots (CSR, V+1 / n_c)
     const float *scene, *sdf, *gmin, *gmax;           // scene cloud [m,3], volume [D^3], bounds [3]
+    const float *sdf_brick;                           // engine-owned copy of the volume in 4x4x4-brick order (nullptr: D % 4 != 0)
     // state
     float *x, *xhr, *cam, *adam_m, *adam_v;
     int *step;
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
 {
     const int b = blockIdx.x, t = threadIdx.x;
     __shared__ float sx[XD + 5], sh1[NH], sh2[NH], so6[128], red[HB / 64];
-    __shared__ f4 part4[4][128], part3[16][32];
+    __shared__ f4 part4[KQ][128], part3[KS3][32];
     const float *x = f.x + (size_t)b * XD;
     if (t < XD) sx[t] = x[t];
     __syncthreads();
@@ -187,21 +195,23 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
     {   // fc1: 32 -> 512, K-quarter = 8
         f4 a = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = kq * 8; k < kq * 8 + 8; k++) a += *(const f4 *)(f.W1T + (size_t)k * NH + og * 4) * z[k];
+        for (int k = kq * (NZ / KQ); k < (kq + 1) * (NZ / KQ); k++) a += *(const f4 *)(f.W1T + (size_t)k * NH + og * 4) * z[k];
         part4[kq][og] = a;
     }
     __syncthreads();
     if (t < 128) {
-        f4 a = part4[0][t] + part4[1][t] + part4[2][t] + part4[3][t] + *(const f4 *)(f.b1 + t * 4);
+        f4 a = *(const f4 *)(f.b1 + t * 4);
+#pragma unroll
+        for (int q = 0; q < KQ; q++) a += part4[q][t];
         for (int c = 0; c < 4; c++) sh1[t * 4 + c] = leaky(a[c], 0.2f);
     }
     __syncthreads();
     {   // fc2: 512 -> 512, K-quarter = 128
         f4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-        const float *w = f.W2T + (size_t)(kq * 128) * NH + og * 4;
-        const float *h = sh1 + kq * 128;
+        const float *w = f.W2T + (size_t)(kq * (NH / KQ)) * NH + og * 4;
+        const float *h = sh1 + kq * (NH / KQ);
 #pragma unroll 8
-        for (int k = 0; k < 128; k += 2) {
+        for (int k = 0; k < NH / KQ; k += 2) {
             a0 += *(const f4 *)(w + (size_t)k * NH) * h[k];
             a1 += *(const f4 *)(w + (size_t)(k + 1) * NH) * h[k + 1];
         }
@@ -210,23 +220,25 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
     }
     __syncthreads();
     if (t < 128) {
-        f4 a = part4[0][t] + part4[1][t] + part4[2][t] + part4[3][t] + *(const f4 *)(f.b2 + t * 4);
+        f4 a = *(const f4 *)(f.b2 + t * 4);
+#pragma unroll
+        for (int q = 0; q < KQ; q++) a += part4[q][t];
         for (int c = 0; c < 4; c++) sh2[t * 4 + c] = leaky(a[c], 0.2f);
     }
     __syncthreads();
     {   // fc3: 512 -> 126 (rows padded to 128): 32 output quads x 16 K-slices of 32
         const int og3 = t & 31, ks = t >> 5;
         f4 a = {0, 0, 0, 0};
-        const float *w = f.W3T + (size_t)(ks * 32) * 128 + og3 * 4;
-        const float *h = sh2 + ks * 32;
+        const float *w = f.W3T + (size_t)(ks * (NH / KS3)) * 128 + og3 * 4;
+        const float *h = sh2 + ks * (NH / KS3);
 #pragma unroll 8
-        for (int k = 0; k < 32; k++) a += *(const f4 *)(w + (size_t)k * 128) * h[k];
+        for (int k = 0; k < NH / KS3; k++) a += *(const f4 *)(w + (size_t)k * 128) * h[k];
         part3[ks][og3] = a;
     }
     __syncthreads();
     if (t < 32) {
         f4 a = *(const f4 *)(f.b3 + t * 4);
-        for (int ks = 0; ks < 16; ks++) a += part3[ks][t];
+        for (int ks = 0; ks < KS3; ks++) a += part3[ks][t];
         for (int c = 0; c < 4; c++) so6[t * 4 + c] = a[c];
     }
     __syncthreads();
@@ -271,7 +283,9 @@ struct SdfPenEpilogue {
     {
         float g[3] = {0, 0, 0};
         float val = 0.0f;
-        if (live) val = psi_trilinear(f.sdf, f.gmin, f.gmax, x, y, z, f.D, f.align_corners, g);
+        if (live)
+            val = f.sdf_brick ? psi_trilinear_bricked(f.sdf_brick, f.gmin, f.gmax, x, y, z, f.D, f.align_corners, g)
+                              : psi_trilinear(f.sdf, f.gmin, f.gmax, x, y, z, f.D, f.align_corners, g);
         const bool neg = live && val < 0.0f;
         if (live) {
             float *o = f.og + ((size_t)b * f.V + v) * 3;
@@ -405,7 +419,7 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
 {
     const int b = blockIdx.x, t = threadIdx.x;
     __shared__ float sx[XD + 5], sg6[128], sga2[NH], sga1[NH], sgx[XD + 5];
-    __shared__ f4 part4[4][128], part1[64][8];
+    __shared__ f4 part4[KQ][128], part1[OS1][8];
     psi_pose_bwd_body(lv.m, f.betas20, f.pose, lv.R, lv.Jl, lv.G, lv.gA + (size_t)b * PSI_JP * 16, lv.gfeat + (size_t)b * lv.m.Kpad, b,
                       f.g_betas, f.g_pose, f.g_rot);
     __syncthreads();                                         // g_betas / g_pose / g_rot of this body are visible to the workgroup
@@ -442,23 +456,25 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
     const int og = t & 127, kq = t >> 7;
     {   // g_h2[k] = sum_o W3[o][k] g6[o]: 128 k-quads x 4 o-quarters (126 rows -> 32,32,32,30)
         f4 a = {0, 0, 0, 0};
-        const int o0 = kq * 32, o1 = min(o0 + 32, NJ6);
+        const int o0 = kq * (128 / KQ), o1 = min(o0 + 128 / KQ, NJ6);
 #pragma unroll 8
         for (int o = o0; o < o1; o++) a += *(const f4 *)(f.W3 + (size_t)o * NH + og * 4) * sg6[o];
         part4[kq][og] = a;
     }
     __syncthreads();
     if (t < 128) {
-        f4 a = part4[0][t] + part4[1][t] + part4[2][t] + part4[3][t];
+        f4 a = part4[0][t];
+#pragma unroll
+        for (int q = 1; q < KQ; q++) a += part4[q][t];
         for (int c = 0; c < 4; c++) sga2[t * 4 + c] = a[c] * (h2[t * 4 + c] > 0.0f ? 1.0f : 0.2f);
     }
     __syncthreads();
     {   // g_h1[k] = sum_o W2[o][k] g_a2[o]
         f4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-        const float *w = f.W2 + (size_t)(kq * 128) * NH + og * 4;
-        const float *g = sga2 + kq * 128;
+        const float *w = f.W2 + (size_t)(kq * (NH / KQ)) * NH + og * 4;
+        const float *g = sga2 + kq * (NH / KQ);
 #pragma unroll 8
-        for (int o = 0; o < 128; o += 2) {
+        for (int o = 0; o < NH / KQ; o += 2) {
             a0 += *(const f4 *)(w + (size_t)o * NH) * g[o];
             a1 += *(const f4 *)(w + (size_t)(o + 1) * NH) * g[o + 1];
         }
@@ -467,7 +483,9 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
     }
     __syncthreads();
     if (t < 128) {
-        f4 a = part4[0][t] + part4[1][t] + part4[2][t] + part4[3][t];
+        f4 a = part4[0][t];
+#pragma unroll
+        for (int q = 1; q < KQ; q++) a += part4[q][t];
         for (int c = 0; c < 4; c++) sga1[t * 4 + c] = a[c] * (h1[t * 4 + c] > 0.0f ? 1.0f : 0.2f);
     }
     __syncthreads();
@@ -475,13 +493,13 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         const int kg = t & 7, os = t >> 3;
         f4 a = {0, 0, 0, 0};
 #pragma unroll
-        for (int o = os * 8; o < os * 8 + 8; o++) a += *(const f4 *)(f.W1 + (size_t)o * NZ + kg * 4) * sga1[o];
+        for (int o = os * (NH / OS1); o < (os + 1) * (NH / OS1); o++) a += *(const f4 *)(f.W1 + (size_t)o * NZ + kg * 4) * sga1[o];
         part1[os][kg] = a;
     }
     __syncthreads();
     if (t < 8) {
         f4 a = {0, 0, 0, 0};
-        for (int os = 0; os < 64; os++) a += part1[os][t];
+        for (int os = 0; os < OS1; os++) a += part1[os][t];
         for (int c = 0; c < 4; c++) sgx[19 + t * 4 + c] = a[c];
     }
     __syncthreads();
@@ -511,6 +529,15 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         float denom = sqrtf(v) / bc2_sqrt + f.eps;
         f.x[o] = sx[t] - step_size * (m / denom);
     }
+}
+
+// one-off re-layout of the caller's [ix][iy][iz] volume into the engine's brick order (sdf_device.h)
+__global__ void sdf_to_bricks_kernel(const float *__restrict__ src, float *__restrict__ dst, int D)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)D * D * D;
+    if (i >= n) return;
+    const int iz = (int)(i % D), iy = (int)((i / D) % D), ix = (int)(i / ((size_t)D * D));
+    dst[psi_brick_offset(ix, iy, iz, D >> 2)] = src[i];
 }
 
 __global__ void adam_reset_kernel(float *m, float *v, int *step, int n)
@@ -661,6 +688,8 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
            o_gq = take((size_t)B * f.n_c * 3 * 4), o_fp = take((size_t)B * f.nfp * 4), o_pp = take((size_t)B * f.nsdfblk * 2 * 4),
            o_rp = take((size_t)B * 4), o_vp = take((size_t)B * 4), o_gb = take((size_t)B * NB * 4), o_gp = take((size_t)B * J * 3 * 4),
            o_gt = take((size_t)B * 3 * 4), o_gr = take((size_t)B * J * 9 * 4), o_hist = take((size_t)f.max_hist * 4 * 4), o_stats = take(256), o_hint = take((size_t)B * f.n_c * 4);
+    const bool bricks = (cfg->D % 4 == 0) && !(getenv("PSI_SDF_LINEAR") && getenv("PSI_SDF_LINEAR")[0] == '1');
+    size_t o_brick = bricks ? take((size_t)f.D * f.D * f.D * 4) : 0;
     size_t lbs_floats = psi_lbs_workspace_floats(lbs, B);
     size_t o_lws = take(lbs_floats * 4), o_nws = take(psi_nn_ws_bytes(B, f.n_c, f.m));
     hipError_t err = hipMalloc((void **)&e->blob, o);
@@ -692,6 +721,19 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.history = F(o_hist);
     f.nn_hint = (int *)(bl + o_hint);
     e->stats_local = F(o_stats);
+    f.sdf_brick = nullptr;
+    if (bricks) {
+        const size_t n = (size_t)f.D * f.D * f.D;
+        hipLaunchKernelGGL(sdf_to_bricks_kernel, dim3((unsigned)psi_cdiv((long)n, 256)), dim3(256), 0, 0, d_sdf, F(o_brick), f.D);
+        err = hipDeviceSynchronize();
+        if (err != hipSuccess) {
+            (void)hipFree(e->blob);
+            delete e;
+            psi_set_error("psi_fit_create: SDF re-layout failed: %s", hipGetErrorString(err));
+            return (int)err;
+        }
+        f.sdf_brick = F(o_brick);
+    }
     e->lbs_ws = F(o_lws);
     {
         int rcv = psi_lbs_view(lbs, B, e->lbs_ws, &e->lv);

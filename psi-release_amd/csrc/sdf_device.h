@@ -72,3 +72,47 @@ __device__ __forceinline__ float psi_trilinear(const float *__restrict__ vol, co
     }
     return c0 * wx0 + c1 * wx1;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Bricked volume layout (the fused fitting engine keeps its own copy in this order): 4 x 4 x 4 bricks of 64 floats (256 bytes),
+// brick-major [bx][by][bz], inside a brick [lx][ly][lz].  In the plain [ix][iy][iz] order the four (x,y) rows of a sample's eight
+// corners are D*4 and D*D*4 bytes apart — four cache lines per sample, no two samples of nearby vertices sharing any unless they
+// agree in (ix,iy); in bricks the eight corners lie in two lines (the two lx slabs of one brick) three times out of four per axis
+// and body vertices that are a few voxels apart hit the same 256 bytes.  D % 4 == 0.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t psi_brick_offset(int ix, int iy, int iz, int nbr)
+{
+    const size_t brick = ((size_t)(ix >> 2) * nbr + (iy >> 2)) * nbr + (iz >> 2);
+    return brick * 64 + ((ix & 3) << 4) + ((iy & 3) << 2) + (iz & 3);
+}
+
+__device__ __forceinline__ float psi_trilinear_bricked(const float *__restrict__ vol, const float *__restrict__ gmin,
+                                                       const float *__restrict__ gmax, float x, float y, float z, int D,
+                                                       int align_corners, float *grad)
+{
+    PsiAxis ax = psi_axis_setup(x, gmin[0], gmax[0], D, align_corners);
+    PsiAxis ay = psi_axis_setup(y, gmin[1], gmax[1], D, align_corners);
+    PsiAxis az = psi_axis_setup(z, gmin[2], gmax[2], D, align_corners);
+    const int nbr = D >> 2;
+    float c000 = vol[psi_brick_offset(ax.i0, ay.i0, az.i0, nbr)], c001 = vol[psi_brick_offset(ax.i0, ay.i0, az.i1, nbr)];
+    float c010 = vol[psi_brick_offset(ax.i0, ay.i1, az.i0, nbr)], c011 = vol[psi_brick_offset(ax.i0, ay.i1, az.i1, nbr)];
+    float c100 = vol[psi_brick_offset(ax.i1, ay.i0, az.i0, nbr)], c101 = vol[psi_brick_offset(ax.i1, ay.i0, az.i1, nbr)];
+    float c110 = vol[psi_brick_offset(ax.i1, ay.i1, az.i0, nbr)], c111 = vol[psi_brick_offset(ax.i1, ay.i1, az.i1, nbr)];
+    const float wx1 = ax.w1, wx0 = 1.0f - ax.w1;
+    const float wy1 = ay.w1, wy0 = 1.0f - ay.w1;
+    const float wz1 = az.w1, wz0 = 1.0f - az.w1;
+    float c00 = c000 * wz0 + c001 * wz1, c01 = c010 * wz0 + c011 * wz1;
+    float c10 = c100 * wz0 + c101 * wz1, c11 = c110 * wz0 + c111 * wz1;
+    float c0 = c00 * wy0 + c01 * wy1, c1 = c10 * wy0 + c11 * wy1;
+    if (grad) {
+        float gx = c1 - c0;
+        float gy = (c01 - c00) * wx0 + (c11 - c10) * wx1;
+        float d00 = c001 - c000, d01 = c011 - c010, d10 = c101 - c100, d11 = c111 - c110;
+        float gz = (d00 * wy0 + d01 * wy1) * wx0 + (d10 * wy0 + d11 * wy1) * wx1;
+        grad[0] = gx * ax.du;
+        grad[1] = gy * ay.du;
+        grad[2] = gz * az.du;
+    }
+    return c0 * wx0 + c1 * wx1;
+}

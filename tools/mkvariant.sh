@@ -3,7 +3,7 @@
 name=$1; src=$2; which=$3; shift 3
 R=/root/repo/psi-release_amd
 objs=""
-for o in $R/lib/obj/*.o; do b=$(basename $o .o); [ "$b.hip" != "$which" ] && objs="$objs $o"; done
+for o in $R/lib/obj/*.o; do b=$(basename $o .o); case $b in *_fma) continue;; esac; [ "$b.hip" != "$which" ] && objs="$objs $o"; done
 extra=""
 [ "$which" = "nnindex.hip" ] && extra="-ffp-contract=off"
 [ "$which" = "chamfer.hip" ] && extra="-ffp-contract=off -fno-slp-vectorize"
