@@ -31,6 +31,35 @@ def test_library_exports_every_declared_symbol(built_lib):
         assert hasattr(lib, s), 'libpsi_hip.so does not export %s' % s
 
 
+def test_fma_mode_library_exports_the_same_abi(built_lib):
+    """libpsi_hip_fma.so (Chamfer distance in nvcc --fmad=true form) is the same ABI; the mode is a build-time property."""
+    from psi_release_amd import build
+    assert os.path.exists(build.LIB_FMA)
+    lib = ctypes.CDLL(build.LIB_FMA)
+    for s in declared_symbols():
+        assert hasattr(lib, s), 'libpsi_hip_fma.so does not export %s' % s
+    assert lib.psi_chamfer_arith_mode() == 1 and ctypes.CDLL(built_lib).psi_chamfer_arith_mode() == 0
+
+
+def test_oracle_builds_in_both_arithmetic_modes():
+    import numpy as np
+    import psi_oracle as O
+    rs = np.random.RandomState(0)
+    x, y = rs.standard_normal((2, 50, 3)).astype(np.float32), rs.standard_normal((2, 700, 3)).astype(np.float32)
+    a, b = O.chamfer_nn_np(x, y, fma=False), O.chamfer_nn_np(x, y, fma=True)
+    ref = ((x[:, :, None, :].astype(np.float64) - y[:, None, :, :]) ** 2).sum(-1)
+    for d1, i1 in ((a[0], a[1]), (b[0], b[1])):
+        assert np.abs(d1 - ref.min(2)).max() < 1e-5 and (i1 == ref.argmin(2)).mean() > 0.98
+    assert np.abs(a[0] - b[0]).max() <= 4 * np.finfo(np.float32).eps * np.abs(a[0]).max()
+    # the fma form is the exactly-rounded-once-per-step evaluation: reproduce it in float64 arithmetic with explicit roundings
+    d = (y[0, b[1][0]] - x[0]).astype(np.float32)
+    f32 = np.float32
+    acc = (d[:, 0] * d[:, 0]).astype(f32)
+    acc = (d[:, 1].astype(np.float64) * d[:, 1].astype(np.float64) + acc.astype(np.float64)).astype(f32)
+    acc = (d[:, 2].astype(np.float64) * d[:, 2].astype(np.float64) + acc.astype(np.float64)).astype(f32)
+    assert np.array_equal(acc, b[0][0])
+
+
 def test_binding_table_matches_header(built_lib):
     from psi_release_amd import hip
     assert sorted(hip.SIGNATURES) == declared_symbols()
