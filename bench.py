@@ -215,6 +215,9 @@ def kernel_work(args):
         'skin_fwd_kernel': ('byte', 55 * Vpad * 4.0 + B * Npad * 4.0 + B * V * 12.0, 'weights + v_posed in, vertices out (660 FMA per vertex: VALU-heavy)'),
         'skin_fwd_sdf_kernel': ('byte', 55 * Vpad * 4.0 + B * Npad * 4.0 + B * V * (12.0 + 32 + 12),
                                 'skinning + SDF lookup fused: weights + v_posed in, vertices out, 8 gathers + 12 B masked gradient per vertex'),
+        'fwd_scene_kernel': ('byte', 55 * Vpad * 4.0 + B * Npad * 4.0 + B * V * (12.0 + 32 + 12) + B * nc * (12 + 8 + 256.0) + m * 16.0,
+                             'ONE launch for both scene terms: skinning + SDF lookup workgroups (weights + v_posed in, vertices out, 8 gathers + 12 B masked '
+                             'gradient per vertex) and the exact NN search of the contact vertices, which skins its own queries (256 B of weights per query)'),
         'skin_bwd_v_kernel': ('byte', 55 * Vpad * 4.0 + B * V * 12.0 + 2 * B * Npad * 4.0, 'weights + grad in, g_local + g_vposed out'),
         'skin_bwd_v_grad_kernel': ('byte', 55 * Vpad * 4.0 + B * V * 12.0 + B * nc * 12.0 + 2 * B * Npad * 4.0,
                                    'loss-gradient assembly + skinning backward fused: weights + SDF gradient + contact gradients in, g_local + g_vposed out'),

@@ -3,7 +3,8 @@
 //                                                                                        source/fitting_proxe.py:101-162,177-189
 // as a fixed sequence of HIP kernels with a hand-derived backward, replayable as a hipGraph (no host sync, no autograd).
 //
-// Eight launches per iteration (single process):
+// Seven launches per iteration (single process, B <= 128: skin_fwd<SdfPen> and kd_query<CONTACT> share ONE launch, fwd_scene_kernel,
+// in which the NN-search workgroups skin their own contact vertices; eight launches above that):
 //   head_fwd          per body: L1 / latent-prior partial sums (fitting_proxe.py:105-110); convert_to_3D_rot (cvae.py:128-137);
 //                     VPoser.decode 32->512->512->126 -> 21 x (6D -> R -> angle-axis) (vposer_smpl.py:107-121,152-161);
 //                     SMPL-X hand PCA + pose_mean (smplx 0.1.13 forward); then the LBS pose stage of the
@@ -28,6 +29,7 @@
 #include "psi_internal.h"
 #include "lbs_device.h"
 #include "sdf_device.h"
+#include "nnindex_device.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -60,6 +62,7 @@ struct FitDev {
     const int *cs_ptr, *cs_idx;                       // vertex -> contact slots (CSR, V+1 / n_c)
     const float *scene, *sdf, *gmin, *gmax;           // scene cloud [m,3], volume [D^3], bounds [3]
     const float *sdf_brick;                           // engine-owned copy of the volume in 4x4x4-brick order (nullptr: D % 4 != 0)
+    const float *Wct;                                 // [n_c][64] skinning weights of the contact vertices, one row per contact slot
     // state
     float *x, *xhr, *cam, *adam_m, *adam_v;
     int *step;
@@ -296,18 +299,93 @@ struct SdfPenEpilogue {
         s = neg ? -val : 0.0f;
         c = neg ? 1.0f : 0.0f;
     }
-    __device__ __forceinline__ void finish(int b)
+    __device__ __forceinline__ void finish(int b, int vblock, int nvb)
     {
         __shared__ float red[4];
         float ss = block_sum(s, red);
         float cc = block_sum(c, red);
         if (threadIdx.x == 0) {
-            size_t o = ((size_t)b * gridDim.x + blockIdx.x) * 2;
+            size_t o = ((size_t)b * nvb + vblock) * 2;
             f.penpart[o] = ss;
             f.penpart[o + 1] = cc;
         }
     }
 };
+
+// ------------------------------------------------------------------------------------------------
+// Query source of the NN search inside the fused forward launch: the contact vertex is SKINNED HERE, by the query's own lane group,
+// instead of being read from `verts` — so the search does not depend on the skinning kernel and both run in ONE launch
+// (fwd_scene_kernel).  Lanes 0..2 of the 4-lane group each build one row of the blended transform (all joints, ascending, the
+// same packed fma as psi_blend_transforms: bit-identical to the vertex the skinning workgroups write), the three coordinates are
+// exchanged with shuffles and every lane applies translation and camera.  Weights come from a compact [n_c][64] table (one
+// contiguous 256-byte row per contact slot; zero beyond J), the body's joint transforms from LDS.
+struct ContactSkinSrc {
+    FitDev f;
+    LbsDev m;
+    const float *As, *v_posed;
+    psi_f2 (*sA)[6];
+    __device__ __forceinline__ void prepare(int b)
+    {
+        __shared__ psi_f2 sA_[PSI_JP][6];
+        for (int idx = threadIdx.x; idx < PSI_JP * 6; idx += blockDim.x)
+            sA_[idx / 6][idx % 6] = idx < m.J * 6 ? *(const psi_f2 *)(As + ((size_t)b * m.J) * 12 + idx * 2) : (psi_f2){0.0f, 0.0f};
+        __syncthreads();
+        sA = sA_;
+    }
+    __device__ __forceinline__ void point(int b, int j, int c, float &qx, float &qy, float &qz) const
+    {
+        const int r = c < 2 ? c : 2;                          // lane 3 repeats row 2 (its result is not used)
+        const int v = f.vid[j];
+        const f4 *wrow = (const f4 *)(f.Wct + (size_t)j * PSI_JP);
+        const float *vp = v_posed + (size_t)b * m.Npad + (size_t)v * 3;
+        const float px = vp[0], py = vp[1], pz = vp[2];
+        psi_f2 T0 = {0.0f, 0.0f}, T1 = {0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < PSI_JP / 4 - 2; q++) {            // 56 joints: J = 55 (SMPL-X) + one zero row; psi_fit_create checks J <= 56
+            const f4 w4 = wrow[q];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const psi_f2 w2 = {w4[t], w4[t]};
+                T0 = __builtin_elementwise_fma(w2, sA[q * 4 + t][2 * r], T0);
+                T1 = __builtin_elementwise_fma(w2, sA[q * 4 + t][2 * r + 1], T1);
+            }
+        }
+        float xr = psi_dot3p(T0.x, T0.y, T1.x, T1.y, px, py, pz) + f.transl[(size_t)b * 3 + r];
+        const int base = (threadIdx.x & 63) & ~3;
+        const float x = __shfl(xr, base, 64), y = __shfl(xr, base + 1, 64), z = __shfl(xr, base + 2, 64);
+        const float *C = f.cam + (size_t)b * 16;
+        qx = psi_dot3p(C[0], C[1], C[2], C[3], x, y, z);
+        qy = psi_dot3p(C[4], C[5], C[6], C[7], x, y, z);
+        qz = psi_dot3p(C[8], C[9], C[10], C[11], x, y, z);
+    }
+};
+
+// ONE launch for the two scene terms of the forward pass: block ids [0, n_kd) are the NN-search workgroups (64 contact queries of
+// one body each; long, VALU-issue-bound pointer chases — dispatched first), the rest are the skinning + SDF workgroups (256
+// vertices of one body each; gather-latency-bound).  As two launches they ran back to back (23 + 18 us); they depend on the same
+// inputs only, so in one grid their waves share the SIMDs and hide each other's stalls.
+__global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, const float *__restrict__ As, const float *__restrict__ v_posed,
+                                                           psikd::KdDev T, int n_kd, int nqb, int rows, float gscale)
+{
+    extern __shared__ int smem_i[];
+    if ((int)blockIdx.x < n_kd) {
+        const int b = blockIdx.x / nqb, bx = blockIdx.x % nqb;
+        psikd::kd_query_body<true, false>(T, ContactSkinSrc{f, m, As, v_posed, nullptr}, f.n_c, (float *)nullptr, (int *)nullptr, f.cconst, gscale,
+                                          f.gq, f.fpart, f.nn_hint, rows, (const psikd::KdDev *)nullptr, (const int *)nullptr, bx, b, nqb, smem_i);
+    } else {
+        const int i = blockIdx.x - n_kd;
+        SdfPenEpilogue epi{f, 0.0f, 0.0f};
+        psi_skin_fwd_body(m, As, v_posed, f.transl, f.cam, f.B, f.verts, epi, i % f.nsdfblk, i / f.nsdfblk, f.nsdfblk);
+    }
+}
+
+__global__ void contact_weight_table_kernel(const float *__restrict__ WT, int Vpad, const int *__restrict__ vid, int n_c, int J, float *__restrict__ Wct)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_c * PSI_JP) return;
+    const int slot = i / PSI_JP, j = i % PSI_JP;
+    Wct[i] = j < J ? WT[(size_t)j * Vpad + vid[slot]] : 0.0f;
+}
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(FitDev f, float *stats)
@@ -560,6 +638,7 @@ struct psi_fit_engine {
     void *nn_ws;
     char *blob;
     float *stats_local;           // engine-owned stats buffer (single-GPU path)
+    bool merged_scene;            // skinning + SDF and the NN search in one launch (kd-tree mode, J <= 56, 4 lanes per query)
     hipGraph_t graph, graphN;     // one iteration / GRAPH_UNROLL iterations
     hipGraphExec_t graph_exec, graphN_exec;
     bool graph_ready, graphN_ready;
@@ -585,11 +664,25 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
     psi_mark("head_fwd_kernel", st);
     int rc = psi_lbs_blend_forward(e->lbs, f.B, e->lbs_ws, st);
     if (rc) return rc;
+    float gscale = f.w_contact / ((float)f.B * (float)f.world * (float)f.n_c);
+    if (e->nn_index && e->merged_scene) {
+        // skinning + SDF and the NN search of the contact vertices as ONE launch (fwd_scene_kernel)
+        const psikd::KdDev T = psi_nn_index_dev(e->nn_index);
+        const int nqb = f.nfp, n_kd = nqb * f.B;
+        hipLaunchKernelGGL(fwd_scene_kernel, dim3(n_kd + f.nsdfblk * f.B), dim3(256), psikd::kd_lds_bytes(T.rows), st, f, e->lv.m, e->lv.A,
+                           e->lv.v_posed, T, n_kd, nqb, T.rows, gscale);
+        PSI_CHECK_LAUNCH("fwd_scene_kernel");
+        psi_mark("fwd_scene_kernel", st);
+        if (local) return 0;
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, f, stats);
+        PSI_CHECK_LAUNCH("loss_finalize_kernel");
+        psi_mark("loss_finalize_kernel", st);
+        return 0;
+    }
     hipLaunchKernelGGL(psi_skin_fwd_kernel<SdfPenEpilogue>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A, e->lv.v_posed,
                            f.transl, f.cam, f.B, f.verts, SdfPenEpilogue{f, 0.0f, 0.0f});
     PSI_CHECK_LAUNCH("skin_fwd_sdf_kernel");
     psi_mark("skin_fwd_sdf_kernel", st);
-    float gscale = f.w_contact / ((float)f.B * (float)f.world * (float)f.n_c);
     if (e->nn_index)
         rc = psi_nn_index_contact(e->nn_index, f.verts, (long)f.V * 3, f.vid, f.B, f.n_c, f.cconst, gscale, f.gq, f.fpart, f.nn_hint, st);
     else
@@ -688,6 +781,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
            o_gq = take((size_t)B * f.n_c * 3 * 4), o_fp = take((size_t)B * f.nfp * 4), o_pp = take((size_t)B * f.nsdfblk * 2 * 4),
            o_rp = take((size_t)B * 4), o_vp = take((size_t)B * 4), o_gb = take((size_t)B * NB * 4), o_gp = take((size_t)B * J * 3 * 4),
            o_gt = take((size_t)B * 3 * 4), o_gr = take((size_t)B * J * 9 * 4), o_hist = take((size_t)f.max_hist * 4 * 4), o_stats = take(256), o_hint = take((size_t)B * f.n_c * 4);
+    size_t o_wct = take((size_t)f.n_c * PSI_JP * 4);
     const bool bricks = (cfg->D % 4 == 0) && !(getenv("PSI_SDF_LINEAR") && getenv("PSI_SDF_LINEAR")[0] == '1');
     size_t o_brick = bricks ? take((size_t)f.D * f.D * f.D * 4) : 0;
     size_t lbs_floats = psi_lbs_workspace_floats(lbs, B);
@@ -721,23 +815,31 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.history = F(o_hist);
     f.nn_hint = (int *)(bl + o_hint);
     e->stats_local = F(o_stats);
-    f.sdf_brick = nullptr;
-    if (bricks) {
-        const size_t n = (size_t)f.D * f.D * f.D;
-        hipLaunchKernelGGL(sdf_to_bricks_kernel, dim3((unsigned)psi_cdiv((long)n, 256)), dim3(256), 0, 0, d_sdf, F(o_brick), f.D);
-        err = hipDeviceSynchronize();
-        if (err != hipSuccess) {
-            (void)hipFree(e->blob);
-            delete e;
-            psi_set_error("psi_fit_create: SDF re-layout failed: %s", hipGetErrorString(err));
-            return (int)err;
-        }
-        f.sdf_brick = F(o_brick);
-    }
     e->lbs_ws = F(o_lws);
     {
         int rcv = psi_lbs_view(lbs, B, e->lbs_ws, &e->lv);
         if (rcv) { (void)hipFree(e->blob); delete e; return rcv; }
+    }
+    f.Wct = F(o_wct);
+    // one launch for both scene terms up to B = 128 (measured: 0.1695 -> 0.1611 ms per iteration at B = 32, 0.2342 -> 0.2258 at 64, 0.3957 ->
+    // 0.3922 at 128; at 256 and above both parts are throughput-bound and the shared launch is 1-2 % slower); PSI_SPLIT_SCENE=1: two launches
+    e->merged_scene = cfg->nn_mode == 1 && J <= PSI_JP - 8 && psikd::LPQ == 4 && cfg->B <= 128 &&
+                      !(getenv("PSI_SPLIT_SCENE") && getenv("PSI_SPLIT_SCENE")[0] == '1');
+    hipLaunchKernelGGL(contact_weight_table_kernel, dim3(psi_cdiv((long)f.n_c * PSI_JP, 256)), dim3(256), 0, 0, e->lv.m.WT, e->lv.m.Vpad, f.vid,
+                       f.n_c, J, (float *)f.Wct);
+    f.sdf_brick = nullptr;
+    if (bricks) {
+        const size_t n = (size_t)f.D * f.D * f.D;
+        hipLaunchKernelGGL(sdf_to_bricks_kernel, dim3((unsigned)psi_cdiv((long)n, 256)), dim3(256), 0, 0, d_sdf, F(o_brick), f.D);
+        f.sdf_brick = F(o_brick);
+    }
+    err = hipDeviceSynchronize();                                // the two one-off layout kernels above ran on the NULL stream
+    if (err == hipSuccess) err = hipGetLastError();
+    if (err != hipSuccess) {
+        (void)hipFree(e->blob);
+        delete e;
+        psi_set_error("psi_fit_create: layout kernels failed: %s", hipGetErrorString(err));
+        return (int)err;
     }
     e->nn_ws = bl + o_nws;
     if (cfg->nn_mode == 1) {

@@ -353,20 +353,20 @@ __device__ __forceinline__ float psi_dot3(float a, float b, float c, float x, fl
 }
 
 // Epilogue hook of skin_fwd: vertex() sees every lane's final world-space vertex (live = false for padding lanes),
-// finish() runs once per workgroup with all threads present.
+// finish(b, vblock, nvb) runs once per workgroup (vertex block vblock of nvb, body b) with all threads present.
 struct PsiSkinNoEpilogue {
     __device__ __forceinline__ void vertex(int, int, float, float, float, bool) {}
-    __device__ __forceinline__ void finish(int) {}
+    __device__ __forceinline__ void finish(int, int, int) {}
 };
 
 // verts = cam_ext * (sum_j W_j A_j [v_posed;1] + transl)      (lbs.py:108-116, cvae.py:141-149)
+// (a device function so that the fused fitting engine can run it inside a launch it shares with the NN search: fit.hip)
 template <class Epi>
-__global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_fwd_kernel(LbsDev m, const float *__restrict__ As, const float *__restrict__ v_posed,
-                                                                     const float *__restrict__ transl, const float *__restrict__ cam_ext,
-                                                                     int B, float *__restrict__ verts, Epi epi)
+__device__ __forceinline__ void psi_skin_fwd_body(const LbsDev &m, const float *__restrict__ As, const float *__restrict__ v_posed,
+                                                  const float *__restrict__ transl, const float *__restrict__ cam_ext, int B,
+                                                  float *__restrict__ verts, Epi &epi, int vblock, int b, int nvb)
 {
-    const int v = blockIdx.x * PSI_SKIN_BLK + threadIdx.x;
-    const int b = blockIdx.y;
+    const int v = vblock * PSI_SKIN_BLK + threadIdx.x;
     psi_f2 T2[6];
     psi_blend_transforms(m, As, b, v, T2);
     const bool live = v < m.V;
@@ -393,7 +393,15 @@ __global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_fwd_kernel(LbsDev m,
         o[0] = x; o[1] = y; o[2] = z;
     }
     epi.vertex(b, v, x, y, z, live);
-    epi.finish(b);
+    epi.finish(b, vblock, nvb);
+}
+
+template <class Epi>
+__global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_fwd_kernel(LbsDev m, const float *__restrict__ As, const float *__restrict__ v_posed,
+                                                                     const float *__restrict__ transl, const float *__restrict__ cam_ext,
+                                                                     int B, float *__restrict__ verts, Epi epi)
+{
+    psi_skin_fwd_body(m, As, v_posed, transl, cam_ext, B, verts, epi, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 // Gradient source of skin_bwd_v: where dL/dverts[b][v] comes from.

@@ -17,6 +17,7 @@
 // In the reference the scene cloud is static per FittingOP (fitting_proxe.py:93-96), so the tree is built once at
 // construction; the brute-force op remains the general `chamfer.forward` replacement (arbitrary, per-sample clouds).
 #include "psi_internal.h"
+#include "nnindex_device.h"
 #include <algorithm>
 #include <math.h>
 #include <string.h>
@@ -26,83 +27,8 @@
 
 namespace {
 
-constexpr int LEAF = 8;             // points per leaf; leaves are PADDED to exactly 8 records (copies of the last point)
-constexpr int WIDE = 8;             // children per internal node == lanes per query
-constexpr int MAXSTACK = 72;        // <= 7 pushes per level; 9 levels of fan-out 8 cover 2^24 points
-constexpr int QBLK = 256;           // threads per workgroup
-#ifndef PSI_KD_LPQ
-#define PSI_KD_LPQ 4
-#endif
-constexpr int LPQ = PSI_KD_LPQ;     // lanes per query (8: one child box / leaf point per lane; 4: two).  Measured at B*n_c = 65536:
-                                    // 4 lanes 28.8 us cold / 23.2 warm, 8 lanes 31.4 / 22.5; the fused iteration is 1.3 us faster with 4
-constexpr int CPL = WIDE / LPQ;     // children (leaf points) per lane
-constexpr int QPB = QBLK / LPQ;     // queries per workgroup
-constexpr int EMPTY = (int)0x80000000;
+using namespace psikd;
 
-// 8-wide node (256 bytes): per child its exact AABB and its reference, 32 bytes each, so lane c of a query's 8-lane group
-// reads child c with two 16-byte loads and the group reads the 256-byte record contiguously.
-// Child reference: >= 0 internal node index;  < 0 leaf number L encoded -(L) - 1 (records pts[8L .. 8L+7]);  EMPTY = none
-// (its box is [+inf, -inf], i.e. infinitely far).
-struct KdChild {
-    float mn[3], mx[3];
-    int ref;
-    int pad;
-};
-struct KdNode {
-    KdChild c[WIDE];
-};
-static_assert(sizeof(KdNode) == 256, "node record is 256 bytes");
-
-struct KdDev {
-    const KdNode *nodes;
-    const float4 *pts;              // leaf-ordered, 8 records per leaf: {x,y,z,bitcast(orig index)}
-    const float4 *opts;             // original order {x,y,z,bitcast(index)}: warm-start lookups
-    int root;                       // child-reference of the root (a leaf when m <= LEAF)
-    int m;
-    int rows;                       // traversal stack rows this tree needs: 7 pushes per level + slack
-};
-
-// lane permutations inside an 8-lane group as DPP modifiers (no LDS traffic)
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
-constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
-constexpr int DPP_HALF_MIRROR = 0x141;  // row_half_mirror: lane i <-> 7 - i inside each 8 lanes
-
-// (d, i) packed into one 64-bit key: d >= +0 always (a sum of squares), so its IEEE-754 bit pattern orders like an
-// unsigned integer and  key = bits(d) << 32 | i  orders lexicographically by (d, i) — the lowest-index-among-minima
-// rule is a single unsigned 64-bit minimum, with no branches.
-typedef unsigned long long kd_key;
-__device__ __forceinline__ kd_key kd_pack(float d, int i) { return ((kd_key)(unsigned)__float_as_int(d) << 32) | (unsigned)i; }
-__device__ __forceinline__ float kd_key_d(kd_key k) { return __int_as_float((int)(k >> 32)); }
-__device__ __forceinline__ int kd_key_i(kd_key k) { return (int)(unsigned)k; }
-
-// minimum of the key over the LPQ (4 or 8) lanes of a group, result in every lane
-template <int LPQ>
-__device__ __forceinline__ kd_key group_min(kd_key k)
-{
-#define PSI_STEP(CTRL)                                                                              \
-    {                                                                                               \
-        kd_key k2 = ((kd_key)(unsigned)dpp_i<CTRL>((int)(k >> 32)) << 32) | (unsigned)dpp_i<CTRL>((int)(unsigned)k); \
-        k = k2 < k ? k2 : k;                                                                        \
-    }
-    PSI_STEP(DPP_XOR1)
-    PSI_STEP(DPP_XOR2)
-    if (LPQ == 8) PSI_STEP(DPP_HALF_MIRROR)
-#undef PSI_STEP
-    return k;
-}
-
-// CONTACT: fused contact-loss epilogue, identical to nn_resolve_kernel<true> in chamfer.hip
-// MULTI: body b is searched in tab[slot[b]] (a set of scenes, one launch) instead of the single tree T0
-//
-// Why a lane group per query: a batch has only B*n_c = 65536 queries.  One lane per query is 1024 waves — one per SIMD, no
-// latency hiding at all — each running ~8000 dependent instructions (measured: 15 cycles per instruction, 41-57 us).
-// With the child boxes / leaf points of a visit spread over the group's lanes the per-wave instruction stream shrinks several
-// fold in the box and leaf arithmetic, there are 4096-8192 waves to overlap the dependent node loads, and a wave diverges
-// over 16 (8) queries, not 64.
 template <bool CONTACT, bool MULTI = false>
 __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *__restrict__ xyz1, const int *__restrict__ qidx,
                                                         long qstride, int n, float *__restrict__ dist, int *__restrict__ idx,
@@ -111,136 +37,10 @@ __global__ __launch_bounds__(QBLK) void kd_query_kernel(KdDev T0, const float *_
                                                         const int *__restrict__ slot = nullptr)
 {
     extern __shared__ int smem_i[];
-    const int tid = threadIdx.x;
-    const int c = tid & (LPQ - 1);                            // my first child / leaf slot (the others: c + LPQ, ...)
-    const int g = tid / LPQ;                                  // query group inside the workgroup
-    int *stk_n = smem_i + (size_t)g * rows * 2;               // [rows] child references
-    float *stk_d = (float *)(stk_n + rows);                   // [rows] box distances
-    const int b = blockIdx.y;
-    const KdDev T = MULTI ? tab[slot[b]] : T0;
-    const int j = blockIdx.x * QPB + g;
-    const bool active = j < n;
-    const size_t o = (size_t)b * n + (active ? j : 0);
-    float qx = 0, qy = 0, qz = 0;
-    if (active) {
-        const size_t qrow = qidx ? (size_t)qidx[j] : (size_t)j;
-        const float *qp = xyz1 + (size_t)b * qstride + qrow * 3;
-        qx = qp[0]; qy = qp[1]; qz = qp[2];
-    }
-    kd_key bestk = kd_pack(INFINITY, 0x7fffffff);
-    float best = INFINITY;                                    // == kd_key_d(bestk)
-    if (active && hint) {
-        // warm start: the target that won for this query last time is evaluated first (an ordinary candidate, so the
-        // result is unchanged); a good initial `best` prunes almost every sibling on the way down
-        int h = hint[o];
-        if (h >= 0 && h < T.m) {
-            const float4 p = T.opts[h];
-            float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
-            best = PSI_SQ3(x2, y2, z2);
-            bestk = kd_pack(best, h);
-        }
-    }
-    int sp = 0;
-    int cur = T.root;
-    float curd = 0.0f;
-    bool have = active;
-    const int gshift = (tid & 63) & ~(LPQ - 1);               // bit position of my group inside the wave's ballot
-    while (true) {
-        while (!have && sp > 0) {                             // pop until something survives the current bound (group-uniform)
-            --sp;
-            cur = stk_n[sp];
-            curd = stk_d[sp];
-            have = !(curd * 0.999999f > best);
-        }
-        if (!have) break;
-        if (cur >= 0) {
-            float dc[CPL];
-            int ref[CPL];
-            kd_key km = ~0ull;
-#pragma unroll
-            for (int u = 0; u < CPL; u++) {
-                const float4 *cp = (const float4 *)(T.nodes + cur) + 2 * (c + u * LPQ);
-                const float4 lo = cp[0], hi = cp[1];          // {mnx,mny,mnz,mxx} {mxy,mxz,ref,-}
-                float dx = fmaxf(fmaxf(lo.x - qx, qx - lo.w), 0.0f);
-                float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.x), 0.0f);
-                float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.y), 0.0f);
-                dc[u] = dx * dx + dy * dy + dz * dz;          // +inf for EMPTY children
-                ref[u] = __float_as_int(hi.z);
-                const kd_key k = kd_pack(dc[u], c + u * LPQ);
-                km = k < km ? k : km;
-            }
-            km = group_min<LPQ>(km);
-            const float dmin = kd_key_d(km);
-            const int cmin = kd_key_i(km);
-            // push the other children that can still matter; descend into the nearest without a stack round trip
-#pragma unroll
-            for (int u = 0; u < CPL; u++) {
-                const bool push = (c + u * LPQ) != cmin && dc[u] * 0.999999f <= best;
-                const unsigned gm = (unsigned)(__ballot(push) >> gshift) & ((1u << LPQ) - 1u);
-                if (push) {
-                    const int pos = sp + __popc(gm & ((1u << c) - 1u));
-                    stk_n[pos] = ref[u];
-                    stk_d[pos] = dc[u];
-                }
-                sp += __popc(gm);
-            }
-            int rsel = ref[0];
-#pragma unroll
-            for (int u = 1; u < CPL; u++) rsel = (cmin / LPQ == u) ? ref[u] : rsel;
-            cur = __shfl(rsel, (tid & 63 & ~(LPQ - 1)) | (cmin & (LPQ - 1)), 64);
-            curd = dmin;
-            have = dmin < INFINITY && !(dmin * 0.999999f > best);
-        }
-        if (have && cur < 0) {                                // leaf — possibly the one just stepped into
-            kd_key k = ~0ull;
-#pragma unroll
-            for (int u = 0; u < CPL; u++) {
-                const float4 p = T.pts[(size_t)(-cur - 1) * LEAF + c + u * LPQ];
-                float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
-                const float d = PSI_SQ3(x2, y2, z2);
-                const kd_key ku = kd_pack(d, __float_as_int(p.w));
-                k = ku < k ? ku : k;
-            }
-            k = group_min<LPQ>(k);
-            bestk = k < bestk ? k : bestk;
-            best = kd_key_d(bestk);
-            have = false;
-        }
-    }
-    float fval = 0.0f;
-    if (active && c == 0) {
-        const int besti = kd_key_i(bestk);
-        if (dist) dist[o] = best;
-        if (idx) idx[o] = besti;
-        if (hint) hint[o] = besti;
-        if (CONTACT) {
-            const float4 w = T.opts[besti];                   // the winner's coordinates (same values the scan used)
-            float sq = sqrtf(best + 1e-4f);
-            float den = sq + cconst;
-            fval = sq / den;
-            float gg = gscale * (cconst / (2.0f * sq * den * den)) * 2.0f;
-            gq[o * 3 + 0] = gg * (qx - w.x);
-            gq[o * 3 + 1] = gg * (qy - w.y);
-            gq[o * 3 + 2] = gg * (qz - w.z);
-        }
-    }
-    if (CONTACT) {
-        __shared__ float wsum[QBLK / 64];
-        float v = fval;
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_down(v, o2, 64);
-        if ((tid & 63) == 0) wsum[tid >> 6] = v;
-        __syncthreads();
-        if (tid == 0) {
-            float t = 0.0f;
-#pragma unroll
-            for (int w = 0; w < QBLK / 64; w++) t += wsum[w];
-            fpart[(size_t)b * gridDim.x + blockIdx.x] = t;
-        }
-    }
+    kd_query_body<CONTACT, MULTI>(T0, KdQueryFromMemory{xyz1, qidx, qstride}, n, dist, idx, cconst, gscale, gq, fpart, hint, rows, tab, slot,
+                                  (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, smem_i);
 }
 
-static inline size_t kd_lds_bytes(int rows) { return (size_t)QPB * rows * 8; }
 
 struct Builder {
     const float *p;
@@ -464,3 +264,4 @@ int psi_nn_index_contact(const psi_nn_index *ix, const float *verts, long vstrid
     return 0;
 }
 int psi_nn_index_fparts(int n) { return psi_cdiv(n, QPB); }
+psikd::KdDev psi_nn_index_dev(const psi_nn_index *ix) { return ix->d; }
