@@ -159,6 +159,9 @@ typedef struct psi_fit_config {
     int nn_mode;   /* 0 = brute-force Chamfer kernel, 1 = exact kd-tree index built from the scene cloud at create */
     float w_rec, w_vposer, w_contact, w_collision, contact_const;
     float lr, beta1, beta2, eps;
+    int independent_bodies;   /* != 0: the B bodies are B INDEPENDENT problems — every loss is normalised per body (rec / 75, prior / 32,
+                                 contact / n_contact, penetration / that body's own count), so one engine run over B bodies equals B runs of
+                                 the reference's loop at batch size 1 (one generated-body file each, fitting_proxe.py:252-263).  world_size 1. */
 } psi_fit_config;
 int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, const psi_fit_config *cfg,
                    const float *h_w1, const float *h_b1, const float *h_w2, const float *h_b2,

@@ -52,6 +52,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct FitDev {
     int B, V, J, NB, n_c, m, D, align_corners, world, ncomp, nfp, nsdfblk;
+    int indep;                                        // 1: the B bodies are B independent problems (per-body loss normalisers)
     float w_rec, w_vp, w_contact, w_col, cconst;
     float lr, beta1, beta2, eps;
     // model constants
@@ -427,13 +428,64 @@ struct FitGradSource {
     FitDev f;
     float *stats;
     float N;
-    __device__ __forceinline__ void prepare()
+    float *sNb;                    // independent-bodies mode: per-body penetration counts of this workgroup's bodies (LDS)
+    int b0;
+    __device__ __forceinline__ void prepare(int b0_, int nb)
     {
         const int t = threadIdx.x;
         const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+        b0 = b0_;
+        sNb = nullptr;
+        __shared__ float red[4];
+        if (f.indep) {
+            // every body is its own problem (its own file in the reference's loop): the penetration mean runs over THIS body's
+            // penetrating vertices — nsdfblk partial pairs per body, summed by one wave per body
+            __shared__ float sN[PSI_SKIN_MB];
+            for (int i0 = 0; i0 < nb; i0 += PSI_SKIN_BLK / 64) {
+                const int i = i0 + (t >> 6);
+                float c = 0.0f;
+                if (i < nb)
+                    for (int k = t & 63; k < f.nsdfblk; k += 64) c += f.penpart[2 * ((size_t)(b0 + i) * f.nsdfblk + k) + 1];
+                c = psi_wave_sum(c);
+                if (i < nb && (t & 63) == 0) sN[i] = c;
+            }
+            __syncthreads();
+            sNb = sN;
+            N = 0.0f;
+            if (first) {                                        // history of the iteration: mean over the bodies of each body's loss
+                float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                for (int b = t; b < f.B; b += PSI_SKIN_BLK) {
+                    a0 += f.recpart[b];
+                    a1 += f.vppart[b];
+                    float sf = 0, sp = 0, cn = 0;
+                    for (int k = 0; k < f.nfp; k++) sf += f.fpart[(size_t)b * f.nfp + k];
+                    for (int k = 0; k < f.nsdfblk; k++) {
+                        sp += f.penpart[2 * ((size_t)b * f.nsdfblk + k)];
+                        cn += f.penpart[2 * ((size_t)b * f.nsdfblk + k) + 1];
+                    }
+                    a2 += sf;
+                    a3 += cn > 0.0f ? sp / cn : 0.0f;
+                }
+                const float s0 = block_sum(a0, red), s1 = block_sum(a1, red), s2 = block_sum(a2, red), s3 = block_sum(a3, red);
+                if (t == 0) {
+                    if (LOCAL) {
+                        stats[0] = s0; stats[1] = s1; stats[2] = s2; stats[3] = s3; stats[4] = 0.0f; stats[5] = 0.0f;
+                        *f.step += 1;
+                    }
+                    const int it = *f.step - 1;
+                    if (it >= 0) {
+                        float *h = f.history + (size_t)(it % f.max_hist) * 4;
+                        h[0] = f.w_rec * s0 / ((float)f.B * XD);
+                        h[1] = f.w_vp * s1 / ((float)f.B * NZ);
+                        h[2] = f.w_contact * s2 / ((float)f.B * f.n_c);
+                        h[3] = f.w_col * s3 / (float)f.B;
+                    }
+                }
+            }
+            return;
+        }
         float st[5];
         if (LOCAL) {
-            __shared__ float red[4];
             float a = 0, c = 0;
             for (int i = t; i < f.B * f.nsdfblk; i += PSI_SKIN_BLK) {
                 a += f.penpart[2 * i];
@@ -475,7 +527,8 @@ struct FitGradSource {
     }
     __device__ __forceinline__ void load(int b, int v, float &gx, float &gy, float &gz) const
     {
-        const float sp = N > 0.0f ? -f.w_col / N : 0.0f;       // d/d sdf_k of w * sum(-sdf)/N on the penetrating entries
+        const float Nb = sNb ? sNb[b - b0] : N;
+        const float sp = Nb > 0.0f ? -f.w_col / Nb : 0.0f;     // d/d sdf_k of w * sum(-sdf)/N on the penetrating entries
         const size_t o = ((size_t)b * f.V + v) * 3;
         gx = sp * f.og[o + 0]; gy = sp * f.og[o + 1]; gz = sp * f.og[o + 2];
         for (int ci = f.cs_ptr[v]; ci < f.cs_ptr[v + 1]; ci++) {
@@ -586,7 +639,7 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         return;
     }
     if (t < XD) {
-        const float Bg = (float)f.B * (float)f.world;
+        const float Bg = f.indep ? 1.0f : (float)f.B * (float)f.world;
         float g = sgx[t];
         // d/dx of w_rec * mean|xhr - x|  (fitting_proxe.py:105)
         float df = f.xhr[(size_t)b * XD + t] - sx[t];
@@ -664,7 +717,7 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
     psi_mark("head_fwd_kernel", st);
     int rc = psi_lbs_blend_forward(e->lbs, f.B, e->lbs_ws, st);
     if (rc) return rc;
-    float gscale = f.w_contact / ((float)f.B * (float)f.world * (float)f.n_c);
+    float gscale = f.w_contact / ((f.indep ? 1.0f : (float)f.B * (float)f.world) * (float)f.n_c);
     if (e->nn_index && e->merged_scene) {
         // skinning + SDF and the NN search of the contact vertices as ONE launch (fwd_scene_kernel)
         const psikd::KdDev T = psi_nn_index_dev(e->nn_index);
@@ -702,15 +755,15 @@ static int fit_backward(psi_fit_engine *e, float *stats, hipStream_t st, bool lo
     const bool mb = f.B >= PSI_SKIN_MB_MIN_B;
     const dim3 bgrid(f.nsdfblk, mb ? psi_cdiv(f.B, PSI_SKIN_MB) : f.B);
     if (local && mb)
-        psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, FitGradSource<true>{f, stats, 0.0f}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
+        psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, FitGradSource<true>{f, stats, 0.0f, nullptr, 0}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
     else if (local)
         hipLaunchKernelGGL(psi_skin_bwd_v_kernel<FitGradSource<true>>, bgrid, dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
-                           FitGradSource<true>{f, stats, 0.0f}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
+                           FitGradSource<true>{f, stats, 0.0f, nullptr, 0}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
     else if (mb)
-        psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, FitGradSource<false>{f, stats, 0.0f}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
+        psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, FitGradSource<false>{f, stats, 0.0f, nullptr, 0}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
     else
         hipLaunchKernelGGL(psi_skin_bwd_v_kernel<FitGradSource<false>>, bgrid, dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
-                           FitGradSource<false>{f, stats, 0.0f}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
+                           FitGradSource<false>{f, stats, 0.0f, nullptr, 0}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
     PSI_CHECK_LAUNCH("skin_bwd_v_grad_kernel");
     psi_mark("skin_bwd_v_grad_kernel", st);
     int rc = psi_lbs_backward_joint_parts(e->lbs, f.B, e->lbs_ws, f.g_transl, st);
@@ -742,6 +795,8 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     FitDev &f = e->d;
     f.B = cfg->B; f.V = V; f.J = J; f.NB = NB; f.n_c = cfg->n_contact; f.m = cfg->m_scene; f.D = cfg->D;
     f.align_corners = cfg->align_corners; f.world = cfg->world_size; f.ncomp = cfg->num_pca_comps;
+    f.indep = cfg->independent_bodies ? 1 : 0;
+    PSI_REQUIRE(!(f.indep && cfg->world_size > 1), "independent bodies have no cross-rank coupling: use world_size 1");
     f.w_rec = cfg->w_rec; f.w_vp = cfg->w_vposer; f.w_contact = cfg->w_contact; f.w_col = cfg->w_collision; f.cconst = cfg->contact_const;
     f.lr = cfg->lr; f.beta1 = cfg->beta1; f.beta2 = cfg->beta2; f.eps = cfg->eps;
     f.nfp = cfg->nn_mode == 1 ? psi_nn_index_fparts(f.n_c) : psi_nn_contact_fparts(f.n_c);

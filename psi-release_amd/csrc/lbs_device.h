@@ -408,7 +408,7 @@ __global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_fwd_kernel(LbsDev m,
 struct PsiGradFromMemory {
     const float *g_verts;     // [B,V,3]
     int V;
-    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ void prepare(int, int) {}
     __device__ __forceinline__ void load(int b, int v, float &gx, float &gy, float &gz) const
     {
         const float *g = g_verts + ((size_t)b * V + v) * 3;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_bwd_v_kernel(LbsDev 
 {
     const int v = blockIdx.x * PSI_SKIN_BLK + threadIdx.x;
     const int b = blockIdx.y;
-    src.prepare();
+    src.prepare(b, 1);
     psi_f2 T2[6];
     psi_blend_transforms(m, As, b, v, T2);
     __shared__ float sh[PSI_SKIN_BLK / 64][3];
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(PSI_SKIN_BLK, 4) void psi_skin_bwd_v_mb_kernel(LbsD
 {
     const int v = blockIdx.x * PSI_SKIN_BLK + threadIdx.x;
     const int b0 = blockIdx.y * PSI_SKIN_MB;
-    src.prepare();
+    src.prepare(b0, min(PSI_SKIN_MB, B - b0));
     __shared__ psi_f2 sA[2][PSI_JP][6];
     __shared__ float sh[2][PSI_SKIN_BLK / 64][3];
     PsiLaneWeights<COMPRESSED> lw;

@@ -68,7 +68,8 @@ class FitConfig(ctypes.Structure):
     _fields_ = [('B', c_int), ('n_contact', c_int), ('m_scene', c_int), ('D', c_int), ('align_corners', c_int),
                 ('world_size', c_int), ('num_pca_comps', c_int), ('max_history', c_int), ('nn_mode', c_int),
                 ('w_rec', c_float), ('w_vposer', c_float), ('w_contact', c_float), ('w_collision', c_float),
-                ('contact_const', c_float), ('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float)]
+                ('contact_const', c_float), ('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float),
+                ('independent_bodies', c_int)]
 
 
 class PsiHipError(RuntimeError):

@@ -33,11 +33,14 @@ def dist_setup():
     return rank, world
 
 
-def fit_files(fop_cls, fittingconfig, lossconfig, gen_dir, fit_dir, max_files, shard, rank, world):
+def fit_files(fop_cls, fittingconfig, lossconfig, gen_dir, fit_dir, max_files, shard, rank, world, concurrency=1, pack=1):
     """The per-scene file loop of the fitting entry points (fitting_proxe.py:252-263) on `world` ranks.
 
     shard='files': rank r fits the pkl files r, r+world, ... — every file is an independent problem (own batch, own loss
     normalisers), no collective on the data path.
+    concurrency > 1 (with shard='files'): a rank keeps that many of ITS engine runs in flight at once, each on its own engine and stream.
+    pack > 1 (with shard='files'): `pack` files form ONE engine run with per-body loss normalisers (FittingOP.independent_bodies) —
+    the same result as fitting them one by one, at the cost of one.
     shard='rows' : every rank opens every file and fits rows [r*B/world, (r+1)*B/world) of its B bodies; the loss normalisers are
     global through the one all-reduce per iteration (psi_release_amd/dist.py), rank 0 gathers the rows and writes the pkl."""
     import os
@@ -53,6 +56,9 @@ def fit_files(fop_cls, fittingconfig, lossconfig, gen_dir, fit_dir, max_files, s
         cfg['data_parallel'] = None
     else:
         cfg['data_parallel'] = False
+        if pack > 1:
+            cfg['batch_size'] = B * pack
+            cfg['independent_bodies'] = True
     fop = fop_cls(cfg, lossconfig)
     todo = []
     for ii in range(max_files):
@@ -79,6 +85,14 @@ def fit_files(fop_cls, fittingconfig, lossconfig, gen_dir, fit_dir, max_files, s
                 fop.cam_ext, fop.cam_int = cam_ext, cam_int
                 fop.save_result(xh_all, outp)
     else:
-        for inp, outp in todo[rank::world] if world > 1 else todo:
-            fop.save_result(fop.fitting(inp), outp)
+        mine = todo[rank::world] if world > 1 else todo
+        if (concurrency > 1 or pack > 1) and mine:
+            # independent files in flight together, one fused engine + stream each (FittingOP.fitting_many)
+            results, cams = fop.fitting_many([inp for inp, _ in mine], concurrency)
+            for (inp, outp), xh, (cam_ext, cam_int) in zip(mine, results, cams):
+                fop.cam_ext, fop.cam_int = cam_ext, cam_int
+                fop.save_result(xh, outp)
+        else:
+            for inp, outp in mine:
+                fop.save_result(fop.fitting(inp), outp)
     return len(todo)

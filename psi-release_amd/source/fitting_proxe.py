@@ -33,6 +33,11 @@ def main(argv=None):
     ap.add_argument('--shard', default='files', choices=['files', 'rows'],
                     help="under torchrun: 'files' = every rank fits its own pkl files (independent problems); 'rows' = every file's batch is "
                          "split over the ranks with one all-reduce of the loss normalisers per iteration (BASELINE configs[3])")
+    ap.add_argument('--concurrency', type=int, default=1,
+                    help='independent pkl files in flight per GPU (each on its own fused engine and HIP stream; implies a fresh Adam state per file)')
+    ap.add_argument('--pack', type=int, default=1,
+                    help='fit this many pkl files as ONE engine run with per-body loss normalisers (identical results to one-by-one fits; '
+                         'the reference fits one batch-1 file at a time, which leaves the GPU idle)')
     ap.add_argument('--reset_optimizer', action='store_true',
                     help='fresh Adam state for every file (the reference carries one optimizer across the files of a scene, fitting_proxe.py:73-74; '
                          'with --shard files the carried state depends on which files a rank sees)')
@@ -60,7 +65,7 @@ def main(argv=None):
         fittingconfig.update(extra)
         lossconfig = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1, 'weight_collision': 0.5}
         _common.fit_files(FittingOP, fittingconfig, lossconfig, os.path.join(a.gen_path, scenename), os.path.join(a.fit_path, scenename),
-                          a.max_files, a.shard, rank, world)
+                          a.max_files, a.shard, rank, world, a.concurrency, a.pack)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
