@@ -70,6 +70,9 @@ struct FitDev {
     // per-iteration buffers
     float *h1, *h2, *o6, *betas20, *pose, *transl, *verts, *og, *gq, *fpart, *penpart, *recpart, *vppart;
     float *g_betas, *g_pose, *g_transl, *g_rot;
+    unsigned long long *hx_o6, *hx_gh1;   // head / tail cluster exchange words {value, tag}: partial fc3 outputs [B][C][128], partial W2^T products [B][C][512]
+    unsigned *hx_epoch;      // [2][B] launch counts of the head / tail kernel per body (the exchange tag)
+    int hc;                  // workgroups per body in the head / tail kernels (1, 2, 4 or 8)
     int *nn_hint;        // [B,n_c] previous nearest-neighbour indices (warm start of the kd-tree search), -1 = none
     float *history;      // [max_hist][4] loss values per iteration
     int max_hist;
@@ -172,108 +175,204 @@ __device__ __forceinline__ float block_sum(float v, float *sh)
 }
 
 // ------------------------------------------------------------------------------------------------
-// ... followed, in the same workgroup, by the LBS pose stage of this body (Rodrigues, joints, kinematic chain): one launch
-// and one round of dependent loads less than a separate 1-wave-per-body kernel.
+// Cluster exchange (head / tail kernels below).  A value travels between two workgroups of one launch as ONE 64-bit word
+// {float value, 32-bit tag of this launch}, written and read with relaxed device-scope atomics: a word either carries this launch's tag
+// — then its value is the one stored with it — or it does not yet, and the reader looks again.  No fences (on gfx950 a device-scope
+// release / acquire pair is a write-back and an invalidate walk of the XCD's whole L2: 8-11 us per exchange, measured), no counters.
+// The reader is the LAST workgroup of its cluster in dispatch order, so every workgroup it waits for was dispatched before it and runs
+// (or has run) regardless of how full the chip is.  The tag is the body's launch count, kept in memory by the reader.
+__device__ __forceinline__ void hx_put(unsigned long long *p, float v, unsigned tag)
+{
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long hx_peek(unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float hx_value(unsigned long long *p, unsigned long long w, unsigned tag)
+{
+    while ((unsigned)(w >> 32) != tag) {
+        __builtin_amdgcn_s_sleep(1);
+        w = hx_peek(p);
+    }
+    return __uint_as_float((unsigned)w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head kernel: VPoser decoder MLP, rotations, hand PCA and the LBS pose stage of one body (Rodrigues, joints, kinematic chain).
+//
+// A body is worked on by a CLUSTER of C workgroups (C = 8 at the BASELINE batch of 32: 256 workgroups instead of 32).  What a single
+// workgroup per body cannot avoid is dragging the 1 MB fc2 matrix (and 0.25 MB of fc3) through ONE compute unit's L1: 13.3 + 4.1 us of
+// a 32 us kernel, measured with in-kernel clocks.  In a cluster, workgroup c computes fc1 in full (64 KB, redundant), the
+// outputs [c*512/C, (c+1)*512/C) of fc2 (1/C of the matrix), and — fc3 being linear in its input — the PARTIAL fc3 output of exactly
+// those activations (1/C of fc3's rows): one exchange of C x 128 floats per body.  The last workgroup of the cluster sums the partials
+// in cluster order and carries on with the per-body tail.  With C > 1 a thread's whole share of the three matrices is 28 16-byte loads:
+// they are issued at the top of the kernel, before the body vector is even read, so the weight fetch overlaps everything else.
+// C = 1 (B > 128: the grid fills the chip anyway) compiles to the exchange-free kernel.  Workgroup id = c * B + b: for B % 8 == 0 a
+// body's cluster shares an XCD (and its L2).
+template <int C>
 __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
 {
-    const int b = blockIdx.x, t = threadIdx.x;
-    __shared__ float sx[XD + 5], sh1[NH], sh2[NH], so6[128], red[HB / 64];
-    __shared__ f4 part4[KQ][128], part3[KS3][32];
+    constexpr int NS = NH / C;              // fc2 outputs of this workgroup
+    constexpr int NQ = NS / 4;              // ... in quads
+    constexpr int KSPL = HB / NQ;           // K-splits of fc2
+    constexpr int KPER = NH / KSPL;         // k per split (>= 16)
+    constexpr int KPER3 = NS / KS3;         // k per fc3 slice
+    constexpr int K1 = NZ / KQ;             // k per fc1 split
+    constexpr int PRE2 = C > 1 ? 16 : 0;    // rows of fc2 / fc3 held in registers from the top of the kernel
+    constexpr int PRE3 = C > 1 ? (KPER3 < 4 ? KPER3 : 4) : 0;
+    static_assert(KPER % 16 == 0 && KPER3 >= 1 && NS >= 64, "cluster too wide for the thread layout");
+    const int b = blockIdx.x % f.B, c = blockIdx.x / f.B, t = threadIdx.x;
+    const bool last = c == C - 1;           // the workgroup that carries on after the exchange
+    __shared__ float sx[XD + 5], sh1[NH], sh2[NS], so6[128], red[HB / 64], spose[PSI_JP * 3], sbetas[32], sJ[PSI_JP][3];
+    __shared__ f4 part4[HB], part3[KS3][32];
+    // ---- loads that depend on nothing computed here
+    const int og1 = t & 127, kq1 = t >> 7, og2 = t % NQ, ks2 = t / NQ, og3 = t & 31, ks3 = t >> 5;
+    const float *w1 = f.W1T + (size_t)(kq1 * K1) * NH + og1 * 4;
+    const float *w2 = f.W2T + (size_t)(ks2 * KPER) * NH + c * NS + og2 * 4;
+    const float *w3 = f.W3T + (size_t)(c * NS + ks3 * KPER3) * 128 + og3 * 4;
+    f4 w1p[K1], w2p[PRE2 ? PRE2 : 1], w3p[PRE3 ? PRE3 : 1];
+#pragma unroll
+    for (int k = 0; k < K1; k++) w1p[k] = *(const f4 *)(w1 + (size_t)k * NH);
+#pragma unroll
+    for (int k = 0; k < PRE2; k++) w2p[k] = *(const f4 *)(w2 + (size_t)k * NH);
+#pragma unroll
+    for (int k = 0; k < PRE3; k++) w3p[k] = *(const f4 *)(w3 + (size_t)k * 128);
     const float *x = f.x + (size_t)b * XD;
     if (t < XD) sx[t] = x[t];
-    __syncthreads();
-    // loss partial sums (fitting_proxe.py:105, :109-110)
-    float dr = t < XD ? fabsf(f.xhr[(size_t)b * XD + t] - sx[t]) : 0.0f;
-    float sr = block_sum(dr, red);
-    float dz = t < NZ ? sx[19 + t] * sx[19 + t] : 0.0f;     // latent = xh_rec[:,16:48] = x[:,19:51] in the 75-D layout
-    float sz = block_sum(dz, red);
-    if (t == 0) {
-        f.recpart[b] = sr;
-        f.vppart[b] = sz;
+    if (t >= 64 && t < 96) sbetas[t - 64] = t - 64 < 10 ? x[9 + (t - 64)] : 0.0f;
+    unsigned tag = 0;
+    float pm[3] = {0, 0, 0}, b3v = 0.0f;
+    int par = -1, lvl = -1;
+    if (C > 1) tag = f.hx_epoch[b] + 1u;
+    if (last) {
+        if (t < 22)
+            for (int e = 0; e < 3; e++) pm[e] = f.pose_mean[t * 3 + e];
+        if (t < 128) b3v = f.b3[t];
+        if (t < lv.m.J) { par = lv.m.parents[t]; lvl = lv.m.level[t]; }
     }
-    // VPoser decoder.  Each thread owns 4 adjacent outputs (one 16-byte weight load per k) and one quarter of K;
-    // the four K-quarters are summed through LDS.  Many independent 16-byte loads in flight per lane: the weights
-    // (1.3 MB, L2 resident) stream at bandwidth instead of one dependent 4-byte load at a time.
+    __syncthreads();
+    if (c == 0) {
+        // loss partial sums (fitting_proxe.py:105, :109-110)
+        float dr = t < XD ? fabsf(f.xhr[(size_t)b * XD + t] - sx[t]) : 0.0f;
+        float sr = block_sum(dr, red);
+        float dz = t < NZ ? sx[19 + t] * sx[19 + t] : 0.0f;     // latent = xh_rec[:,16:48] = x[:,19:51] in the 75-D layout
+        float sz = block_sum(dz, red);
+        if (t == 0) {
+            f.recpart[b] = sr;
+            f.vppart[b] = sz;
+        }
+    }
+    float *pose = f.pose + (size_t)b * f.J * 3;
+    if (last) {
+        // the part of the per-body tail that needs the body vector only: hand PCA, jaw / eyes, shape, translation, rest joints.  The
+        // pose row goes to LDS for the pose stage below and to global memory for the backward.
+        if (t >= 64 && t < 64 + 9) {
+            int e = 66 + (t - 64);                               // jaw, leye, reye: zero parameters + mean
+            pose[e] = spose[e] = f.pose_mean[e];
+        } else if (t >= 128 && t < 128 + 90) {
+            int e = t - 128;                                     // hand PCA: 12 -> 45 per hand
+            const float *comp = e < 45 ? f.lhc : f.rhc;
+            const float *hx = sx + (e < 45 ? 51 : 63);
+            int cc = e < 45 ? e : e - 45;
+            float a = 0;
+            for (int i = 0; i < f.ncomp; i++) a += hx[i] * comp[i * 45 + cc];
+            pose[75 + e] = spose[75 + e] = a + f.pose_mean[75 + e];
+        } else if (t >= 224 && t < 224 + f.NB) {
+            f.betas20[(size_t)b * f.NB + (t - 224)] = sbetas[t - 224];
+        } else if (t >= 32 && t < 35) {
+            f.transl[(size_t)b * 3 + (t - 32)] = sx[t - 32];
+        }
+        psi_pose_fwd_rest(lv.m, sbetas, f.B, b, sJ, lv.feat, lv.Jl);
+    }
+    // VPoser decoder.  Each thread owns 4 adjacent outputs (one 16-byte weight load per k) and one slice of K; the K-slices are
+    // summed through LDS.
     const float *z = sx + 19;
-    const int og = t & 127, kq = t >> 7;
-    {   // fc1: 32 -> 512, K-quarter = 8
+    {   // fc1: 32 -> 512, K-quarter = 8 (every workgroup of the cluster, in full)
         f4 a = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = kq * (NZ / KQ); k < (kq + 1) * (NZ / KQ); k++) a += *(const f4 *)(f.W1T + (size_t)k * NH + og * 4) * z[k];
-        part4[kq][og] = a;
+        for (int k = 0; k < K1; k++) a += w1p[k] * z[kq1 * K1 + k];
+        part4[kq1 * 128 + og1] = a;
     }
     __syncthreads();
     if (t < 128) {
         f4 a = *(const f4 *)(f.b1 + t * 4);
 #pragma unroll
-        for (int q = 0; q < KQ; q++) a += part4[q][t];
-        for (int c = 0; c < 4; c++) sh1[t * 4 + c] = leaky(a[c], 0.2f);
+        for (int q = 0; q < KQ; q++) a += part4[q * 128 + t];
+        for (int e = 0; e < 4; e++) sh1[t * 4 + e] = leaky(a[e], 0.2f);
     }
     __syncthreads();
-    {   // fc2: 512 -> 512, K-quarter = 128
+    {   // fc2: 512 -> this workgroup's NS outputs: NQ output quads x KSPL K-splits
         f4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-        const float *w = f.W2T + (size_t)(kq * (NH / KQ)) * NH + og * 4;
-        const float *h = sh1 + kq * (NH / KQ);
-#pragma unroll 8
-        for (int k = 0; k < NH / KQ; k += 2) {
-            a0 += *(const f4 *)(w + (size_t)k * NH) * h[k];
-            a1 += *(const f4 *)(w + (size_t)(k + 1) * NH) * h[k + 1];
+        const float *h = sh1 + ks2 * KPER;
+#pragma unroll
+        for (int k = 0; k < PRE2; k += 2) {
+            a0 += w2p[k] * h[k];
+            a1 += w2p[k + 1] * h[k + 1];
         }
-        __syncthreads();
-        part4[kq][og] = a0 + a1;
+#pragma unroll 8
+        for (int k = PRE2; k < KPER; k += 2) {
+            a0 += *(const f4 *)(w2 + (size_t)k * NH) * h[k];
+            a1 += *(const f4 *)(w2 + (size_t)(k + 1) * NH) * h[k + 1];
+        }
+        part4[ks2 * NQ + og2] = a0 + a1;
+    }
+    __syncthreads();
+    if (t < NS) {
+        float a = f.b2[c * NS + t];
+        const float *p = (const float *)part4;
+#pragma unroll
+        for (int q = 0; q < KSPL; q++) a += p[q * NS + t];
+        a = leaky(a, 0.2f);
+        sh2[t] = a;
+        f.h2[(size_t)b * NH + c * NS + t] = a;
+    }
+    if (c == 0)
+        for (int o = t; o < NH; o += HB) f.h1[(size_t)b * NH + o] = sh1[o];
+    __syncthreads();
+    {   // fc3 over this workgroup's activations: NS -> 126 (rows padded to 128): 32 output quads x KS3 K-slices
+        f4 a = {0, 0, 0, 0};
+        const float *h = sh2 + ks3 * KPER3;
+#pragma unroll
+        for (int k = 0; k < PRE3; k++) a += w3p[k] * h[k];
+#pragma unroll
+        for (int k = PRE3; k < KPER3; k++) a += *(const f4 *)(w3 + (size_t)k * 128) * h[k];
+        part3[ks3][og3] = a;
     }
     __syncthreads();
     if (t < 128) {
-        f4 a = *(const f4 *)(f.b2 + t * 4);
+        float a = 0.0f;
+        const float *p = (const float *)part3;
 #pragma unroll
-        for (int q = 0; q < KQ; q++) a += part4[q][t];
-        for (int c = 0; c < 4; c++) sh2[t * 4 + c] = leaky(a[c], 0.2f);
+        for (int ks = 0; ks < KS3; ks++) a += p[ks * 128 + t];
+        if (C == 1) {
+            so6[t] = a + b3v;
+        } else if (!last) {
+            hx_put(f.hx_o6 + ((size_t)b * C + c) * 128 + t, a, tag);
+        } else {
+            unsigned long long *p8 = f.hx_o6 + (size_t)b * C * 128 + t;
+            unsigned long long w[C - 1 ? C - 1 : 1];
+#pragma unroll
+            for (int cc = 0; cc < C - 1; cc++) w[cc] = hx_peek(p8 + cc * 128);
+            float o = b3v;
+#pragma unroll
+            for (int cc = 0; cc < C - 1; cc++) o += hx_value(p8 + cc * 128, w[cc], tag);
+            so6[t] = o + a;
+        }
     }
+    if (C > 1 && !last) return;
     __syncthreads();
-    {   // fc3: 512 -> 126 (rows padded to 128): 32 output quads x 16 K-slices of 32
-        const int og3 = t & 31, ks = t >> 5;
-        f4 a = {0, 0, 0, 0};
-        const float *w = f.W3T + (size_t)(ks * (NH / KS3)) * 128 + og3 * 4;
-        const float *h = sh2 + ks * (NH / KS3);
-#pragma unroll 8
-        for (int k = 0; k < NH / KS3; k++) a += *(const f4 *)(w + (size_t)k * 128) * h[k];
-        part3[ks][og3] = a;
-    }
-    __syncthreads();
-    if (t < 32) {
-        f4 a = *(const f4 *)(f.b3 + t * 4);
-        for (int ks = 0; ks < KS3; ks++) a += part3[ks][t];
-        for (int c = 0; c < 4; c++) so6[t * 4 + c] = a[c];
-    }
-    __syncthreads();
-    for (int o = t; o < NH; o += HB) {
-        f.h1[(size_t)b * NH + o] = sh1[o];
-        f.h2[(size_t)b * NH + o] = sh2[o];
-    }
     if (t < NJ6) f.o6[(size_t)b * 128 + t] = so6[t];
-    float *pose = f.pose + (size_t)b * f.J * 3;
     // rotations: thread 0 = global orient (x[3:9]), threads 1..21 = VPoser body joints
     if (t < 22) {
         float R[9], aa[3];
         gs_forward(t == 0 ? sx + 3 : so6 + (t - 1) * 6, R);
         rotmat_to_aa(R, aa);
-        for (int c = 0; c < 3; c++) pose[t * 3 + c] = aa[c] + f.pose_mean[t * 3 + c];
-    } else if (t >= 64 && t < 64 + 9) {
-        int e = 66 + (t - 64);                               // jaw, leye, reye: zero parameters + mean
-        pose[e] = f.pose_mean[e];
-    } else if (t >= 128 && t < 128 + 90) {
-        int e = t - 128;                                     // hand PCA: 12 -> 45 per hand
-        const float *comp = e < 45 ? f.lhc : f.rhc;
-        const float *hx = sx + (e < 45 ? 51 : 63);
-        int c = e < 45 ? e : e - 45;
-        float a = 0;
-        for (int i = 0; i < f.ncomp; i++) a += hx[i] * comp[i * 45 + c];
-        pose[75 + e] = a + f.pose_mean[75 + e];
+        for (int e = 0; e < 3; e++) pose[t * 3 + e] = spose[t * 3 + e] = aa[e] + pm[e];
     }
-    if (t < f.NB) f.betas20[(size_t)b * f.NB + t] = t < 10 ? sx[9 + t] : 0.0f;
-    if (t < 3) f.transl[(size_t)b * 3 + t] = sx[t];
-    __syncthreads();                                         // pose / betas20 of this body are visible to the workgroup
-    psi_pose_fwd_body(lv.m, f.betas20, f.pose, f.transl, f.B, b, lv.feat, lv.R, lv.Jl, lv.G, lv.A, nullptr);
+    __syncthreads();
+    psi_pose_fwd_chain(lv.m, spose, f.transl, f.B, b, sJ, par, lvl, lv.feat, lv.R, lv.G, lv.A, nullptr);
+    if (C > 1 && t == 0) f.hx_epoch[b] = tag;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -545,95 +644,164 @@ struct FitGradSource {
 // separate all-CU kernel: 32 workgroups pulling 7.5 MB of freshly written partials through 32 CUs took 15 us.)
 // ADAM = false (psi_fit_decode_backward): the chain-rule gradient wrt the 75-D body vector is written to g_out instead of
 // being combined with the fitting losses' own terms and applied.
-template <bool ADAM>
+// Tail kernel, the head kernel's mirror: LBS pose backward, Gram-Schmidt / hand-PCA backward, VPoser MLP backward, Adam.  Same
+// clusters: every workgroup of a body's cluster runs the (cheap, latency-bound) pose backward redundantly, then takes the columns
+// [c*512/C, ...) of W3^T — which gives it the gradient of exactly its own slice of fc2's output — and from those the PARTIAL
+// product with the matching rows of W2 (1/C of the 1 MB matrix); one exchange of C x 512 floats per body, the last workgroup sums
+// them in cluster order and finishes (W1^T, Adam).  The weight shares (and the last workgroup's Adam operands) are loaded at the top.
+template <int C, bool ADAM>
 __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView lv, float *__restrict__ g_out)
 {
-    const int b = blockIdx.x, t = threadIdx.x;
-    __shared__ float sx[XD + 5], sg6[128], sga2[NH], sga1[NH], sgx[XD + 5];
-    __shared__ f4 part4[KQ][128], part1[OS1][8];
-    psi_pose_bwd_body(lv.m, f.betas20, f.pose, lv.R, lv.Jl, lv.G, lv.gA + (size_t)b * PSI_JP * 16, lv.gfeat + (size_t)b * lv.m.Kpad, b,
-                      f.g_betas, f.g_pose, f.g_rot);
-    __syncthreads();                                         // g_betas / g_pose / g_rot of this body are visible to the workgroup
+    constexpr int NS = NH / C, NQ = NS / 4;
+    constexpr int OSPL = HB / NQ;           // splits of W3's 126 rows
+    constexpr int OPER = 128 / OSPL;        // rows per split
+    constexpr int RPER = NS / KQ;           // rows of W2 per split
+    constexpr int O1 = NH / OS1;            // rows of W1 per slice
+    constexpr int PRE3 = C > 1 ? (OPER < 16 ? OPER : 16) : 0;
+    constexpr int PRE2 = C > 1 ? 16 : 0;
+    static_assert(RPER % 16 == 0, "cluster too wide for the thread layout");
+    const int b = blockIdx.x % f.B, c = blockIdx.x / f.B, t = threadIdx.x;
+    const bool last = c == C - 1;
+    __shared__ float sx[XD + 5], sg6[128], sga2[NS], sga1[NH], sgx[XD + 5];
+    __shared__ float sgbetas[32], sgpose[PSI_JP * 3], sgrot[PSI_JP * 9];
+    __shared__ f4 part4[HB], part1[OS1][8];
+    // ---- loads that depend on nothing computed here
+    const int og3 = t % NQ, os3 = t / NQ, og2 = t & 127, kq2 = t >> 7, kg1 = t & 7, os1 = t >> 3;
+    const int o0 = os3 * OPER, o1 = min(o0 + OPER, NJ6);
+    const float *w3 = f.W3 + c * NS + og3 * 4;
+    const float *w2 = f.W2 + (size_t)(c * NS + kq2 * RPER) * NH + og2 * 4;
+    const float *w1 = f.W1 + (size_t)(os1 * O1) * NZ + kg1 * 4;
+    f4 w3p[PRE3 ? PRE3 : 1], w2p[PRE2 ? PRE2 : 1], w1p[O1];
+#pragma unroll
+    for (int i = 0; i < PRE3; i++) w3p[i] = *(const f4 *)(w3 + (size_t)min(o0 + i, NJ6 - 1) * NH);   // rows past 125 meet sg6 = 0
+#pragma unroll
+    for (int i = 0; i < PRE2; i++) w2p[i] = *(const f4 *)(w2 + (size_t)i * NH);
+    const float *h1 = f.h1 + (size_t)b * NH, *h2 = f.h2 + (size_t)b * NH;
+    const float h2v = t < NS ? h2[c * NS + t] : 0.0f;
+    unsigned tag = 0;
+    if (C > 1) tag = f.hx_epoch[f.B + b] + 1u;
+    float h1v = 0.0f, xhrv = 0.0f, am = 0.0f, av = 0.0f;
+    int step = 0;
+    if (last) {
+#pragma unroll
+        for (int i = 0; i < O1; i++) w1p[i] = *(const f4 *)(w1 + (size_t)i * NZ);
+        h1v = h1[t];
+        if (ADAM && t < XD) {
+            xhrv = f.xhr[(size_t)b * XD + t];
+            am = f.adam_m[(size_t)b * XD + t];
+            av = f.adam_v[(size_t)b * XD + t];
+            step = *f.step;
+        }
+    }
+    psi_pose_bwd_body(lv.m, f.pose + (size_t)b * f.J * 3, lv.R, lv.Jl, lv.G, lv.gA + (size_t)b * PSI_JP * 16, lv.gfeat + (size_t)b * lv.m.Kpad, b,
+                      sgbetas, sgpose, sgrot);
     const float *x = f.x + (size_t)b * XD;
     if (t < XD) { sx[t] = x[t]; sgx[t] = 0.0f; }
     if (t < 128) sg6[t] = 0.0f;
-    __syncthreads();
-    const float *grot = f.g_rot + (size_t)b * f.J * 9;
-    const float *gpose = f.g_pose + (size_t)b * f.J * 3;
+    __syncthreads();                                         // g_betas / g_pose / g_rot of this body are in LDS
+    if (c == 0) {                                            // inspection copies (psi_fit_copy_buffer)
+        for (int i = t; i < f.J * 9; i += HB) f.g_rot[(size_t)b * f.J * 9 + i] = sgrot[i];
+        for (int i = t; i < f.J * 3; i += HB) f.g_pose[(size_t)b * f.J * 3 + i] = sgpose[i];
+        if (t < f.NB) f.g_betas[(size_t)b * f.NB + t] = sgbetas[t];
+    }
     if (t == 0) {
         float g6[6];
-        gs_backward(sx + 3, grot, g6);
+        gs_backward(sx + 3, sgrot, g6);
         for (int i = 0; i < 6; i++) sgx[3 + i] = g6[i];
     } else if (t >= 1 && t < 22) {
         float g6[6];
-        gs_backward(f.o6 + (size_t)b * 128 + (t - 1) * 6, grot + t * 9, g6);
+        gs_backward(f.o6 + (size_t)b * 128 + (t - 1) * 6, sgrot + t * 9, g6);
         for (int i = 0; i < 6; i++) sg6[(t - 1) * 6 + i] = g6[i];
     } else if (t >= 64 && t < 64 + 2 * f.ncomp) {
         int i = t - 64;                                   // hand PCA backward
         const float *comp = i < f.ncomp ? f.lhc : f.rhc;
         int ii = i < f.ncomp ? i : i - f.ncomp;
-        const float *gp = gpose + (i < f.ncomp ? 75 : 120);
+        const float *gp = sgpose + (i < f.ncomp ? 75 : 120);
         float a = 0;
-        for (int c = 0; c < 45; c++) a += comp[ii * 45 + c] * gp[c];
+        for (int e = 0; e < 45; e++) a += comp[ii * 45 + e] * gp[e];
         sgx[(i < f.ncomp ? 51 : 63) + ii] = a;
     } else if (t >= 128 && t < 128 + 3) {
         sgx[t - 128] = f.g_transl[(size_t)b * 3 + (t - 128)];
     } else if (t >= 160 && t < 160 + 10) {
-        sgx[9 + (t - 160)] = f.g_betas[(size_t)b * f.NB + (t - 160)];
+        sgx[9 + (t - 160)] = sgbetas[t - 160];
     }
     __syncthreads();
-    // VPoser MLP backward (weights are constants): same 16-byte / K-split scheme on the [out][in] layouts
-    const float *h1 = f.h1 + (size_t)b * NH, *h2 = f.h2 + (size_t)b * NH;
-    const int og = t & 127, kq = t >> 7;
-    {   // g_h2[k] = sum_o W3[o][k] g6[o]: 128 k-quads x 4 o-quarters (126 rows -> 32,32,32,30)
+    // VPoser MLP backward (weights are constants): same 16-byte / split scheme on the [out][in] layouts
+    {   // g_h2[k] = sum_o W3[o][k] g6[o] for this workgroup's k: NQ k-quads x OSPL row-splits (126 rows)
         f4 a = {0, 0, 0, 0};
-        const int o0 = kq * (128 / KQ), o1 = min(o0 + 128 / KQ, NJ6);
-#pragma unroll 8
-        for (int o = o0; o < o1; o++) a += *(const f4 *)(f.W3 + (size_t)o * NH + og * 4) * sg6[o];
-        part4[kq][og] = a;
-    }
-    __syncthreads();
-    if (t < 128) {
-        f4 a = part4[0][t];
 #pragma unroll
-        for (int q = 1; q < KQ; q++) a += part4[q][t];
-        for (int c = 0; c < 4; c++) sga2[t * 4 + c] = a[c] * (h2[t * 4 + c] > 0.0f ? 1.0f : 0.2f);
+        for (int i = 0; i < PRE3; i++) a += w3p[i] * sg6[o0 + i];
+#pragma unroll 8
+        for (int o = o0 + PRE3; o < o1; o++) a += *(const f4 *)(w3 + (size_t)o * NH) * sg6[o];
+        part4[os3 * NQ + og3] = a;
     }
     __syncthreads();
-    {   // g_h1[k] = sum_o W2[o][k] g_a2[o]
+    if (t < NS) {
+        float a = 0.0f;
+        const float *p = (const float *)part4;
+#pragma unroll
+        for (int q = 0; q < OSPL; q++) a += p[q * NS + t];
+        sga2[t] = a * (h2v > 0.0f ? 1.0f : 0.2f);
+    }
+    __syncthreads();
+    {   // g_h1[k] (partial over this workgroup's rows o) = sum_o W2[o][k] g_a2[o]: 128 k-quads x KQ row-splits
         f4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-        const float *w = f.W2 + (size_t)(kq * (NH / KQ)) * NH + og * 4;
-        const float *g = sga2 + kq * (NH / KQ);
-#pragma unroll 8
-        for (int o = 0; o < NH / KQ; o += 2) {
-            a0 += *(const f4 *)(w + (size_t)o * NH) * g[o];
-            a1 += *(const f4 *)(w + (size_t)(o + 1) * NH) * g[o + 1];
+        const float *g = sga2 + kq2 * RPER;
+#pragma unroll
+        for (int o = 0; o < PRE2; o += 2) {
+            a0 += w2p[o] * g[o];
+            a1 += w2p[o + 1] * g[o + 1];
         }
-        __syncthreads();
-        part4[kq][og] = a0 + a1;
+#pragma unroll 8
+        for (int o = PRE2; o < RPER; o += 2) {
+            a0 += *(const f4 *)(w2 + (size_t)o * NH) * g[o];
+            a1 += *(const f4 *)(w2 + (size_t)(o + 1) * NH) * g[o + 1];
+        }
+        part4[kq2 * 128 + og2] = a0 + a1;
     }
     __syncthreads();
-    if (t < 128) {
-        f4 a = part4[0][t];
+    {
+        // every thread sums one output over the KQ row-splits
+        const float *p = (const float *)part4;
+        float a = p[t];
 #pragma unroll
-        for (int q = 1; q < KQ; q++) a += part4[q][t];
-        for (int c = 0; c < 4; c++) sga1[t * 4 + c] = a[c] * (h1[t * 4 + c] > 0.0f ? 1.0f : 0.2f);
+        for (int q = 1; q < KQ; q++) a += p[q * NH + t];
+        if (C == 1) {
+            sga1[t] = a * (h1[t] > 0.0f ? 1.0f : 0.2f);
+        } else if (!last) {
+            hx_put(f.hx_gh1 + ((size_t)b * C + c) * NH + t, a, tag);
+            return;
+        } else {
+            unsigned long long *p8 = f.hx_gh1 + (size_t)b * C * NH + t;
+            unsigned long long w[C - 1 ? C - 1 : 1];
+#pragma unroll
+            for (int cc = 0; cc < C - 1; cc++) w[cc] = hx_peek(p8 + (size_t)cc * NH);
+            float o = 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < C - 1; cc++) o += hx_value(p8 + (size_t)cc * NH, w[cc], tag);
+            sga1[t] = (o + a) * (h1v > 0.0f ? 1.0f : 0.2f);
+        }
     }
     __syncthreads();
     {   // g_z[k] = sum_o W1[o][k] g_a1[o]: 8 k-quads x 64 o-slices of 8
-        const int kg = t & 7, os = t >> 3;
         f4 a = {0, 0, 0, 0};
+        if (C == 1) {
 #pragma unroll
-        for (int o = os * (NH / OS1); o < (os + 1) * (NH / OS1); o++) a += *(const f4 *)(f.W1 + (size_t)o * NZ + kg * 4) * sga1[o];
-        part1[os][kg] = a;
+            for (int i = 0; i < O1; i++) a += *(const f4 *)(w1 + (size_t)i * NZ) * sga1[os1 * O1 + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < O1; i++) a += w1p[i] * sga1[os1 * O1 + i];
+        }
+        part1[os1][kg1] = a;
     }
     __syncthreads();
     if (t < 8) {
         f4 a = {0, 0, 0, 0};
         for (int os = 0; os < OS1; os++) a += part1[os][t];
-        for (int c = 0; c < 4; c++) sgx[19 + t * 4 + c] = a[c];
+        for (int e = 0; e < 4; e++) sgx[19 + t * 4 + e] = a[e];
     }
     __syncthreads();
+    if (C > 1 && t == 0) f.hx_epoch[f.B + b] = tag;
     if (!ADAM) {
         if (t < XD) g_out[(size_t)b * XD + t] = sgx[t];
         return;
@@ -642,15 +810,14 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         const float Bg = f.indep ? 1.0f : (float)f.B * (float)f.world;
         float g = sgx[t];
         // d/dx of w_rec * mean|xhr - x|  (fitting_proxe.py:105)
-        float df = f.xhr[(size_t)b * XD + t] - sx[t];
+        float df = xhrv - sx[t];
         g += f.w_rec / (Bg * XD) * (df > 0.0f ? -1.0f : (df < 0.0f ? 1.0f : 0.0f));
         // d/dz of w_vp * mean(z^2)       (fitting_proxe.py:109-110)
         if (t >= 19 && t < 19 + NZ) g += f.w_vp / (Bg * NZ) * 2.0f * sx[t];
         // torch.optim.Adam (defaults: amsgrad False, weight_decay 0), fitting_proxe.py:73-74
-        const int step = *f.step;
         size_t o = (size_t)b * XD + t;
-        float m = f.adam_m[o] * f.beta1 + (1.0f - f.beta1) * g;
-        float v = f.adam_v[o] * f.beta2 + (1.0f - f.beta2) * g * g;
+        float m = am * f.beta1 + (1.0f - f.beta1) * g;
+        float v = av * f.beta2 + (1.0f - f.beta2) * g * g;
         f.adam_m[o] = m;
         f.adam_v[o] = v;
         double bc1 = 1.0 - pow((double)f.beta1, (double)step);
@@ -702,6 +869,30 @@ struct psi_fit_engine {
     const float *half_stats[2];
 };
 
+// head / tail launches: grid = B bodies x hc workgroups per body (template instance per cluster width)
+static void launch_head_fwd(const FitDev &f, const PsiLbsView &lv, hipStream_t st)
+{
+    const dim3 g(f.B * f.hc), blk(HB);
+    switch (f.hc) {
+    case 8: hipLaunchKernelGGL(head_fwd_kernel<8>, g, blk, 0, st, f, lv); break;
+    case 4: hipLaunchKernelGGL(head_fwd_kernel<4>, g, blk, 0, st, f, lv); break;
+    case 2: hipLaunchKernelGGL(head_fwd_kernel<2>, g, blk, 0, st, f, lv); break;
+    default: hipLaunchKernelGGL(head_fwd_kernel<1>, g, blk, 0, st, f, lv); break;
+    }
+}
+
+template <bool ADAM>
+static void launch_head_bwd(const FitDev &f, const PsiLbsView &lv, float *g_out, hipStream_t st)
+{
+    const dim3 g(f.B * f.hc), blk(HB);
+    switch (f.hc) {
+    case 8: hipLaunchKernelGGL((head_bwd_adam_kernel<8, ADAM>), g, blk, 0, st, f, lv, g_out); break;
+    case 4: hipLaunchKernelGGL((head_bwd_adam_kernel<4, ADAM>), g, blk, 0, st, f, lv, g_out); break;
+    case 2: hipLaunchKernelGGL((head_bwd_adam_kernel<2, ADAM>), g, blk, 0, st, f, lv, g_out); break;
+    default: hipLaunchKernelGGL((head_bwd_adam_kernel<1, ADAM>), g, blk, 0, st, f, lv, g_out); break;
+    }
+}
+
 // local: single-process iteration — the statistics are produced inside the backward's first kernel (no loss_finalize launch)
 // Single-process iterations fold the statistics into the first backward kernel (every workgroup re-derives the global
 // penetration count from the per-workgroup partials: no loss_finalize launch).  That re-derivation reads B * 41 partial pairs per
@@ -712,7 +903,7 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
 {
     FitDev &f = e->d;
     local = fit_use_local_stats(f, local);
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(f.B), dim3(HB), 0, st, f, e->lv);
+    launch_head_fwd(f, e->lv, st);
     PSI_CHECK_LAUNCH("head_fwd_kernel");
     psi_mark("head_fwd_kernel", st);
     int rc = psi_lbs_blend_forward(e->lbs, f.B, e->lbs_ws, st);
@@ -768,7 +959,7 @@ static int fit_backward(psi_fit_engine *e, float *stats, hipStream_t st, bool lo
     psi_mark("skin_bwd_v_grad_kernel", st);
     int rc = psi_lbs_backward_joint_parts(e->lbs, f.B, e->lbs_ws, f.g_transl, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(head_bwd_adam_kernel<true>, dim3(f.B), dim3(HB), 0, st, f, e->lv, (float *)nullptr);
+    launch_head_bwd<true>(f, e->lv, nullptr, st);
     PSI_CHECK_LAUNCH("head_bwd_adam_kernel");
     psi_mark("head_bwd_adam_kernel", st);
     return 0;
@@ -784,7 +975,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
                 h_contact_ids && d_scene_verts && d_sdf && h_gmin && h_gmax, "null pointer");
     int V, J, NB;
     psi_lbs_dims(lbs, &V, &J, &NB);
-    PSI_REQUIRE(J == 55 && NB >= 10, "the fused engine is SMPL-X shaped (J=55, >=10 betas)");
+    PSI_REQUIRE(J == 55 && NB >= 10 && NB <= 32, "the fused engine is SMPL-X shaped (J=55, 10..32 betas)");
     PSI_REQUIRE(cfg->B > 0 && cfg->n_contact > 0 && cfg->m_scene > 0 && cfg->D >= 2 && cfg->world_size >= 1, "bad sizes");
     PSI_REQUIRE(cfg->num_pca_comps > 0 && cfg->num_pca_comps <= 12, "1..12 hand PCA components");
     for (int i = 0; i < 66; i++) PSI_REQUIRE(h_pose_mean[i] == 0.0f, "pose_mean must be zero for global_orient/body joints");
@@ -802,6 +993,12 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.nfp = cfg->nn_mode == 1 ? psi_nn_index_fparts(f.n_c) : psi_nn_contact_fparts(f.n_c);
     f.nsdfblk = psi_cdiv(V, 256);
     f.max_hist = cfg->max_history > 0 ? cfg->max_history : 1024;
+    // workgroups per body in the head / tail kernels: enough to put ~256 workgroups on the chip, none once the bodies alone do
+    f.hc = cfg->B <= 32 ? 8 : cfg->B <= 64 ? 4 : cfg->B <= 128 ? 2 : 1;
+    if (const char *hcv = getenv("PSI_HEAD_CLUSTER")) {
+        const int v = atoi(hcv);
+        if (v == 1 || v == 2 || v == 4 || v == 8) f.hc = v;
+    }
     f.scene = d_scene_verts;
     f.sdf = d_sdf;
     const int B = f.B;
@@ -836,6 +1033,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
            o_gq = take((size_t)B * f.n_c * 3 * 4), o_fp = take((size_t)B * f.nfp * 4), o_pp = take((size_t)B * f.nsdfblk * 2 * 4),
            o_rp = take((size_t)B * 4), o_vp = take((size_t)B * 4), o_gb = take((size_t)B * NB * 4), o_gp = take((size_t)B * J * 3 * 4),
            o_gt = take((size_t)B * 3 * 4), o_gr = take((size_t)B * J * 9 * 4), o_hist = take((size_t)f.max_hist * 4 * 4), o_stats = take(256), o_hint = take((size_t)B * f.n_c * 4);
+    size_t o_hxo = take((size_t)B * f.hc * 128 * 8), o_hxg = take((size_t)B * f.hc * NH * 8), o_hxc = take((size_t)2 * B * 4);
     size_t o_wct = take((size_t)f.n_c * PSI_JP * 4);
     const bool bricks = (cfg->D % 4 == 0) && !(getenv("PSI_SDF_LINEAR") && getenv("PSI_SDF_LINEAR")[0] == '1');
     size_t o_brick = bricks ? take((size_t)f.D * f.D * f.D * 4) : 0;
@@ -869,6 +1067,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.recpart = F(o_rp); f.vppart = F(o_vp); f.g_betas = F(o_gb); f.g_pose = F(o_gp); f.g_transl = F(o_gt); f.g_rot = F(o_gr);
     f.history = F(o_hist);
     f.nn_hint = (int *)(bl + o_hint);
+    f.hx_o6 = (unsigned long long *)(bl + o_hxo); f.hx_gh1 = (unsigned long long *)(bl + o_hxg); f.hx_epoch = (unsigned *)(bl + o_hxc);
     e->stats_local = F(o_stats);
     e->lbs_ws = F(o_lws);
     {
@@ -1045,7 +1244,7 @@ extern "C" int psi_fit_decode_forward(psi_fit_engine *e, const float *d_x75, con
     hipStream_t st = (hipStream_t)stream;
     PSI_CHECK_HIP(hipMemcpyAsync(f.x, d_x75, (size_t)f.B * XD * 4, hipMemcpyDeviceToDevice, st));
     PSI_CHECK_HIP(hipMemcpyAsync(f.cam, d_cam_ext, (size_t)f.B * 16 * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(f.B), dim3(HB), 0, st, f, e->lv);
+    launch_head_fwd(f, e->lv, st);
     PSI_CHECK_LAUNCH("head_fwd_kernel");
     int rc = psi_lbs_blend_forward(e->lbs, f.B, e->lbs_ws, st);
     if (rc) return rc;
@@ -1068,7 +1267,7 @@ extern "C" int psi_fit_decode_backward(psi_fit_engine *e, const float *d_grad_ve
     PSI_CHECK_LAUNCH("skin_bwd_v_kernel");
     int rc = psi_lbs_backward_joint_parts(e->lbs, f.B, e->lbs_ws, f.g_transl, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(head_bwd_adam_kernel<false>, dim3(f.B), dim3(HB), 0, st, f, e->lv, d_grad_x75);
+    launch_head_bwd<false>(f, e->lv, d_grad_x75, st);
     PSI_CHECK_LAUNCH("head_bwd_kernel");
     return 0;
 }

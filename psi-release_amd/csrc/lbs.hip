@@ -95,7 +95,8 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(LbsDev m, const float *__r
                                                       float *__restrict__ Rs, float *__restrict__ Jls, float *__restrict__ Gs,
                                                       float *__restrict__ As, float *__restrict__ joints)
 {
-    psi_pose_fwd_body(m, betas, pose, transl, B, blockIdx.x, feat, Rs, Jls, Gs, As, joints);
+    const int b = blockIdx.x;
+    psi_pose_fwd_body(m, betas + (size_t)b * m.NB, pose + (size_t)b * m.J * 3, transl, B, b, feat, Rs, Jls, Gs, As, joints);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -424,7 +425,9 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(LbsDev m, const float *__r
                                                       float *__restrict__ g_betas, float *__restrict__ g_pose, float *__restrict__ g_rot)
 {
     const int b = blockIdx.x;
-    psi_pose_bwd_body(m, betas, pose, Rs, Jls, Gs, gAr + (size_t)b * JP * 16, gfeat + (size_t)b * m.Kpad, b, g_betas, g_pose, g_rot);
+    psi_pose_bwd_body(m, pose + (size_t)b * m.J * 3, Rs, Jls, Gs, gAr + (size_t)b * JP * 16, gfeat + (size_t)b * m.Kpad, b,
+                      g_betas ? g_betas + (size_t)b * m.NB : nullptr, g_pose ? g_pose + (size_t)b * m.J * 3 : nullptr,
+                      g_rot ? g_rot + (size_t)b * m.J * 9 : nullptr);
 }
 
 }  // namespace

@@ -44,29 +44,45 @@ __device__ __forceinline__ void psi_rodrigues(const float *aa, float *R)
     R[8] = 1.0f + c1 * (-(rx * rx + ry * ry));
 }
 
-// Body of the pose-forward stage for body b, executed by a whole workgroup (threads >= J idle through the joint part).
+// Pose-forward stage of body b, executed by a whole workgroup, in two parts so that a caller can run the first (which only needs
+// the shape coefficients) ahead of the second (which needs the pose).  betas_b [NB] and pose_b [J*3] are THIS body's rows (global
+// memory in pose_fwd_kernel, LDS in the fused fitting head kernel); sJ is the caller's LDS array for the rest joints.
 // Callers: pose_fwd_kernel (lbs.hip) and the fused fitting head kernel (fit.hip).
-__device__ __forceinline__ void psi_pose_fwd_body(const LbsDev &m, const float *__restrict__ betas, const float *__restrict__ pose,
-                                                  const float *__restrict__ transl, int B, int b, float *__restrict__ feat,
-                                                  float *__restrict__ Rs, float *__restrict__ Jls, float *__restrict__ Gs,
-                                                  float *__restrict__ As, float *__restrict__ joints)
+//
+// part 1: rest joints J = J_t + J_s betas, and the shape entries / zero tail of the blend-shape feature row
+__device__ __forceinline__ void psi_pose_fwd_rest(const LbsDev &m, const float *betas_b, int B, int b, float (*sJ)[3],
+                                                  float *__restrict__ feat, float *__restrict__ Jls)
 {
     const int j = threadIdx.x, nthr = blockDim.x;
     const int Bpad = (B + 15) & ~15;
-    __shared__ float sJ[PSI_JP][3];
-    __shared__ float sG[PSI_JP][12];
-    const bool act = j < m.J;
-    // rest joints J = J_t + J_s betas: one (joint, axis) pair per thread, all threads of the workgroup take part
+    // one (joint, axis) pair per thread, all threads of the workgroup take part
     for (int q = j; q < m.J * 3; q += nthr) {
         float a = m.J_t[q];
         const float *js = m.J_s + (size_t)q * m.NB;
-        for (int l = 0; l < m.NB; l++) a += js[l] * betas[(size_t)b * m.NB + l];
+        for (int l = 0; l < m.NB; l++) a += js[l] * betas_b[l];
         (&sJ[0][0])[q] = a;
         Jls[(size_t)b * m.J * 3 + q] = a;
     }
+    // betas and the zero tail of the feature row (feat is stored as k-quads: [Kpad/4][Bpad][4])
+    for (int l = j; l < m.NB; l += nthr) feat[((size_t)(l >> 2) * Bpad + b) * 4 + (l & 3)] = betas_b[l];
+    for (int l = m.K + j; l < m.Kpad; l += nthr) feat[((size_t)(l >> 2) * Bpad + b) * 4 + (l & 3)] = 0.0f;
+}
+
+// part 2: Rodrigues, pose feature, kinematic chain, skinning transforms.  sJ must be complete (the first barrier below orders it
+// when part 1 ran in the same workgroup just before).
+// par / lvl: m.parents[j] / m.level[j] of this thread's joint (-1 for threads >= J), loaded by the caller ahead of time.
+__device__ __forceinline__ void psi_pose_fwd_chain(const LbsDev &m, const float *pose_b, const float *__restrict__ transl, int B, int b,
+                                                   const float (*sJ)[3], int par, int lvl, float *__restrict__ feat,
+                                                   float *__restrict__ Rs, float *__restrict__ Gs, float *__restrict__ As,
+                                                   float *__restrict__ joints)
+{
+    const int j = threadIdx.x;
+    const int Bpad = (B + 15) & ~15;
+    __shared__ float sG[PSI_JP][12];
+    const bool act = j < m.J;
     float R[9], Jl[3] = {0, 0, 0};
     if (act) {
-        psi_rodrigues(pose + ((size_t)b * m.J + j) * 3, R);
+        psi_rodrigues(pose_b + j * 3, R);
         psi_f4 *Ro = (psi_f4 *)(Rs + ((size_t)b * m.J + j) * 12);      // rows padded to 4: three 16-byte stores
         Ro[0] = psi_f4{R[0], R[1], R[2], 0.0f};
         Ro[1] = psi_f4{R[3], R[4], R[5], 0.0f};
@@ -77,13 +93,7 @@ __device__ __forceinline__ void psi_pose_fwd_body(const LbsDev &m, const float *
                 feat[((size_t)(k >> 2) * Bpad + b) * 4 + (k & 3)] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
             }
     }
-    {   // betas and the zero tail of the feature row (feat is stored as k-quads: [Kpad/4][Bpad][4])
-        for (int l = j; l < m.NB; l += nthr) feat[((size_t)(l >> 2) * Bpad + b) * 4 + (l & 3)] = betas[(size_t)b * m.NB + l];
-        for (int l = m.K + j; l < m.Kpad; l += nthr) feat[((size_t)(l >> 2) * Bpad + b) * 4 + (l & 3)] = 0.0f;
-    }
     __syncthreads();
-    const int par = act ? m.parents[j] : -1;
-    const int lvl = act ? m.level[j] : -1;
     if (act)
         for (int c = 0; c < 3; c++) Jl[c] = sJ[j][c];
     float rel[3] = {Jl[0], Jl[1], Jl[2]};
@@ -124,12 +134,26 @@ __device__ __forceinline__ void psi_pose_fwd_body(const LbsDev &m, const float *
 }
 
 
+__device__ __forceinline__ void psi_pose_fwd_body(const LbsDev &m, const float *betas_b, const float *pose_b,
+                                                  const float *__restrict__ transl, int B, int b, float *__restrict__ feat,
+                                                  float *__restrict__ Rs, float *__restrict__ Jls, float *__restrict__ Gs,
+                                                  float *__restrict__ As, float *__restrict__ joints)
+{
+    __shared__ float sJ[PSI_JP][3];
+    const int par = threadIdx.x < m.J ? m.parents[threadIdx.x] : -1;
+    const int lvl = threadIdx.x < m.J ? m.level[threadIdx.x] : -1;
+    psi_pose_fwd_rest(m, betas_b, B, b, sJ, feat, Jls);
+    psi_pose_fwd_chain(m, pose_b, transl, B, b, sJ, par, lvl, feat, Rs, Gs, As, joints);
+}
+
+
 // Body of the pose-backward stage for body b (whole workgroup).  gA_b [PSI_JP][16] and gfeat_b [Kpad] are THIS body's reduced
-// gradients (global memory in pose_bwd_kernel, LDS in the fused fitting tail kernel).
-__device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *__restrict__ betas, const float *__restrict__ pose,
+// gradients, pose_b [J*3] its pose row; the outputs g_betas_b [NB], g_pose_b [J*3], g_rot_b [J*9] are this body's rows too (global
+// memory in pose_bwd_kernel, LDS in the fused fitting tail kernel).
+__device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *pose_b,
                                                   const float *__restrict__ Rs, const float *__restrict__ Jls,
                                                   const float *__restrict__ Gs, const float *gA_b, const float *gfeat_b, int b,
-                                                  float *__restrict__ g_betas, float *__restrict__ g_pose, float *__restrict__ g_rot)
+                                                  float *g_betas_b, float *g_pose_b, float *g_rot_b)
 {
     const int j = threadIdx.x, nthr = blockDim.x;
     const bool act = j < m.J;
@@ -224,7 +248,7 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
     }
     __syncthreads();
     // feature gradient (reduced over n-slices): betas part and pose-feature part
-    if (g_betas) {
+    if (g_betas_b) {
         // g_betas[l] = g_feat[l] + sum_q gJ[q] J_s[q][l]: the (joint, axis) range is cut into nthr/NB parts summed through LDS,
         // so a thread has only a handful of independent loads (they were 165 dependent rounds for NB threads before)
         __shared__ float sgb[32][32];
@@ -248,18 +272,18 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
             } else {
                 for (int q = 0; q < nq; q++) a += (&sgJ[0][0])[q] * m.J_s[(size_t)q * m.NB + l];
             }
-            g_betas[(size_t)b * m.NB + l] = a;
+            g_betas_b[l] = a;
         }
     }
-    if (act && (g_pose || g_rot)) {
+    if (act && (g_pose_b || g_rot_b)) {
         if (j >= 1)
             for (int e = 0; e < 9; e++) gR[e] += gfeat_b[m.NB + (j - 1) * 9 + e];
-        if (g_rot)
-            for (int e = 0; e < 9; e++) g_rot[((size_t)b * m.J + j) * 9 + e] = gR[e];
+        if (g_rot_b)
+            for (int e = 0; e < 9; e++) g_rot_b[j * 9 + e] = gR[e];
     }
-    if (act && g_pose) {
+    if (act && g_pose_b) {
         // Rodrigues backward (lbs.py:177-191)
-        const float *aa = pose + ((size_t)b * m.J + j) * 3;
+        const float *aa = pose_b + j * 3;
         float x = aa[0] + 1e-8f, y = aa[1] + 1e-8f, z = aa[2] + 1e-8f;
         float th = sqrtf(x * x + y * y + z * z);
         float d[3] = {aa[0] / th, aa[1] / th, aa[2] / th};
@@ -281,7 +305,7 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
         float gth = gs * c + gc1 * s;                      // d sin = cos, d(1-cos) = sin
         gth -= (gd[0] * aa[0] + gd[1] * aa[1] + gd[2] * aa[2]) / (th * th);
         float ga[3] = {gd[0] / th + gth * x / th, gd[1] / th + gth * y / th, gd[2] / th + gth * z / th};
-        for (int q = 0; q < 3; q++) g_pose[((size_t)b * m.J + j) * 3 + q] = ga[q];
+        for (int q = 0; q < 3; q++) g_pose_b[j * 3 + q] = ga[q];
     }
 }
 
