@@ -162,7 +162,8 @@ def make_op(args, rank, device, scene_seed=0, habitat=False, assets=None):
     cfg = {'scene_verts_path': None, 'scene_sdf_path': None, 'human_model_path': None, 'vposer_ckpt_path': None,
            'init_lr_h': 0.1, 'num_iter': 1, 'batch_size': args.batch, 'device': device,
            'contact_part': synth.CONTACT_PARTS, 'contact_id_folder': None, 'verbose': False,
-           'smplx_data': smplx, 'vposer_state': vposer, 'scene': scene, 'engine': args.engine_resolved}
+           'smplx_data': smplx, 'vposer_state': vposer, 'scene': scene, 'engine': args.engine_resolved,
+           'concurrent_engines': ROOMS if habitat else 1}           # the 7 rooms of the sweep are 7 engines on 7 streams
     op = (fitting.FittingOPHabitat if habitat else fitting.FittingOP)(cfg, dict(LOSS))
     bodies = synth.make_bodies(11 + rank + 1000 * scene_seed, args.batch)
     if habitat:

@@ -162,6 +162,9 @@ typedef struct psi_fit_config {
     int independent_bodies;   /* != 0: the B bodies are B INDEPENDENT problems — every loss is normalised per body (rec / 75, prior / 32,
                                  contact / n_contact, penetration / that body's own count), so one engine run over B bodies equals B runs of
                                  the reference's loop at batch size 1 (one generated-body file each, fitting_proxe.py:252-263).  world_size 1. */
+    int concurrent_engines;   /* how many engines the caller keeps in flight on this GPU at the same time (other streams; 0 or 1 = this one
+                                 alone).  The per-body head / tail kernels spread a body over up to 8 workgroups so that a lone engine with
+                                 few bodies still covers the chip; engines that share the chip are told not to (B x engines x width <= 256). */
 } psi_fit_config;
 int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, const psi_fit_config *cfg,
                    const float *h_w1, const float *h_b1, const float *h_w2, const float *h_b2,

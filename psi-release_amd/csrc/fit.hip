@@ -73,6 +73,14 @@ struct FitDev {
     unsigned long long *hx_o6, *hx_gh1;   // head / tail cluster exchange words {value, tag}: partial fc3 outputs [B][C][128], partial W2^T products [B][C][512]
     unsigned *hx_epoch;      // [2][B] launch counts of the head / tail kernel per body (the exchange tag)
     int hc;                  // workgroups per body in the head / tail kernels (1, 2, 4 or 8)
+#ifdef PSI_HEAD_STOPS
+    int stop_h, stop_t;      // dev: leave the head / tail kernel at this point (differential timing; tools/head_stops.sh)
+#define HSTOP(k) do { if (f.stop_h == (k)) return; } while (0)
+#define TSTOP(k) do { if (f.stop_t == (k)) return; } while (0)
+#else
+#define HSTOP(k)
+#define TSTOP(k)
+#endif
     int *nn_hint;        // [B,n_c] previous nearest-neighbour indices (warm start of the kd-tree search), -1 = none
     float *history;      // [max_hist][4] loss values per iteration
     int max_hist;
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
     constexpr int PRE2 = C > 1 ? 16 : 0;    // rows of fc2 / fc3 held in registers from the top of the kernel
     constexpr int PRE3 = C > 1 ? (KPER3 < 4 ? KPER3 : 4) : 0;
     static_assert(KPER % 16 == 0 && KPER3 >= 1 && NS >= 64, "cluster too wide for the thread layout");
-    const int b = blockIdx.x % f.B, c = blockIdx.x / f.B, t = threadIdx.x;
+    const int b = blockIdx.x / C, c = blockIdx.x % C, t = threadIdx.x;
     const bool last = c == C - 1;           // the workgroup that carries on after the exchange
     __shared__ float sx[XD + 5], sh1[NH], sh2[NS], so6[128], red[HB / 64], spose[PSI_JP * 3], sbetas[32], sJ[PSI_JP][3];
     __shared__ f4 part4[HB], part3[KS3][32];
@@ -245,6 +253,9 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
     float pm[3] = {0, 0, 0}, b3v = 0.0f;
     int par = -1, lvl = -1;
     if (C > 1) tag = f.hx_epoch[b] + 1u;
+    f4 b1v = {0, 0, 0, 0};
+    if (t < 128) b1v = *(const f4 *)(f.b1 + t * 4);
+    const float b2v = t < NS ? f.b2[c * NS + t] : 0.0f;
     if (last) {
         if (t < 22)
             for (int e = 0; e < 3; e++) pm[e] = f.pose_mean[t * 3 + e];
@@ -252,6 +263,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
         if (t < lv.m.J) { par = lv.m.parents[t]; lvl = lv.m.level[t]; }
     }
     __syncthreads();
+    HSTOP(1);
     if (c == 0) {
         // loss partial sums (fitting_proxe.py:105, :109-110)
         float dr = t < XD ? fabsf(f.xhr[(size_t)b * XD + t] - sx[t]) : 0.0f;
@@ -263,13 +275,12 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
             f.vppart[b] = sz;
         }
     }
-    float *pose = f.pose + (size_t)b * f.J * 3;
     if (last) {
-        // the part of the per-body tail that needs the body vector only: hand PCA, jaw / eyes, shape, translation, rest joints.  The
-        // pose row goes to LDS for the pose stage below and to global memory for the backward.
+        // the part of the per-body tail that needs the body vector only: hand PCA, jaw / eyes, rest joints — into LDS; what the
+        // later kernels need of it is stored at the very end (a wait for a load also waits for the wave's earlier stores)
         if (t >= 64 && t < 64 + 9) {
             int e = 66 + (t - 64);                               // jaw, leye, reye: zero parameters + mean
-            pose[e] = spose[e] = f.pose_mean[e];
+            spose[e] = f.pose_mean[e];
         } else if (t >= 128 && t < 128 + 90) {
             int e = t - 128;                                     // hand PCA: 12 -> 45 per hand
             const float *comp = e < 45 ? f.lhc : f.rhc;
@@ -277,14 +288,11 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
             int cc = e < 45 ? e : e - 45;
             float a = 0;
             for (int i = 0; i < f.ncomp; i++) a += hx[i] * comp[i * 45 + cc];
-            pose[75 + e] = spose[75 + e] = a + f.pose_mean[75 + e];
-        } else if (t >= 224 && t < 224 + f.NB) {
-            f.betas20[(size_t)b * f.NB + (t - 224)] = sbetas[t - 224];
-        } else if (t >= 32 && t < 35) {
-            f.transl[(size_t)b * 3 + (t - 32)] = sx[t - 32];
+            spose[75 + e] = a + f.pose_mean[75 + e];
         }
-        psi_pose_fwd_rest(lv.m, sbetas, f.B, b, sJ, lv.feat, lv.Jl);
+        psi_pose_fwd_rest(lv.m, sbetas, sJ);
     }
+    HSTOP(2);
     // VPoser decoder.  Each thread owns 4 adjacent outputs (one 16-byte weight load per k) and one slice of K; the K-slices are
     // summed through LDS.
     const float *z = sx + 19;
@@ -296,12 +304,13 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
     }
     __syncthreads();
     if (t < 128) {
-        f4 a = *(const f4 *)(f.b1 + t * 4);
+        f4 a = b1v;
 #pragma unroll
         for (int q = 0; q < KQ; q++) a += part4[q * 128 + t];
         for (int e = 0; e < 4; e++) sh1[t * 4 + e] = leaky(a[e], 0.2f);
     }
     __syncthreads();
+    HSTOP(3);
     {   // fc2: 512 -> this workgroup's NS outputs: NQ output quads x KSPL K-splits
         f4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
         const float *h = sh1 + ks2 * KPER;
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
     }
     __syncthreads();
     if (t < NS) {
-        float a = f.b2[c * NS + t];
+        float a = b2v;
         const float *p = (const float *)part4;
 #pragma unroll
         for (int q = 0; q < KSPL; q++) a += p[q * NS + t];
@@ -330,6 +339,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
     if (c == 0)
         for (int o = t; o < NH; o += HB) f.h1[(size_t)b * NH + o] = sh1[o];
     __syncthreads();
+    HSTOP(4);
     {   // fc3 over this workgroup's activations: NS -> 126 (rows padded to 128): 32 output quads x KS3 K-slices
         f4 a = {0, 0, 0, 0};
         const float *h = sh2 + ks3 * KPER3;
@@ -340,6 +350,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
         part3[ks3][og3] = a;
     }
     __syncthreads();
+    HSTOP(5);
     if (t < 128) {
         float a = 0.0f;
         const float *p = (const float *)part3;
@@ -362,16 +373,24 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
     }
     if (C > 1 && !last) return;
     __syncthreads();
+    HSTOP(6);
     if (t < NJ6) f.o6[(size_t)b * 128 + t] = so6[t];
     // rotations: thread 0 = global orient (x[3:9]), threads 1..21 = VPoser body joints
     if (t < 22) {
         float R[9], aa[3];
         gs_forward(t == 0 ? sx + 3 : so6 + (t - 1) * 6, R);
         rotmat_to_aa(R, aa);
-        for (int e = 0; e < 3; e++) pose[t * 3 + e] = spose[t * 3 + e] = aa[e] + pm[e];
+        for (int e = 0; e < 3; e++) spose[t * 3 + e] = aa[e] + pm[e];
     }
     __syncthreads();
-    psi_pose_fwd_chain(lv.m, spose, f.transl, f.B, b, sJ, par, lvl, lv.feat, lv.R, lv.G, lv.A, nullptr);
+    HSTOP(7);
+    psi_pose_fwd_chain(lv.m, spose, nullptr, f.B, b, sJ, par, lvl, lv.feat, lv.R, lv.G, lv.A, nullptr);
+    HSTOP(8);
+    // what the skinning kernels and the backward read of the body-vector part
+    psi_pose_fwd_rest_store(lv.m, sbetas, f.B, b, sJ, lv.feat, lv.Jl);
+    for (int i = t; i < f.J * 3; i += HB) f.pose[(size_t)b * f.J * 3 + i] = spose[i];
+    if (t < f.NB) f.betas20[(size_t)b * f.NB + t] = sbetas[t];
+    if (t >= 64 && t < 67) f.transl[(size_t)b * 3 + (t - 64)] = sx[t - 64];
     if (C > 1 && t == 0) f.hx_epoch[b] = tag;
 }
 
@@ -660,7 +679,7 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
     constexpr int PRE3 = C > 1 ? (OPER < 16 ? OPER : 16) : 0;
     constexpr int PRE2 = C > 1 ? 16 : 0;
     static_assert(RPER % 16 == 0, "cluster too wide for the thread layout");
-    const int b = blockIdx.x % f.B, c = blockIdx.x / f.B, t = threadIdx.x;
+    const int b = blockIdx.x / C, c = blockIdx.x % C, t = threadIdx.x;
     const bool last = c == C - 1;
     __shared__ float sx[XD + 5], sg6[128], sga2[NS], sga1[NH], sgx[XD + 5];
     __shared__ float sgbetas[32], sgpose[PSI_JP * 3], sgrot[PSI_JP * 9];
@@ -682,6 +701,11 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
     if (C > 1) tag = f.hx_epoch[f.B + b] + 1u;
     float h1v = 0.0f, xhrv = 0.0f, am = 0.0f, av = 0.0f;
     int step = 0;
+    float o6v[6] = {0, 0, 0, 0, 0, 0}, gtv = 0.0f;
+    if (t >= 1 && t < 22)
+        for (int i = 0; i < 6; i++) o6v[i] = f.o6[(size_t)b * 128 + (t - 1) * 6 + i];
+    if (t >= 128 && t < 128 + 3) gtv = f.g_transl[(size_t)b * 3 + (t - 128)];
+    TSTOP(1);
     if (last) {
 #pragma unroll
         for (int i = 0; i < O1; i++) w1p[i] = *(const f4 *)(w1 + (size_t)i * NZ);
@@ -699,6 +723,7 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
     if (t < XD) { sx[t] = x[t]; sgx[t] = 0.0f; }
     if (t < 128) sg6[t] = 0.0f;
     __syncthreads();                                         // g_betas / g_pose / g_rot of this body are in LDS
+    TSTOP(2);
     if (c == 0) {                                            // inspection copies (psi_fit_copy_buffer)
         for (int i = t; i < f.J * 9; i += HB) f.g_rot[(size_t)b * f.J * 9 + i] = sgrot[i];
         for (int i = t; i < f.J * 3; i += HB) f.g_pose[(size_t)b * f.J * 3 + i] = sgpose[i];
@@ -710,7 +735,7 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         for (int i = 0; i < 6; i++) sgx[3 + i] = g6[i];
     } else if (t >= 1 && t < 22) {
         float g6[6];
-        gs_backward(f.o6 + (size_t)b * 128 + (t - 1) * 6, sgrot + t * 9, g6);
+        gs_backward(o6v, sgrot + t * 9, g6);
         for (int i = 0; i < 6; i++) sg6[(t - 1) * 6 + i] = g6[i];
     } else if (t >= 64 && t < 64 + 2 * f.ncomp) {
         int i = t - 64;                                   // hand PCA backward
@@ -721,11 +746,12 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         for (int e = 0; e < 45; e++) a += comp[ii * 45 + e] * gp[e];
         sgx[(i < f.ncomp ? 51 : 63) + ii] = a;
     } else if (t >= 128 && t < 128 + 3) {
-        sgx[t - 128] = f.g_transl[(size_t)b * 3 + (t - 128)];
+        sgx[t - 128] = gtv;
     } else if (t >= 160 && t < 160 + 10) {
         sgx[9 + (t - 160)] = sgbetas[t - 160];
     }
     __syncthreads();
+    TSTOP(3);
     // VPoser MLP backward (weights are constants): same 16-byte / split scheme on the [out][in] layouts
     {   // g_h2[k] = sum_o W3[o][k] g6[o] for this workgroup's k: NQ k-quads x OSPL row-splits (126 rows)
         f4 a = {0, 0, 0, 0};
@@ -744,6 +770,7 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         sga2[t] = a * (h2v > 0.0f ? 1.0f : 0.2f);
     }
     __syncthreads();
+    TSTOP(4);
     {   // g_h1[k] (partial over this workgroup's rows o) = sum_o W2[o][k] g_a2[o]: 128 k-quads x KQ row-splits
         f4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
         const float *g = sga2 + kq2 * RPER;
@@ -760,6 +787,7 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         part4[kq2 * 128 + og2] = a0 + a1;
     }
     __syncthreads();
+    TSTOP(5);
     {
         // every thread sums one output over the KQ row-splits
         const float *p = (const float *)part4;
@@ -783,6 +811,7 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         }
     }
     __syncthreads();
+    TSTOP(6);
     {   // g_z[k] = sum_o W1[o][k] g_a1[o]: 8 k-quads x 64 o-slices of 8
         f4 a = {0, 0, 0, 0};
         if (C == 1) {
@@ -801,6 +830,7 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         for (int e = 0; e < 4; e++) sgx[19 + t * 4 + e] = a[e];
     }
     __syncthreads();
+    TSTOP(7);
     if (C > 1 && t == 0) f.hx_epoch[f.B + b] = tag;
     if (!ADAM) {
         if (t < XD) g_out[(size_t)b * XD + t] = sgx[t];
@@ -994,7 +1024,14 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.nsdfblk = psi_cdiv(V, 256);
     f.max_hist = cfg->max_history > 0 ? cfg->max_history : 1024;
     // workgroups per body in the head / tail kernels: enough to put ~256 workgroups on the chip, none once the bodies alone do
-    f.hc = cfg->B <= 32 ? 8 : cfg->B <= 64 ? 4 : cfg->B <= 128 ? 2 : 1;
+    {
+        const long bodies = (long)cfg->B * (cfg->concurrent_engines > 1 ? cfg->concurrent_engines : 1);
+        f.hc = bodies <= 32 ? 8 : bodies <= 64 ? 4 : bodies <= 128 ? 2 : 1;
+    }
+#ifdef PSI_HEAD_STOPS
+    f.stop_h = getenv("PSI_HEAD_STOP") ? atoi(getenv("PSI_HEAD_STOP")) : 0;
+    f.stop_t = getenv("PSI_TAIL_STOP") ? atoi(getenv("PSI_TAIL_STOP")) : 0;
+#endif
     if (const char *hcv = getenv("PSI_HEAD_CLUSTER")) {
         const int v = atoi(hcv);
         if (v == 1 || v == 2 || v == 4 || v == 8) f.hc = v;

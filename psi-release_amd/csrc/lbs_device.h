@@ -49,21 +49,26 @@ __device__ __forceinline__ void psi_rodrigues(const float *aa, float *R)
 // memory in pose_fwd_kernel, LDS in the fused fitting head kernel); sJ is the caller's LDS array for the rest joints.
 // Callers: pose_fwd_kernel (lbs.hip) and the fused fitting head kernel (fit.hip).
 //
-// part 1: rest joints J = J_t + J_s betas, and the shape entries / zero tail of the blend-shape feature row
-__device__ __forceinline__ void psi_pose_fwd_rest(const LbsDev &m, const float *betas_b, int B, int b, float (*sJ)[3],
-                                                  float *__restrict__ feat, float *__restrict__ Jls)
+// part 1: rest joints J = J_t + J_s betas into LDS (no global stores: on gfx950 a later wait for ANY load also waits for every
+// earlier store of the wave, so a caller with loads still to come keeps the stores for last) ...
+__device__ __forceinline__ void psi_pose_fwd_rest(const LbsDev &m, const float *betas_b, float (*sJ)[3])
 {
-    const int j = threadIdx.x, nthr = blockDim.x;
-    const int Bpad = (B + 15) & ~15;
     // one (joint, axis) pair per thread, all threads of the workgroup take part
-    for (int q = j; q < m.J * 3; q += nthr) {
+    for (int q = threadIdx.x; q < m.J * 3; q += blockDim.x) {
         float a = m.J_t[q];
         const float *js = m.J_s + (size_t)q * m.NB;
         for (int l = 0; l < m.NB; l++) a += js[l] * betas_b[l];
         (&sJ[0][0])[q] = a;
-        Jls[(size_t)b * m.J * 3 + q] = a;
     }
-    // betas and the zero tail of the feature row (feat is stored as k-quads: [Kpad/4][Bpad][4])
+}
+
+// ... and its outputs: the rest joints, the shape entries / zero tail of the blend-shape feature row ([Kpad/4][Bpad][4] k-quads)
+__device__ __forceinline__ void psi_pose_fwd_rest_store(const LbsDev &m, const float *betas_b, int B, int b, const float (*sJ)[3],
+                                                        float *__restrict__ feat, float *__restrict__ Jls)
+{
+    const int j = threadIdx.x, nthr = blockDim.x;
+    const int Bpad = (B + 15) & ~15;
+    for (int q = j; q < m.J * 3; q += nthr) Jls[(size_t)b * m.J * 3 + q] = (&sJ[0][0])[q];
     for (int l = j; l < m.NB; l += nthr) feat[((size_t)(l >> 2) * Bpad + b) * 4 + (l & 3)] = betas_b[l];
     for (int l = m.K + j; l < m.Kpad; l += nthr) feat[((size_t)(l >> 2) * Bpad + b) * 4 + (l & 3)] = 0.0f;
 }
@@ -107,8 +112,9 @@ __device__ __forceinline__ void psi_pose_fwd_chain(const LbsDev &m, const float 
         }
         for (int e = 0; e < 12; e++) sG[j][e] = G[e];
     }
-    for (int L = 1; L <= m.maxlevel; L++) {
-        __syncthreads();
+    // every joint lives in wave 0 (J <= 64) and a wave's LDS operations execute in order: the level sweep needs no workgroup barrier
+    for (int L = 1; L <= m.maxlevel && j < 64; L++) {
+        __builtin_amdgcn_wave_barrier();
         if (act && lvl == L) {
             float P[12];
             for (int e = 0; e < 12; e++) P[e] = sG[par][e];
@@ -142,7 +148,9 @@ __device__ __forceinline__ void psi_pose_fwd_body(const LbsDev &m, const float *
     __shared__ float sJ[PSI_JP][3];
     const int par = threadIdx.x < m.J ? m.parents[threadIdx.x] : -1;
     const int lvl = threadIdx.x < m.J ? m.level[threadIdx.x] : -1;
-    psi_pose_fwd_rest(m, betas_b, B, b, sJ, feat, Jls);
+    psi_pose_fwd_rest(m, betas_b, sJ);
+    __syncthreads();
+    psi_pose_fwd_rest_store(m, betas_b, B, b, sJ, feat, Jls);
     psi_pose_fwd_chain(m, pose_b, transl, B, b, sJ, par, lvl, feat, Rs, Gs, As, joints);
 }
 
@@ -166,7 +174,29 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
     __shared__ int sChild[PSI_JP];       // child lists (CSR) staged once: the level sweep must not wait on global loads
     float R[9], Jl[3], G[12], gG[12], gJ[3] = {0, 0, 0};
     for (int e = 0; e < 12; e++) gG[e] = 0.0f;
+    // operands of the LAST steps first: their loads are in flight while the level sweep runs
+    float gf9[9], aa[3] = {0, 0, 0};
+    for (int e = 0; e < 9; e++) gf9[e] = 0.0f;
+    if (act && (g_pose_b || g_rot_b) && j >= 1)
+        for (int e = 0; e < 9; e++) gf9[e] = gfeat_b[m.NB + (j - 1) * 9 + e];
+    if (act && g_pose_b)
+        for (int e = 0; e < 3; e++) aa[e] = pose_b[j * 3 + e];
+    constexpr int JSP = 8;                               // J_s entries of the g_betas part held in registers
+    const int nq = m.J * 3;
+    const int npart = m.NB > 0 ? min(32, max(1, nthr / m.NB)) : 1;
+    const int per = (nq + npart - 1) / npart;
+    const bool par_ok = m.NB <= 32, js_pre = g_betas_b && par_ok && per <= JSP && j < npart * m.NB;
+    const int bpart = m.NB > 0 ? j / m.NB : 0, bl = j - bpart * m.NB;
+    float js[JSP];
+    for (int i = 0; i < JSP; i++) js[i] = 0.0f;
+    if (js_pre)
+        for (int i = 0; i < JSP; i++) {
+            const int q = bpart * per + i;
+            if (i < per && q < nq) js[i] = m.J_s[(size_t)q * m.NB + bl];
+        }
     const int cp0 = act ? m.child_ptr[j] : 0, cp1 = act ? m.child_ptr[j + 1] : 0;
+    const int par = act ? m.parents[j] : -1;
+    const int lvl = act ? m.level[j] : -1;
     if (j < m.J - 1) sChild[j] = m.child_idx[j];
     if (act) {
         const psi_f4 *Rp = (const psi_f4 *)(Rs + ((size_t)b * m.J + j) * 12);
@@ -190,14 +220,13 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
         for (int e = 0; e < 12; e++) sgG[j][e] = gG[e];
     }
     __syncthreads();
-    const int par = act ? m.parents[j] : -1;
-    const int lvl = act ? m.level[j] : -1;
     if (act) {
         for (int c = 0; c < 3; c++) sRel[j][c] = (par >= 0) ? Jl[c] - sJ[par][c] : Jl[c];
     }
     __syncthreads();
     // reverse sweep over levels: a joint first gathers from its children (whose gG are final), then publishes its own
-    for (int L = m.maxlevel - 1; L >= 0; L--) {
+    // (every joint lives in wave 0 and a wave's LDS operations execute in order: no workgroup barrier inside the sweep)
+    for (int L = m.maxlevel - 1; L >= 0 && j < 64; L--) {
         if (act && lvl == L) {
             for (int ci = cp0; ci < cp1; ci++) {
                 int ch = sChild[ci];
@@ -213,7 +242,7 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
             }
             for (int e = 0; e < 12; e++) sgG[j][e] = gG[e];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
     // local gradients: gR_j = P_R^T gG_j.R, grel_j = P_R^T gG_j.t  (P = parent's G; root: identity)
     float gR[9], grel[3] = {0, 0, 0};
@@ -252,11 +281,16 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
         // g_betas[l] = g_feat[l] + sum_q gJ[q] J_s[q][l]: the (joint, axis) range is cut into nthr/NB parts summed through LDS,
         // so a thread has only a handful of independent loads (they were 165 dependent rounds for NB threads before)
         __shared__ float sgb[32][32];
-        const int nq = m.J * 3;
-        const int npart = m.NB > 0 ? min(32, max(1, nthr / m.NB)) : 1;
-        const int per = (nq + npart - 1) / npart;
-        const bool par_ok = m.NB <= 32;
-        for (int i = j; i < npart * m.NB && par_ok; i += nthr) {
+        if (js_pre) {
+            float a = 0.0f;
+#pragma unroll
+            for (int i = 0; i < JSP; i++) {
+                const int q = bpart * per + i;
+                if (i < per && q < nq) a += (&sgJ[0][0])[q] * js[i];
+            }
+            sgb[bpart][bl] = a;
+        }
+        for (int i = j; i < npart * m.NB && par_ok && per > JSP; i += nthr) {
             const int part = i / m.NB, l = i - part * m.NB;
             const int q1 = min(nq, (part + 1) * per);
             float a = 0.0f;
@@ -277,13 +311,12 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
     }
     if (act && (g_pose_b || g_rot_b)) {
         if (j >= 1)
-            for (int e = 0; e < 9; e++) gR[e] += gfeat_b[m.NB + (j - 1) * 9 + e];
+            for (int e = 0; e < 9; e++) gR[e] += gf9[e];
         if (g_rot_b)
             for (int e = 0; e < 9; e++) g_rot_b[j * 9 + e] = gR[e];
     }
     if (act && g_pose_b) {
         // Rodrigues backward (lbs.py:177-191)
-        const float *aa = pose_b + j * 3;
         float x = aa[0] + 1e-8f, y = aa[1] + 1e-8f, z = aa[2] + 1e-8f;
         float th = sqrtf(x * x + y * y + z * z);
         float d[3] = {aa[0] / th, aa[1] / th, aa[2] / th};

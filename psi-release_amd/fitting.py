@@ -57,6 +57,8 @@ class FittingOP:
         self.reset_optimizer = False
         self.independent_bodies = False  # True: the batch is B independent problems (per-body loss normalisers): one engine run over B
                                          # bodies == B runs of the reference's loop at batch size 1 (fused engine only; fitting_many packs files)
+        self.concurrent_engines = 1      # engines (of this or other FittingOPs) the caller keeps in flight on this GPU at once: sizes the
+                                         # per-body head / tail kernels (psi_fit_config.concurrent_engines); fitting_many sets it itself
         self.data_parallel = None        # None: rows are sharded over the ranks whenever torch.distributed runs with > 1 rank;
                                          # False: this instance fits its own independent batch (file-sharded scripts)
         for key, val in fittingconfig.items():
@@ -205,10 +207,6 @@ class FittingOP:
             raise ValueError('fitting_many fits independent problems: build the FittingOP with data_parallel=False')
         if not inputs:
             return [], []
-        if getattr(self, '_fused', None) is None:
-            self._fused = FusedEngine(self)
-        if not hasattr(self, '_fused_pool'):
-            self._fused_pool = [self._fused]
         # host-side glue ONCE for the whole list (per file it is ~100 small torch launches = 1.8 ms of host time, more than the
         # 20 iterations themselves take on the GPU): parse and stack the records, one batched 3D->6D conversion in, one 6D->3D out
         recs = []
@@ -253,9 +251,18 @@ class FittingOP:
         n_runs = len(recs) // pack
         R = pack * B                                                                                  # rows per engine run (== batch_size)
         K = max(1, min(int(concurrency), n_runs))
-        while len(self._fused_pool) < K:
-            self._fused_pool.append(FusedEngine(self))
-        engines = self._fused_pool[:K]
+        # the engines are built for the number of them that share the GPU (psi_fit_config.concurrent_engines)
+        pool = getattr(self, '_fused_pool', [])
+        if not pool or pool[0].concurrent_engines != K:
+            self.concurrent_engines = K
+            pool = []
+            self._fused = None
+        while len(pool) < K:
+            pool.append(FusedEngine(self))
+        self._fused_pool = pool
+        if self._fused is None:
+            self._fused = pool[0]
+        engines = pool[:K]
         torch.cuda.current_stream().synchronize()                                                    # inputs are ready for every engine stream
         L = hip.lib()
         for i in range(n_runs):
@@ -354,7 +361,9 @@ class FusedEngine:
                             max_history=4096, nn_mode=1 if op.nn_mode == 'kdtree' else 0, w_rec=op.weight_loss_rec, w_vposer=op.weight_loss_vposer,
                             w_contact=op.weight_contact, w_collision=op.weight_collision, contact_const=op.contact_const,
                             lr=op.init_lr_h, beta1=0.9, beta2=0.999, eps=1e-8,
-                            independent_bodies=int(bool(getattr(op, 'independent_bodies', False))))
+                            independent_bodies=int(bool(getattr(op, 'independent_bodies', False))),
+                            concurrent_engines=int(getattr(op, 'concurrent_engines', 1)))
+        self.concurrent_engines = int(getattr(op, 'concurrent_engines', 1))
         self._keep = (op.s_verts, op.s_sdf)                    # device arrays the engine points into
         h = ctypes.c_void_p()
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)

@@ -69,7 +69,7 @@ class FitConfig(ctypes.Structure):
                 ('world_size', c_int), ('num_pca_comps', c_int), ('max_history', c_int), ('nn_mode', c_int),
                 ('w_rec', c_float), ('w_vposer', c_float), ('w_contact', c_float), ('w_collision', c_float),
                 ('contact_const', c_float), ('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float),
-                ('independent_bodies', c_int)]
+                ('independent_bodies', c_int), ('concurrent_engines', c_int)]
 
 
 class PsiHipError(RuntimeError):

@@ -14,10 +14,10 @@ buf = (ctypes.c_ulonglong * 64)()
 lib = ctypes.CDLL(os.environ['PSI_HIP_LIB'])
 lib.psi_dbg_read(buf)
 v = np.array(list(buf), dtype=np.float64) * 0.01    # wall_clock64: 100 MHz -> us
-names = {0: 'head start', 1: 'x + loss partials', 2: 'fc1', 3: 'fc2 slice', 4: 'fc3 partial', 7: 'exchange (release, ticket, acquire)', 8: 'sum partials', 5: 'stores/rot/pca', 40: '  pose_fwd: rodrigues + joints', 41: '  pose_fwd: chain', 6: '  pose_fwd: stores',
+names = {0: 'head start (consumer workgroup)', 1: 'x, loss partials, x-only tail work', 2: 'fc1', 3: 'fc2 slice', 4: 'fc3 partial', 8: 'exchange + sum', 5: 'rotations', 40: '  pose_fwd: rodrigues', 41: '  pose_fwd: chain', 6: '  pose_fwd: stores',
          16: 'tail start', 32: '  pose_bwd: loads', 33: '  pose_bwd: level sweep', 34: '  pose_bwd: local grads + gJ',
-         35: '  pose_bwd: g_betas', 18: '  pose_bwd: rest (rodrigues bwd, stores)', 19: 'gs_backward/pca bwd', 20: 'W3^T slice', 21: 'W2^T partial', 24: 'exchange', 25: 'sum partials', 22: 'W1^T', 23: 'adam'}
-order = [0, 1, 2, 3, 4, 7, 8, 5, 40, 41, 6, 16, 32, 33, 34, 35, 18, 19, 20, 21, 24, 25, 22, 23]
+         35: '  pose_bwd: g_betas', 18: '  pose_bwd: rest (rodrigues bwd, stores)', 19: 'gs_backward/pca bwd', 20: 'W3^T slice', 21: 'W2^T partial', 25: 'exchange + sum', 22: 'W1^T', 23: 'adam'}
+order = [0, 1, 2, 3, 4, 8, 5, 40, 41, 6, 16, 32, 33, 34, 35, 18, 19, 20, 21, 25, 22, 23]
 prev = None
 for i in order:
     if i in (0, 16, 48): prev = v[i]; print(names[i]); continue
