@@ -446,10 +446,13 @@ __device__ __forceinline__ void psi_skin_fwd_body(const LbsDev &m, const float *
             float Z = psi_dot3p(C[8], C[9], C[10], C[11], x, y, z);
             x = X; y = Y; z = Z;
         }
+    }
+    epi.vertex(b, v, x, y, z, live);
+    if (live) {
+        // stored AFTER the epilogue's lookups: a wait for a load also waits for the wave's earlier stores (one counter on gfx950)
         float *o = verts + ((size_t)b * m.V + v) * 3;
         o[0] = x; o[1] = y; o[2] = z;
     }
-    epi.vertex(b, v, x, y, z, live);
     epi.finish(b, vblock, nvb);
 }
 
