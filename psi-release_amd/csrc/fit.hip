@@ -251,7 +251,8 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
     if (t >= 64 && t < 96) sbetas[t - 64] = t - 64 < 10 ? x[9 + (t - 64)] : 0.0f;
     unsigned tag = 0;
     float pm[3] = {0, 0, 0}, b3v = 0.0f;
-    int par = -1, lvl = -1;
+    PsiJump jp;
+    for (int r = 0; r < PSI_NJUMP; r++) jp.a[r] = -1;
     if (C > 1) tag = f.hx_epoch[b] + 1u;
     f4 b1v = {0, 0, 0, 0};
     if (t < 128) b1v = *(const f4 *)(f.b1 + t * 4);
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
         if (t < 22)
             for (int e = 0; e < 3; e++) pm[e] = f.pose_mean[t * 3 + e];
         if (t < 128) b3v = f.b3[t];
-        if (t < lv.m.J) { par = lv.m.parents[t]; lvl = lv.m.level[t]; }
+        jp = psi_load_jump(lv.m);
     }
     __syncthreads();
     HSTOP(1);
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
     }
     __syncthreads();
     HSTOP(7);
-    psi_pose_fwd_chain(lv.m, spose, nullptr, f.B, b, sJ, par, lvl, lv.feat, lv.R, lv.G, lv.A, nullptr);
+    psi_pose_fwd_chain(lv.m, spose, nullptr, f.B, b, sJ, jp, lv.feat, lv.R, lv.G, lv.A, nullptr);
     HSTOP(8);
     // what the skinning kernels and the backward read of the body-vector part
     psi_pose_fwd_rest_store(lv.m, sbetas, f.B, b, sJ, lv.feat, lv.Jl);

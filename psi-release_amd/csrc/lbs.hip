@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int Kpad, c
     }
 }
 
-__global__ __launch_bounds__(64) void pose_bwd_kernel(LbsDev m, const float *__restrict__ betas, const float *__restrict__ pose,
+__global__ __launch_bounds__(256) void pose_bwd_kernel(LbsDev m, const float *__restrict__ betas, const float *__restrict__ pose,
                                                       const float *__restrict__ Rs, const float *__restrict__ Jls,
                                                       const float *__restrict__ Gs, const float *__restrict__ gAr,
                                                       const float *__restrict__ gfeat, int B,
@@ -463,6 +463,37 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     }
     cptr[J] = (int)cidx.size();
     if (cidx.empty()) cidx.push_back(0);
+    // pointer-jumping table (2^r-th ancestors) and subtree sets (lbs_device.h: psi_pose_fwd_chain / psi_pose_bwd_body)
+    std::vector<int> jump((size_t)PSI_NJUMP * JP, -1);
+    std::vector<unsigned char> sub_list, sub_first(J + 1, 0);
+    std::vector<unsigned int> sub_item;
+    for (int j = 0; j < J; j++) jump[j] = h_parents[j] < 0 ? -1 : h_parents[j];
+    d.njump = 0;
+    while ((1 << d.njump) <= d.maxlevel) d.njump++;              // rounds needed: 2^njump > maxlevel
+    for (int r = 1; r < PSI_NJUMP; r++)
+        for (int j = 0; j < J; j++) {
+            const int a = jump[(size_t)(r - 1) * JP + j];
+            jump[(size_t)r * JP + j] = a < 0 ? -1 : jump[(size_t)(r - 1) * JP + a];
+        }
+    {
+        std::vector<std::vector<int>> sub(J);
+        size_t total = 0;
+        for (int j = 0; j < J; j++)
+            for (int a = j; a >= 0; a = h_parents[a]) { sub[a].push_back(j); total++; }          // ascending in j
+        const int chunk = std::max(8, (int)((total + JP - 1) / JP));                                // => at most J + JP chunks
+        for (int j = 0; j < J; j++) {
+            sub_first[j] = (unsigned char)sub_item.size();
+            for (size_t q = 0; q < sub[j].size(); q += chunk) {
+                const size_t cnt = std::min((size_t)chunk, sub[j].size() - q);
+                sub_item.push_back((unsigned int)sub_list.size() | ((unsigned int)cnt << 16));
+                for (size_t i = 0; i < cnt; i++) sub_list.push_back((unsigned char)sub[j][q + i]);
+            }
+        }
+        sub_first[J] = (unsigned char)sub_item.size();
+        PSI_REQUIRE(sub_item.size() <= (size_t)PSI_ITEM_MAX && sub_list.size() <= (size_t)PSI_SUB_MAX, "kinematic tree tables out of range");
+        d.n_sub = (int)sub_list.size();
+        d.n_items = (int)sub_item.size();
+    }
     // host staging
     std::vector<float> dirs((size_t)d.Kpad * d.Npad, 0.0f), vt(d.Npad, 0.0f), WT((size_t)JP * d.Vpad, 0.0f);
     auto dirs_at = [&](int k, int n) -> float & { return dirs[((size_t)(n >> 6) * d.Kpad + k) * 64 + (n & 63)]; };
@@ -522,7 +553,8 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     size_t o_dirs = take(dirs.size() * 4), o_vt = take(vt.size() * 4), o_wt = take(WT.size() * 4), o_jt = take(Jt.size() * 4),
-           o_js = take(Js.size() * 4), o_wc = take(Wc.size() * 4 + 4), o_wj = take(Wj.size() * 4 + 4), o_par = take(J * 4), o_lvl = take(J * 4), o_cp = take((J + 1) * 4), o_ci = take(cidx.size() * 4);
+           o_js = take(Js.size() * 4), o_wc = take(Wc.size() * 4 + 4), o_wj = take(Wj.size() * 4 + 4), o_par = take(J * 4), o_lvl = take(J * 4), o_cp = take((J + 1) * 4), o_ci = take(cidx.size() * 4),
+           o_jump = take(jump.size() * 4), o_sl = take(sub_list.size()), o_si = take(sub_item.size() * 4), o_sf = take(sub_first.size());
     char *blob = nullptr;
     PSI_CHECK_HIP(hipMalloc((void **)&blob, o));
     std::vector<int> par(h_parents, h_parents + J);
@@ -530,7 +562,9 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
         {o_dirs, dirs.data(), dirs.size() * 4}, {o_vt, vt.data(), vt.size() * 4}, {o_wt, WT.data(), WT.size() * 4},
         {o_jt, Jt.data(), Jt.size() * 4}, {o_js, Js.data(), Js.size() * 4}, {o_wc, Wc.data(), Wc.size() * 4}, {o_wj, Wj.data(), Wj.size() * 4},
         {o_par, par.data(), (size_t)J * 4},
-        {o_lvl, level.data(), (size_t)J * 4}, {o_cp, cptr.data(), (size_t)(J + 1) * 4}, {o_ci, cidx.data(), cidx.size() * 4}};
+        {o_lvl, level.data(), (size_t)J * 4}, {o_cp, cptr.data(), (size_t)(J + 1) * 4}, {o_ci, cidx.data(), cidx.size() * 4},
+        {o_jump, jump.data(), jump.size() * 4}, {o_sl, sub_list.data(), sub_list.size()}, {o_si, sub_item.data(), sub_item.size() * 4},
+        {o_sf, sub_first.data(), sub_first.size()}};
     for (auto &c : cp) {
         if (!c.bytes) continue;
         hipError_t e = hipMemcpy(blob + c.off, c.src, c.bytes, hipMemcpyHostToDevice);
@@ -551,6 +585,10 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     d.level = (const int *)(blob + o_lvl);
     d.child_ptr = (const int *)(blob + o_cp);
     d.child_idx = (const int *)(blob + o_ci);
+    d.jump = (const int *)(blob + o_jump);
+    d.sub_list = (const unsigned char *)(blob + o_sl);
+    d.sub_item = (const unsigned int *)(blob + o_si);
+    d.sub_first = (const unsigned char *)(blob + o_sf);
     psi_lbs_model *mdl = new psi_lbs_model;
     mdl->d = d;
     mdl->blob = blob;
@@ -708,7 +746,7 @@ int psi_lbs_backward_ex(const psi_lbs_model *mdl, const float *grad_verts, const
     if (rc) return rc;
     rc = lbs_launch_reduce(m, L, B, ws, out.g_transl, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(64), 0, st, m, betas, pose, ws + L.R, ws + L.Jl, ws + L.G, ws + L.gA,
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, st, m, betas, pose, ws + L.R, ws + L.Jl, ws + L.G, ws + L.gA,
                        ws + L.gfeat, B, out.g_betas, out.g_pose, out.g_rot);
     PSI_CHECK_LAUNCH("pose_bwd_kernel");
     psi_mark("pose_bwd_kernel", st);

@@ -7,14 +7,23 @@
 typedef float psi_f4 __attribute__((ext_vector_type(4)));
 
 constexpr int PSI_JP = 64;          // padded joint count
+constexpr int PSI_SUB_MAX = PSI_JP * (PSI_JP + 1) / 2;   // most subtree members over all joints (a 64-joint chain)
+constexpr int PSI_ITEM_MAX = 2 * PSI_JP;                 // most chunks (psi_lbs_create sizes the chunks for this)
+constexpr int PSI_NJUMP = 6;       // ceil(log2(PSI_JP)) rounds of pointer jumping cover any tree
 constexpr int PSI_WNZ = 8;          // compressed skinning rows are used when no vertex has more non-zero weights than this
 
 struct LbsDev {
-    int V, J, NB, P, K, Kpad, N, Npad, Vpad, maxlevel;
+    int V, J, NB, P, K, Kpad, N, Npad, Vpad, maxlevel, njump;
     const float *dirs, *v_template, *WT, *J_t, *J_s;
     const float *Wc;                                 // compressed rows [PSI_WNZ][Vpad]: the k-th non-zero weight of each vertex (ascending joint), or nullptr
     const int *Wj;                                   //                 [PSI_WNZ][Vpad]: its joint index (padding: weight 0, joint 0)
     const int *parents, *level, *child_ptr, *child_idx;
+    const int *jump;                                 // [PSI_NJUMP][PSI_JP]: the 2^r-th ancestor of joint j (-1: none) — pointer jumping down the chain
+    // subtree sets for the chain backward (psi_pose_bwd_body): the members of subtree(j), ascending, cut into chunks of <= sub_chunk
+    const unsigned char *sub_list;                   // [n_sub]    subtree members of joint 0, joint 1, ... back to back
+    const unsigned int *sub_item;                    // [n_items]  one chunk: offset into sub_list | count << 16
+    const unsigned char *sub_first;                  // [J + 1]    first chunk of joint j (chunks of a joint are consecutive)
+    int n_sub, n_items;
 };
 
 // Pointers into an LBS workspace (psi_lbs_workspace_floats) for a batch of B bodies
@@ -75,17 +84,34 @@ __device__ __forceinline__ void psi_pose_fwd_rest_store(const LbsDev &m, const f
 
 // part 2: Rodrigues, pose feature, kinematic chain, skinning transforms.  sJ must be complete (the first barrier below orders it
 // when part 1 ran in the same workgroup just before).
-// par / lvl: m.parents[j] / m.level[j] of this thread's joint (-1 for threads >= J), loaded by the caller ahead of time.
+// The chain G_j = G_parent(j) [R_j | J_j - J_parent] is evaluated by POINTER JUMPING instead of a sweep over the tree levels: every
+// joint starts with its local transform and in round r multiplies it from the left by the current value of its 2^r-th ancestor, so
+// ceil(log2(depth)) = 4 rounds for SMPL-X's 11 levels instead of 10 (same products, associated differently).  All joints live in wave 0
+// (J <= 64) and a wave's LDS operations execute in order: reads of a round precede its writes, no workgroup barrier in the loop.
+struct PsiJump { int a[PSI_NJUMP]; };      // this thread's row of m.jump (a[0] = parent), loaded by the caller ahead of time
+
+__device__ __forceinline__ PsiJump psi_load_jump(const LbsDev &m)
+{
+    PsiJump jp;
+#pragma unroll
+    for (int r = 0; r < PSI_NJUMP; r++) jp.a[r] = (threadIdx.x < m.J && r < m.njump) ? m.jump[r * PSI_JP + threadIdx.x] : -1;
+    return jp;
+}
+
 __device__ __forceinline__ void psi_pose_fwd_chain(const LbsDev &m, const float *pose_b, const float *__restrict__ transl, int B, int b,
-                                                   const float (*sJ)[3], int par, int lvl, float *__restrict__ feat,
+                                                   const float (*sJ)[3], const PsiJump &jp, float *__restrict__ feat,
                                                    float *__restrict__ Rs, float *__restrict__ Gs, float *__restrict__ As,
                                                    float *__restrict__ joints)
 {
     const int j = threadIdx.x;
     const int Bpad = (B + 15) & ~15;
     __shared__ float sG[PSI_JP][12];
+    __shared__ int sJmp[PSI_NJUMP][PSI_JP];          // the jump rows, so that the round loop below stays a (compact) loop
     const bool act = j < m.J;
     float R[9], Jl[3] = {0, 0, 0};
+    if (j < PSI_JP)
+#pragma unroll
+        for (int r = 0; r < PSI_NJUMP; r++) sJmp[r][j] = jp.a[r];
     if (act) {
         psi_rodrigues(pose_b + j * 3, R);
         psi_f4 *Ro = (psi_f4 *)(Rs + ((size_t)b * m.J + j) * 12);      // rows padded to 4: three 16-byte stores
@@ -99,31 +125,31 @@ __device__ __forceinline__ void psi_pose_fwd_chain(const LbsDev &m, const float 
             }
     }
     __syncthreads();
-    if (act)
-        for (int c = 0; c < 3; c++) Jl[c] = sJ[j][c];
-    float rel[3] = {Jl[0], Jl[1], Jl[2]};
-    if (act && par >= 0)
-        for (int c = 0; c < 3; c++) rel[c] = Jl[c] - sJ[par][c];
     float G[12];   // row-major 3x4: [R | t]
-    if (act && lvl == 0) {
+    if (act) {
+        const int par = jp.a[0];
+        for (int c = 0; c < 3; c++) Jl[c] = sJ[j][c];
         for (int r = 0; r < 3; r++) {
             for (int c = 0; c < 3; c++) G[r * 4 + c] = R[r * 3 + c];
-            G[r * 4 + 3] = rel[r];
+            G[r * 4 + 3] = par >= 0 ? Jl[r] - sJ[par][r] : Jl[r];
         }
         for (int e = 0; e < 12; e++) sG[j][e] = G[e];
     }
-    // every joint lives in wave 0 (J <= 64) and a wave's LDS operations execute in order: the level sweep needs no workgroup barrier
-    for (int L = 1; L <= m.maxlevel && j < 64; L++) {
+#pragma nounroll
+    for (int r = 0; r < m.njump && j < 64; r++) {
         __builtin_amdgcn_wave_barrier();
-        if (act && lvl == L) {
-            float P[12];
-            for (int e = 0; e < 12; e++) P[e] = sG[par][e];
-            for (int r = 0; r < 3; r++) {
-                for (int c = 0; c < 3; c++)
-                    G[r * 4 + c] = P[r * 4 + 0] * R[0 * 3 + c] + P[r * 4 + 1] * R[1 * 3 + c] + P[r * 4 + 2] * R[2 * 3 + c];
-                G[r * 4 + 3] = P[r * 4 + 0] * rel[0] + P[r * 4 + 1] * rel[1] + P[r * 4 + 2] * rel[2] + P[r * 4 + 3];
+        const int a = sJmp[r][j];
+        float P[12];
+        if (act && a >= 0)
+            for (int e = 0; e < 12; e++) P[e] = sG[a][e];
+        __builtin_amdgcn_wave_barrier();
+        if (act && a >= 0) {
+            float N[12];
+            for (int q = 0; q < 3; q++) {
+                for (int c = 0; c < 3; c++) N[q * 4 + c] = P[q * 4 + 0] * G[0 * 4 + c] + P[q * 4 + 1] * G[1 * 4 + c] + P[q * 4 + 2] * G[2 * 4 + c];
+                N[q * 4 + 3] = P[q * 4 + 0] * G[3] + P[q * 4 + 1] * G[7] + P[q * 4 + 2] * G[11] + P[q * 4 + 3];
             }
-            for (int e = 0; e < 12; e++) sG[j][e] = G[e];
+            for (int e = 0; e < 12; e++) { G[e] = N[e]; sG[j][e] = N[e]; }
         }
     }
     if (act) {
@@ -146,18 +172,25 @@ __device__ __forceinline__ void psi_pose_fwd_body(const LbsDev &m, const float *
                                                   float *__restrict__ As, float *__restrict__ joints)
 {
     __shared__ float sJ[PSI_JP][3];
-    const int par = threadIdx.x < m.J ? m.parents[threadIdx.x] : -1;
-    const int lvl = threadIdx.x < m.J ? m.level[threadIdx.x] : -1;
+    const PsiJump jp = psi_load_jump(m);
     psi_pose_fwd_rest(m, betas_b, sJ);
     __syncthreads();
     psi_pose_fwd_rest_store(m, betas_b, B, b, sJ, feat, Jls);
-    psi_pose_fwd_chain(m, pose_b, transl, B, b, sJ, par, lvl, feat, Rs, Gs, As, joints);
+    psi_pose_fwd_chain(m, pose_b, transl, B, b, sJ, jp, feat, Rs, Gs, As, joints);
 }
 
 
 // Body of the pose-backward stage for body b (whole workgroup).  gA_b [PSI_JP][16] and gfeat_b [Kpad] are THIS body's reduced
 // gradients, pose_b [J*3] its pose row; the outputs g_betas_b [NB], g_pose_b [J*3], g_rot_b [J*9] are this body's rows too (global
 // memory in pose_bwd_kernel, LDS in the fused fitting tail kernel).
+//
+// Gradient through the kinematic chain WITHOUT a sweep over the tree levels.  With G_d = G_j M_jd for every joint d in the subtree of
+// j (M_jd = G_j^-1 G_d, rotations orthonormal), the gradient reaching G_j = [GR_j | Gt_j] from everything below it is
+//     g(G_j).t = sum_d w_d,                  g(G_j).R = [ sum_d U_d  -  (sum_d w_d) Gt_j^T ] GR_j,      d over subtree(j)
+//     w_d = gown(G_d).t,  U_d = gown(G_d).R GR_d^T + w_d Gt_d^T,    gown = the gradient G_d receives directly from its own A_d
+// i.e. twelve numbers per joint summed over subtrees.  The subtree sets are constants of the model, stored as chunks of at most eight
+// members: all chunks are summed at once (one thread per chunk and component), then every joint adds up its chunks — two short
+// rounds over all threads of the workgroup instead of ten dependent rounds on one wave, in a fixed order.
 __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *pose_b,
                                                   const float *__restrict__ Rs, const float *__restrict__ Jls,
                                                   const float *__restrict__ Gs, const float *gA_b, const float *gfeat_b, int b,
@@ -165,16 +198,16 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
 {
     const int j = threadIdx.x, nthr = blockDim.x;
     const bool act = j < m.J;
-    __shared__ float sgG[PSI_JP][12];    // gradient wrt G_j (3x4)
+    __shared__ float sX[PSI_JP][12];     // U_d (3x3 row-major), w_d
+    __shared__ float sS[PSI_JP][12];     // their sums over subtree(j)
+    __shared__ float sP[PSI_ITEM_MAX][12];               // ... per chunk
+    __shared__ unsigned int sItem[PSI_ITEM_MAX];
+    __shared__ unsigned char sList[PSI_SUB_MAX], sFirst[PSI_JP + 1];
     __shared__ float sgJ[PSI_JP][3];     // gradient wrt the rest joint location J_j
     __shared__ float sgrel[PSI_JP][3];
-    __shared__ float sRel[PSI_JP][3];
-    __shared__ float sR[PSI_JP][9];
-    __shared__ float sJ[PSI_JP][3];
-    __shared__ int sChild[PSI_JP];       // child lists (CSR) staged once: the level sweep must not wait on global loads
-    float R[9], Jl[3], G[12], gG[12], gJ[3] = {0, 0, 0};
-    for (int e = 0; e < 12; e++) gG[e] = 0.0f;
-    // operands of the LAST steps first: their loads are in flight while the level sweep runs
+    __shared__ int sChild[PSI_JP];       // child lists (CSR)
+    (void)Rs;
+    // operands of the LAST steps first: their loads are in flight while the chain part runs
     float gf9[9], aa[3] = {0, 0, 0};
     for (int e = 0; e < 9; e++) gf9[e] = 0.0f;
     if (act && (g_pose_b || g_rot_b) && j >= 1)
@@ -196,65 +229,76 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
         }
     const int cp0 = act ? m.child_ptr[j] : 0, cp1 = act ? m.child_ptr[j + 1] : 0;
     const int par = act ? m.parents[j] : -1;
-    const int lvl = act ? m.level[j] : -1;
     if (j < m.J - 1) sChild[j] = m.child_idx[j];
+    for (int i = j; i < m.n_sub; i += nthr) sList[i] = m.sub_list[i];
+    for (int i = j; i < m.n_items; i += nthr) sItem[i] = m.sub_item[i];
+    for (int i = j; i <= m.J; i += nthr) sFirst[i] = m.sub_first[i];
+    float G[12], gJ[3] = {0, 0, 0};
+    for (int e = 0; e < 12; e++) G[e] = 0.0f;
     if (act) {
-        const psi_f4 *Rp = (const psi_f4 *)(Rs + ((size_t)b * m.J + j) * 12);
         const psi_f4 *Gp = (const psi_f4 *)(Gs + ((size_t)b * m.J + j) * 12);
         const psi_f4 *Ap = (const psi_f4 *)(gA_b + j * 16);
-        float gA[12];
+        float gA[12], Jl[3];
         for (int r = 0; r < 3; r++) {
-            const psi_f4 rr = Rp[r], gg = Gp[r], aa4 = Ap[r];
-            for (int c = 0; c < 3; c++) { R[r * 3 + c] = rr[c]; sR[j][r * 3 + c] = rr[c]; }
+            const psi_f4 gg = Gp[r], aa4 = Ap[r];
             for (int c = 0; c < 4; c++) { G[r * 4 + c] = gg[c]; gA[r * 4 + c] = aa4[c]; }
         }
-        for (int c = 0; c < 3; c++) { Jl[c] = Jls[((size_t)b * m.J + j) * 3 + c]; sJ[j][c] = Jl[c]; }
-        // A = [G_R | G_t - G_R J]
+        for (int c = 0; c < 3; c++) Jl[c] = Jls[((size_t)b * m.J + j) * 3 + c];
+        // A = [G_R | G_t - G_R J]: own gradient of G_j and the direct part of the rest-joint gradient
+        float go[9], w[3];
         for (int r = 0; r < 3; r++) {
-            float gt = gA[r * 4 + 3];
-            for (int c = 0; c < 3; c++) gG[r * 4 + c] = gA[r * 4 + c] - gt * Jl[c];
-            gG[r * 4 + 3] = gt;
+            w[r] = gA[r * 4 + 3];
+            for (int c = 0; c < 3; c++) go[r * 3 + c] = gA[r * 4 + c] - w[r] * Jl[c];
         }
         for (int c = 0; c < 3; c++)
             gJ[c] = -(G[0 * 4 + c] * gA[0 * 4 + 3] + G[1 * 4 + c] * gA[1 * 4 + 3] + G[2 * 4 + c] * gA[2 * 4 + 3]);
-        for (int e = 0; e < 12; e++) sgG[j][e] = gG[e];
-    }
-    __syncthreads();
-    if (act) {
-        for (int c = 0; c < 3; c++) sRel[j][c] = (par >= 0) ? Jl[c] - sJ[par][c] : Jl[c];
-    }
-    __syncthreads();
-    // reverse sweep over levels: a joint first gathers from its children (whose gG are final), then publishes its own
-    // (every joint lives in wave 0 and a wave's LDS operations execute in order: no workgroup barrier inside the sweep)
-    for (int L = m.maxlevel - 1; L >= 0 && j < 64; L--) {
-        if (act && lvl == L) {
-            for (int ci = cp0; ci < cp1; ci++) {
-                int ch = sChild[ci];
-                // G_ch.R = G_j.R R_ch ; G_ch.t = G_j.R rel_ch + G_j.t
-                for (int r = 0; r < 3; r++) {
-                    for (int c = 0; c < 3; c++) {
-                        float a = 0;
-                        for (int k = 0; k < 3; k++) a += sgG[ch][r * 4 + k] * sR[ch][c * 3 + k];   // gG_ch.R R_ch^T
-                        gG[r * 4 + c] += a + sgG[ch][r * 4 + 3] * sRel[ch][c];
-                    }
-                    gG[r * 4 + 3] += sgG[ch][r * 4 + 3];
-                }
-            }
-            for (int e = 0; e < 12; e++) sgG[j][e] = gG[e];
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++)
+                sX[j][r * 3 + c] = go[r * 3 + 0] * G[c * 4 + 0] + go[r * 3 + 1] * G[c * 4 + 1] + go[r * 3 + 2] * G[c * 4 + 2] + w[r] * G[c * 4 + 3];
+            sX[j][9 + r] = w[r];
         }
-        __builtin_amdgcn_wave_barrier();
     }
+    // the parent's transform for the local gradients below
+    float P[12];
+    for (int e = 0; e < 12; e++) P[e] = 0.0f;
+    if (act && par >= 0) {
+        const psi_f4 *Pp = (const psi_f4 *)(Gs + ((size_t)b * m.J + par) * 12);
+        for (int r = 0; r < 3; r++) {
+            const psi_f4 pr = Pp[r];
+            for (int c = 0; c < 4; c++) P[r * 4 + c] = pr[c];
+        }
+    }
+    __syncthreads();
+    for (int i = j; i < m.n_items * 12; i += nthr) {
+        const int it = i / 12, e = i - it * 12;
+        const unsigned int d = sItem[it];
+        const unsigned char *l = sList + (d & 0xffffu);
+        const int cnt = (int)(d >> 16);
+        float a = 0.0f;
+        for (int q = 0; q < cnt; q++) a += sX[l[q]][e];
+        sP[it][e] = a;
+    }
+    __syncthreads();
+    for (int i = j; i < m.J * 12; i += nthr) {
+        const int jj = i / 12, e = i - jj * 12;
+        float a = 0.0f;
+        for (int it = sFirst[jj]; it < sFirst[jj + 1]; it++) a += sP[it][e];
+        sS[jj][e] = a;
+    }
+    __syncthreads();
     // local gradients: gR_j = P_R^T gG_j.R, grel_j = P_R^T gG_j.t  (P = parent's G; root: identity)
     float gR[9], grel[3] = {0, 0, 0};
     for (int e = 0; e < 9; e++) gR[e] = 0.0f;
     if (act) {
+        float gG[12];
+        for (int r = 0; r < 3; r++) {
+            const float wr = sS[j][9 + r];
+            float T[3];
+            for (int k = 0; k < 3; k++) T[k] = sS[j][r * 3 + k] - wr * G[k * 4 + 3];
+            for (int c = 0; c < 3; c++) gG[r * 4 + c] = T[0] * G[0 * 4 + c] + T[1] * G[1 * 4 + c] + T[2] * G[2 * 4 + c];
+            gG[r * 4 + 3] = wr;
+        }
         if (par >= 0) {
-            const psi_f4 *Pp = (const psi_f4 *)(Gs + ((size_t)b * m.J + par) * 12);
-            float P[12];
-            for (int r = 0; r < 3; r++) {
-                const psi_f4 pr = Pp[r];
-                for (int c = 0; c < 4; c++) P[r * 4 + c] = pr[c];
-            }
             for (int r = 0; r < 3; r++) {
                 for (int c = 0; c < 3; c++) gR[r * 3 + c] = P[0 * 4 + r] * gG[0 * 4 + c] + P[1 * 4 + r] * gG[1 * 4 + c] + P[2 * 4 + r] * gG[2 * 4 + c];
                 grel[r] = P[0 * 4 + r] * gG[0 * 4 + 3] + P[1 * 4 + r] * gG[1 * 4 + 3] + P[2 * 4 + r] * gG[2 * 4 + 3];
