@@ -27,6 +27,10 @@
 // the backward uses that R' == R on SO(3) and that Gram-Schmidt only moves along SO(3), so J_GS^T dL/dR' is the exact
 // gradient (requires pose_mean == 0 for global_orient/body joints, which holds for SMPL-X; checked at creation).
 #include "psi_internal.h"
+#ifdef PSI_HEAD_STOPS
+__device__ int psi_dbg_sstop;            // dev: leave the skinning / scene kernels at this point (tools/head_stops.sh)
+#define PSI_SSTOP(k) do { if (psi_dbg_sstop == (k)) return; } while (0)
+#endif
 #include "lbs_device.h"
 #include "sdf_device.h"
 #include "nnindex_device.h"
@@ -61,6 +65,7 @@ struct FitDev {
     const float *lhc, *rhc, *pose_mean;               // [ncomp][45] x2, [J*3]
     const int *vid;                                   // [n_c] contact vertex ids
     const int *cs_ptr, *cs_idx;                       // vertex -> contact slots (CSR, V+1 / n_c)
+    const int *cs_first;                              // [V] first contact slot of the vertex | number of its slots << 24 (0: none)
     const float *scene, *sdf, *gmin, *gmax;           // scene cloud [m,3], volume [D^3], bounds [3]
     const float *sdf_brick;                           // engine-owned copy of the volume in 4x4x4-brick order (nullptr: D % 4 != 0)
     const float *Wct;                                 // [n_c][64] skinning weights of the contact vertices, one row per contact slot
@@ -180,6 +185,29 @@ __device__ __forceinline__ float block_sum(float v, float *sh)
     float s = 0;
     for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += sh[i];
     return s;
+}
+
+// two block sums in one round (one pair of barriers instead of two)
+__device__ __forceinline__ void block_sum2(float &a, float &c, float *sh2)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        c += __shfl_down(c, o, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        sh2[2 * (threadIdx.x >> 6)] = a;
+        sh2[2 * (threadIdx.x >> 6) + 1] = c;
+    }
+    __syncthreads();
+    float sa = 0, sc = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) {
+        sa += sh2[2 * i];
+        sc += sh2[2 * i + 1];
+    }
+    a = sa;
+    c = sc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -488,6 +516,11 @@ __global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, c
                                                            psikd::KdDev T, int n_kd, int nqb, int rows, float gscale)
 {
     extern __shared__ int smem_i[];
+#ifdef PSI_HEAD_STOPS
+    if (psi_dbg_sstop == 1 && (int)blockIdx.x >= n_kd) return;      // NN-search workgroups only
+    if (psi_dbg_sstop == 2 && (int)blockIdx.x < n_kd) return;       // skinning + SDF workgroups only
+    if (psi_dbg_sstop == 3) return;                                  // neither: the launch itself
+#endif
     if ((int)blockIdx.x < n_kd) {
         const int b = blockIdx.x / nqb, bx = blockIdx.x % nqb;
         psikd::kd_query_body<true, false>(T, ContactSkinSrc{f, m, As, v_posed, nullptr}, f.n_c, (float *)nullptr, (int *)nullptr, f.cconst, gscale,
@@ -549,6 +582,53 @@ struct FitGradSource {
     float N;
     float *sNb;                    // independent-bodies mode: per-body penetration counts of this workgroup's bodies (LDS)
     int b0;
+    // Split form of load() for the one-body-per-workgroup kernel, which requests everything it will need before it waits for anything:
+    // issue() = the vertex's SDF gradient, its contact-slot word and (coupled single-process mode) this thread's first partial pairs of the
+    // penetration statistics; issue_late() = the contact gradient, whose address needs the slot word; take() = load()'s arithmetic.
+    static constexpr int NPF = 4;  // partial pairs per thread requested ahead (B * 41 / 256 = 5.1 strides at B = 32; the rest is looped)
+    psi_f2 pp[NPF];
+    bool pp_valid;
+    struct Pre { float og[3], q[3]; int cw; };
+    __device__ __forceinline__ Pre issue(int b, int v, bool live)
+    {
+        Pre p;
+        p.cw = live ? f.cs_first[v] : 0;
+        for (int e = 0; e < 3; e++) { p.og[e] = 0.0f; p.q[e] = 0.0f; }
+        if (live) {
+            const size_t o = ((size_t)b * f.V + v) * 3;
+            p.og[0] = f.og[o + 0]; p.og[1] = f.og[o + 1]; p.og[2] = f.og[o + 2];
+        }
+        pp_valid = LOCAL && !f.indep;
+        if (pp_valid) {
+            const int n = f.B * f.nsdfblk;
+#pragma unroll
+            for (int k = 0; k < NPF; k++) {
+                const int i = threadIdx.x + k * PSI_SKIN_BLK;
+                pp[k] = i < n ? *(const psi_f2 *)(f.penpart + 2 * (size_t)i) : (psi_f2){0.0f, 0.0f};
+            }
+        }
+        return p;
+    }
+    __device__ __forceinline__ void issue_late(Pre &p, int b) const
+    {
+        if (p.cw >> 24) {
+            const float *q = f.gq + ((size_t)b * f.n_c + (p.cw & 0xffffff)) * 3;
+            p.q[0] = q[0]; p.q[1] = q[1]; p.q[2] = q[2];
+        }
+    }
+    __device__ __forceinline__ void take(const Pre &p, int b, int v, float &gx, float &gy, float &gz) const
+    {
+        const float Nb = sNb ? sNb[b - b0] : N;
+        const float sp = Nb > 0.0f ? -f.w_col / Nb : 0.0f;
+        gx = sp * p.og[0]; gy = sp * p.og[1]; gz = sp * p.og[2];
+        const int cnt = p.cw >> 24;
+        if (cnt) { gx += p.q[0]; gy += p.q[1]; gz += p.q[2]; }
+        if (cnt > 1)                                            // a vertex listed more than once among the contact ids: the rest of its slots
+            for (int ci = f.cs_ptr[v] + 1; ci < f.cs_ptr[v + 1]; ci++) {
+                const float *q = f.gq + ((size_t)b * f.n_c + f.cs_idx[ci]) * 3;
+                gx += q[0]; gy += q[1]; gz += q[2];
+            }
+    }
     __device__ __forceinline__ void prepare(int b0_, int nb)
     {
         const int t = threadIdx.x;
@@ -606,12 +686,20 @@ struct FitGradSource {
         float st[5];
         if (LOCAL) {
             float a = 0, c = 0;
-            for (int i = t; i < f.B * f.nsdfblk; i += PSI_SKIN_BLK) {
+            int i = t;
+            if (pp_valid) {                                     // the first NPF strides were requested by issue()
+#pragma unroll
+                for (int k = 0; k < NPF; k++) { a += pp[k].x; c += pp[k].y; }
+                i += NPF * PSI_SKIN_BLK;
+            }
+            for (; i < f.B * f.nsdfblk; i += PSI_SKIN_BLK) {
                 a += f.penpart[2 * i];
                 c += f.penpart[2 * i + 1];
             }
-            st[3] = block_sum(a, red);
-            st[4] = block_sum(c, red);
+            __shared__ float red2[2 * PSI_SKIN_BLK / 64];
+            block_sum2(a, c, red2);
+            st[3] = a;
+            st[4] = c;
             if (first) {                                        // same reductions as loss_finalize_kernel
                 a = 0;
                 for (int i = t; i < f.B; i += PSI_SKIN_BLK) a += f.recpart[i];
@@ -977,15 +1065,15 @@ static int fit_backward(psi_fit_engine *e, float *stats, hipStream_t st, bool lo
     const bool mb = f.B >= PSI_SKIN_MB_MIN_B;
     const dim3 bgrid(f.nsdfblk, mb ? psi_cdiv(f.B, PSI_SKIN_MB) : f.B);
     if (local && mb)
-        psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, FitGradSource<true>{f, stats, 0.0f, nullptr, 0}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
+        psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, FitGradSource<true>{f, stats, 0.0f, nullptr, 0, {}, false}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
     else if (local)
         hipLaunchKernelGGL(psi_skin_bwd_v_kernel<FitGradSource<true>>, bgrid, dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
-                           FitGradSource<true>{f, stats, 0.0f, nullptr, 0}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
+                           FitGradSource<true>{f, stats, 0.0f, nullptr, 0, {}, false}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
     else if (mb)
-        psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, FitGradSource<false>{f, stats, 0.0f, nullptr, 0}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
+        psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, FitGradSource<false>{f, stats, 0.0f, nullptr, 0, {}, false}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
     else
         hipLaunchKernelGGL(psi_skin_bwd_v_kernel<FitGradSource<false>>, bgrid, dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
-                           FitGradSource<false>{f, stats, 0.0f, nullptr, 0}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
+                           FitGradSource<false>{f, stats, 0.0f, nullptr, 0, {}, false}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
     PSI_CHECK_LAUNCH("skin_bwd_v_grad_kernel");
     psi_mark("skin_bwd_v_grad_kernel", st);
     int rc = psi_lbs_backward_joint_parts(e->lbs, f.B, e->lbs_ws, f.g_transl, st);
@@ -1007,7 +1095,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     int V, J, NB;
     psi_lbs_dims(lbs, &V, &J, &NB);
     PSI_REQUIRE(J == 55 && NB >= 10 && NB <= 32, "the fused engine is SMPL-X shaped (J=55, 10..32 betas)");
-    PSI_REQUIRE(cfg->B > 0 && cfg->n_contact > 0 && cfg->m_scene > 0 && cfg->D >= 2 && cfg->world_size >= 1, "bad sizes");
+    PSI_REQUIRE(cfg->B > 0 && cfg->n_contact > 0 && cfg->n_contact < (1 << 24) && cfg->m_scene > 0 && cfg->D >= 2 && cfg->world_size >= 1, "bad sizes");
     PSI_REQUIRE(cfg->num_pca_comps > 0 && cfg->num_pca_comps <= 12, "1..12 hand PCA components");
     for (int i = 0; i < 66; i++) PSI_REQUIRE(h_pose_mean[i] == 0.0f, "pose_mean must be zero for global_orient/body joints");
     for (int i = 0; i < cfg->n_contact; i++) PSI_REQUIRE(h_contact_ids[i] >= 0 && h_contact_ids[i] < V, "contact id out of range");
@@ -1032,6 +1120,10 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
 #ifdef PSI_HEAD_STOPS
     f.stop_h = getenv("PSI_HEAD_STOP") ? atoi(getenv("PSI_HEAD_STOP")) : 0;
     f.stop_t = getenv("PSI_TAIL_STOP") ? atoi(getenv("PSI_TAIL_STOP")) : 0;
+    {
+        int sst = getenv("PSI_SKIN_STOP") ? atoi(getenv("PSI_SKIN_STOP")) : 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(psi_dbg_sstop), &sst, sizeof(int));
+    }
 #endif
     if (const char *hcv = getenv("PSI_HEAD_CLUSTER")) {
         const int v = atoi(hcv);
@@ -1046,12 +1138,14 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     for (int o = 0; o < NH; o++) for (int k = 0; k < NZ; k++) W1T[(size_t)k * NH + o] = h_w1[(size_t)o * NZ + k];
     for (int o = 0; o < NH; o++) for (int k = 0; k < NH; k++) W2T[(size_t)k * NH + o] = h_w2[(size_t)o * NH + k];
     for (int o = 0; o < NJ6; o++) for (int k = 0; k < NH; k++) W3T[(size_t)k * 128 + o] = h_w3[(size_t)o * NH + k];
-    std::vector<int> cs_ptr(V + 1, 0), cs_idx(f.n_c);
+    std::vector<int> cs_ptr(V + 1, 0), cs_idx(f.n_c), cs_first(V, 0);
     for (int i = 0; i < f.n_c; i++) cs_ptr[h_contact_ids[i] + 1]++;
     for (int v = 0; v < V; v++) cs_ptr[v + 1] += cs_ptr[v];
     {
         std::vector<int> fill(cs_ptr.begin(), cs_ptr.end() - 1);
         for (int i = 0; i < f.n_c; i++) cs_idx[fill[h_contact_ids[i]]++] = i;   // ascending slot order per vertex
+        for (int v = 0; v < V; v++)
+            if (cs_ptr[v + 1] > cs_ptr[v]) cs_first[v] = cs_idx[cs_ptr[v]] | (std::min(cs_ptr[v + 1] - cs_ptr[v], 127) << 24);
     }
     struct Item { const void *src; size_t bytes; size_t off; };
     std::vector<Item> items;
@@ -1062,7 +1156,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
            o_w3t = cst(W3T.data(), W3T.size() * 4), o_b3 = cst(b3p.data(), 128 * 4), o_w1 = cst(h_w1, (size_t)NH * NZ * 4),
            o_w2 = cst(h_w2, (size_t)NH * NH * 4), o_w3 = cst(h_w3, (size_t)NJ6 * NH * 4), o_lh = cst(h_lh_comp, (size_t)f.ncomp * 45 * 4),
            o_rh = cst(h_rh_comp, (size_t)f.ncomp * 45 * 4), o_pm = cst(h_pose_mean, (size_t)J * 3 * 4), o_vid = cst(h_contact_ids, (size_t)f.n_c * 4),
-           o_cp = cst(cs_ptr.data(), cs_ptr.size() * 4), o_ci = cst(cs_idx.data(), cs_idx.size() * 4), o_gmin = cst(h_gmin, 12), o_gmax = cst(h_gmax, 12);
+           o_cp = cst(cs_ptr.data(), cs_ptr.size() * 4), o_ci = cst(cs_idx.data(), cs_idx.size() * 4), o_cf = cst(cs_first.data(), cs_first.size() * 4), o_gmin = cst(h_gmin, 12), o_gmax = cst(h_gmax, 12);
     size_t zero_begin = o;
     size_t o_x = take((size_t)B * XD * 4), o_xhr = take((size_t)B * XD * 4), o_cam = take((size_t)B * 16 * 4), o_am = take((size_t)B * XD * 4),
            o_av = take((size_t)B * XD * 4), o_step = take(256), o_h1 = take((size_t)B * NH * 4), o_h2 = take((size_t)B * NH * 4),
@@ -1097,7 +1191,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     auto F = [&](size_t off) { return (float *)(bl + off); };
     f.W1T = F(o_w1t); f.b1 = F(o_b1); f.W2T = F(o_w2t); f.b2 = F(o_b2); f.W3T = F(o_w3t); f.b3 = F(o_b3);
     f.W1 = F(o_w1); f.W2 = F(o_w2); f.W3 = F(o_w3); f.lhc = F(o_lh); f.rhc = F(o_rh); f.pose_mean = F(o_pm);
-    f.vid = (const int *)(bl + o_vid); f.cs_ptr = (const int *)(bl + o_cp); f.cs_idx = (const int *)(bl + o_ci);
+    f.vid = (const int *)(bl + o_vid); f.cs_ptr = (const int *)(bl + o_cp); f.cs_idx = (const int *)(bl + o_ci); f.cs_first = (const int *)(bl + o_cf);
     f.gmin = F(o_gmin); f.gmax = F(o_gmax);
     f.x = F(o_x); f.xhr = F(o_xhr); f.cam = F(o_cam); f.adam_m = F(o_am); f.adam_v = F(o_av); f.step = (int *)(bl + o_step);
     f.h1 = F(o_h1); f.h2 = F(o_h2); f.o6 = F(o_o6); f.betas20 = F(o_b20); f.pose = F(o_pose); f.transl = F(o_tr);

@@ -528,7 +528,7 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     // compressed skinning rows: used by the skinning kernels when no vertex has more than PSI_WNZ non-zero weights
     // (PSI_LBS_DENSE=1 keeps the dense loop, for A/B tests)
     std::vector<float> Wc;
-    std::vector<int> Wj;
+    std::vector<unsigned> Wj;
     {
         int nnz_max = 0;
         for (int v = 0; v < V; v++) {
@@ -539,12 +539,12 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
         const char *dense = getenv("PSI_LBS_DENSE");
         if (nnz_max <= PSI_WNZ && !(dense && dense[0] == '1')) {
             Wc.assign((size_t)PSI_WNZ * d.Vpad, 0.0f);
-            Wj.assign((size_t)PSI_WNZ * d.Vpad, 0);
+            Wj.assign((size_t)(PSI_WNZ / 4) * d.Vpad, 0u);
             for (int v = 0; v < V; v++) {
                 int k = 0;
                 for (int j = 0; j < J; j++) {
                     float w = h_weights[(size_t)v * J + j];
-                    if (w != 0.0f) { Wc[(size_t)k * d.Vpad + v] = w; Wj[(size_t)k * d.Vpad + v] = j; k++; }
+                    if (w != 0.0f) { Wc[(size_t)k * d.Vpad + v] = w; Wj[(size_t)(k >> 2) * d.Vpad + v] |= (unsigned)j << (8 * (k & 3)); k++; }
                 }
             }
         }
@@ -578,7 +578,7 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     d.v_template = (const float *)(blob + o_vt);
     d.WT = (const float *)(blob + o_wt);
     d.Wc = Wc.empty() ? nullptr : (const float *)(blob + o_wc);
-    d.Wj = Wj.empty() ? nullptr : (const int *)(blob + o_wj);
+    d.Wj = Wj.empty() ? nullptr : (const unsigned *)(blob + o_wj);
     d.J_t = (const float *)(blob + o_jt);
     d.J_s = (const float *)(blob + o_js);
     d.parents = (const int *)(blob + o_par);

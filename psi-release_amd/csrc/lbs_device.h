@@ -2,6 +2,9 @@
 // workspace view, and the per-body pose stages (executed by one workgroup per body), which the fused fitting engine
 // (fit.hip) inlines into its head / tail kernels.  Reference arithmetic: human_body_prior/body_model/lbs.py:165-262.
 #pragma once
+#ifndef PSI_SSTOP
+#define PSI_SSTOP(k)
+#endif
 #include <hip/hip_runtime.h>
 
 typedef float psi_f4 __attribute__((ext_vector_type(4)));
@@ -16,7 +19,7 @@ struct LbsDev {
     int V, J, NB, P, K, Kpad, N, Npad, Vpad, maxlevel, njump;
     const float *dirs, *v_template, *WT, *J_t, *J_s;
     const float *Wc;                                 // compressed rows [PSI_WNZ][Vpad]: the k-th non-zero weight of each vertex (ascending joint), or nullptr
-    const int *Wj;                                   //                 [PSI_WNZ][Vpad]: its joint index (padding: weight 0, joint 0)
+    const unsigned *Wj;                              //                 [PSI_WNZ/4][Vpad]: their joint indices, one byte each (padding: weight 0, joint 0)
     const int *parents, *level, *child_ptr, *child_idx;
     const int *jump;                                 // [PSI_NJUMP][PSI_JP]: the 2^r-th ancestor of joint j (-1: none) — pointer jumping down the chain
     // subtree sets for the chain backward (psi_pose_bwd_body): the members of subtree(j), ascending, cut into chunks of <= sub_chunk
@@ -406,40 +409,68 @@ __device__ __forceinline__ float psi_wave_sum(float x)
 // Blend the body's joint transforms with this lane's skinning weights: T = sum_j w_j A_j (3x4 as six float pairs).
 // The 55 transforms are staged in LDS once (2.6 KB); the j loop then has no scalar-load round trip per joint, the
 // per-lane weights are prefetched 11 joints ahead (unroll 11 of J = 55), and the accumulation is packed (v_pk_fma_f32).
-__device__ __forceinline__ void psi_blend_transforms(const LbsDev &m, const float *__restrict__ As, int b, int v, psi_f2 (&T2)[6])
-{
-    __shared__ psi_f2 sA[PSI_JP][6];
-    for (int idx = threadIdx.x; idx < m.J * 6; idx += PSI_SKIN_BLK)
-        sA[idx / 6][idx % 6] = *(const psi_f2 *)(As + ((size_t)b * m.J) * 12 + idx * 2);
-    __syncthreads();
+//
+// The skinning kernels are latency-bound at the BASELINE batch, and what they read at the start — the transforms to stage, the
+// lane's weight row, its vertex / gradient operands — are independent of each other: PsiBlend splits the blend into issue() (all
+// the loads, to be called together with the caller's own first loads), commit() (LDS writes + barrier) and blend().  Requested
+// one after the other, as a staged-then-blend function does, these were three to six dependent L2 round trips per workgroup.
+struct PsiBlend {
+    psi_f2 st[2];                 // this thread's share of the body's transforms (J * 6 float pairs over 256 threads, J <= 85)
+    float wk[PSI_WNZ];            // compressed weight row of the lane's vertex (when the model has one)
+    unsigned jk[PSI_WNZ / 4];     // ... and its joint indices, a byte each
+    __device__ __forceinline__ void issue(const LbsDev &m, const float *__restrict__ As, int b, int v)
+    {
 #pragma unroll
-    for (int e = 0; e < 6; e++) T2[e] = (psi_f2){0.0f, 0.0f};
-    if (m.Wc) {
-        // compressed rows (real SMPL-X weight rows have a handful of non-zeros): the same sum with the exact zeros skipped,
-        // in ascending joint order — bit-identical to the dense loop, 8 instead of 55 terms
-        float wk[PSI_WNZ];
-        int jk[PSI_WNZ];
-#pragma unroll
-        for (int k = 0; k < PSI_WNZ; k++) {
-            wk[k] = m.Wc[(size_t)k * m.Vpad + v];
-            jk[k] = m.Wj[(size_t)k * m.Vpad + v];
+        for (int q = 0; q < 2; q++) {
+            const int idx = threadIdx.x + q * PSI_SKIN_BLK;
+            st[q] = idx < m.J * 6 ? *(const psi_f2 *)(As + ((size_t)b * m.J) * 12 + idx * 2) : (psi_f2){0.0f, 0.0f};
         }
+        if (m.Wc) {
 #pragma unroll
-        for (int k = 0; k < PSI_WNZ; k++) {
-            psi_f2 w2 = {wk[k], wk[k]};
+            for (int k = 0; k < PSI_WNZ; k++) wk[k] = m.Wc[(size_t)k * m.Vpad + v];
 #pragma unroll
-            for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, sA[jk[k]][e], T2[e]);
+            for (int k = 0; k < PSI_WNZ / 4; k++) jk[k] = m.Wj[(size_t)k * m.Vpad + v];
         }
-        return;
     }
+    __device__ __forceinline__ psi_f2 (*commit(const LbsDev &m))[6]
+    {
+        __shared__ psi_f2 sA[PSI_JP][6];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int idx = threadIdx.x + q * PSI_SKIN_BLK;
+            if (idx < m.J * 6) sA[idx / 6][idx % 6] = st[q];
+        }
+        __syncthreads();
+        return sA;
+    }
+    __device__ __forceinline__ void blend(const LbsDev &m, const psi_f2 (*sA)[6], int v, psi_f2 (&T2)[6]) const
+    {
+#pragma unroll
+        for (int e = 0; e < 6; e++) T2[e] = (psi_f2){0.0f, 0.0f};
+        if (m.Wc) {
+            // compressed rows (real SMPL-X weight rows have a handful of non-zeros): the same sum with the exact zeros skipped,
+            // in ascending joint order — bit-identical to the dense loop, 8 instead of 55 terms
+#pragma unroll
+            for (int k = 0; k < PSI_WNZ; k++) {
+                // a slot that is zero in every lane of the wave ends the row for all of them (rows are filled front to back, and adding
+                // w = 0 terms changes nothing: T starts at +0): 5 of 8 slots at SMPL-X's 4-5 non-zeros — the blend is LDS-bandwidth-bound
+                if (__builtin_amdgcn_ballot_w64(wk[k] != 0.0f) == 0) break;
+                psi_f2 w2 = {wk[k], wk[k]};
+                const int jj = (jk[k >> 2] >> (8 * (k & 3))) & 0xff;
+#pragma unroll
+                for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, sA[jj][e], T2[e]);
+            }
+            return;
+        }
 #pragma unroll 11
-    for (int j = 0; j < m.J; j++) {
-        float wj = m.WT[(size_t)j * m.Vpad + v];
-        psi_f2 w2 = {wj, wj};
+        for (int j = 0; j < m.J; j++) {
+            float wj = m.WT[(size_t)j * m.Vpad + v];
+            psi_f2 w2 = {wj, wj};
 #pragma unroll
-        for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, sA[j][e], T2[e]);
+            for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, sA[j][e], T2[e]);
+        }
     }
-}
+};
 
 // The per-vertex affine maps of the skinning kernels with an EXPLICIT operation order (fma chains), so that every instantiation
 // — one body or several per workgroup, dense or compressed rows — rounds identically (left to the compiler's contraction the
@@ -468,13 +499,19 @@ __device__ __forceinline__ void psi_skin_fwd_body(const LbsDev &m, const float *
                                                   float *__restrict__ verts, Epi &epi, int vblock, int b, int nvb)
 {
     const int v = vblock * PSI_SKIN_BLK + threadIdx.x;
-    psi_f2 T2[6];
-    psi_blend_transforms(m, As, b, v, T2);
     const bool live = v < m.V;
-    float x = 0, y = 0, z = 0;
+    // all first loads in one go: transforms to stage, weight row, posed vertex
+    PsiBlend bl;
+    bl.issue(m, As, b, v);
+    float px = 0, py = 0, pz = 0;
     if (live) {
         const float *vp = v_posed + (size_t)b * m.Npad + (size_t)v * 3;
-        float px = vp[0], py = vp[1], pz = vp[2];
+        px = vp[0]; py = vp[1]; pz = vp[2];
+    }
+    psi_f2 T2[6];
+    bl.blend(m, bl.commit(m), v, T2);
+    float x = 0, y = 0, z = 0;
+    if (live) {
         x = psi_dot3p(T2[0].x, T2[0].y, T2[1].x, T2[1].y, px, py, pz);
         y = psi_dot3p(T2[2].x, T2[2].y, T2[3].x, T2[3].y, px, py, pz);
         z = psi_dot3p(T2[4].x, T2[4].y, T2[5].x, T2[5].y, px, py, pz);
@@ -518,6 +555,16 @@ struct PsiGradFromMemory {
         const float *g = g_verts + ((size_t)b * V + v) * 3;
         gx = g[0]; gy = g[1]; gz = g[2];
     }
+    // split form for kernels that request their operands ahead of prepare(): issue() = the loads, take() = their use
+    struct Pre { float g[3]; };
+    __device__ __forceinline__ Pre issue(int b, int v, bool live) const
+    {
+        Pre p = {{0.0f, 0.0f, 0.0f}};
+        if (live) load(b, v, p.g[0], p.g[1], p.g[2]);
+        return p;
+    }
+    __device__ __forceinline__ void issue_late(Pre &, int) const {}
+    __device__ __forceinline__ void take(const Pre &p, int, int, float &gx, float &gy, float &gz) const { gx = p.g[0]; gy = p.g[1]; gz = p.g[2]; }
 };
 
 // per-vertex part of the skinning backward: g_local = R_c^T g_verts;  g_vposed = T_R^T g_local;  partial g_transl
@@ -528,14 +575,23 @@ __global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_bwd_v_kernel(LbsDev 
 {
     const int v = blockIdx.x * PSI_SKIN_BLK + threadIdx.x;
     const int b = blockIdx.y;
+    // all first loads in one go: transforms to stage, weight row, the gradient source's operands and its statistics inputs
+    PSI_SSTOP(11);
+    typename Src::Pre pre = src.issue(b, v, v < m.V);
+    PsiBlend bl;
+    bl.issue(m, As, b, v);
+    src.issue_late(pre, b);
+    PSI_SSTOP(12);
     src.prepare(b, 1);
+    PSI_SSTOP(13);
     psi_f2 T2[6];
-    psi_blend_transforms(m, As, b, v, T2);
+    bl.blend(m, bl.commit(m), v, T2);
+    PSI_SSTOP(14);
     __shared__ float sh[PSI_SKIN_BLK / 64][3];
     float lx = 0, ly = 0, lz = 0;
     if (v < m.V) {
         float gx, gy, gz;
-        src.load(b, v, gx, gy, gz);
+        src.take(pre, b, v, gx, gy, gz);
         if (cam_ext) {   // g_local = R_c^T g
             const float *C = cam_ext + (size_t)b * 16;
             lx = psi_dot3(C[0], C[4], C[8], gx, gy, gz);
@@ -625,15 +681,14 @@ struct PsiLaneWeights<false> {
 };
 template <>
 struct PsiLaneWeights<true> {
-    float wk[PSI_WNZ];                    // compressed row: the k-th non-zero weight and its joint
-    int jk[PSI_WNZ];
+    float wk[PSI_WNZ];                    // compressed row: the k-th non-zero weight and its joint (a byte each)
+    unsigned jk[PSI_WNZ / 4];
     __device__ __forceinline__ void load(const LbsDev &m, int v)
     {
 #pragma unroll
-        for (int k = 0; k < PSI_WNZ; k++) {
-            wk[k] = m.Wc[(size_t)k * m.Vpad + v];
-            jk[k] = m.Wj[(size_t)k * m.Vpad + v];
-        }
+        for (int k = 0; k < PSI_WNZ; k++) wk[k] = m.Wc[(size_t)k * m.Vpad + v];
+#pragma unroll
+        for (int k = 0; k < PSI_WNZ / 4; k++) jk[k] = m.Wj[(size_t)k * m.Vpad + v];
     }
     __device__ __forceinline__ void blend(const LbsDev &, const psi_f2 (*sA)[6], psi_f2 (&T2)[6]) const
     {
@@ -641,9 +696,11 @@ struct PsiLaneWeights<true> {
         for (int e = 0; e < 6; e++) T2[e] = (psi_f2){0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < PSI_WNZ; k++) {
+            if (__builtin_amdgcn_ballot_w64(wk[k] != 0.0f) == 0) break;      // (see PsiBlend::blend)
             psi_f2 w2 = {wk[k], wk[k]};
+            const int jj = (jk[k >> 2] >> (8 * (k & 3))) & 0xff;
 #pragma unroll
-            for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, sA[jk[k]][e], T2[e]);
+            for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, sA[jj][e], T2[e]);
         }
     }
 };
