@@ -420,12 +420,13 @@ struct PsiBlend {
     unsigned jk[PSI_WNZ / 4];     // ... and its joint indices, a byte each
     __device__ __forceinline__ void issue(const LbsDev &m, const float *__restrict__ As, int b, int v)
     {
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int idx = threadIdx.x + q * PSI_SKIN_BLK;
-            st[q] = idx < m.J * 6 ? *(const psi_f2 *)(As + ((size_t)b * m.J) * 12 + idx * 2) : (psi_f2){0.0f, 0.0f};
-        }
+        As_b = As + (size_t)b * m.J * 12;
         if (m.Wc) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int idx = threadIdx.x + q * PSI_SKIN_BLK;
+                st[q] = idx < m.J * 6 ? *(const psi_f2 *)(As + ((size_t)b * m.J) * 12 + idx * 2) : (psi_f2){0.0f, 0.0f};
+            }
 #pragma unroll
             for (int k = 0; k < PSI_WNZ; k++) wk[k] = m.Wc[(size_t)k * m.Vpad + v];
 #pragma unroll
@@ -435,6 +436,7 @@ struct PsiBlend {
     __device__ __forceinline__ psi_f2 (*commit(const LbsDev &m))[6]
     {
         __shared__ psi_f2 sA[PSI_JP][6];
+        if (!m.Wc) return sA;                                   // dense rows read the transforms through the scalar cache (blend)
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int idx = threadIdx.x + q * PSI_SKIN_BLK;
@@ -443,6 +445,7 @@ struct PsiBlend {
         __syncthreads();
         return sA;
     }
+    const float *As_b;            // this body's transforms in global memory (set by issue)
     __device__ __forceinline__ void blend(const LbsDev &m, const psi_f2 (*sA)[6], int v, psi_f2 (&T2)[6]) const
     {
 #pragma unroll
@@ -462,12 +465,17 @@ struct PsiBlend {
             }
             return;
         }
+        // dense rows: the transforms are the same for every lane of the workgroup — read through the SCALAR cache (48 bytes per joint
+        // and wave) instead of LDS broadcasts (3 KB per joint and wave: at 55 joints the LDS return path, 128 B/clk per CU, bounded
+        // the skinning kernels: 26 k cycles per CU = 11 us for the 20 resident waves).  (Requesting the next joint's transform by hand before the
+        // current one is used measured slower than the compiler's own three 16-byte scalar loads per joint.)
+        const psi_f2 *Ab = (const psi_f2 *)As_b;
 #pragma unroll 11
         for (int j = 0; j < m.J; j++) {
             float wj = m.WT[(size_t)j * m.Vpad + v];
             psi_f2 w2 = {wj, wj};
 #pragma unroll
-            for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, sA[j][e], T2[e]);
+            for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, Ab[j * 6 + e], T2[e]);
         }
     }
 };
