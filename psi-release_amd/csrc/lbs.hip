@@ -220,22 +220,32 @@ __device__ __forceinline__ void skin_bwd_A_body(const LbsDev &m, const float *__
 #pragma unroll
         for (int jt = 0; jt < 4; jt++) wa[st][jt] = *(const f4 *)(m.WT + (size_t)(jt * 16 + li) * m.Vpad + vs + st * 16 + 4 * lk);
     const int nb = min(nbody, B - b0);
-    auto load_ops = [&](int b, float (&g)[4][4], float (&p)[4][4]) {
-        const float *glb = gl + (size_t)b * m.Npad, *vpb = v_posed + (size_t)b * m.Npad;
+    // ALL bodies' operands of this slice are requested up front, coalesced (768 consecutive floats of g_local and of v_posed per
+    // body: one 16-byte load each for threads 0..191), and parked in LDS; the MFMA operand order (component r / s of vertex
+    // 4*lk + t) is then a gather from LDS.  One memory round trip for the whole workgroup — it used to be one per body, of
+    // 32 four-byte loads per lane that fetched 48 useful bytes each, and behind the blend_bwd stream's traffic (the two share the
+    // launch) those six dependent round trips took as long as the stream itself.
+    f4 (*red)[4][64] = (f4 (*)[4][64])smem;                                     // [4][4][64] f4 = 16 KB
+    float *sg = (float *)(smem + 4 * 4 * 64);                                   // [SKA_NBODY][2][768]
+    {
+        f4 og[SKA_NBODY], op[SKA_NBODY];
+        const int t4 = threadIdx.x;
 #pragma unroll
-        for (int st = 0; st < 4; st++) {
-            const int v0 = vs + st * 16 + 4 * lk;
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                g[st][t] = (r < 3) ? glb[(size_t)(v0 + t) * 3 + r] : 0.0f;
-                p[st][t] = (s < 3) ? vpb[(size_t)(v0 + t) * 3 + s] : 1.0f;
+        for (int bb = 0; bb < SKA_NBODY; bb++)
+            if (bb < nb && t4 < 192) {
+                og[bb] = *(const f4 *)(gl + (size_t)(b0 + bb) * m.Npad + (size_t)vslice * 768 + t4 * 4);
+                op[bb] = *(const f4 *)(v_posed + (size_t)(b0 + bb) * m.Npad + (size_t)vslice * 768 + t4 * 4);
             }
-        }
-    };
-    f4 (*red)[4][64] = (f4 (*)[4][64])smem;      // [4][4][64]
-    float gA_[4][4], pA_[4][4], gB_[4][4], pB_[4][4];
-    load_ops(b0, gA_, pA_);
-    auto body = [&](int bb, const float (&g)[4][4], const float (&p)[4][4]) {
+#pragma unroll
+        for (int bb = 0; bb < SKA_NBODY; bb++)
+            if (bb < nb && t4 < 192) {
+                *(f4 *)(sg + (bb * 2 + 0) * 768 + t4 * 4) = og[bb];
+                *(f4 *)(sg + (bb * 2 + 1) * 768 + t4 * 4) = op[bb];
+            }
+    }
+    __syncthreads();
+    for (int bb = 0; bb < nb; bb++) {
+        const float *g_ = sg + (bb * 2 + 0) * 768 + (w * 64 + 4 * lk) * 3, *p_ = sg + (bb * 2 + 1) * 768 + (w * 64 + 4 * lk) * 3;
         f4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[t] = (f4){0, 0, 0, 0};
@@ -243,7 +253,9 @@ __device__ __forceinline__ void skin_bwd_A_body(const LbsDev &m, const float *__
         for (int st = 0; st < 4; st++)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                const float bop = g[st][t] * p[st][t];
+                const float gv = (r < 3) ? g_[(st * 16 + t) * 3 + r] : 0.0f;
+                const float pv = (s < 3) ? p_[(st * 16 + t) * 3 + s] : 1.0f;
+                const float bop = gv * pv;
 #pragma unroll
                 for (int jt = 0; jt < 4; jt++) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[st][jt][t], bop, acc[jt], 0, 0, 0);
             }
@@ -256,16 +268,6 @@ __device__ __forceinline__ void skin_bwd_A_body(const LbsDev &m, const float *__
         float *o = part + ((size_t)vslice * B + b0 + bb) * JP * 16;
 #pragma unroll
         for (int e = 0; e < 4; e++) o[(w * 16 + lk * 4 + e) * 16 + li] = o4[e];
-    };
-    for (int bb = 0; bb < nb; bb += 2) {
-        if (bb + 1 < nb) load_ops(b0 + bb + 1, gB_, pB_);
-        __builtin_amdgcn_sched_barrier(0);       // the next body's operand loads are issued before this body's MFMAs wait
-        body(bb, gA_, pA_);
-        if (bb + 1 < nb) {
-            if (bb + 2 < nb) load_ops(b0 + bb + 2, gA_, pA_);
-            __builtin_amdgcn_sched_barrier(0);
-            body(bb + 1, gB_, pB_);
-        }
     }
 }
 
@@ -354,7 +356,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     LbsDev m, const float *__restrict__ g_vp, const float *__restrict__ gl, const float *__restrict__ v_posed, int B, int steps_per_slice,
     float *__restrict__ gfeat_part, float *__restrict__ gA_part, int n_blend, int kgroups, int nslices, int nsv, int nbody)
 {
-    __shared__ f4 smem[4 * 4 * MT * 64 > 4 * 4 * 64 ? 4 * 4 * MT * 64 : 4 * 4 * 64];
+    // blend_bwd: [4][KT][MT][64] f4; skin_bwd_A: [4][4][64] f4 for the reduction + SKA_NBODY bodies' staged operands (2 x 768 floats each)
+    constexpr int SMEM_A = 4 * 4 * 64 + SKA_NBODY * 2 * 768 / 4;
+    __shared__ f4 smem[4 * 4 * MT * 64 > SMEM_A ? 4 * 4 * MT * 64 : SMEM_A];
     const int bid = blockIdx.x;
     if (bid < n_blend) {
         int kg, slice, bg;
