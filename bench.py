@@ -21,7 +21,8 @@ MEDIAN block (min / max are reported next to it) and value = N / median seconds 
 Workloads:  --workload fitting (default, configs[1]; configs[3] at --gpus 8) | fitting_habitat (configs[4]: contact
 constant 1.0, Habitat camera flip, 64 bodies per GPU, a sweep over 7 synthetic rooms) | train_s2 (configs[2]).
 The default line also carries `secondary.train_s2` (a bounded train_s2 measurement, N=1 only) so configs[2] is measured
-by the same run.
+by the same run, and `secondary.fitting_smplx_sparse_weights`: the headline workload on a body model whose skinning rows have the
+released SMPL-X model's 4 non-zeros (the headline keeps the dense random [V, 55] weight matrix of the earlier rounds).
 
 The JSON line also carries
   roofline     — the dominant kernel of the iteration: algorithmic bytes per launch / its average
@@ -439,6 +440,24 @@ def bench_fitting(args):
     torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not habitat and args.secondary and (args.batch, args.nc, args.m, args.D) == (32, 2048, 32768, 256):
+            out['secondary'] = {}
+            try:
+                # the same workload on a body model with the RELEASED SMPL-X model's skinning sparsity (4 non-zero weights per vertex,
+                # tree-local): the headline line above keeps the dense random [V, J] weight matrix of rounds 1-2
+                from psi_release_amd import synth
+                sp_assets = (synth.make_smplx(7, weight_nnz=4), assets[1])
+                op_s, bodies_s, _ = make_op(args, rank, device, assets=sp_assets)
+                run_s = op_s.make_step_runner(bodies_s)
+                ts = timed_blocks(run_s.steps, lambda: torch.cuda.synchronize(), args.steps, args.warmup, 1, device, min_repeats=5, min_total_s=0.2)
+                run_s.finish()
+                med = statistics.median(ts) / args.steps
+                out['secondary']['fitting_smplx_sparse_weights'] = {
+                    'metric': out['metric'], 'value': round(1.0 / med, 1), 'ms_per_step': round(med * 1e3, 4), 'blocks': len(ts),
+                    'body_model': 'synthetic SMPL-X, 4 non-zero skinning weights per vertex (as the released model)'}
+                del run_s, op_s
+                torch.cuda.empty_cache()
+            except Exception as e:
+                out['secondary']['fitting_smplx_sparse_weights'] = {'error': repr(e)}
             try:
                 import contextlib
                 import io
@@ -446,9 +465,9 @@ def bench_fitting(args):
                 with contextlib.redirect_stdout(buf):
                     sec = bench_train_s2(argparse.Namespace(**dict(vars(args), batch=128, steps=10, warmup=3, repeats=5, min_timed_s=0.3)))
                 sys.stderr.write(buf.getvalue())
-                out['secondary'] = {'train_s2': sec}
+                out['secondary']['train_s2'] = sec
             except Exception as e:
-                out['secondary'] = {'train_s2': {'error': repr(e)}}
+                out['secondary']['train_s2'] = {'error': repr(e)}
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

@@ -40,6 +40,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
+#ifndef PSI_BLEND_FWD_BUFS
+#define PSI_BLEND_FWD_BUFS 2          // operand buffers of blend_fwd (3 measured no faster)
+#endif
 constexpr int JP = PSI_JP;      // padded joint count (one wave)
 constexpr int SKIN_BLK = PSI_SKIN_BLK;
 
@@ -178,6 +181,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         zero_acc();
     };
 
+#if PSI_BLEND_FWD_BUFS == 3
+    // three operand buffers: the chunk two positions ahead is requested before the current chunk's MFMAs issue
+    f4 qA[16], qB[16], qC[16], aA[MT][4], aB[MT][4], aC[MT][4];
+    zero_acc();
+    load_chunk(0, qA, aA);
+    if (total > 1) load_chunk(1, qB, aB);
+    for (int it = 0; it < total; it += 3) {
+        if (it + 2 < total) load_chunk(it + 2, qC, aC);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(qA, aA);
+        finish_tile(it);
+        if (it + 1 < total) {
+            if (it + 3 < total) load_chunk(it + 3, qA, aA);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(qB, aB);
+            finish_tile(it + 1);
+        }
+        if (it + 2 < total) {
+            if (it + 4 < total) load_chunk(it + 4, qB, aB);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(qC, aC);
+            finish_tile(it + 2);
+        }
+    }
+#else
     f4 qA[16], qB[16], aA[MT][4], aB[MT][4];
     zero_acc();
     load_chunk(0, qA, aA);
@@ -193,6 +221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             finish_tile(it + 1);
         }
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -65,8 +65,11 @@ class SMPLXData:
 
 
 def make_smplx(seed: int = 7, V: int = V_SMPLX, J: int = J_SMPLX, parents: np.ndarray | None = None,
-               nb: int = NB_SMPLX) -> SMPLXData:
-    """SMPL-X-shaped model: peaky (approximately sparse) regressor / skinning weights."""
+               nb: int = NB_SMPLX, weight_nnz: int = 0) -> SMPLXData:
+    """SMPL-X-shaped model: peaky (approximately sparse) regressor / skinning weights.  ``weight_nnz`` > 0: every vertex is bound to
+    exactly that many joints — a joint and its neighbours in the kinematic tree, consecutive vertices mostly to the same joint —
+    as in the released SMPL-X model, whose skinning rows have at most 4 non-zeros (the default is a DENSE random [V, J] matrix,
+    which is what the reference's dense matmul is indifferent to and the harder case for this package's kernels)."""
     rs = np.random.RandomState(seed)
     if parents is None:
         parents = SMPLX_PARENTS if J == J_SMPLX else np.array([-1] + [(i - 1) // 2 for i in range(1, J)])
@@ -76,6 +79,17 @@ def make_smplx(seed: int = 7, V: int = V_SMPLX, J: int = J_SMPLX, parents: np.nd
     jr = rs.uniform(0, 1, (J, V)) ** 8
     J_regressor = _f32(jr / jr.sum(1, keepdims=True))
     w = rs.uniform(0, 1, (V, J)) ** 8
+    if weight_nnz > 0:
+        par = np.asarray(parents)
+        nbrs = [[j] + ([int(par[j])] if par[j] >= 0 else []) + [int(c) for c in np.nonzero(par == j)[0]] for j in range(J)]
+        prim = np.minimum((np.arange(V) * J) // V, J - 1)                      # consecutive vertices share their primary joint
+        mask = np.zeros((V, J), bool)
+        for v in range(V):
+            cand = list(nbrs[int(prim[v])])
+            while len(cand) < weight_nnz:                                      # leaves: widen to the neighbours' neighbours
+                cand += [c for q in list(cand) for c in nbrs[q] if c not in cand] or [int(rs.randint(J))]
+            mask[v, cand[:weight_nnz]] = True
+        w = np.where(mask, w + 1e-3, 0.0)
     weights = _f32(w / w.sum(1, keepdims=True))
     kintree = np.stack([parents.astype(np.int64), np.arange(J, dtype=np.int64)])
     kintree[0, 0] = -1

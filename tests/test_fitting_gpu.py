@@ -280,3 +280,25 @@ def test_packed_independent_bodies_equal_one_by_one_fits(smplx_data, vposer_sd, 
     stack = {k: np.concatenate([f[k] for f in files[:5]]) for k in files[0]}
     xc = coupled.fitting(stack).detach().cpu().numpy()
     assert np.abs(xc - np.concatenate(seq[:5])).max() > 1e-3
+
+
+def test_head_cluster_widths_agree_and_repeat_exactly(smplx_data, vposer_sd, monkeypatch):
+    """The per-body head / tail kernels spread a body over 1, 2, 4 or 8 workgroups that exchange partial sums inside the launch
+    (fit.hip: tagged 64-bit words, summed in cluster order).  Every width must (a) repeat bit-for-bit from run to run — a stale or
+    torn exchange word would show up as run-to-run differences — and (b) agree with the single-workgroup kernel up to the fp32
+    re-association of the split sums (40 Adam iterations, B = 5 so that clusters straddle XCDs)."""
+    scene = synth.make_scene(3, 3000, 24, 300)
+    B = 5
+    bodies = synth.make_bodies(33, B)
+    bodies['cam_ext'] = synth.make_cam_ext(9, B)
+    out = {}
+    for hc in (1, 2, 4, 8):
+        monkeypatch.setenv('PSI_HEAD_CLUSTER', str(hc))
+        runs = []
+        for rep in range(3):
+            op = make_op(smplx_data, vposer_sd, scene, B, 'fused', num_iter=40, lr=0.05)
+            runs.append(op.fitting(dict(bodies)).detach().cpu().numpy().copy())
+        assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2]), 'width %d is not repeatable' % hc
+        out[hc] = runs[0]
+    for hc in (2, 4, 8):
+        assert np.abs(out[hc] - out[1]).max() < 5e-4, (hc, np.abs(out[hc] - out[1]).max())
