@@ -284,14 +284,15 @@ def test_packed_independent_bodies_equal_one_by_one_fits(smplx_data, vposer_sd, 
 
 def test_head_cluster_widths_agree_and_repeat_exactly(smplx_data, vposer_sd, monkeypatch):
     """The per-body head / tail kernels spread a body over 1, 2, 4 or 8 workgroups that exchange partial sums inside the launch
-    (fit.hip: tagged 64-bit words, summed in cluster order).  Every width must (a) repeat bit-for-bit from run to run — a stale or
-    torn exchange word would show up as run-to-run differences — and (b) agree with the single-workgroup kernel up to the fp32
-    re-association of the split sums (40 Adam iterations, B = 5 so that clusters straddle XCDs)."""
+    (fit.hip: tagged 64-bit words, summed in cluster order).  Every width must (a) repeat bit-for-bit from run to run over a long
+    fit — a stale or torn exchange word would show up as run-to-run differences — and (b) agree with the single-workgroup kernel up
+    to the fp32 re-association of the split sums (compared after 3 iterations: Adam's normalised steps amplify last-bit differences
+    over a long trajectory).  B = 5, so that clusters straddle XCDs."""
     scene = synth.make_scene(3, 3000, 24, 300)
     B = 5
     bodies = synth.make_bodies(33, B)
     bodies['cam_ext'] = synth.make_cam_ext(9, B)
-    out = {}
+    short = {}
     for hc in (1, 2, 4, 8):
         monkeypatch.setenv('PSI_HEAD_CLUSTER', str(hc))
         runs = []
@@ -299,6 +300,7 @@ def test_head_cluster_widths_agree_and_repeat_exactly(smplx_data, vposer_sd, mon
             op = make_op(smplx_data, vposer_sd, scene, B, 'fused', num_iter=40, lr=0.05)
             runs.append(op.fitting(dict(bodies)).detach().cpu().numpy().copy())
         assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2]), 'width %d is not repeatable' % hc
-        out[hc] = runs[0]
+        op = make_op(smplx_data, vposer_sd, scene, B, 'fused', num_iter=3, lr=0.05)
+        short[hc] = op.fitting(dict(bodies)).detach().cpu().numpy().copy()
     for hc in (2, 4, 8):
-        assert np.abs(out[hc] - out[1]).max() < 5e-4, (hc, np.abs(out[hc] - out[1]).max())
+        assert np.abs(short[hc] - short[1]).max() < 1e-4, (hc, np.abs(short[hc] - short[1]).max())
