@@ -14,6 +14,7 @@ timeout 900 python tools/sensitivity.py > $O/sens.log 2>&1; cp gpurun_out/sensit
 ( time PSI_DIST_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 20 --warmup 5 ) > $O/bench_n2_gloo.json 2> $O/bench_n2_gloo.err
 ( PSI_FORCE_DP_PATH=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 ) > $O/bench_dp1_nccl.json 2> $O/bench_dp1_nccl.err
 timeout 300 python bench.py --workload fitting_habitat --steps 21 --warmup 7 --cpu-seconds 6 > $O/bench_habitat.json 2> $O/bench_habitat.err
+timeout 600 python tools/time_files.py > $O/time_files.log 2>&1; cp gpurun_out/files_per_s.json $O/
 python - <<'PY'
 import json
 for f in ('bench_default','bench_n2_gloo','bench_dp1_nccl','bench_habitat'):
