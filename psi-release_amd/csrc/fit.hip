@@ -49,6 +49,7 @@ constexpr int XD = 75;         // body vector with 6D global rotation (cvae.py:1
 #define PSI_HEAD_THREADS 512
 #endif
 constexpr int HB = PSI_HEAD_THREADS;   // threads per body in the head kernels: 128 output quads x KQ K-splits
+static_assert(HB >= 384 && HB % 128 == 0, "the head / tail kernels place work on threads up to 256 + 75");
 constexpr int KQ = HB / 128;            // K-splits of the 512-wide layers
 constexpr int KS3 = HB / 32;            // K-slices of fc3 (32 output quads)
 constexpr int OS1 = HB / 8;             // output slices of W1^T (8 latent quads)
@@ -788,8 +789,9 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
     const float h2v = t < NS ? h2[c * NS + t] : 0.0f;
     unsigned tag = 0;
     if (C > 1) tag = f.hx_epoch[f.B + b] + 1u;
-    float h1v = 0.0f, xhrv = 0.0f, am = 0.0f, av = 0.0f;
+    float h1v = 0.0f, xhrv = 0.0f, am = 0.0f, av = 0.0f, step_size = 0.0f, bc2_sqrt = 1.0f;
     int step = 0;
+    const int ta = (int)threadIdx.x - 256;       // the Adam update of entry ta is done by thread 256 + ta (waves 4-5)
     float o6v[6] = {0, 0, 0, 0, 0, 0}, gtv = 0.0f;
     if (t >= 1 && t < 22)
         for (int i = 0; i < 6; i++) o6v[i] = f.o6[(size_t)b * 128 + (t - 1) * 6 + i];
@@ -799,11 +801,17 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
 #pragma unroll
         for (int i = 0; i < O1; i++) w1p[i] = *(const f4 *)(w1 + (size_t)i * NZ);
         h1v = h1[t];
-        if (ADAM && t < XD) {
-            xhrv = f.xhr[(size_t)b * XD + t];
-            am = f.adam_m[(size_t)b * XD + t];
-            av = f.adam_v[(size_t)b * XD + t];
+        if (ADAM && ta >= 0 && ta < XD) {
+            xhrv = f.xhr[(size_t)b * XD + ta];
+            am = f.adam_m[(size_t)b * XD + ta];
+            av = f.adam_v[(size_t)b * XD + ta];
             step = *f.step;
+            // the bias corrections (double-precision pow: a few hundred instructions) are computed HERE, by waves that idle through
+            // the pose backward, not at the end of the kernel's critical path
+            const double bc1 = 1.0 - pow((double)f.beta1, (double)step);
+            const double bc2 = 1.0 - pow((double)f.beta2, (double)step);
+            step_size = (float)((double)f.lr / bc1);
+            bc2_sqrt = (float)sqrt(bc2);
         }
     }
     psi_pose_bwd_body(lv.m, f.pose + (size_t)b * f.J * 3, lv.R, lv.Jl, lv.G, lv.gA + (size_t)b * PSI_JP * 16, lv.gfeat + (size_t)b * lv.m.Kpad, b,
@@ -925,26 +933,22 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         if (t < XD) g_out[(size_t)b * XD + t] = sgx[t];
         return;
     }
-    if (t < XD) {
+    if (ta >= 0 && ta < XD) {
         const float Bg = f.indep ? 1.0f : (float)f.B * (float)f.world;
-        float g = sgx[t];
+        float g = sgx[ta];
         // d/dx of w_rec * mean|xhr - x|  (fitting_proxe.py:105)
-        float df = xhrv - sx[t];
+        float df = xhrv - sx[ta];
         g += f.w_rec / (Bg * XD) * (df > 0.0f ? -1.0f : (df < 0.0f ? 1.0f : 0.0f));
         // d/dz of w_vp * mean(z^2)       (fitting_proxe.py:109-110)
-        if (t >= 19 && t < 19 + NZ) g += f.w_vp / (Bg * NZ) * 2.0f * sx[t];
-        // torch.optim.Adam (defaults: amsgrad False, weight_decay 0), fitting_proxe.py:73-74
-        size_t o = (size_t)b * XD + t;
+        if (ta >= 19 && ta < 19 + NZ) g += f.w_vp / (Bg * NZ) * 2.0f * sx[ta];
+        // torch.optim.Adam (defaults: amsgrad False, weight_decay 0), fitting_proxe.py:73-74 (step_size, bc2_sqrt: top of the kernel)
+        size_t o = (size_t)b * XD + ta;
         float m = am * f.beta1 + (1.0f - f.beta1) * g;
         float v = av * f.beta2 + (1.0f - f.beta2) * g * g;
         f.adam_m[o] = m;
         f.adam_v[o] = v;
-        double bc1 = 1.0 - pow((double)f.beta1, (double)step);
-        double bc2 = 1.0 - pow((double)f.beta2, (double)step);
-        float step_size = (float)((double)f.lr / bc1);
-        float bc2_sqrt = (float)sqrt(bc2);
         float denom = sqrtf(v) / bc2_sqrt + f.eps;
-        f.x[o] = sx[t] - step_size * (m / denom);
+        f.x[o] = sx[ta] - step_size * (m / denom);
     }
 }
 
