@@ -522,12 +522,17 @@ __global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, c
     if (psi_dbg_sstop == 2 && (int)blockIdx.x < n_kd) return;       // skinning + SDF workgroups only
     if (psi_dbg_sstop == 3) return;                                  // neither: the launch itself
 #endif
-    if ((int)blockIdx.x < n_kd) {
-        const int b = blockIdx.x / nqb, bx = blockIdx.x % nqb;
+    // The NN-search workgroups come FIRST in the grid: they are the long ones.  Measured with the skinning workgroups first the launch
+    // takes 43.6 us instead of 36.6 (HIP-event), with the two kinds spread evenly through the grid 45.8.
+    int bid = blockIdx.x;
+    const bool is_kd = bid < n_kd;
+    if (!is_kd) bid -= n_kd;
+    if (is_kd) {
+        const int b = bid / nqb, bx = bid % nqb;
         psikd::kd_query_body<true, false>(T, ContactSkinSrc{f, m, As, v_posed, nullptr}, f.n_c, (float *)nullptr, (int *)nullptr, f.cconst, gscale,
                                           f.gq, f.fpart, f.nn_hint, rows, (const psikd::KdDev *)nullptr, (const int *)nullptr, bx, b, nqb, smem_i);
     } else {
-        const int i = blockIdx.x - n_kd;
+        const int i = bid;
         SdfPenEpilogue epi{f, 0.0f, 0.0f};
         psi_skin_fwd_body(m, As, v_posed, f.transl, f.cam, f.B, f.verts, epi, i % f.nsdfblk, i / f.nsdfblk, f.nsdfblk);
     }

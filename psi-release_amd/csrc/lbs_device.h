@@ -590,10 +590,11 @@ __global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_bwd_v_kernel(LbsDev 
     bl.issue(m, As, b, v);
     src.issue_late(pre, b);
     PSI_SSTOP(12);
-    src.prepare(b, 1);
-    PSI_SSTOP(13);
+    // the blend first (its weight loads run while the statistics inputs requested above are still in flight), then the statistics
     psi_f2 T2[6];
     bl.blend(m, bl.commit(m), v, T2);
+    PSI_SSTOP(13);
+    src.prepare(b, 1);
     PSI_SSTOP(14);
     __shared__ float sh[PSI_SKIN_BLK / 64][3];
     float lx = 0, ly = 0, lz = 0;
