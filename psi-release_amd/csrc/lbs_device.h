@@ -470,7 +470,10 @@ struct PsiBlend {
         // the skinning kernels: 26 k cycles per CU = 11 us for the 20 resident waves).  (Requesting the next joint's transform by hand before the
         // current one is used measured slower than the compiler's own three 16-byte scalar loads per joint.)
         const psi_f2 *Ab = (const psi_f2 *)As_b;
-#pragma unroll 11
+#ifndef PSI_DENSE_UNROLL
+#define PSI_DENSE_UNROLL 11
+#endif
+#pragma unroll PSI_DENSE_UNROLL
         for (int j = 0; j < m.J; j++) {
             float wj = m.WT[(size_t)j * m.Vpad + v];
             psi_f2 w2 = {wj, wj};
