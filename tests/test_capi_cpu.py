@@ -78,3 +78,44 @@ def test_ops_refuse_cpu_tensors(built_lib):
     from psi_release_amd import ops, hip
     with pytest.raises(hip.PsiHipError):
         ops.chamfer_forward_raw(torch.zeros(1, 4, 3), torch.zeros(1, 5, 3))
+
+
+def test_fit_config_struct_matches_header():
+    """`hip.FitConfig` (ctypes) must list the fields of `struct psi_fit_config` (include/psi_hip.h) with the same names, order and
+    types — a field added on one side only would shift every later field of the struct the engine is created from."""
+    import ctypes
+    import re
+    from psi_release_amd import hip
+    text = open(os.path.join(ROOT, 'include', 'psi_hip.h')).read()
+    body = re.search(r'typedef struct psi_fit_config \{(.*?)\} psi_fit_config;', text, re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = decl.split(None, 1)
+        for nm in names.split(','):
+            fields.append((nm.strip(), ctype))
+    want = {'int': ctypes.c_int, 'float': ctypes.c_float}
+    got = [(n, t) for n, t in hip.FitConfig._fields_]
+    assert [n for n, _ in got] == [n for n, _ in fields]
+    assert all(t is want[c] for (_, t), (_, c) in zip(got, fields))
+
+
+def test_synthetic_smplx_sparse_weight_rows():
+    """`synth.make_smplx(weight_nnz=4)`: exactly four non-zero skinning weights per vertex, rows sum to one, and the four joints are
+    a joint with neighbours of its own in the kinematic tree (the structure of the released SMPL-X model's `weights`)."""
+    import numpy as np
+    from psi_release_amd import synth
+    m = synth.make_smplx(7, weight_nnz=4)
+    w = np.asarray(m.weights)
+    assert w.shape == (synth.V_SMPLX, synth.J_SMPLX)
+    assert ((w != 0).sum(1) == 4).all() and np.abs(w.sum(1) - 1).max() < 1e-6 and (w >= 0).all()
+    par = np.asarray(synth.SMPLX_PARENTS)
+    for v in (0, 777, 5000, synth.V_SMPLX - 1):
+        js = set(np.nonzero(w[v])[0].tolist())
+        # connected in the tree: every joint of the row has its parent or one of its children in the row
+        assert all((par[j] in js) or any(par[c] == j for c in js) for j in js)
+    d = np.asarray(synth.make_smplx(7).weights)
+    assert (d != 0).sum(1).min() > synth.J_SMPLX - 8               # the default stays dense (more than PSI_WNZ = 8 non-zeros everywhere)
