@@ -229,9 +229,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // wave = one body x one 256-vertex slice x all 64 padded joints (4 accumulators).
 // ------------------------------------------------------------------------------------------------
 // NBODY bodies per workgroup: the weight tile of the slice (64 joints x 256 vertices = 64 KB, 16 registers x 16 B per lane) is
-// loaded ONCE and reused for every body (it was re-read from L2 per body: 86 MB per launch at B = 32), the next body's
-// operands are requested before the current body's MFMAs issue, and there are Vpad/256 * ceil(B/NBODY) workgroups (164 at
-// B = 32) instead of 1312 — few enough to be resident all at once beside the blend_bwd stream workgroups.
+// loaded ONCE and reused for every body (it was re-read from L2 per body: 86 MB per launch at B = 32), all bodies' operands are
+// requested up front and parked in LDS, and there are Vpad/256 * ceil(B/NBODY) workgroups (246 at B = 32) instead of 1312 — few
+// enough to be resident all at once beside the blend_bwd stream workgroups.  (In blend_fwd, requesting a tile's v_template slice
+// with its last chunk instead of after the reduction's barrier changed nothing: 21.9 us either way.)
 constexpr int SKA_NBODY = 8;
 
 __device__ __forceinline__ void skin_bwd_A_body(const LbsDev &m, const float *__restrict__ gl, const float *__restrict__ v_posed,
