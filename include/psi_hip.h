@@ -185,7 +185,8 @@ int psi_fit_backward_step(psi_fit_engine *engine, const float *d_stats, int use_
 int psi_fit_iterate(psi_fit_engine *engine, int n_iter, int use_graph, void *stream);
 /* Copies x [B,75] and the first n_hist rows of the loss-history RING [max_history,4] (row = (adam_step-1) % max_history) =
  * (l_rec, l_vposer, l_contact, l_collision as printed by fitting_proxe.py:184-186) to device buffers;
- * h_step (host, nullable) receives the Adam step count and forces a stream sync. */
+ * h_step (host, nullable) receives the Adam step count and forces a stream sync; with h_step the call also checks the engine's error
+ * word and returns non-zero if one of the in-kernel cluster exchanges of the per-body kernels gave up waiting (results invalid). */
 int psi_fit_read(psi_fit_engine *engine, float *d_x_out, float *d_history_out, int n_hist, int *h_step, void *stream);
 /* The four loss values recorded by Adam step `adam_step` (1-based; the row (adam_step-1) % max_history of the ring) -> d_out4
  * (device, 4 floats): what the reference prints per iteration (fitting_proxe.py:184-186) without copying the whole ring.

@@ -78,6 +78,7 @@ struct FitDev {
     float *g_betas, *g_pose, *g_transl, *g_rot;
     unsigned long long *hx_o6, *hx_gh1;   // head / tail cluster exchange words {value, tag}: partial fc3 outputs [B][C][128], partial W2^T products [B][C][512]
     unsigned *hx_epoch;      // [2][B] launch counts of the head / tail kernel per body (the exchange tag)
+    int *hx_err;             // != 0: a cluster exchange gave up waiting (psi_fit_read reports it)
     int hc;                  // workgroups per body in the head / tail kernels (1, 2, 4 or 8)
 #ifdef PSI_HEAD_STOPS
     int stop_h, stop_t;      // dev: leave the head / tail kernel at this point (differential timing; tools/head_stops.sh)
@@ -226,9 +227,17 @@ __device__ __forceinline__ unsigned long long hx_peek(unsigned long long *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float hx_value(unsigned long long *p, unsigned long long w, unsigned tag)
+// The wait is bounded (about a second of polling): if a producer never shows up — which in-order dispatch rules out — the reader
+// raises the engine's error word (reported by psi_fit_read) and goes on with whatever the word holds, instead of hanging the GPU.
+constexpr int HX_MAX_POLLS = 1 << 20;
+__device__ __forceinline__ float hx_value(unsigned long long *p, unsigned long long w, unsigned tag, int *err)
 {
+    int polls = 0;
     while ((unsigned)(w >> 32) != tag) {
+        if (++polls > HX_MAX_POLLS) {
+            *err = 1;
+            break;
+        }
         __builtin_amdgcn_s_sleep(1);
         w = hx_peek(p);
     }
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
             for (int cc = 0; cc < C - 1; cc++) w[cc] = hx_peek(p8 + cc * 128);
             float o = b3v;
 #pragma unroll
-            for (int cc = 0; cc < C - 1; cc++) o += hx_value(p8 + cc * 128, w[cc], tag);
+            for (int cc = 0; cc < C - 1; cc++) o += hx_value(p8 + cc * 128, w[cc], tag, f.hx_err);
             so6[t] = o + a;
         }
     }
@@ -908,7 +917,7 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
             for (int cc = 0; cc < C - 1; cc++) w[cc] = hx_peek(p8 + (size_t)cc * NH);
             float o = 0.0f;
 #pragma unroll
-            for (int cc = 0; cc < C - 1; cc++) o += hx_value(p8 + (size_t)cc * NH, w[cc], tag);
+            for (int cc = 0; cc < C - 1; cc++) o += hx_value(p8 + (size_t)cc * NH, w[cc], tag, f.hx_err);
             sga1[t] = (o + a) * (h1v > 0.0f ? 1.0f : 0.2f);
         }
     }
@@ -1202,7 +1211,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.W1 = F(o_w1); f.W2 = F(o_w2); f.W3 = F(o_w3); f.lhc = F(o_lh); f.rhc = F(o_rh); f.pose_mean = F(o_pm);
     f.vid = (const int *)(bl + o_vid); f.cs_ptr = (const int *)(bl + o_cp); f.cs_idx = (const int *)(bl + o_ci); f.cs_first = (const int *)(bl + o_cf);
     f.gmin = F(o_gmin); f.gmax = F(o_gmax);
-    f.x = F(o_x); f.xhr = F(o_xhr); f.cam = F(o_cam); f.adam_m = F(o_am); f.adam_v = F(o_av); f.step = (int *)(bl + o_step);
+    f.x = F(o_x); f.xhr = F(o_xhr); f.cam = F(o_cam); f.adam_m = F(o_am); f.adam_v = F(o_av); f.step = (int *)(bl + o_step); f.hx_err = f.step + 1;
     f.h1 = F(o_h1); f.h2 = F(o_h2); f.o6 = F(o_o6); f.betas20 = F(o_b20); f.pose = F(o_pose); f.transl = F(o_tr);
     f.verts = F(o_verts); f.og = F(o_og); f.gq = F(o_gq); f.fpart = F(o_fp); f.penpart = F(o_pp);
     f.recpart = F(o_rp); f.vppart = F(o_vp); f.g_betas = F(o_gb); f.g_pose = F(o_gp); f.g_transl = F(o_gt); f.g_rot = F(o_gr);
@@ -1467,8 +1476,16 @@ extern "C" int psi_fit_read(psi_fit_engine *e, float *d_x_out, float *d_history_
         PSI_CHECK_HIP(hipMemcpyAsync(d_history_out, f.history, (size_t)n_hist * 16, hipMemcpyDeviceToDevice, st));
     }
     if (h_step) {
-        PSI_CHECK_HIP(hipMemcpyAsync(h_step, f.step, 4, hipMemcpyDeviceToHost, st));
+        int hs[2] = {0, 0};                                      // {Adam step, cluster-exchange error word}
+        PSI_CHECK_HIP(hipMemcpyAsync(hs, f.step, 8, hipMemcpyDeviceToHost, st));
         PSI_CHECK_HIP(hipStreamSynchronize(st));
+        *h_step = hs[0];
+        if (hs[1]) {
+            (void)hipMemsetAsync(f.hx_err, 0, 4, st);
+            psi_set_error("psi_fit_read: a head / tail cluster exchange timed out (a producer workgroup never published its partials); "
+                          "the results of this fit are invalid.  PSI_HEAD_CLUSTER=1 runs the kernels without clusters");
+            return 902;
+        }
     }
     return 0;
 }
