@@ -272,8 +272,12 @@ class FittingOP:
                       'psi_fit_set_problem')
             eng.iterate(self.num_iter, self.use_graph)
             hip.check(L.psi_fit_read(eng.handle, hip.ptr(x_out[i * R:(i + 1) * R]), None, 0, None, eng.stream.cuda_stream), 'psi_fit_read')
+        import ctypes
         for eng in engines:
-            eng.stream.synchronize()
+            # synchronises the engine's stream AND inspects its error word (sticky until read): a head / tail cluster exchange that gave
+            # up waiting in ANY of this engine's runs makes psi_fit_read fail here instead of a silently invalid fit reaching the pkl
+            step = ctypes.c_int(0)
+            hip.check(L.psi_fit_read(eng.handle, None, None, 0, ctypes.byref(step), eng.stream.cuda_stream), 'psi_fit_read (fitting_many)')
         xh_fit = GeometryTransformer.convert_to_3D_rot(x_out)
         recs = recs[:n_real]
         results = [xh_fit[i * B:(i + 1) * B] for i in range(n_real)]
@@ -284,8 +288,8 @@ class FittingOP:
     def save_result(self, xh_rec, output_data_file):
         """fitting_proxe.py:199-214 (one pkl per call; with batch>1 the last body wins, as in the reference)."""
         dirname = os.path.dirname(output_data_file)
-        if dirname and not os.path.exists(dirname):
-            os.makedirs(dirname)
+        if dirname:
+            os.makedirs(dirname, exist_ok=True)      # several ranks of a file-sharded run create the same scene directory at once
         body_param_list = BodyParamParser.body_params_encapsulate(xh_rec)
         print('[INFO] save results to: ' + output_data_file)
         if getattr(self, 'save_all_rows', False) and len(body_param_list) > 1:

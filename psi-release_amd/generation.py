@@ -115,8 +115,7 @@ class TestOP:
 
     @staticmethod
     def write(body_param_list, outdir, first_index=0):
-        if not os.path.exists(outdir):
-            os.makedirs(outdir)
+        os.makedirs(outdir, exist_ok=True)
         print('[INFO] save results to: ' + outdir)
         for jj, body_param in enumerate(body_param_list):
             with open(os.path.join(outdir, 'body_gen_{:06d}.pkl'.format(first_index + jj)), 'wb') as f:

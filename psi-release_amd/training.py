@@ -51,8 +51,7 @@ class _TrainBase:
         self.device = torch.device(self.device)
         if self.device.type != 'cuda':
             raise RuntimeError('TrainOP runs on the GPU (HIP operators); there is no CPU path')
-        if not os.path.exists(self.save_dir):
-            os.makedirs(self.save_dir)
+        os.makedirs(self.save_dir, exist_ok=True)        # every rank of a torchrun job constructs TrainOP on the same save_dir
         n_dim_body = 72 + 3 if self.use_cont_rot else 72
         self.model_h_latentD = 256
         self.model_h = self._make_model(n_dim_body)

@@ -17,6 +17,24 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+# Collection order of the -m gpu suite (the driver runs it with -x): the oracle / golden parity tests come first, the multi-process
+# tests (gloo rendezvous, torchrun subprocesses) last, so that a launcher or port problem can never hide a parity result.
+_ORDER = ['test_hip_ops_gpu', 'test_lbs_gpu', 'test_fitting_gpu', 'test_parity_gaps_gpu', 'test_configs_gpu', 'test_linear_gpu', 'test_conv_gpu',
+          'test_training_gpu', 'test_section8f_gpu']
+_LAST = ['test_stress_gpu', 'test_dist_gpu', 'test_entrypoints_gpu']
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if mod in _ORDER:
+            return (0, _ORDER.index(mod))
+        if mod in _LAST:
+            return (2, _LAST.index(mod))
+        return (1, 0)
+    items.sort(key=key)            # stable: the order inside a module is kept
+
+
 def golden(name):
     return np.load(os.path.join(GOLD, name + '.npz'))
 

@@ -2,8 +2,10 @@
 import glob
 import os
 import pickle
+import shutil
 import subprocess
 import sys
+import tempfile
 
 import pytest
 import torch
@@ -60,9 +62,17 @@ def _torchrun(args, nproc, env_extra, timeout=900):
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, **env_extra)
+    logdir = tempfile.mkdtemp(prefix='psi_torchrun_')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
-                        '--master-port', str(port)] + args, capture_output=True, text=True, timeout=timeout, cwd=SRC, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+                        '--master-port', str(port), '--tee', '3', '--log-dir', logdir] + args,
+                       capture_output=True, text=True, timeout=timeout, cwd=SRC, env=env)
+    if r.returncode != 0:          # every rank's own stderr (the launcher's output only carries the tail of the first failure)
+        per_rank = []
+        for fn in sorted(glob.glob(os.path.join(logdir, '**', 'stderr.log'), recursive=True)):
+            with open(fn, errors='replace') as f:
+                per_rank.append('---- %s ----\n%s' % (os.path.relpath(fn, logdir), f.read()[-3000:]))
+        raise AssertionError('torchrun exit %d\n%s\n==== launcher ====\n%s' % (r.returncode, '\n'.join(per_rank), r.stderr[-3000:]))
+    shutil.rmtree(logdir, ignore_errors=True)
     return r.stdout
 
 
