@@ -54,6 +54,10 @@ size_t psi_chamfer_workspace_bytes(int B, int n, int m);
 int psi_chamfer_forward(const float *xyz1, const float *xyz2, int B, int n, int m,
                         float *dist1, int32_t *idx1, float *dist2, int32_t *idx2,
                         void *workspace, void *stream);
+/* Frees the library's internal scratch buffer of `stream` on the current device (all != 0: of every stream of every device).  The
+ * buffers behind `workspace = NULL` are per (device, stream) and otherwise live as long as the process; call this before destroying a
+ * stream that was used with workspace = NULL. */
+int psi_scratch_release(void *stream, int all);
 /* Accumulates (+=) into gradxyz1 [B,n,3] / gradxyz2 [B,m,3] exactly like the reference, which is
  * handed zero-filled buffers (dist_chamfer.py:40-45).  gradxyz2 may be NULL (scene needs no grad);
  * graddist2/idx2 may be NULL (then direction 2 contributes nothing). */

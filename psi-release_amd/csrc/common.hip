@@ -71,4 +71,28 @@ void *psi_scratch(size_t bytes, hipStream_t stream)
     return e.ptr;
 }
 
+// Give back the internal scratch of one stream (NULL = the default stream) on the current device, or of EVERY stream of every device
+// (all != 0).  Entries are otherwise kept for the life of the process: a caller that cycles through many short-lived streams (PyTorch's
+// stream pool, one stream per engine in fitting_many) calls this before destroying a stream so that its buffer — and a stale map key a
+// later stream handle could alias — does not stay behind.
+extern "C" int psi_scratch_release(void *stream, int all)
+{
+    int dev = 0;
+    PSI_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+        if (all || (it->first.first == dev && it->first.second == (hipStream_t)stream)) {
+            if (it->second.ptr) {
+                if (it->first.first == dev) (void)hipStreamSynchronize(it->first.second);
+                else (void)hipDeviceSynchronize();
+                (void)hipFree(it->second.ptr);
+            }
+            it = g_scratch.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return 0;
+}
+
 thread_local PsiStageTimer *g_psi_timer = nullptr;

@@ -29,6 +29,7 @@ SIGNATURES = {
     'psi_chamfer_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     'psi_chamfer_backward': (c_int, [c_void_p] * 8 + [c_int] * 3 + [c_void_p]),
+    'psi_scratch_release': (c_int, [c_void_p, c_int]),
     'psi_nn_index_create': (c_int, [c_void_p, c_void_p, c_int]),
     'psi_nn_index_destroy': (None, [c_void_p]),
     'psi_nn_index_query': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -40,7 +40,9 @@ def fit_files(fop_cls, fittingconfig, lossconfig, gen_dir, fit_dir, max_files, s
     normalisers), no collective on the data path.
     concurrency > 1 (with shard='files'): a rank keeps that many of ITS engine runs in flight at once, each on its own engine and stream.
     pack > 1 (with shard='files'): `pack` files form ONE engine run with per-body loss normalisers (FittingOP.independent_bodies) —
-    the same result as fitting them one by one, at the cost of one.
+    the same result as fitting them one by one WITH A FRESH ADAM STATE PER FILE (--reset_optimizer semantics: fitting_many resets the
+    optimizer for every run, whereas the default file loop carries one optimizer across the files of a scene like the reference,
+    fitting_proxe.py:73-74), at the cost of one.
     shard='rows' : every rank opens every file and fits rows [r*B/world, (r+1)*B/world) of its B bodies; the loss normalisers are
     global through the one all-reduce per iteration (psi_release_amd/dist.py), rank 0 gathers the rows and writes the pkl."""
     import os
@@ -50,6 +52,9 @@ def fit_files(fop_cls, fittingconfig, lossconfig, gen_dir, fit_dir, max_files, s
     B = fittingconfig['batch_size']
     cfg = dict(fittingconfig)
     if shard == 'rows' and world > 1:
+        if concurrency > 1 or pack > 1:
+            raise SystemExit('--concurrency / --pack fit INDEPENDENT files side by side; they cannot be combined with --shard rows '
+                             '(one file at a time, its batch split over the ranks)')
         if B % world:
             raise SystemExit('--shard rows needs batch_size %% world_size == 0 (got %d / %d)' % (B, world))
         cfg['batch_size'] = B // world

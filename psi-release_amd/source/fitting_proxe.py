@@ -36,7 +36,7 @@ def main(argv=None):
     ap.add_argument('--concurrency', type=int, default=1,
                     help='independent pkl files in flight per GPU (each on its own fused engine and HIP stream; implies a fresh Adam state per file)')
     ap.add_argument('--pack', type=int, default=1,
-                    help='fit this many pkl files as ONE engine run with per-body loss normalisers (identical results to one-by-one fits; '
+                    help='fit this many pkl files as ONE engine run with per-body loss normalisers (identical results to one-by-one fits run with --reset_optimizer: every file starts from a fresh Adam state; '
                          'the reference fits one batch-1 file at a time, which leaves the GPU idle)')
     ap.add_argument('--reset_optimizer', action='store_true',
                     help='fresh Adam state for every file (the reference carries one optimizer across the files of a scene, fitting_proxe.py:73-74; '

@@ -1,29 +1,6 @@
 #!/usr/bin/env python
-"""Generation for PROX-E snapshots (source/test_proxe_s1.py / test_proxe_s2.py __main__; --stage selects the model)."""
-import argparse
-import os
-
-import _common  # noqa: F401
-import torch
-
-from psi_release_amd.batch_gen import BatchGeneratorTest
-from psi_release_amd.generation import TestOP
-
-SNAPSHOTS = ['MPH16_00157_01', 'N0SittingBooth_00162_01', 'MPH1Library_00034_01', 'N3OpenArea_00157_01']
+"""source/test_proxe_s1.py of the reference: generation with the stage-1 model (see _gen_main.py)."""
+from _gen_main import main_proxe
 
 if __name__ == '__main__':
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--ckpt_dir', required=True)
-    ap.add_argument('--proxe_path', default='/home/yzhang/Videos/PROXE')
-    ap.add_argument('--output_dir', default='results_prox_stage1_nosceneloss/virtualrealcams')
-    ap.add_argument('--n_samples', type=int, default=300)
-    ap.add_argument('--stage', default='s1', choices=['s1', 's2'])
-    a = ap.parse_args()
-    dev = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
-    for snap in SNAPSHOTS:
-        path = os.path.join(a.proxe_path, 'snapshot_for_testing/' + snap)
-        bg = BatchGeneratorTest(dataset_path=path, device=dev)
-        bg.reset()
-        op = TestOP({'ckpt_dir': a.ckpt_dir, 'stage': a.stage, 'n_samples': a.n_samples, 'device': dev, 'use_cont_rot': True,
-                     'output_dir': a.output_dir, 'test_data_path': path})
-        op.test_proxe(bg.next_batch(batch_size=1), scene_name=snap.split('_')[0])
+    main_proxe('s1')

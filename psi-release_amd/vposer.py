@@ -3,8 +3,8 @@
 Reference: human_body_prior/train/vposer_smpl.py:66-171 (class VPoser) and
 human_body_prior/tools/model_loader.py:26-72 (expid2model / load_vposer).  PSI only ever calls
 ``vposer.decode(z, output_type='aa')`` on a pre-trained, ``.eval()`` model (fitting_proxe.py:115-116);
-the encoder is kept so that ``load_state_dict`` of a real ``vposer_v1_0`` snapshot is strict.
-The trainer (vposer_smpl.py:174-479) is out of scope.
+the encoder PARAMETERS are kept so that ``load_state_dict`` of a real ``vposer_v1_0`` snapshot is strict; the encoder's methods
+(``encode`` / ``forward`` / ``sample_poses``) and the trainer (vposer_smpl.py:174-479) are not on the path and are not provided.
 """
 from __future__ import annotations
 
@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .geometry import ContinousRotReprDecoder, angle_axis_to_rotation_matrix, rotation_matrix_to_angle_axis
+from .geometry import ContinousRotReprDecoder, rotation_matrix_to_angle_axis
 
 
 class VPoser(nn.Module):
@@ -40,14 +40,6 @@ class VPoser(nn.Module):
             self.rot_decoder = ContinousRotReprDecoder()
         self.bodyprior_dec_out = nn.Linear(num_neurons, self.num_joints * 6)
 
-    def encode(self, Pin):
-        x = Pin.view(Pin.size(0), -1)
-        x = self.bodyprior_enc_bn1(x)
-        x = F.leaky_relu(self.bodyprior_enc_fc1(x), negative_slope=.2)
-        x = self.dropout(self.bodyprior_enc_bn2(x))
-        x = F.leaky_relu(self.bodyprior_enc_fc2(x), negative_slope=.2)
-        return torch.distributions.normal.Normal(self.bodyprior_enc_mu(x), F.softplus(self.bodyprior_enc_logvar(x)))
-
     def decode(self, Zin, output_type='matrot'):
         assert output_type in ['matrot', 'aa']
         x = F.leaky_relu(self.bodyprior_dec_fc1(Zin), negative_slope=.2)
@@ -58,31 +50,11 @@ class VPoser(nn.Module):
         x = x.view([-1, 1, self.num_joints, 9])
         return VPoser.matrot2aa(x) if output_type == 'aa' else x
 
-    def forward(self, Pin, input_type='matrot', output_type='matrot'):
-        q_z = self.encode(Pin)
-        prec = self.decode(q_z.rsample())
-        res = {'mean': q_z.mean, 'std': q_z.scale}
-        res['pose_aa' if output_type == 'aa' else 'pose_matrot'] = VPoser.matrot2aa(prec) if output_type == 'aa' else prec
-        return res
-
-    def sample_poses(self, num_poses, output_type='aa', seed=None):
-        np.random.seed(seed)
-        w = self.bodyprior_dec_fc1.weight
-        self.eval()
-        with torch.no_grad():
-            z = torch.tensor(np.random.normal(0., 1., size=(num_poses, self.latentD)), dtype=w.dtype).to(w.device)
-        return self.decode(z, output_type=output_type)
-
     @staticmethod
     def matrot2aa(pose_matrot):
         bs = pose_matrot.size(0)
         homogen = F.pad(pose_matrot.view(-1, 3, 3), [0, 1])
         return rotation_matrix_to_angle_axis(homogen).view(bs, 1, -1, 3).contiguous()
-
-    @staticmethod
-    def aa2matrot(pose):
-        bs = pose.size(0)
-        return angle_axis_to_rotation_matrix(pose.reshape(-1, 3))[:, :3, :3].contiguous().view(bs, 1, -1, 9)
 
 
 def _read_settings(expr_dir):
