@@ -494,8 +494,9 @@ def bench_fitting(args):
                 out['secondary']['train_s2'] = {'error': repr(e)}
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()
+        pd.rccl_comm_release()
         torch.distributed.destroy_process_group()
 
 

@@ -206,6 +206,29 @@ int psi_fit_read_losses(psi_fit_engine *engine, int adam_step, float *d_out4, vo
 int psi_fit_decode_forward(psi_fit_engine *engine, const float *d_x75, const float *d_cam_ext, float *d_verts, void *stream);
 int psi_fit_decode_backward(psi_fit_engine *engine, const float *d_grad_verts, float *d_grad_x75, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Data-parallel fitting with the collective issued from C (RCCL over xGMI; one process per GPU).
+ * The reference has no multi-GPU code (cluster_mpi/htcondor_submission.sub:15 submits independent processes); what is sharded
+ * here is the batch of FittingOP.fitting (fitting_proxe.py:167-195): rank r owns its rows of xhr_rec and their Adam state, the
+ * loss normalisers of fitting_proxe.py:105-110,139,155-158 run over the GLOBAL batch through one 6-float all-reduce per iteration.
+ * A communicator is created once per process: rank 0 calls psi_dp_unique_id and hands the 128 bytes to every rank (any side channel:
+ * torch.distributed's store, MPI, a file), then every rank calls psi_dp_comm_create with its rank — a collective call, made with the
+ * rank's GPU current.  psi_fit_iterate_dp runs n_iter iterations of [forward half, ncclAllReduce(stats[0..5]), backward half] on
+ * `stream`; with use_graph != 0 as 10-iteration hipGraphs that CONTAIN the RCCL kernel (no host code between iterations).  The engine
+ * must have been created with world_size == the communicator's size.  d_stats (device, >= 8 floats, nullable = engine-owned) is the
+ * buffer the all-reduce runs in place on.
+ * ------------------------------------------------------------------------------------------- */
+#define PSI_DP_ID_BYTES 128
+typedef struct psi_dp_comm psi_dp_comm;
+int psi_dp_unique_id(char *h_id128);
+int psi_dp_comm_create(psi_dp_comm **out, const char *h_id128, int rank, int world);
+void psi_dp_comm_destroy(psi_dp_comm *comm);
+int psi_dp_comm_info(const psi_dp_comm *comm, int *rank, int *world, int *rccl_version);
+/* In-place sum over the ranks of d_buf[0..n) on `stream` (the collective psi_fit_iterate_dp issues; exported for tests and for the
+ * training path's scalar reductions). */
+int psi_dp_allreduce_sum(psi_dp_comm *comm, float *d_buf, int n, void *stream);
+int psi_fit_iterate_dp(psi_fit_engine *engine, psi_dp_comm *comm, int n_iter, int use_graph, float *d_stats, void *stream);
+
 /* Per-kernel timing of one fitting iteration with HIP events on the launch stream (an event is recorded right after
  * every kernel launch of the sequence psi_fit_iterate runs; ungraphed), averaged over n_rep iterations.  Advances the
  * optimisation by n_rep steps.  h_names: [max_stages][name_stride] chars, h_ms: [max_stages] milliseconds. */

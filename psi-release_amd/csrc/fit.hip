@@ -1004,6 +1004,14 @@ struct psi_fit_engine {
     hipGraphExec_t ge_half[2];
     bool half_ready[2];
     const float *half_stats[2];
+    // data-parallel path with the collective issued from C (psi_fit_iterate_dp): whole iterations — forward, RCCL all-reduce, backward —
+    // captured like the single-process graphs; the captured graphs bake the communicator and the statistics pointer in
+    hipGraph_t g_dp[2];           // [0] one iteration, [1] GRAPH_UNROLL iterations
+    hipGraphExec_t ge_dp[2];
+    bool dp_ready[2];
+    const void *dp_comm;
+    const float *dp_stats;
+    bool dp_warm;                 // the communicator has run a collective for this engine outside capture
 };
 
 // head / tail launches: grid = B bodies x hc workgroups per body (template instance per cluster width)
@@ -1272,11 +1280,16 @@ extern "C" void psi_fit_destroy(psi_fit_engine *e)
         (void)hipGraphExecDestroy(e->graphN_exec);
         (void)hipGraphDestroy(e->graphN);
     }
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++) {
         if (e->half_ready[i]) {
             (void)hipGraphExecDestroy(e->ge_half[i]);
             (void)hipGraphDestroy(e->g_half[i]);
         }
+        if (e->dp_ready[i]) {
+            (void)hipGraphExecDestroy(e->ge_dp[i]);
+            (void)hipGraphDestroy(e->g_dp[i]);
+        }
+    }
     (void)hipFree(e->blob);
     delete e;
 }
@@ -1382,6 +1395,74 @@ extern "C" int psi_fit_iterate(psi_fit_engine *e, int n_iter, int use_graph, voi
         e->graph_ready = true;
     }
     for (; done < n_iter; done++) PSI_CHECK_HIP(hipGraphLaunch(e->graph_exec, st));
+    return 0;
+}
+
+// Data-parallel iterations with the collective issued from C: forward half -> ncclAllReduce(stats[0..5], sum) -> backward half, n_iter
+// times, on ONE stream.  use_graph: 10-iteration hipGraphs (+ single-iteration graphs for the remainder) that contain the RCCL kernel,
+// so a 100-iteration fit is 10 graph launches per rank and no host code runs between iterations.  The first iteration an engine runs
+// with a given communicator is launched eagerly: RCCL connects its channels lazily at a communicator's first collective, and that
+// setup (allocations, host synchronisation) is illegal under stream capture.
+extern "C" int psi_fit_iterate_dp(psi_fit_engine *e, psi_dp_comm *comm, int n_iter, int use_graph, float *d_stats, void *stream)
+{
+    PSI_REQUIRE(e && comm && n_iter >= 0, "bad arguments");
+    PSI_REQUIRE(psi_dp_world(comm) == e->d.world, "the communicator's size differs from psi_fit_config.world_size");
+    hipStream_t st = (hipStream_t)stream;
+    float *stats = d_stats ? d_stats : e->stats_local;
+    auto one = [&]() -> int {
+        int rc = fit_forward(e, stats, st);
+        if (!rc) rc = psi_dp_allreduce_sum(comm, stats, 6, st);
+        if (!rc) rc = fit_backward(e, stats, st);
+        return rc;
+    };
+    if (e->dp_comm != comm || e->dp_stats != stats) {
+        for (int i = 0; i < 2; i++)
+            if (e->dp_ready[i]) {
+                (void)hipGraphExecDestroy(e->ge_dp[i]);
+                (void)hipGraphDestroy(e->g_dp[i]);
+                e->dp_ready[i] = false;
+            }
+        e->dp_warm = e->dp_warm && e->dp_comm == comm;
+        e->dp_comm = comm;
+        e->dp_stats = stats;
+    }
+    int done = 0;
+    if (!use_graph || (!e->dp_warm && n_iter > 0)) {
+        const int n_eager = use_graph ? 1 : n_iter;
+        for (; done < n_eager; done++) {
+            int rc = one();
+            if (rc) return rc;
+        }
+        e->dp_warm = true;
+        if (!use_graph) return 0;
+    }
+    auto capture = [&](int iters, int slot) -> int {
+        PSI_REQUIRE(st != nullptr, "graph capture needs a non-default stream");
+        PSI_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        int rc = 0;
+        for (int i = 0; i < iters && !rc; i++) rc = one();
+        hipError_t ce = hipStreamEndCapture(st, &e->g_dp[slot]);
+        if (rc) {
+            if (ce == hipSuccess && e->g_dp[slot]) (void)hipGraphDestroy(e->g_dp[slot]);
+            return rc;
+        }
+        PSI_CHECK_HIP(ce);
+        PSI_CHECK_HIP(hipGraphInstantiate(&e->ge_dp[slot], e->g_dp[slot], nullptr, nullptr, 0));
+        e->dp_ready[slot] = true;
+        return 0;
+    };
+    if (n_iter - done >= GRAPH_UNROLL) {
+        if (!e->dp_ready[1]) {
+            int rc = capture(GRAPH_UNROLL, 1);
+            if (rc) return rc;
+        }
+        for (; done + GRAPH_UNROLL <= n_iter; done += GRAPH_UNROLL) PSI_CHECK_HIP(hipGraphLaunch(e->ge_dp[1], st));
+    }
+    if (done < n_iter && !e->dp_ready[0]) {
+        int rc = capture(1, 0);
+        if (rc) return rc;
+    }
+    for (; done < n_iter; done++) PSI_CHECK_HIP(hipGraphLaunch(e->ge_dp[0], st));
     return 0;
 }
 

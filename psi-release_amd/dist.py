@@ -60,6 +60,42 @@ def assert_equal_across_ranks(value, what='value'):
         raise ValueError('%s differs across ranks (this rank: %s, max %s, min %s): shard the rows evenly' % (what, value, float(t[0]), -float(t[1])))
 
 
+_RCCL_COMM = {}
+
+
+def rccl_comm():
+    """The library-owned RCCL communicator of this process (include/psi_hip.h: psi_dp_comm), created on first use over the ranks of
+    the default torch.distributed group: rank 0 draws the unique id, torch.distributed's own channel hands it to the other ranks, every
+    rank joins with its current GPU.  It is what psi_fit_iterate_dp issues the per-iteration all-reduce on — from C, on the engine's
+    stream, inside the iteration's hipGraph.  Only for the nccl (= RCCL) backend: gloo groups (several ranks on one GPU, the
+    single-GPU test boxes) keep the torch.distributed collective between the two half-iterations."""
+    import ctypes
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError('rccl_comm() needs an initialised torch.distributed process group')
+    key = (dist.get_rank(), dist.get_world_size(), torch.cuda.current_device())
+    if key in _RCCL_COMM:
+        return _RCCL_COMM[key]
+    L = hip.lib()
+    buf = ctypes.create_string_buffer(128)
+    if dist.get_rank() == 0:
+        hip.check(L.psi_dp_unique_id(buf), 'psi_dp_unique_id')
+    box = [bytes(buf.raw)]
+    if dist.get_world_size() > 1:
+        dist.broadcast_object_list(box, src=0)
+    h = ctypes.c_void_p()
+    hip.check(L.psi_dp_comm_create(ctypes.byref(h), ctypes.create_string_buffer(box[0], 128), dist.get_rank(), dist.get_world_size()),
+              'psi_dp_comm_create')
+    _RCCL_COMM[key] = h
+    return h
+
+
+def rccl_comm_release():
+    """Destroy the library-owned communicators (before torch.distributed.destroy_process_group at the end of a run)."""
+    for h in _RCCL_COMM.values():
+        hip.lib().psi_dp_comm_destroy(h)
+    _RCCL_COMM.clear()
+
+
 def gather_rows(x):
     """[b,...] per rank -> [b*world,...] on every rank, rank order (rows were sharded contiguously by shard_rows)."""
     if not is_dist():

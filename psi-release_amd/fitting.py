@@ -400,9 +400,15 @@ class FusedEngine:
             hip.check(L.psi_fit_iterate(self.handle, n, int(bool(use_graph)), self.stream.cuda_stream), 'psi_fit_iterate')
             return
         import torch.distributed as tdist
-        # Plain launches by default: two half-graphs per iteration pay the ~8 us graph-launch latency twice (measured over a 1-rank
-        # nccl group: 0.203 ms with half-graphs, 0.190 ms with plain launches, 0.181 ms single-process).  op.dp_use_graph / PSI_DP_GRAPH=1
-        # select the half-graphs.
+        if tdist.get_backend() == 'nccl' and os.environ.get('PSI_DP_PYTHON_LOOP') != '1':
+            # RCCL: the whole loop is device-resident — psi_fit_iterate_dp issues the all-reduce from C on the engine's stream, and with
+            # use_graph the kernels AND the collective of 10 iterations replay as one hipGraph (no Python between iterations)
+            hip.check(L.psi_fit_iterate_dp(self.handle, psi_dist.rccl_comm(), n, int(bool(use_graph)), hip.ptr(self.stats), self.stream.cuda_stream),
+                      'psi_fit_iterate_dp')
+            return
+        # gloo (several ranks on one GPU: the single-GPU test boxes) has no device-side collective: forward half, torch.distributed
+        # all-reduce, backward half.  Plain launches by default: two half-graphs per iteration pay the ~8 us graph-launch latency twice;
+        # op.dp_use_graph / PSI_DP_GRAPH=1 select the half-graphs.
         use_graph = bool(use_graph) and (getattr(self.op, 'dp_use_graph', False) or os.environ.get('PSI_DP_GRAPH') == '1')
         with torch.cuda.stream(self.stream):
             for _ in range(n):

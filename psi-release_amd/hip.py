@@ -55,6 +55,12 @@ SIGNATURES = {
     'psi_fit_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'psi_fit_backward_step': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'psi_fit_iterate': (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    'psi_dp_unique_id': (c_int, [c_void_p]),
+    'psi_dp_comm_create': (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    'psi_dp_comm_destroy': (None, [c_void_p]),
+    'psi_dp_comm_info': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'psi_dp_allreduce_sum': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'psi_fit_iterate_dp': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'psi_fit_read': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'psi_fit_read_losses': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     'psi_fit_decode_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

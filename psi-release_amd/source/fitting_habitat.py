@@ -62,6 +62,8 @@ def main(argv=None):
                           a.max_files, a.shard, rank, world, a.concurrency, a.pack)
     if world > 1:
         torch.distributed.barrier()
+        from psi_release_amd import dist as psi_dist
+        psi_dist.rccl_comm_release()
         torch.distributed.destroy_process_group()
 
 

@@ -110,14 +110,16 @@ def test_training_gradient_allreduce_equals_full_batch(tmp_path, ep):
         assert float((dp[k] - full[k]).abs().max()) / scale < 1e-3, k
 
 
-def test_rccl_leg_at_world_size_one():
-    """The data-parallel sequence (forward half-graph -> RCCL all-reduce of stats[6] -> backward half-graph) over a 1-rank
-    nccl group (PSI_FORCE_DP_PATH=1) reproduces the single-process result: the collective leg the multi-GPU bench relies on,
-    exercised on the one GPU this box has."""
+@pytest.mark.parametrize('iters', [5, 27])
+def test_rccl_leg_at_world_size_one(iters):
+    """The data-parallel loop issued from C (psi_fit_iterate_dp: forward half -> ncclAllReduce of stats[6] on the library's own RCCL
+    communicator -> backward half; the first iteration eager, the rest as hipGraphs that contain the RCCL kernel — 27 iterations = 1
+    eager + two 10-iteration graphs + 6 single-iteration graphs) over a 1-rank nccl group (PSI_FORCE_DP_PATH=1) reproduces the
+    single-process result bit for bit: the collective leg the multi-GPU bench relies on, exercised on the one GPU this box has."""
     import subprocess
     out = {}
     for force in ('0', '1'):
-        env = dict(os.environ, PSI_FORCE_DP_PATH=force, GRAFT_REPO_ROOT=ROOT)
+        env = dict(os.environ, PSI_FORCE_DP_PATH=force, GRAFT_REPO_ROOT=ROOT, PSI_TEST_ITERS=str(iters))
         for attempt in range(2):                               # one retry: a failed rendezvous is not what this test is about
             port = _free_port()
             r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
