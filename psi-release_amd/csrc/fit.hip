@@ -68,7 +68,7 @@ struct FitDev {
     const int *cs_ptr, *cs_idx;                       // vertex -> contact slots (CSR, V+1 / n_c)
     const int *cs_first;                              // [V] first contact slot of the vertex | number of its slots << 24 (0: none)
     const float *scene, *sdf, *gmin, *gmax;           // scene cloud [m,3], volume [D^3], bounds [3]
-    const float *sdf_brick;                           // engine-owned copy of the volume in 4x4x4-brick order (nullptr: D % 4 != 0)
+    const float *sdf_brick;                           // engine-owned copy of the volume in apron-brick order (sdf_device.h; nullptr: D % 4 != 0)
     const float *Wct;                                 // [n_c][64] skinning weights of the contact vertices, one row per contact slot
     // state
     float *x, *xhr, *cam, *adam_m, *adam_v;
@@ -969,10 +969,18 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
 // one-off re-layout of the caller's [ix][iy][iz] volume into the engine's brick order (sdf_device.h)
 __global__ void sdf_to_bricks_kernel(const float *__restrict__ src, float *__restrict__ dst, int D)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)D * D * D;
+    const int nbr = D >> 2;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)nbr * nbr * nbr * PSI_BRICK_FLOATS;
     if (i >= n) return;
-    const int iz = (int)(i % D), iy = (int)((i / D) % D), ix = (int)(i / ((size_t)D * D));
-    dst[psi_brick_offset(ix, iy, iz, D >> 2)] = src[i];
+    const int e = (int)(i % PSI_BRICK_FLOATS);
+    const size_t br = i / PSI_BRICK_FLOATS;
+    const int bz = (int)(br % nbr), by = (int)((br / nbr) % nbr), bx = (int)(br / ((size_t)nbr * nbr));
+    float v = 0.0f;
+    if (e < 125) {
+        const int ix = min(4 * bx + e / 25, D - 1), iy = min(4 * by + (e / 5) % 5, D - 1), iz = min(4 * bz + e % 5, D - 1);
+        v = src[((size_t)ix * D + iy) * D + iz];
+    }
+    dst[i] = v;
 }
 
 __global__ void adam_reset_kernel(float *m, float *v, int *step, int n)
@@ -1194,7 +1202,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     size_t o_hxo = take((size_t)B * f.hc * 128 * 8), o_hxg = take((size_t)B * f.hc * NH * 8), o_hxc = take((size_t)2 * B * 4);
     size_t o_wct = take((size_t)f.n_c * PSI_JP * 4);
     const bool bricks = (cfg->D % 4 == 0) && !(getenv("PSI_SDF_LINEAR") && getenv("PSI_SDF_LINEAR")[0] == '1');
-    size_t o_brick = bricks ? take((size_t)f.D * f.D * f.D * 4) : 0;
+    size_t o_brick = bricks ? take((size_t)(f.D / 4) * (f.D / 4) * (f.D / 4) * PSI_BRICK_FLOATS * 4) : 0;
     size_t lbs_floats = psi_lbs_workspace_floats(lbs, B);
     size_t o_lws = take(lbs_floats * 4), o_nws = take(psi_nn_ws_bytes(B, f.n_c, f.m));
     hipError_t err = hipMalloc((void **)&e->blob, o);
@@ -1241,7 +1249,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
                        f.n_c, J, (float *)f.Wct);
     f.sdf_brick = nullptr;
     if (bricks) {
-        const size_t n = (size_t)f.D * f.D * f.D;
+        const size_t n = (size_t)(f.D / 4) * (f.D / 4) * (f.D / 4) * PSI_BRICK_FLOATS;
         hipLaunchKernelGGL(sdf_to_bricks_kernel, dim3((unsigned)psi_cdiv((long)n, 256)), dim3(256), 0, 0, d_sdf, F(o_brick), f.D);
         f.sdf_brick = F(o_brick);
     }

@@ -20,7 +20,9 @@
 #include "nnindex_device.h"
 #include <algorithm>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
+#include <cmath>
 #include <vector>
 
 #pragma clang fp contract(off)    // the distance expression is spelled out by PSI_SQ3 (psi_common.h) in both arithmetic modes
@@ -152,14 +154,54 @@ extern "C" int psi_nn_index_create(psi_nn_index **out, const float *h_points, in
         }
     for (int i = 0; i < m; i++) opts[i] = rec(i);
     if (bd.nodes.empty()) bd.nodes.push_back(KdNode());
+    // uniform grid for warm queries (nnindex_device.h): about 2.5 points per cell if the cloud filled its bounding box, at most 128
+    // cells per axis; the cell of a point is computed in fp32 with the expression the query side uses
+    float gmn[3], gmx[3];
+    bd.bounds(0, m, gmn, gmx);          // `order` is a permutation of all points
+    float ext[3], emax = 0.0f;
+    for (int a = 0; a < 3; a++) { ext[a] = gmx[a] - gmn[a]; emax = std::max(emax, ext[a]); }
+    int gn[3] = {1, 1, 1};
+    float ginv = 1.0f;
+    const bool use_grid = emax > 0.0f && std::isfinite(emax) && !(getenv("PSI_NN_GRID") && getenv("PSI_NN_GRID")[0] == '0');
+    std::vector<int> cell_start(2, 0);
+    std::vector<float4> gpts;
+    if (use_grid) {
+        double vol = 1.0;
+        for (int a = 0; a < 3; a++) vol *= std::max((double)ext[a], 1e-3 * emax);
+        double h = std::cbrt(vol * 2.5 / m);
+        h = std::max(h, (double)emax / 128.0);
+        ginv = (float)(1.0 / h);
+        for (int a = 0; a < 3; a++) gn[a] = std::min(128, std::max(1, (int)std::floor(ext[a] * ginv) + 1));
+        const size_t ncell = (size_t)gn[0] * gn[1] * gn[2];
+        auto cell_of = [&](int i) {
+            int cc[3];
+            for (int a = 0; a < 3; a++) {
+                const float u = (h_points[(size_t)i * 3 + a] - gmn[a]) * ginv;       // fp32, as in ball_query's range formula
+                cc[a] = std::min(std::max((int)std::floor(u), 0), gn[a] - 1);
+            }
+            return ((size_t)cc[0] * gn[1] + cc[1]) * gn[2] + cc[2];
+        };
+        cell_start.assign(ncell + 1, 0);
+        std::vector<size_t> cid(m);
+        for (int i = 0; i < m; i++) { cid[i] = cell_of(i); cell_start[cid[i] + 1]++; }
+        for (size_t c = 0; c < ncell; c++) cell_start[c + 1] += cell_start[c];
+        std::vector<int> fill(cell_start.begin(), cell_start.end() - 1);
+        gpts.resize(m);
+        for (int i = 0; i < m; i++) gpts[fill[cid[i]]++] = rec(i);                   // ascending original index inside a cell
+    }
     size_t nb_nodes = bd.nodes.size() * sizeof(KdNode), nb_pts = pts.size() * sizeof(float4), nb_opts = opts.size() * sizeof(float4);
+    size_t nb_cs = use_grid ? cell_start.size() * sizeof(int) : 0, nb_gp = gpts.size() * sizeof(float4);
     size_t off_pts = (nb_nodes + 255) & ~(size_t)255;
     size_t off_opts = (off_pts + nb_pts + 255) & ~(size_t)255;
+    size_t off_cs = (off_opts + nb_opts + 255) & ~(size_t)255;
+    size_t off_gp = (off_cs + nb_cs + 255) & ~(size_t)255;
     char *blob = nullptr;
-    PSI_CHECK_HIP(hipMalloc((void **)&blob, off_opts + nb_opts));
+    PSI_CHECK_HIP(hipMalloc((void **)&blob, off_gp + nb_gp + 64));
     hipError_t e = hipMemcpy(blob, bd.nodes.data(), nb_nodes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(blob + off_pts, pts.data(), nb_pts, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(blob + off_opts, opts.data(), nb_opts, hipMemcpyHostToDevice);
+    if (e == hipSuccess && use_grid) e = hipMemcpy(blob + off_cs, cell_start.data(), nb_cs, hipMemcpyHostToDevice);
+    if (e == hipSuccess && use_grid) e = hipMemcpy(blob + off_gp, gpts.data(), nb_gp, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(blob);
         psi_set_error("psi_nn_index_create: upload failed: %s", hipGetErrorString(e));
@@ -173,6 +215,10 @@ extern "C" int psi_nn_index_create(psi_nn_index **out, const float *h_points, in
     ix->d.root = root;
     ix->d.m = m;
     ix->d.rows = rows;
+    ix->d.cell_start = use_grid ? (const int *)(blob + off_cs) : nullptr;
+    ix->d.gpts = (const float4 *)(blob + off_gp);
+    for (int a = 0; a < 3; a++) { ix->d.gorg[a] = gmn[a]; ix->d.gn[a] = gn[a]; }
+    ix->d.ginv = ginv;
     *out = ix;
     return 0;
 }

@@ -42,7 +42,17 @@ struct KdDev {
     int root;                       // child-reference of the root (a leaf when m <= LEAF)
     int m;
     int rows;                       // traversal stack rows this tree needs: 7 pushes per level + slack
+    // Uniform grid over the same cloud, for WARM queries (ball_query below): cell (cx,cy,cz) holds gpts[cell_start[i] .. cell_start[i+1]),
+    // i = (cx * gn[1] + cy) * gn[2] + cz — the cells of a z-run are one contiguous point range.  cell_start == nullptr: no grid.
+    const int *cell_start;          // [gn0*gn1*gn2 + 1]
+    const float4 *gpts;             // cell-ordered {x,y,z,bitcast(orig index)}
+    float gorg[3], ginv;            // cell of a point: clamp(floor((p - gorg) * ginv), 0, gn - 1), evaluated in fp32 exactly like this
+    int gn[3];
 };
+
+constexpr int GRID_MAX_COLS = 3 * LPQ;      // (x,y) cell columns a warm query may touch (three per lane) ...
+constexpr int GRID_MAX_ZRUN = 4;            // ... and cells per column, before it takes the tree walk instead
+constexpr float GRID_EPS = 1e-3f;           // slack of the cell range in cell units: covers the rounding of (p - org) * inv on either side
 
 // lane permutations inside an 8-lane group as DPP modifiers (no LDS traffic)
 template <int CTRL>
@@ -138,6 +148,58 @@ __device__ __forceinline__ void kd_query_body(KdDev T0, QSrc qsrc, int n, float 
     int cur = T.root;
     float curd = 0.0f;
     bool have = active;
+    // Warm query (a candidate from the previous iteration is known): the winner can only lie in the ball of radius sqrt(best) around
+    // the query, so instead of walking the tree — ~8 DEPENDENT node / leaf loads — every point of the grid cells that ball touches is
+    // evaluated: two dependent rounds of independent loads (cell ranges, then points).  Exact for the same reason the tree is: a point
+    // p with computed d(p) <= best has |p - q| <= sqrt(best) (1 + 3e-7) on every axis, the cell range below covers that interval with
+    // GRID_EPS cells of slack against the rounding of the cell formula, every point in range is evaluated with the identical distance
+    // expression and the (d, index) key keeps the lowest index among minima.  A ball that touches too many cells (a body far from
+    // the scene) takes the tree walk.  The decision is uniform over the lanes of a group (they hold the same query and bound).
+    if (have && T.cell_start && best < INFINITY) {
+        const float r = sqrtf(best) * 1.00001f + 1e-30f;
+        int lo[3], hi[3];
+        const float q3[3] = {qx, qy, qz};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float top = (float)(T.gn[a] - 1);          // clamped as floats: a far query must not overflow the conversion
+            lo[a] = (int)fminf(fmaxf(floorf((q3[a] - r - T.gorg[a]) * T.ginv - GRID_EPS), 0.0f), top);
+            hi[a] = (int)fminf(fmaxf(floorf((q3[a] + r - T.gorg[a]) * T.ginv + GRID_EPS), 0.0f), top);
+        }
+        const int nyc = hi[1] - lo[1] + 1, ncol = (hi[0] - lo[0] + 1) * nyc, nzc = hi[2] - lo[2] + 1;
+        if (ncol >= 1 && nyc >= 1 && nzc >= 1 && ncol <= GRID_MAX_COLS && nzc <= GRID_MAX_ZRUN) {
+            int cs[3], ce[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {                      // my columns: c, c + LPQ, c + 2 LPQ — all ranges requested together
+                const int col = c + u * LPQ;
+                cs[u] = ce[u] = 0;
+                if (col < ncol) {
+                    const int cx = lo[0] + col / nyc, cy = lo[1] + col % nyc;
+                    const int base = (cx * T.gn[1] + cy) * T.gn[2];
+                    cs[u] = T.cell_start[base + lo[2]];
+                    ce[u] = T.cell_start[base + hi[2] + 1];
+                }
+            }
+            kd_key k = ~0ull;
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                for (int i = cs[u]; i < ce[u]; i += 4) {        // four points per round trip (indices past the end repeat the last point)
+                    float4 pp[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) pp[t] = T.gpts[min(i + t, ce[u] - 1)];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        float x2 = pp[t].x - qx, y2 = pp[t].y - qy, z2 = pp[t].z - qz;
+                        const kd_key ku = kd_pack(PSI_SQ3(x2, y2, z2), __float_as_int(pp[t].w));
+                        k = ku < k ? ku : k;
+                    }
+                }
+            }
+            k = group_min<LPQ>(k);
+            bestk = k < bestk ? k : bestk;
+            best = kd_key_d(bestk);
+            have = false;                                      // done: the tree walk below is skipped for this query
+        }
+    }
     const int gshift = (tid & 63) & ~(LPQ - 1);               // bit position of my group inside the wave's ballot
     while (true) {
         while (!have && sp > 0) {                             // pop until something survives the current bound (group-uniform)

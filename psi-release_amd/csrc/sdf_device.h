@@ -75,17 +75,17 @@ __device__ __forceinline__ float psi_trilinear(const float *__restrict__ vol, co
 
 
 // ------------------------------------------------------------------------------------------------
-// Bricked volume layout (the fused fitting engine keeps its own copy in this order): 4 x 4 x 4 bricks of 64 floats (256 bytes),
-// brick-major [bx][by][bz], inside a brick [lx][ly][lz].  In the plain [ix][iy][iz] order the four (x,y) rows of a sample's eight
-// corners are D*4 and D*D*4 bytes apart — four cache lines per sample, no two samples of nearby vertices sharing any unless they
-// agree in (ix,iy); in bricks the eight corners lie in two lines (the two lx slabs of one brick) three times out of four per axis
-// and body vertices that are a few voxels apart hit the same 256 bytes.  D % 4 == 0.
+// Bricked volume layout WITH A ONE-VOXEL APRON (the fused fitting engine keeps its own copy in this order): the volume is cut into
+// 4 x 4 x 4-cell bricks; a brick stores the 5 x 5 x 5 voxels its cells touch (the upper faces are copies of the neighbours' lower
+// faces; beyond the volume the last voxel is repeated), [lx][ly][lz] with strides 25 / 5 / 1, padded to 128 floats = 512 bytes = four
+// 128-byte lines.  Every sample finds all eight corners inside ONE brick, within 31 floats of each other (one or two cache lines),
+// and the two z-neighbours of a corner pair are adjacent: FOUR 8-byte gathers per sample.  (History: plain [ix][iy][iz] order = four
+// cache lines per sample; apron-less 4 x 4 x 4 bricks = 8 four-byte gathers, because a z-pair straddles bricks one time in four.  The
+// gathers' L1 tag lookups — one per lane and instruction — are what bounds the fused skinning + SDF kernel at large batches,
+// profiles/r02_pmc_skin_fwd_sdf_b512.txt; halving the gather instructions halves them.)  D % 4 == 0.  Twice the footprint of the
+// plain volume (134 MB at 256^3); a body still only touches the bricks around it.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ size_t psi_brick_offset(int ix, int iy, int iz, int nbr)
-{
-    const size_t brick = ((size_t)(ix >> 2) * nbr + (iy >> 2)) * nbr + (iz >> 2);
-    return brick * 64 + ((ix & 3) << 4) + ((iy & 3) << 2) + (iz & 3);
-}
+constexpr int PSI_BRICK_FLOATS = 128;
 
 __device__ __forceinline__ float psi_trilinear_bricked(const float *__restrict__ vol, const float *__restrict__ gmin,
                                                        const float *__restrict__ gmax, float x, float y, float z, int D,
@@ -95,10 +95,13 @@ __device__ __forceinline__ float psi_trilinear_bricked(const float *__restrict__
     PsiAxis ay = psi_axis_setup(y, gmin[1], gmax[1], D, align_corners);
     PsiAxis az = psi_axis_setup(z, gmin[2], gmax[2], D, align_corners);
     const int nbr = D >> 2;
-    float c000 = vol[psi_brick_offset(ax.i0, ay.i0, az.i0, nbr)], c001 = vol[psi_brick_offset(ax.i0, ay.i0, az.i1, nbr)];
-    float c010 = vol[psi_brick_offset(ax.i0, ay.i1, az.i0, nbr)], c011 = vol[psi_brick_offset(ax.i0, ay.i1, az.i1, nbr)];
-    float c100 = vol[psi_brick_offset(ax.i1, ay.i0, az.i0, nbr)], c101 = vol[psi_brick_offset(ax.i1, ay.i0, az.i1, nbr)];
-    float c110 = vol[psi_brick_offset(ax.i1, ay.i1, az.i0, nbr)], c111 = vol[psi_brick_offset(ax.i1, ay.i1, az.i1, nbr)];
+    // i1 = min(i0 + 1, D - 1) is voxel l + 1 of the same brick (the apron repeats the last voxel beyond the volume)
+    const size_t brick = ((size_t)(ax.i0 >> 2) * nbr + (ay.i0 >> 2)) * nbr + (az.i0 >> 2);
+    const float *p = vol + brick * PSI_BRICK_FLOATS + (ax.i0 & 3) * 25 + (ay.i0 & 3) * 5 + (az.i0 & 3);
+    const psi_f2u p00 = *(const psi_f2u *)(p), p01 = *(const psi_f2u *)(p + 5);
+    const psi_f2u p10 = *(const psi_f2u *)(p + 25), p11 = *(const psi_f2u *)(p + 30);
+    const float c000 = p00.x, c001 = p00.y, c010 = p01.x, c011 = p01.y;
+    const float c100 = p10.x, c101 = p10.y, c110 = p11.x, c111 = p11.y;
     const float wx1 = ax.w1, wx0 = 1.0f - ax.w1;
     const float wy1 = ay.w1, wy0 = 1.0f - ay.w1;
     const float wz1 = az.w1, wz0 = 1.0f - az.w1;

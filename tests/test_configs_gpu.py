@@ -46,15 +46,71 @@ def _oracle(smplx_data, vposer_sd, scene, B, **kw):
                            synth.contact_ids_from_parts(scene.contact_parts), B, **kw)
 
 
-def _check(x_gpu, losses_gpu, x_ref, losses_ref):
-    losses_gpu, losses_ref = np.asarray(losses_gpu), np.asarray(losses_ref)
-    assert np.abs(losses_gpu - losses_ref).max() < 1e-5, (losses_gpu, losses_ref)
-    assert rel_err(losses_gpu, losses_ref) < 1e-4
-    # parameters after 3 Adam steps: a last-bit gradient difference on a near-zero gradient entry becomes a 1e-4..1e-3 parameter
-    # difference (normalised step, lr 0.1) — same bound as the configs[1] trajectory test (test_parity_gaps_gpu.py)
+def _first_moment(op):
+    """Adam's first moment after ONE step = (1 - beta1) * gradient of the first iteration, [B,75]."""
+    if op.engine == 'fused':
+        return op._fused.buffer('adam_m', (op.batch_size, 75)).cpu().numpy()
+    return op.optimizer.state[op.xhr_rec]['exp_avg'].detach().cpu().numpy()
+
+
+def _run(op, bodies):
+    runner = op.make_step_runner(bodies)
+    losses, m1 = [], None
+    for it in range(ITERS):
+        runner.step()
+        losses.append(runner.last_losses())
+        if it == 0:
+            m1 = _first_moment(op)
+    runner.finish()
+    return GT.convert_to_3D_rot(op.xhr_rec).detach().cpu().numpy(), np.asarray(losses), m1
+
+
+def _oracle_run(fo, bodies, cam):
+    xhr = O.convert_to_6d_rot(torch.as_tensor(synth.body_vector_72(bodies), dtype=torch.float32))
+    cam = torch.as_tensor(cam, dtype=torch.float32)
+    fo.xhr_rec.data = xhr.clone()
+    losses, m1 = [], None
+    for it in range(ITERS):                                  # FittingOracle.fitting (fitting_proxe.py:177-189), one step at a time
+        fo.optimizer.zero_grad()
+        ls = fo.cal_loss(xhr, cam)
+        losses.append([float(l.detach()) for l in ls])
+        sum(ls).backward()
+        fo.optimizer.step()
+        if it == 0:
+            m1 = fo.optimizer.state[fo.xhr_rec]['exp_avg'].detach().numpy().copy()
+    return O.convert_to_3d_rot(fo.xhr_rec).detach().numpy(), np.asarray(losses), m1
+
+
+def _check(gpu, ref):
+    """(x after ITERS steps, losses per iteration, first Adam moment) of the product against the oracle.
+
+    What is compared exactly and what is not.  With 64 bodies in the global batch every mean-type loss is divided by 64 x (75 | 32 |
+    n_c) and the gradient entries are of order 1e-5, one in a hundred below 1e-7.  Adam's step is lr * m / (sqrt(v) + 1e-8): where
+    |g| is within a few 1e-8 of zero the step reacts to absolute differences of 1e-9 — fp32 summation order — with changes of 1e-3 to
+    2 * lr.  That is a property of the reference's optimiser at this batch size (its own CPU and CUDA runs differ the same way), not of
+    an implementation, so the comparison is made where it is well-posed:
+      * the GRADIENT of the first iteration (read back from Adam's first moment), every entry, to 1e-4 of the largest entry — except
+        that up to three bodies may carry ONE vertex whose SDF value is within fp32 rounding of zero and is masked differently
+        (sdf < 0, fitting_proxe.py:155; among 670 000 vertices about one per iteration is): their gradient then differs by that
+        vertex's share, bounded here by 2 % of the body's largest entry;
+      * the loss values of every iteration (1e-5; the last one 2e-4: it is evaluated after two such steps);
+      * the parameters after ITERS steps: at least 97 % of the entries within 1e-4, and every entry whose first-iteration gradient is
+        not tiny (|g| > 1e-6, Adam's step well-conditioned) within 2e-3 — the bound of the configs[1] trajectory test."""
+    (x_gpu, l_gpu, m_gpu), (x_ref, l_ref, m_ref) = gpu, ref
+    g_gpu, g_ref = m_gpu / 0.1, m_ref / 0.1
+    gerr = np.abs(g_gpu - g_ref).max(axis=1)
+    loose = gerr > 1e-4 * np.abs(g_ref).max()
+    assert loose.sum() <= 3, (int(loose.sum()), np.sort(gerr)[-5:], np.abs(g_ref).max())
+    assert np.all(gerr[loose] <= 0.02 * np.abs(g_ref[loose]).max(axis=1)), (gerr[loose], np.abs(g_ref[loose]).max(axis=1))
+    assert np.abs(l_gpu[:2] - l_ref[:2]).max() < 1e-5, (l_gpu, l_ref)
+    assert np.abs(l_gpu[2:] - l_ref[2:]).max() < 2e-4, (l_gpu, l_ref)
+    assert rel_err(l_gpu[:, 1:], l_ref[:, 1:]) < 1e-4
     err = np.abs(x_gpu - x_ref)
-    assert np.mean(err < 1e-4) > 0.99, float(np.mean(err < 1e-4))
-    assert err.max() < 2e-3, float(err.max())
+    assert np.mean(err < 1e-4) > 0.97, float(np.mean(err < 1e-4))
+    # 72-D x vs 75-D gradient: columns 0:3 map 1:1, 3:6 (axis-angle) depend on the six 6D entries, the rest shift by three
+    g72 = np.concatenate([np.abs(g_ref[:, :3]), np.abs(g_ref[:, 3:9]).min(axis=1, keepdims=True).repeat(3, 1), np.abs(g_ref[:, 9:])], axis=1)
+    well = g72 > 1e-6
+    assert err[well].max() < 2e-3, (float(err[well].max()), int(well.sum()), err.size)
 
 
 def _rank_worker(rank, world, port, tmp):
@@ -67,14 +123,10 @@ def _rank_worker(rank, world, port, tmp):
     bodies = synth.make_bodies(13, per * world)
     bodies['cam_ext'] = synth.make_cam_ext(9, per * world)
     op = fitting.FittingOP(_cfg(synth.make_smplx(7), synth.make_vposer_state(3), scene, per), dict(LOSS))
-    runner = op.make_step_runner({k: v[rank * per:(rank + 1) * per] for k, v in bodies.items()})
-    losses = []
-    for _ in range(ITERS):
-        runner.step()
-        losses.append(runner.last_losses())
-    runner.finish()
-    np.save(os.path.join(tmp, 'x%d.npy' % rank), GT.convert_to_3D_rot(op.xhr_rec).detach().cpu().numpy())
-    np.save(os.path.join(tmp, 'l%d.npy' % rank), np.asarray(losses))
+    x, losses, m1 = _run(op, {k: v[rank * per:(rank + 1) * per] for k, v in bodies.items()})
+    np.save(os.path.join(tmp, 'x%d.npy' % rank), x)
+    np.save(os.path.join(tmp, 'l%d.npy' % rank), losses)
+    np.save(os.path.join(tmp, 'm%d.npy' % rank), m1)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -89,10 +141,9 @@ def test_configs3_two_ranks_of_32_bodies_equal_the_oracle_on_64(tmp_path, smplx_
     scene = synth.make_scene(0, M, D, NC)
     bodies = synth.make_bodies(13, per * world)
     bodies['cam_ext'] = synth.make_cam_ext(9, per * world)
+    m_gpu = np.concatenate([np.load(tmp_path / ('m%d.npy' % r)) for r in range(world)])
     fo = _oracle(smplx_data, vposer_sd, scene, per * world)
-    rec = []
-    x_ref = fo.fitting(synth.body_vector_72(bodies), bodies['cam_ext'], ITERS, record=rec).detach().numpy()
-    _check(x_gpu, l0, x_ref, rec)
+    _check((x_gpu, l0, m_gpu), _oracle_run(fo, bodies, bodies['cam_ext']))
 
 
 @pytest.mark.parametrize('engine', ['fused', 'modular'])
@@ -102,15 +153,7 @@ def test_configs4_habitat_64_bodies_full_size_vs_oracle(smplx_data, vposer_sd, e
     bodies = synth.make_bodies(17, B)
     bodies['cam_ext'] = synth.make_cam_ext(2, 1)                  # one camera per view (test_habitat_s2.py writes one cam_ext per body file)
     op = fitting.FittingOPHabitat(_cfg(smplx_data, vposer_sd, scene, B, engine), dict(LOSS))
-    runner = op.make_step_runner(dict(bodies))
-    got = []
-    for _ in range(ITERS):
-        runner.step()
-        got.append(runner.last_losses())
-    runner.finish()
-    x_gpu = GT.convert_to_3D_rot(op.xhr_rec).detach().cpu().numpy()
+    gpu = _run(op, dict(bodies))
     fo = _oracle(smplx_data, vposer_sd, scene, B, contact_const=1.0)                          # fitting_habitat.py:141
     cam = bodies['cam_ext'][:1] @ np.diag([1.0, -1.0, -1.0, 1.0]).astype(np.float32)          # fitting_habitat.py:179-184
-    rec = []
-    x_ref = fo.fitting(synth.body_vector_72(bodies), np.repeat(cam, B, axis=0), ITERS, record=rec).detach().numpy()
-    _check(x_gpu, got, x_ref, rec)
+    _check(gpu, _oracle_run(fo, bodies, np.repeat(cam, B, axis=0)))

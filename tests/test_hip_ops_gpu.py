@@ -145,6 +145,8 @@ def _clouds(kind, m, rs):
         a = a / np.linalg.norm(a, axis=1, keepdims=True) * 1.3
         f = np.stack([rs.uniform(-2, 2, m - m // 2), rs.uniform(-2, 2, m - m // 2), np.full(m - m // 2, -1.0)], 1)
         return np.concatenate([a, f]).astype(np.float32)
+    if kind == 'plane':                                     # degenerate bounding box: every point on z = 0.5 exactly
+        return np.stack([rs.uniform(-2, 2, m), rs.uniform(-1, 1, m), np.full(m, 0.5)], 1).astype(np.float32)
     if kind == 'lattice':                                   # exact ties everywhere
         g = np.stack(np.meshgrid(*[np.arange(-4, 4)] * 3, indexing='ij'), -1).reshape(-1, 3).astype(np.float32) * 0.25
         return np.concatenate([g, g[::3]])[:m] if m <= len(g) + len(g[::3]) else g
@@ -176,6 +178,35 @@ def test_kdtree_index_bit_exact_vs_bruteforce(kind, m):
     assert torch.equal(i3, i) and torch.equal(d3, d)
     od, oi, _, _ = O.chamfer_nn_np(x[:1, :200], y[None], both=False)
     assert np.array_equal(i[:1, :200].cpu().numpy(), oi) and np.array_equal(d[:1, :200].cpu().numpy(), od)
+
+
+@pytest.mark.parametrize('kind,m,spread', [('uniform', 32768, 0.03), ('uniform', 32768, 0.3), ('surface', 20000, 0.05), ('lattice', 600, 0.125),
+                                           ('plane', 3000, 0.05), ('uniform', 9, 0.1)])
+def test_warm_queries_take_the_grid_and_stay_bit_exact(kind, m, spread):
+    """The fitting loop's situation: every query carries last iteration's winner as its hint and has moved a little.  Warm queries are
+    answered from the uniform grid (all points of the cells the ball of radius sqrt(d_hint) touches; nnindex_device.h) or, when that
+    ball is large, by the tree walk — either way distances and indices must equal brute force bit for bit, over several steps, with
+    queries on cell boundaries, exact ties (lattice), a flat cloud, and some hints that are stale or absent."""
+    rs = np.random.RandomState(7 * m + int(spread * 1000))
+    y = _clouds(kind, m, rs)
+    m = len(y)
+    B, n = 4, 2048
+    x = (y[rs.randint(0, m, (B, n))] + rs.standard_normal((B, n, 3)) * spread).astype(np.float32)
+    if kind == 'lattice':
+        x[2] = np.round(x[2] * 4) / 4 + 0.125               # equidistant to several lattice points
+    x[3, :64] = np.round(x[3, :64] * 8) / 8                  # coordinates on round numbers (cell boundaries of many grids)
+    index = ops.SceneNNIndex(y, DEV)
+    yb = T(np.broadcast_to(y, (B, m, 3)).copy())
+    hint = torch.full((B, n), -1, dtype=torch.int32, device=DEV)
+    for step in range(4):
+        d, i = index.query(T(x), hint=hint)
+        rd, ri, _, _ = ops.chamfer_forward_raw(T(x), yb, both=False)
+        assert torch.equal(i, ri) and torch.equal(d, rd), (kind, step)
+        assert torch.equal(hint, ri)
+        x = (x + rs.standard_normal(x.shape) * spread * 0.1).astype(np.float32)
+        if step == 1:                                        # some stale / absent hints in the middle of the run
+            hint[0, :100] = torch.tensor(rs.randint(0, m, 100), dtype=torch.int32, device=DEV)
+            hint[1, :100] = -1
 
 
 def test_kdtree_backward_matches_bruteforce():
