@@ -159,6 +159,20 @@ def chamfer_dist(xyz1, xyz2):
     return ChamferOracleFn.apply(xyz1, xyz2)
 
 
+def chamfer_dist_expanded(xyz1, xyz2):
+    """The pure-PyTorch Chamfer of the reference, chamfer_pytorch/chamfer_python.py:4-9,18-28: P = |x|^2 + |y|^2 - 2 x.y^T (expanded
+    form, matrix products) and a min over it — differentiable through autograd, one body at a time so that P stays 268 MB at
+    n = 2048, m = 32768.  Used only as the second CPU-baseline variant: its rounding differs from
+    chamfer.cu's direct-difference expression, so it is NOT what parity is measured against."""
+    d1, d2 = [], []
+    for b in range(xyz1.shape[0]):
+        x, y = xyz1[b], xyz2[b]
+        P = (x * x).sum(1, keepdim=True) + (y * y).sum(1).unsqueeze(0) - 2.0 * torch.mm(x, y.t())
+        d1.append(P.min(dim=1)[0])
+        d2.append(P.min(dim=0)[0])
+    return torch.stack(d1), torch.stack(d2)
+
+
 def sdf_sample_c(sdf, scene_id, gmin, gmax, verts, align_corners=True):
     """Scalar C statement of SURVEY Appendix C trilinear + analytic gradient."""
     lib = c_oracle()
@@ -442,7 +456,7 @@ class FittingOracle:
     """FittingOP (fitting_proxe.py:40-195) with explicit inputs instead of files."""
 
     def __init__(self, smplx_model: SMPLXOracle, vposer_sd: dict, scene_verts, sdf, grid_min, grid_max,
-                 contact_ids, batch_size, weights=None, lr=0.1, contact_const=0.01, align_corners=True):
+                 contact_ids, batch_size, weights=None, lr=0.1, contact_const=0.01, align_corners=True, chamfer='direct'):
         self.bm = smplx_model
         self.vp = {k: torch.tensor(np.asarray(v)) for k, v in vposer_sd.items() if 'dec' in k}
         self.B = batch_size
@@ -456,6 +470,7 @@ class FittingOracle:
         self.w = w
         self.contact_const = contact_const
         self.align_corners = align_corners
+        self.chamfer = chamfer_dist if chamfer == 'direct' else chamfer_dist_expanded     # 'expanded': CPU-baseline variant only
         self.xhr_rec = torch.zeros(batch_size, 75, requires_grad=True)
         self.optimizer = torch.optim.Adam([self.xhr_rec], lr=lr)                   # fitting_proxe.py:73-74
 
@@ -473,7 +488,7 @@ class FittingOracle:
         loss_vposer = self.w['weight_loss_vposer'] * torch.mean(xh_rec[:, 16:48] ** 2)
         verts = self.body_verts(xh_rec, cam_ext)
         contact = verts[:, self.vid, :]
-        d1, _ = chamfer_dist(contact.contiguous(), self.s_verts.contiguous())
+        d1, _ = self.chamfer(contact.contiguous(), self.s_verts.contiguous())
         loss_contact = self.w['weight_contact'] * contact_loss(d1, self.contact_const)
         # the reference replicates the volume per sample (fitting_proxe.py:90); expand() is arithmetic-neutral
         body_sdf = sdf_sample(self.sdf.expand(self.B, -1, -1, -1), self.gmin, self.gmax, verts, self.align_corners)
@@ -490,7 +505,7 @@ class FittingOracle:
             self.optimizer.zero_grad()
             losses = self.cal_loss(xhr, cam_ext)
             if record is not None:
-                record.append([float(l) for l in losses])
+                record.append([float(l.detach()) for l in losses])
             sum(losses).backward()
             self.optimizer.step()
         return convert_to_3d_rot(self.xhr_rec)
