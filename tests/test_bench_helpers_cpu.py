@@ -30,15 +30,20 @@ def test_work_table_and_roofline_of_the_dominant_kernel():
     for k in ('head_fwd_kernel', 'blend_fwd_kernel', 'fwd_scene_kernel', 'skin_bwd_v_grad_kernel', 'bwd_joint_kernel',
               'reduce_partials_kernel', 'head_bwd_adam_kernel'):
         assert k in work and work[k][0] == 'byte' and work[k][1] > 0, k
-    assert abs(work['bwd_joint_kernel'][1] - 79.1e6) < 0.2e6
+    # SURVEY 8(d) bytes only, unpadded model dimensions: dirs [506, 31425] streamed once + g_vposed in + g_feat out, skinning weights
+    # + g_local + v_posed in + joint-transform gradients out
+    V, K = 10475, 506
+    want = K * 3 * V * 4 + 32 * 3 * V * 4 + 32 * K * 4 + 55 * V * 4 + 2 * 32 * 3 * V * 4 + 32 * 55 * 16 * 4
+    assert work['bwd_joint_kernel'][1] == want and abs(want - 78.2e6) < 0.2e6
+    # the search lanes' weight-row re-reads are implementation traffic: the scene kernel counts 32 B per contact query, not 276
+    assert work['fwd_scene_kernel'][1] < 55 * V * 4 + 32 * 3 * V * 4 + 32 * V * 56 + 32 * 2048 * 40 + 32768 * 16
     agg = {k: 0.02 for k in work if work[k][0] == 'byte'}                    # 20 us each
-    agg['bwd_joint_kernel'] = 0.0264
+    agg['fwd_scene_kernel'] = 0.0264                                           # the LONGEST kernel is the dominant one
     roof, per = bench.roofline_from_kernels(args, agg, work)
-    assert roof['kernel'] == 'bwd_joint_kernel' and roof['bound'] == 'hbm' and roof['peak'] == 8000.0 and roof['unit'] == 'GB/s'
-    assert abs(roof['achieved'] - 79.08e6 / 26.4e-6 * 1e-9) < 5 and abs(roof['frac'] - roof['achieved'] / 8000.0) < 1e-3
+    assert roof['kernel'] == 'fwd_scene_kernel' and roof['bound'] == 'hbm' and roof['peak'] == 8000.0 and roof['unit'] == 'GB/s'
+    assert abs(roof['achieved'] - work['fwd_scene_kernel'][1] / 26.4e-6 * 1e-9) < 5 and abs(roof['frac'] - roof['achieved'] / 8000.0) < 1e-3
+    assert 0.15 < roof['share_of_iteration_time'] < 0.2
     assert set(per) == set(agg)
-    if os.path.exists(os.path.join(ROOT, 'profiles', 'r02_kernel_stats.csv')):
-        assert 0.2 < roof['rocprofv3_frac'] < 1.0 and roof['rocprofv3_avg_launch_ms'] > 0
 
 
 def test_rank_launcher_command_line(monkeypatch):
