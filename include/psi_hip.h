@@ -259,6 +259,27 @@ int psi_linear_forward(const void *x, int x_is_bf16, const float *W, const float
 int psi_linear_backward(const float *gy, const float *act_out, const void *x, int x_is_bf16, const float *W, int M, int N, int K,
                         float slope, void *gx, float *gW, float *gbias, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Batch normalisation of the scene trunk with its ReLU and skip connection fused in — replaces, inside the BasicBlocks and the stem of
+ * the ResNet-18 prefix the reference builds (cvae.py:427-435; torchvision resnet18 children[1:6] = bn1, relu, maxpool, layer1, layer2),
+ *   out = relu(bn1(conv1(x)))          out = relu(bn2(conv2(out)) + identity)          identity = downsample_bn(downsample_conv(x))
+ * in TRAINING mode (train_s1.py / train_s2.py call model_h.train(): batch statistics, running statistics updated with `momentum`,
+ * unbiased running variance, num_batches_tracked += 1 — nn.BatchNorm2d semantics).
+ * x, residual (nullable), y: bf16 feature maps [M, C] with the channel fastest (M = N*H*W: an NHWC / torch channels_last tensor),
+ * C % 8 == 0, C <= 256.  y = act(gamma * (x - mean) * invstd + beta (+ residual)), act = ReLU when relu != 0.  save_mean / save_invstd
+ * [C] fp32 are kept for the backward.  running_mean / running_var / num_batches_tracked (int64) may be NULL.
+ * Backward: dy [M,C] bf16 = dL/dy -> dx [M,C] bf16, dresidual [M,C] bf16 (nullable: the gradient of the skip input = dy masked by the
+ * ReLU), dgamma / dbeta [C] fp32 (OVERWRITTEN).  y is the forward output (needed only when relu != 0, for the mask).
+ * ws: psi_bn_workspace_floats(M, C) floats of device scratch per call (per-block partial sums; deterministic summation order).
+ * ------------------------------------------------------------------------------------------- */
+size_t psi_bn_workspace_floats(long M, int C);
+int psi_bn_forward(const void *x, const void *residual, const float *gamma, const float *beta, float *running_mean,
+                   float *running_var, long long *num_batches_tracked, long M, int C, int relu, float momentum, float eps,
+                   void *y, float *save_mean, float *save_invstd, float *ws, void *stream);
+int psi_bn_backward(const void *dy, const void *x, const void *y, const float *gamma, const float *save_mean,
+                    const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
+                    float *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,354 @@
+// Batch normalisation of the scene trunk fused with what follows it — ReLU and the BasicBlock's skip connection — for NHWC bf16
+// feature maps, forward (training statistics) and backward, gfx950.
+//
+// Replaces, inside torchvision's BasicBlock as the reference builds it (cvae.py:427-435 -> resnet18 children[1:6]; train_s1.py /
+// train_s2.py run the trunk in .train() mode, so the statistics are the batch's):
+//     out = relu(bn1(conv1(x)));  out = bn2(conv2(out));  out = relu(out + identity)          and the stem's relu(bn1(conv(x)))
+// i.e.  y = act(gamma * (x - mean_c) / sqrt(var_c + eps) + beta (+ residual)),  act = ReLU or identity, with
+// running_mean / running_var updated like nn.BatchNorm2d (momentum, unbiased variance) and num_batches_tracked += 1.
+//
+// These are HBM-bound passes over [M = N*H*W, C] tensors (C = 64 or 128 channels, channel-fastest), so what matters is how many
+// times the feature map crosses HBM and that every access is a full 16-byte lane load: the library path (MIOpen spatial BN: three
+// launches forward, three backward, plus separate ReLU / add / clamp launches) moves a 17 MB layer1 map in 25-31 us per pass;
+// a plain bandwidth-bound pass is ~6 us.
+//   forward : stats (read x) -> finalize (C values) -> apply (read x [+ residual], write y)
+//   backward: reduce (read dy, y|x) -> finalize -> apply (read dy, x, y, write dx [, d_residual])
+// The reductions are deterministic: fixed per-block partials, summed in order by the one-block finalize kernels (double precision
+// for the variance, so E[x^2] - mean^2 does not cancel).
+#include "psi_internal.h"
+#include <hip/hip_bf16.h>
+
+namespace {
+
+typedef unsigned short bf16raw;
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f)           // round to nearest even (finite inputs; NaN stays NaN)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ void unpack8(const u4 &v, float (&f)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u4 pack8(const float (&f)[8])
+{
+    u4 v;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = (unsigned)f2bf(f[2 * i]) | ((unsigned)f2bf(f[2 * i + 1]) << 16);
+    return v;
+}
+
+constexpr int BN_BLK = 256;
+constexpr int BN_MAXC = 256;
+
+// A block covers RPB = 256 / (C/8) rows per pass; thread (r, g): row r, channels 8g..8g+7.  NACC accumulators per channel per thread
+// are reduced over the block's rows through LDS; result for channel c in out[blockIdx.x][q][c].
+template <int NQ>
+__device__ __forceinline__ void block_reduce_store(float (&acc)[NQ][8], int C, int cg, int rr, int rpb, float *__restrict__ out)
+{
+    __shared__ float sh[NQ][BN_BLK][8 + 1];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) sh[q][t][i] = acc[q][i];
+    __syncthreads();
+    // thread t < NQ * C sums channel c of quantity q over the rpb row-threads, in row order
+    const int ngrp = C / 8;
+    for (int o = t; o < NQ * C; o += BN_BLK) {
+        const int q = o / C, c = o % C, g = c >> 3, i = c & 7;
+        float s = 0.0f;
+        for (int r = 0; r < rpb; r++) s += sh[q][r * ngrp + g][i];
+        out[((size_t)blockIdx.x * NQ + q) * C + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(BN_BLK) void bn_stats_kernel(const u4 *__restrict__ x, long M, int C, float *__restrict__ part)
+{
+    const int ngrp = C / 8, rpb = BN_BLK / ngrp;
+    const int g = threadIdx.x % ngrp, rr = threadIdx.x / ngrp;
+    float acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[0][i] = acc[1][i] = 0.0f;
+    const long stride = (long)gridDim.x * rpb;
+    long r = (long)blockIdx.x * rpb + rr;
+    // two rows in flight per thread
+    for (; r + stride < M; r += 2 * stride) {
+        const u4 a = x[r * ngrp + g], b = x[(r + stride) * ngrp + g];
+        float fa[8], fb[8];
+        unpack8(a, fa);
+        unpack8(b, fb);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            acc[0][i] += fa[i] + fb[i];
+            acc[1][i] += fa[i] * fa[i] + fb[i] * fb[i];
+        }
+    }
+    if (r < M) {
+        float fa[8];
+        unpack8(x[r * ngrp + g], fa);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            acc[0][i] += fa[i];
+            acc[1][i] += fa[i] * fa[i];
+        }
+    }
+    block_reduce_store<2>(acc, C, g, rr, rpb, part);
+}
+
+// Sum of the per-block partials for every (quantity, channel) output by ONE block of 1024 threads: output o = q * C + c is handled by
+// 1024 / (2C) threads, thread slice s adding partials s, s + nsl, ... with four independent accumulators (the loads of a 512-partial
+// column issued by one thread would be 512 dependent-latency steps), the slices are then combined in slice order: deterministic.
+__device__ __forceinline__ void sum_partials(const float *__restrict__ part, int nblk, int C, double *sh /* [1024] */, double &s_out, double &q_out)
+{
+    const int t = threadIdx.x, no = 2 * C, nsl = 1024 / no;
+    const int o = t % no, sl = t / no;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (sl < nsl) {
+        int b = sl;
+        for (; b + 3 * nsl < nblk; b += 4 * nsl) {
+            a0 += (double)part[(size_t)b * no + o];
+            a1 += (double)part[(size_t)(b + nsl) * no + o];
+            a2 += (double)part[(size_t)(b + 2 * nsl) * no + o];
+            a3 += (double)part[(size_t)(b + 3 * nsl) * no + o];
+        }
+        for (; b < nblk; b += nsl) a0 += (double)part[(size_t)b * no + o];
+    }
+    sh[t] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    s_out = q_out = 0.0;
+    if (t < C) {
+        for (int k = 0; k < nsl; k++) {
+            s_out += sh[k * no + t];
+            q_out += sh[k * no + C + t];
+        }
+    }
+}
+
+// one block: sums the per-block partials in order; mean / invstd / scale / shift; running statistics (nn.BatchNorm2d semantics:
+// running = (1 - momentum) * running + momentum * batch, the variance unbiased) and the batch counter
+__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(const float *__restrict__ part, int nblk, long M, int C, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, float eps, float momentum,
+                                                                 float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                                 long long *__restrict__ num_batches, float *__restrict__ save_mean,
+                                                                 float *__restrict__ save_invstd, float *__restrict__ scale_shift)
+{
+    __shared__ double shd[1024];
+    const int c = threadIdx.x;
+    if (c == 0 && num_batches) *num_batches += 1;
+    double s, q;
+    sum_partials(part, nblk, C, shd, s, q);
+    if (c >= C) return;
+    const double mean = s / (double)M;
+    double var = q / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    scale_shift[c] = sc;
+    scale_shift[C + c] = beta[c] - (float)mean * sc;
+    if (running_mean) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(BN_BLK) void bn_fwd_apply_kernel(const u4 *__restrict__ x, const u4 *__restrict__ res, long n16, int C,
+                                                              const float *__restrict__ scale_shift, u4 *__restrict__ y)
+{
+    __shared__ float ss[2 * BN_MAXC];
+    for (int i = threadIdx.x; i < 2 * C; i += BN_BLK) ss[i] = scale_shift[i];
+    __syncthreads();
+    const int ngrp = C / 8;
+    const bool pow2 = (ngrp & (ngrp - 1)) == 0;
+    for (long i = (long)blockIdx.x * BN_BLK + threadIdx.x; i < n16; i += (long)gridDim.x * BN_BLK) {
+        const int c0 = (pow2 ? (int)(i & (ngrp - 1)) : (int)(i % ngrp)) * 8;
+        const u4 xv = x[i];
+        u4 rv;
+        if (RES) rv = res[i];
+        float f[8], r[8];
+        unpack8(xv, f);
+        if (RES) unpack8(rv, r);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float v = f[k] * ss[c0 + k] + ss[C + c0 + k];
+            if (RES) v += r[k];
+            if (RELU) v = v > 0.0f ? v : 0.0f;
+            f[k] = v;
+        }
+        y[i] = pack8(f);
+    }
+}
+
+// backward, pass 1: dz = dy * (y > 0) [ReLU] ; partial sums of dz and dz * xhat per channel, xhat = (x - mean) * invstd
+template <bool RELU>
+__global__ __launch_bounds__(BN_BLK) void bn_bwd_reduce_kernel(const u4 *__restrict__ dy, const u4 *__restrict__ x, const u4 *__restrict__ y,
+                                                               long M, int C, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                               float *__restrict__ part)
+{
+    const int ngrp = C / 8, rpb = BN_BLK / ngrp;
+    const int g = threadIdx.x % ngrp, rr = threadIdx.x / ngrp;
+    float mu[8], is[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { mu[i] = mean[g * 8 + i]; is[i] = invstd[g * 8 + i]; }
+    float acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[0][i] = acc[1][i] = 0.0f;
+    const long stride = (long)gridDim.x * rpb;
+    for (long r = (long)blockIdx.x * rpb + rr; r < M; r += stride) {
+        const u4 dv = dy[r * ngrp + g], xv = x[r * ngrp + g];
+        u4 yv;
+        if (RELU) yv = y[r * ngrp + g];
+        float d[8], xf[8], yf[8];
+        unpack8(dv, d);
+        unpack8(xv, xf);
+        if (RELU) unpack8(yv, yf);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float dz = (RELU && !(yf[i] > 0.0f)) ? 0.0f : d[i];
+            acc[0][i] += dz;
+            acc[1][i] += dz * ((xf[i] - mu[i]) * is[i]);
+        }
+    }
+    block_reduce_store<2>(acc, C, g, rr, rpb, part);
+}
+
+// one block: dbeta = sum dz, dgamma = sum dz * xhat; coefficients of pass 2:  dx = a * dz + b * xhat + c  with
+//   a = gamma * invstd,  b = -a * dgamma / M,  c = -a * dbeta / M     (batch-statistics BN backward)
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ part, int nblk, long M, int C, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ invstd, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                                 float *__restrict__ coef)
+{
+    __shared__ double shd[1024];
+    const int c = threadIdx.x;
+    double s, q;
+    sum_partials(part, nblk, C, shd, s, q);
+    if (c >= C) return;
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)q;
+    const float a = gamma[c] * invstd[c];
+    coef[c] = a;
+    coef[C + c] = (float)(-(double)a * q / (double)M);
+    coef[2 * C + c] = (float)(-(double)a * s / (double)M);
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(BN_BLK) void bn_bwd_apply_kernel(const u4 *__restrict__ dy, const u4 *__restrict__ x, const u4 *__restrict__ y, long n16,
+                                                              int C, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                              const float *__restrict__ coef, u4 *__restrict__ dx, u4 *__restrict__ dres)
+{
+    __shared__ float sc[5 * BN_MAXC];
+    for (int i = threadIdx.x; i < C; i += BN_BLK) {
+        sc[i] = coef[i];
+        sc[C + i] = coef[C + i];
+        sc[2 * C + i] = coef[2 * C + i];
+        sc[3 * C + i] = mean[i];
+        sc[4 * C + i] = invstd[i];
+    }
+    __syncthreads();
+    const int ngrp = C / 8;
+    const bool pow2 = (ngrp & (ngrp - 1)) == 0;
+    for (long i = (long)blockIdx.x * BN_BLK + threadIdx.x; i < n16; i += (long)gridDim.x * BN_BLK) {
+        const int c0 = (pow2 ? (int)(i & (ngrp - 1)) : (int)(i % ngrp)) * 8;
+        const u4 dv = dy[i], xv = x[i];
+        u4 yv;
+        if (RELU) yv = y[i];
+        float d[8], xf[8], yf[8], o[8];
+        unpack8(dv, d);
+        unpack8(xv, xf);
+        if (RELU) unpack8(yv, yf);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float dz = (RELU && !(yf[k] > 0.0f)) ? 0.0f : d[k];
+            d[k] = dz;
+            const float xhat = (xf[k] - sc[3 * C + c0 + k]) * sc[4 * C + c0 + k];
+            o[k] = sc[c0 + k] * dz + sc[C + c0 + k] * xhat + sc[2 * C + c0 + k];
+        }
+        dx[i] = pack8(o);
+        if (RES) dres[i] = pack8(d);
+    }
+}
+
+int bn_blocks(long M, int C)
+{
+    const int rpb = BN_BLK / (C / 8);
+    long need = (M + rpb - 1) / rpb;
+    long nb = need < 512 ? need : 512;            // two blocks per CU: enough loads in flight for a bandwidth-bound pass, few partials to sum
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+}  // namespace
+
+extern "C" size_t psi_bn_workspace_floats(long M, int C) { return (size_t)bn_blocks(M, C) * 2 * C + 5 * (size_t)C + 64; }
+
+extern "C" int psi_bn_forward(const void *x, const void *residual, const float *gamma, const float *beta, float *running_mean,
+                              float *running_var, long long *num_batches_tracked, long M, int C, int relu, float momentum, float eps,
+                              void *y, float *save_mean, float *save_invstd, float *ws, void *stream)
+{
+    PSI_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "null pointer");
+    PSI_REQUIRE(M > 0 && C >= 8 && C <= BN_MAXC && C % 8 == 0 && BN_BLK % (C / 8) == 0 && 1024 % (2 * C) == 0, "C must be 8, 16, 32, 64, 128 or 256");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = bn_blocks(M, C);
+    float *part = ws, *ss = ws + (size_t)nb * 2 * C;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(BN_BLK), 0, st, (const u4 *)x, M, C, part);
+    PSI_CHECK_LAUNCH("bn_stats_kernel");
+    psi_mark("bn_stats_kernel", st);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nb, M, C, gamma, beta, eps, momentum, running_mean, running_var,
+                       num_batches_tracked, save_mean, save_invstd, ss);
+    PSI_CHECK_LAUNCH("bn_fwd_finalize_kernel");
+    const long n16 = M * (C / 8);
+    const int ga = (int)((n16 + BN_BLK - 1) / BN_BLK < 2048 ? (n16 + BN_BLK - 1) / BN_BLK : 2048);
+#define PSI_BN_APPLY(R_, S_) hipLaunchKernelGGL((bn_fwd_apply_kernel<R_, S_>), dim3(ga), dim3(BN_BLK), 0, st, (const u4 *)x, (const u4 *)residual, n16, C, ss, (u4 *)y)
+    if (relu && residual) PSI_BN_APPLY(true, true);
+    else if (relu) PSI_BN_APPLY(true, false);
+    else if (residual) PSI_BN_APPLY(false, true);
+    else PSI_BN_APPLY(false, false);
+#undef PSI_BN_APPLY
+    PSI_CHECK_LAUNCH("bn_fwd_apply_kernel");
+    psi_mark("bn_fwd_apply_kernel", st);
+    return 0;
+}
+
+extern "C" int psi_bn_backward(const void *dy, const void *x, const void *y, const float *gamma, const float *save_mean,
+                               const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
+                               float *ws, void *stream)
+{
+    PSI_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && ws, "null pointer");
+    PSI_REQUIRE(!relu || y, "the ReLU mask needs the forward output");
+    PSI_REQUIRE(M > 0 && C >= 8 && C <= BN_MAXC && C % 8 == 0 && BN_BLK % (C / 8) == 0 && 1024 % (2 * C) == 0, "C must be 8, 16, 32, 64, 128 or 256");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = bn_blocks(M, C);
+    float *part = ws, *coef = ws + (size_t)nb * 2 * C;
+    if (relu)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nb), dim3(BN_BLK), 0, st, (const u4 *)dy, (const u4 *)x, (const u4 *)y, M, C, save_mean,
+                           save_invstd, part);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nb), dim3(BN_BLK), 0, st, (const u4 *)dy, (const u4 *)x, (const u4 *)y, M, C, save_mean,
+                           save_invstd, part);
+    PSI_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    psi_mark("bn_bwd_reduce_kernel", st);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nb, M, C, gamma, save_invstd, dgamma, dbeta, coef);
+    PSI_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+    const long n16 = M * (C / 8);
+    const int ga = (int)((n16 + BN_BLK - 1) / BN_BLK < 2048 ? (n16 + BN_BLK - 1) / BN_BLK : 2048);
+#define PSI_BN_BAPPLY(R_, S_) hipLaunchKernelGGL((bn_bwd_apply_kernel<R_, S_>), dim3(ga), dim3(BN_BLK), 0, st, (const u4 *)dy, (const u4 *)x, (const u4 *)y, n16, C, save_mean, save_invstd, coef, (u4 *)dx, (u4 *)dresidual)
+    if (relu && dresidual) PSI_BN_BAPPLY(true, true);
+    else if (relu) PSI_BN_BAPPLY(true, false);
+    else if (dresidual) PSI_BN_BAPPLY(false, true);
+    else PSI_BN_BAPPLY(false, false);
+#undef PSI_BN_BAPPLY
+    PSI_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    psi_mark("bn_bwd_apply_kernel", st);
+    return 0;
+}

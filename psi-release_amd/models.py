@@ -56,10 +56,36 @@ class _BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
 
     def forward(self, x):
+        if _use_hip_bn(self.bn1, x):
+            # training statistics on bf16 NHWC maps: BN + ReLU (+ the skip connection) as ONE fused HIP op per BN (ops.bn_act) instead
+            # of the library's three launches per BN and separate ReLU / add launches — same arithmetic, same running-statistics update
+            from .ops import bn_act
+            identity = x if self.downsample is None else bn_act(self.downsample[0](x), self.downsample[1], relu=False)
+            out = bn_act(self.conv1(x), self.bn1, relu=True)
+            return bn_act(self.conv2(out), self.bn2, relu=True, residual=identity)
         identity = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
         return self.relu(out + identity)
+
+
+def _use_hip_bn(bn, x):
+    """The fused BN kernels cover the training-mode trunk under bf16 autocast (PSI_HIP_BN=0 keeps the library path)."""
+    import os
+    return (bn.training and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+            and bn.num_features % 8 == 0 and os.environ.get('PSI_HIP_BN', '1') != '0')
+
+
+def run_trunk(trunk, x):
+    """forward of ``scene_trunk`` (an nn.Sequential, so that the state_dict keys stay ``resnet.0.weight``, ``resnet.1.*`` ...) with the
+    stem's BN + ReLU fused when the fused kernels apply."""
+    if _use_hip_bn(trunk[1], x):
+        from .ops import bn_act
+        x = bn_act(trunk[0](x), trunk[1], relu=True)
+        for i in range(3, len(trunk)):
+            x = trunk[i](x)
+        return x
+    return trunk(x)
 
 
 def scene_trunk(in_dim=2):
@@ -127,7 +153,7 @@ class _SceneCond(nn.Module):
                 self._nhwc = True
             scene = scene.contiguous(memory_format=torch.channels_last)
             with torch.autocast('cuda', dtype=torch.bfloat16):
-                f = self.conv(self.resnet(scene))
+                f = self.conv(run_trunk(self.resnet, scene))
                 if _use_hip_linear(self, scene):
                     # the 8192 / 32768 -> num_hidden layer: the bf16 feature map goes straight into the MFMA kernel, the fp32 master
                     # weight (up to 33.5 MB) is read once and rounded on load instead of being cast by a separate kernel every step

@@ -345,3 +345,67 @@ def linear_act(x, weight, bias=None, act=None, slope=0.01, residual=None):
     if act not in (None, 'leaky_relu'):
         raise ValueError('act must be None or "leaky_relu"')
     return _LinearAct.apply(x, weight, bias, residual, 1 if act else 0, slope)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BatchNorm (training statistics) + ReLU + skip connection of the scene trunk: psi_bn_forward / psi_bn_backward
+# ------------------------------------------------------------------------------------------------------------------
+def _ptr_cl(t):
+    """Device pointer of a channels_last (NHWC in memory) 4-D tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.is_contiguous(memory_format=torch.channels_last)):
+        raise hip.PsiHipError('expected a channels_last GPU tensor')
+    return t.data_ptr()
+
+
+class _BNAct(Function):
+    """y = act(batch_norm(x) (+ residual)) on NHWC bf16 maps, batch statistics (include/psi_hip.h: psi_bn_forward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, bn, relu):
+        N, C, H, W = x.shape
+        M = N * H * W
+        xc = x.contiguous(memory_format=torch.channels_last)
+        rc = residual.contiguous(memory_format=torch.channels_last) if residual is not None else None
+        y = torch.empty_like(xc, memory_format=torch.channels_last)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        L = hip.lib()
+        ws = torch.empty(L.psi_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
+        track = bn.track_running_stats and bn.running_mean is not None
+        hip.check(L.psi_bn_forward(_ptr_cl(xc), _ptr_cl(rc), hip.ptr(weight), hip.ptr(bias),
+                                   hip.ptr(bn.running_mean) if track else None, hip.ptr(bn.running_var) if track else None,
+                                   hip.ptr(bn.num_batches_tracked) if track else None, M, C, int(relu),
+                                   float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), _ptr_cl(y), hip.ptr(mean),
+                                   hip.ptr(invstd), hip.ptr(ws), hip.stream()), 'psi_bn_forward')
+        ctx.save_for_backward(xc, y if relu else None, weight, mean, invstd)
+        ctx.relu, ctx.has_res, ctx.dims = bool(relu), residual is not None, (M, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, y, weight, mean, invstd = ctx.saved_tensors
+        M, C = ctx.dims
+        dyc = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(xc, memory_format=torch.channels_last)
+        dres = torch.empty_like(xc, memory_format=torch.channels_last) if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        dgamma = torch.empty(C, device=xc.device, dtype=torch.float32)
+        dbeta = torch.empty(C, device=xc.device, dtype=torch.float32)
+        L = hip.lib()
+        ws = torch.empty(L.psi_bn_workspace_floats(M, C), device=xc.device, dtype=torch.float32)
+        hip.check(L.psi_bn_backward(_ptr_cl(dyc), _ptr_cl(xc), _ptr_cl(y), hip.ptr(weight), hip.ptr(mean), hip.ptr(invstd), M, C,
+                                    int(ctx.relu), _ptr_cl(dx), _ptr_cl(dres), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), hip.stream()),
+                  'psi_bn_backward')
+        return dx, dgamma, dbeta, dres, None, None
+
+
+def bn_act(x, bn, relu=True, residual=None):
+    """``relu(bn(x) + residual)`` (each part optional) of an ``nn.BatchNorm2d`` in TRAINING mode on a bf16 channels_last map, as one
+    fused HIP op (statistics pass + one apply pass; the backward likewise) instead of the library's three BN launches plus separate
+    ReLU / add launches.  Updates ``bn.running_mean / running_var / num_batches_tracked`` like the module would."""
+    if x.dtype != torch.bfloat16 or not x.is_cuda or x.dim() != 4:
+        raise ValueError('bn_act: expected a 4-D bf16 CUDA tensor')
+    if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape):
+        raise ValueError('bn_act: residual must match x')
+    return _BNAct.apply(x, bn.weight, bn.bias, residual, bn, relu)
