@@ -114,24 +114,29 @@ def load_pretrained_resnet18(trunk, ckpt_path):
 def set_hip_linear(model, on=True):
     """Route the dense layers of ``model`` (ResBlock stacks and the scene-feature ``fc``) through the hand-written bf16 MFMA kernels of
     libpsi_hip.so (ops.linear_act: Linear + bias + LeakyReLU + skip in one launch, fp32 master weights rounded to bf16 on load).
-    Enabled together with ``autocast_bf16`` (same operand precision as the autocast GEMMs, fp32 output).  Policy (PSI_HIP_LINEAR):
-    unset — used whenever no gradient is recorded (the forward / sampling path: generation drivers, evaluation), while training
-    keeps the library GEMMs (measured on MI355X at batch 128: the fused forward equals the library forward, 12 vs 5-9 us + cast +
-    epilogue kernels, but the backward GEMMs are the library's either way and the extra casts cost 1.8 % of a train_s2 step);
-    '1' — also while training; '0' — never."""
+    Enabled together with ``autocast_bf16``.  Which layers actually take the kernels is decided per call by ``_use_hip_linear``
+    (PSI_HIP_LINEAR): by default only the scene-feature ``fc`` on the sampling path — the one dense layer whose operands are bf16 in the
+    library path too — so that a model gives the same numbers in training and in no_grad mode; PSI_HIP_LINEAR=1 opts the ResBlock stacks
+    in as well (bf16 operands instead of fp32, in both modes)."""
     for m in model.modules():
         if isinstance(m, (ResBlock, _SceneCond)):
             m.hip_linear = bool(on)
 
 
 def _use_hip_linear(module, x):
+    """PSI_HIP_LINEAR: unset — the scene-feature ``fc`` layer only (it sits inside the bf16 autocast region either way, so routing it
+    through the MFMA kernel changes no operand precision: same numbers in train and no_grad mode); '1' — also the ResBlock stacks,
+    which the library path runs in fp32 (their operands are then rounded to bf16 in BOTH modes: an explicit opt-in precision change);
+    '0' — never."""
     import os
     if not getattr(module, 'hip_linear', False) or not x.is_cuda:
         return False
     mode = os.environ.get('PSI_HIP_LINEAR', '')
     if mode == '0':
         return False
-    return mode == '1' or not torch.is_grad_enabled()
+    if mode == '1':
+        return True
+    return isinstance(module, _SceneCond) and not torch.is_grad_enabled()
 
 
 def _reparam(mu, logvar, eps=None):
