@@ -221,113 +221,210 @@ __device__ __forceinline__ float gmask(float g, const float *act_out, size_t o, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// dX[M,K] = G[M,N] W[N,K]: workgroup = 128 rows x 32 columns of K, contraction over N
+// Backward.  Both products contract over an index along which one operand is NOT contiguous (dX = G W contracts over n: W[n][k] has
+// k fastest; dW = G^T X contracts over m: G[m][n] and X[m][k] have n / k fastest), so a lane cannot read "its" eight consecutive
+// contraction elements from memory.  The first version did exactly that — eight 4-byte loads per lane and operand, each lane on a
+// different row — and ran 4-7x slower than the library GEMM (85 us for 128 x 512 x 512).  Here every tile is read from memory the way
+// it is stored (16-byte lane loads, a wave covering whole rows), rounded to bf16, and TRANSPOSED ON THE WAY INTO LDS, so that the MFMA
+// operands are contiguous LDS reads again; the activation-derivative mask G = gy * act'(.) is applied in the same pass.
 // ------------------------------------------------------------------------------------------------
+constexpr int DXK = 64;                  // dX: output columns (k) per workgroup
+constexpr int DXN = 64;                  // dX: contraction tile (n)
+constexpr int DXP = DXN + 8;             // LDS pitch (elements): 16-byte aligned rows, conflict-free 16-byte reads
+
+// dX[M,K] = G[M,N] W[N,K]: workgroup = 128 rows x 64 k-columns, wave w = rows [32w, 32w+32) x two 32-column tiles; contraction over n in
+// tiles of 64: G tile [128][64] row-major (A operand as in the forward), W tile [64 n][64 k] stored TRANSPOSED as Wt[k][n].
 template <typename XT>
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restrict__ gy, const float *__restrict__ act_out,
                                                             const float *__restrict__ W, int M, int N, int K, float slope,
                                                             XT *__restrict__ gx)
 {
+    __shared__ __attribute__((aligned(16))) __bf16 Gs[2][128][DXP];
+    __shared__ __attribute__((aligned(16))) __bf16 Wt[2][DXK][DXP];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int k0 = blockIdx.x * TN, m0 = blockIdx.y * 128 + w * TM;
-    const int li = lane & 31, nb = (lane >> 5) * 8;
-    const int row = m0 + li, col = k0 + li;
-    const bool rok = row < M, cok = col < K;
-    f16v acc;
+    const int k0 = blockIdx.x * DXK, mblk = blockIdx.y * 128, m0 = mblk + w * TM;
+    const int li = lane & 31, kb = (lane >> 5) * 8;
+    f16v acc[2];
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-    constexpr int U = 4;
-    for (int n = 0; n < N; n += U * TK) {                       // N % 16 == 0 (host); U steps' loads in flight together
-        f4 g0[U], g1[U], m0v[U], m1v[U];
-        float wv[U][8];
+    for (int t = 0; t < 2; t++)
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int nn = n + u * TK;
-            const bool in = nn < N;
-            const size_t go = (size_t)(rok ? row : 0) * N + (in ? nn : 0) + nb;
-            const bool ld = rok && in;
-            g0[u] = ld ? *(const f4 *)(gy + go) : (f4){0, 0, 0, 0};
-            g1[u] = ld ? *(const f4 *)(gy + go + 4) : (f4){0, 0, 0, 0};
-            if (act_out) {
-                m0v[u] = ld ? *(const f4 *)(act_out + go) : (f4){1, 1, 1, 1};
-                m1v[u] = ld ? *(const f4 *)(act_out + go + 4) : (f4){1, 1, 1, 1};
-            }
+        for (int i = 0; i < 16; i++) acc[t][i] = 0.0f;
+    f4 gr[8], mr[8], wr[4];
+    auto load_tiles = [&](int n0) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) wv[u][i] = (cok && in) ? W[(size_t)(nn + nb + i) * K + col] : 0.0f;
+        for (int i = 0; i < 8; i++) {                       // G: 128 rows x 64 n = 2048 float4, 8 per thread, a wave covers 4 whole rows
+            const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
+            const bool ok = mblk + row < M && n0 + c < N;
+            const size_t o = (size_t)(mblk + row) * N + n0 + c;
+            gr[i] = ok ? *(const f4 *)(gy + o) : (f4){0, 0, 0, 0};
+            if (act_out) mr[i] = ok ? *(const f4 *)(act_out + o) : (f4){1, 1, 1, 1};
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            bf16x8 a, b;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                a[i] = (__bf16)(act_out ? (m0v[u][i] > 0.0f ? g0[u][i] : g0[u][i] * slope) : g0[u][i]);
-                a[i + 4] = (__bf16)(act_out ? (m1v[u][i] > 0.0f ? g1[u][i] : g1[u][i] * slope) : g1[u][i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++) b[i] = (__bf16)wv[u][i];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        for (int i = 0; i < 4; i++) {                       // W: 64 n-rows x 64 k = 1024 float4, 4 per thread
+            const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
+            const bool ok = n0 + row < N && k0 + c < K;
+            wr[i] = ok ? *(const f4 *)(W + (size_t)(n0 + row) * K + k0 + c) : (f4){0, 0, 0, 0};
         }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
+            bf4 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = (__bf16)(act_out ? (mr[i][e] > 0.0f ? gr[i][e] : gr[i][e] * slope) : gr[i][e]);
+            *(bf4 *)&Gs[buf][row][c] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                       // transposed: element (n = row, k = c + e) -> Wt[c + e][row]
+            const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) Wt[buf][c + e][row] = (__bf16)wr[i][e];
+        }
+    };
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    int buf = 0;
+    for (int n0 = 0; n0 < N; n0 += DXN, buf ^= 1) {
+        const bool more = n0 + DXN < N;
+        if (more) load_tiles(n0 + DXN);                     // next tile's global loads in flight during this tile's MFMAs
+#pragma unroll
+        for (int st = 0; st < DXN / TK; st++) {
+            const bf16x8 a = *(const bf16x8 *)&Gs[buf][w * TM + li][st * TK + kb];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const bf16x8 b = *(const bf16x8 *)&Wt[buf][t * TN + li][st * TK + kb];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
     }
-    if (m0 >= M || col >= K) return;
+    if (m0 >= M) return;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int i = m0 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-        if (i < M) gx[(size_t)i * K + col] = (XT)acc[r];
+    for (int t = 0; t < 2; t++) {
+        const int col = k0 + t * TN + li;
+        if (col >= K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = m0 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            if (i < M) gx[(size_t)i * K + col] = (XT)acc[t][r];
+        }
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// dW[N,K] = G^T[N,M] X[M,K]: wave = one 32 x 32 tile of dW, contraction over M; workgroup = 4 adjacent K tiles of one N tile.
-// The workgroups with blockIdx.x == 0 also produce gbias[n] = sum_m G[m][n] for their N tile.
-// ------------------------------------------------------------------------------------------------
+// dW[N,K] = G^T[N,M] X[M,K] (+ gbias[n] = sum_m G[m][n]): workgroup = 32 n-rows x 128 k-columns (wave w: k tile w), contraction over m in
+// tiles of 128 — the whole batch in one tile for the CVAEs' M = 128.  Both operands are stored transposed: Gt[n][m], Xt[k][m], two
+// consecutive m packed into one 32-bit LDS store (a thread loads the float4s of rows 2p and 2p + 1).
+constexpr int DWK = 128;
+constexpr int DWM = 128;
+constexpr int DWP = DWM + 8;             // pitch in elements (16-byte aligned rows)
+
+template <typename XT> struct XPair;     // the float4 / 4 x bf16 of rows 2p and 2p+1 at columns c..c+3 -> four packed bf16 pairs
+template <> struct XPair<float> {
+    __device__ static __forceinline__ void load(const float *x, size_t o0, size_t o1, bool ok0, bool ok1, float (&a)[4], float (&b)[4])
+    {
+        const f4 v0 = ok0 ? *(const f4 *)(x + o0) : (f4){0, 0, 0, 0}, v1 = ok1 ? *(const f4 *)(x + o1) : (f4){0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { a[e] = v0[e]; b[e] = v1[e]; }
+    }
+};
+template <> struct XPair<__bf16> {
+    __device__ static __forceinline__ void load(const __bf16 *x, size_t o0, size_t o1, bool ok0, bool ok1, float (&a)[4], float (&b)[4])
+    {
+        bf4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v0[e] = v1[e] = (__bf16)0.0f;
+        if (ok0) v0 = *(const bf4 *)(x + o0);
+        if (ok1) v1 = *(const bf4 *)(x + o1);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { a[e] = (float)v0[e]; b[e] = (float)v1[e]; }
+    }
+};
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
+{
+    const __bf16 l = (__bf16)lo, h = (__bf16)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
+}
+
 template <typename XT>
 __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float *__restrict__ gy, const float *__restrict__ act_out,
                                                             const XT *__restrict__ x, int M, int N, int K, float slope,
                                                             float *__restrict__ gW, float *__restrict__ gbias)
 {
+    __shared__ __attribute__((aligned(16))) __bf16 Gt[TM][DWP];
+    __shared__ __attribute__((aligned(16))) __bf16 Xt[DWK][DWP];
+    __shared__ float bsum_s[8][TM];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int n0 = blockIdx.y * TM, k0 = (blockIdx.x * 4 + w) * TN;
+    const int n0 = blockIdx.y * TM, k0 = blockIdx.x * DWK;
     const int li = lane & 31, mb = (lane >> 5) * 8;
-    const int nrow = n0 + li, kcol = k0 + li;
-    const bool nok = nrow < N, kok = kcol < K;
     f16v acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-    float bsum = 0.0f;
-    constexpr int U = 4;
-    for (int m = 0; m < M; m += U * TK) {                       // U steps' loads (8 + 8 + 8 per step and lane) in flight together
-        float gv[U][8], mv[U][8], xv[U][8];
+    float bsum = 0.0f;                                      // thread (pair p, quad q) accumulates G over its rows for columns 4q..4q+3 -> gbias
+    float bs4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int mt = 0; mt < M; mt += DWM) {
+        // G tile: 128 m x 32 n = 64 row pairs x 8 column quads = 512 items, 2 per thread
 #pragma unroll
-        for (int u = 0; u < U; u++)
+        for (int i = 0; i < 2; i++) {
+            const int idx = threadIdx.x + 256 * i, q = idx & 7, p = idx >> 3;
+            const int ma = mt + 2 * p, c = n0 + 4 * q;
+            const bool ok0 = ma < M && c < N, ok1 = ma + 1 < M && c < N;
+            const size_t o0 = (size_t)ma * N + c, o1 = o0 + N;
+            float a[4], b[4], ma4[4], mb4[4];
+            XPair<float>::load(gy, o0, o1, ok0, ok1, a, b);
+            if (act_out) {
+                XPair<float>::load(act_out, o0, o1, ok0, ok1, ma4, mb4);
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int mm = m + u * TK + mb + i;
-                const bool mok = mm < M;
-                const size_t go = (size_t)(mok ? mm : 0) * N + (nok ? nrow : 0);
-                gv[u][i] = (mok && nok) ? gy[go] : 0.0f;
-                mv[u][i] = (act_out && mok && nok) ? act_out[go] : 1.0f;
-                xv[u][i] = (mok && kok) ? ldf(x + (size_t)mm * K + kcol) : 0.0f;
+                for (int e = 0; e < 4; e++) {
+                    a[e] = (ok0 && !(ma4[e] > 0.0f)) ? a[e] * slope : a[e];
+                    b[e] = (ok1 && !(mb4[e] > 0.0f)) ? b[e] * slope : b[e];
+                }
             }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            bf16x8 a, b;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float g = mv[u][i] > 0.0f ? gv[u][i] : gv[u][i] * slope;
-                bsum += g;
-                a[i] = (__bf16)g;
-                b[i] = (__bf16)xv[u][i];
+            for (int e = 0; e < 4; e++) {
+                bs4[e] += a[e] + b[e];
+                *(unsigned *)&Gt[4 * q + e][2 * p] = pack_bf16x2(a[e], b[e]);
             }
+        }
+        // X tile: 128 m x 128 k = 64 row pairs x 32 column quads = 2048 items, 8 per thread
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = threadIdx.x + 256 * i, q = idx & 31, p = idx >> 5;
+            const int ma = mt + 2 * p, c = k0 + 4 * q;
+            const bool ok0 = ma < M && c < K, ok1 = ma + 1 < M && c < K;
+            float a[4], b[4];
+            XPair<XT>::load(x, (size_t)ma * K + c, (size_t)(ma + 1) * K + c, ok0, ok1, a, b);
+#pragma unroll
+            for (int e = 0; e < 4; e++) *(unsigned *)&Xt[4 * q + e][2 * p] = pack_bf16x2(a[e], b[e]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < DWM / TK; st++) {
+            const bf16x8 a = *(const bf16x8 *)&Gt[li][st * TK + mb];
+            const bf16x8 b = *(const bf16x8 *)&Xt[w * TN + li][st * TK + mb];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
+        __syncthreads();
     }
-    if (gbias && blockIdx.x == 0 && w == 0) {                  // lanes l and l+32 hold the two halves of every 16-row step
-        bsum += __shfl_xor(bsum, 32, 64);
-        if (lane < 32 && nok) gbias[nrow] = bsum;
+    (void)bsum;
+    if (gbias && blockIdx.x == 0) {
+        // column sums of G: thread (p, q) of item slots i = 0, 1 holds partial sums of columns 4q..4q+3 over its row pairs; the 64 threads
+        // sharing q (p = idx >> 3 over both slots) are combined in a fixed order through LDS
+        __shared__ float bred[256][4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) bred[threadIdx.x][e] = bs4[e];
+        __syncthreads();
+        if (threadIdx.x < TM) {
+            const int q = threadIdx.x >> 2, e = threadIdx.x & 3;
+            float s = 0.0f;
+            for (int t = q; t < 256; t += 8) s += bred[t][e];
+            if (n0 + threadIdx.x < N) gbias[n0 + threadIdx.x] = s;
+        }
     }
-    if (!kok) return;
+    const int kcol = k0 + w * TN + li;
+    if (kcol >= K) return;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int i = n0 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
@@ -390,10 +487,10 @@ extern "C" int psi_linear_backward(const float *gy, const float *act_out, const 
                                    float slope, void *gx, float *gW, float *gbias, void *stream)
 {
     PSI_REQUIRE(gy && x && W, "null pointer");
-    PSI_REQUIRE(M > 0 && N > 0 && K > 0 && N % 16 == 0, "N must be a positive multiple of 16");
+    PSI_REQUIRE(M > 0 && N > 0 && K > 0 && N % 16 == 0 && K % 4 == 0, "N must be a positive multiple of 16 and K of 4");
     hipStream_t st = (hipStream_t)stream;
     if (gx) {
-        dim3 grid(psi_cdiv(K, TN), psi_cdiv(M, 128));
+        dim3 grid(psi_cdiv(K, DXK), psi_cdiv(M, 128));
         if (x_is_bf16)
             hipLaunchKernelGGL(linear_bwd_dx_kernel<__bf16>, grid, dim3(256), 0, st, gy, act_out, W, M, N, K, slope, (__bf16 *)gx);
         else
@@ -401,7 +498,7 @@ extern "C" int psi_linear_backward(const float *gy, const float *act_out, const 
         PSI_CHECK_LAUNCH("linear_bwd_dx_kernel");
     }
     if (gW) {
-        dim3 grid(psi_cdiv(K, 4 * TN), psi_cdiv(N, TM));
+        dim3 grid(psi_cdiv(K, DWK), psi_cdiv(N, TM));
         if (x_is_bf16)
             hipLaunchKernelGGL(linear_bwd_dw_kernel<__bf16>, grid, dim3(256), 0, st, gy, act_out, (const __bf16 *)x, M, N, K, slope, gW, gbias);
         else

@@ -322,10 +322,10 @@ class _LinearAct(Function):
         N = w.shape[0]
         gy = gy.contiguous().float()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        if os.environ.get('PSI_HIP_LINEAR_BWD', '0') != '1':
-            # default: the two backward GEMMs go to the library (hipBLASLt) on the same bf16-rounded operands.  The hand-written
-            # dX / dW kernels (csrc/linear.hip, selected by PSI_HIP_LINEAR_BWD=1) are exact to the same reference but read their
-            # transposed operands lane-per-row and are slower than the library at these shapes (85 vs ~10 us for a 512 x 512 layer)
+        if os.environ.get('PSI_HIP_LINEAR_BWD', '1') == '0':
+            # PSI_HIP_LINEAR_BWD=0: the two backward GEMMs through the library (hipBLASLt) on the same bf16-rounded operands — mask, cast,
+            # two GEMMs, column sum: seven launches.  The default is the hand-written pair below (dX, dW + dbias; LDS-staged transposed
+            # operands): 26 vs 38 us for a 128 x 512 x 512 layer, 42 vs 66 us for the 32768 -> 256 layer (tools/time_linear_bwd.py)
             g = gy if not ctx.act else torch.where(a_out > 0, gy, gy * ctx.slope)
             gb16 = g.to(torch.bfloat16)
             gx = (gb16 @ w.to(torch.bfloat16)).to(xc.dtype) if need_x else None

@@ -112,23 +112,24 @@ def test_cvae_on_hip_linear_matches_reference_golden(stage, monkeypatch):
 
 
 def test_hip_linear_policy(monkeypatch):
-    """No-grad forward (sampling / generation) takes the hand-written kernels by default; training only with PSI_HIP_LINEAR=1."""
+    """A model built for bf16 takes the hand-written dense kernels in training and in no_grad mode alike (one arithmetic for both);
+    PSI_HIP_LINEAR=0 switches them off."""
     calls = []
     real = ops.linear_act
     monkeypatch.setattr(ops, 'linear_act', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     rb = models.ResBlock(512).to(DEV)
-    models.set_hip_linear(rb, True)
     x = torch.randn(8, 512, device=DEV)
     monkeypatch.delenv('PSI_HIP_LINEAR', raising=False)
+    rb(x)
+    assert len(calls) == 0                                                  # not a bf16 model: library path
+    models.set_hip_linear(rb, True)
     with torch.no_grad():
-        rb(x)
+        y2 = rb(x)
     assert len(calls) == 2
-    rb(x)                                                                   # grad mode: library path
-    assert len(calls) == 2
-    monkeypatch.setenv('PSI_HIP_LINEAR', '1')
     y = rb(x.requires_grad_())
     y.sum().backward()
     assert len(calls) == 4 and rb.fc1.weight.grad is not None and x.grad is not None
+    assert torch.equal(y2, y.detach())                                      # one arithmetic for both modes
     monkeypatch.setenv('PSI_HIP_LINEAR', '0')
     with torch.no_grad():
         rb(x)
