@@ -280,6 +280,12 @@ int psi_bn_backward(const void *dy, const void *x, const void *y, const float *g
                     const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
                     float *ws, void *stream);
 
+/* MaxPool2d(kernel_size=3, stride=2, padding=1) of the trunk's stem (torchvision resnet18 children[3]; cvae.py:431-435) on an NHWC bf16 map
+ * x [N,H,W,C] -> y [N,OH,OW,C], OH = (H - 1) / 2 + 1; idx [N,OH,OW,C] uint8 = position kh * 3 + kw of the maximum inside its window (first
+ * maximum in scan order, like at::max_pool2d_with_indices).  Backward: dx [N,H,W,C] bf16 (OVERWRITTEN) gathers dy through idx. */
+int psi_maxpool3x3s2_forward(const void *x, int N, int H, int W, int C, void *y, void *idx, void *stream);
+int psi_maxpool3x3s2_backward(const void *dy, const void *idx, int N, int H, int W, int C, void *dx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,19 +80,23 @@ __global__ __launch_bounds__(BN_BLK) void bn_stats_kernel(const u4 *__restrict__
     for (int i = 0; i < 8; i++) acc[0][i] = acc[1][i] = 0.0f;
     const long stride = (long)gridDim.x * rpb;
     long r = (long)blockIdx.x * rpb + rr;
-    // two rows in flight per thread
-    for (; r + stride < M; r += 2 * stride) {
-        const u4 a = x[r * ngrp + g], b = x[(r + stride) * ngrp + g];
-        float fa[8], fb[8];
-        unpack8(a, fa);
-        unpack8(b, fb);
+    // four rows in flight per thread
+    for (; r + 3 * stride < M; r += 4 * stride) {
+        u4 v[4];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            acc[0][i] += fa[i] + fb[i];
-            acc[1][i] += fa[i] * fa[i] + fb[i] * fb[i];
+        for (int u = 0; u < 4; u++) v[u] = x[(r + u * stride) * ngrp + g];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float f[8];
+            unpack8(v[u], f);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                acc[0][i] += f[i];
+                acc[1][i] += f[i] * f[i];
+            }
         }
     }
-    if (r < M) {
+    for (; r < M; r += stride) {
         float fa[8];
         unpack8(x[r * ngrp + g], fa);
 #pragma unroll
@@ -113,12 +117,20 @@ __device__ __forceinline__ void sum_partials(const float *__restrict__ part, int
     const int o = t % no, sl = t / no;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (sl < nsl) {
+        // sixteen loads requested before the first add: the partials were written by other compute units a moment ago, every dependent
+        // round is a trip to L2 / memory (the 4-deep version of this loop took 11 us for 512 partials; the kernel is pure latency)
         int b = sl;
-        for (; b + 3 * nsl < nblk; b += 4 * nsl) {
-            a0 += (double)part[(size_t)b * no + o];
-            a1 += (double)part[(size_t)(b + nsl) * no + o];
-            a2 += (double)part[(size_t)(b + 2 * nsl) * no + o];
-            a3 += (double)part[(size_t)(b + 3 * nsl) * no + o];
+        for (; b + 15 * nsl < nblk; b += 16 * nsl) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = part[(size_t)(b + u * nsl) * no + o];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                a0 += (double)v[u];
+                a1 += (double)v[u + 1];
+                a2 += (double)v[u + 2];
+                a3 += (double)v[u + 3];
+            }
         }
         for (; b < nblk; b += nsl) a0 += (double)part[(size_t)b * no + o];
     }
@@ -206,10 +218,7 @@ __global__ __launch_bounds__(BN_BLK) void bn_bwd_reduce_kernel(const u4 *__restr
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[0][i] = acc[1][i] = 0.0f;
     const long stride = (long)gridDim.x * rpb;
-    for (long r = (long)blockIdx.x * rpb + rr; r < M; r += stride) {
-        const u4 dv = dy[r * ngrp + g], xv = x[r * ngrp + g];
-        u4 yv;
-        if (RELU) yv = y[r * ngrp + g];
+    auto row = [&](const u4 &dv, const u4 &xv, const u4 &yv) {
         float d[8], xf[8], yf[8];
         unpack8(dv, d);
         unpack8(xv, xf);
@@ -220,6 +229,22 @@ __global__ __launch_bounds__(BN_BLK) void bn_bwd_reduce_kernel(const u4 *__restr
             acc[0][i] += dz;
             acc[1][i] += dz * ((xf[i] - mu[i]) * is[i]);
         }
+    };
+    long r = (long)blockIdx.x * rpb + rr;
+    for (; r + stride < M; r += 2 * stride) {               // two rows (six 16-byte loads) in flight per thread
+        const long i0 = r * ngrp + g, i1 = (r + stride) * ngrp + g;
+        const u4 d0 = dy[i0], x0 = x[i0], d1 = dy[i1], x1 = x[i1];
+        u4 y0 = d0, y1 = d1;
+        if (RELU) { y0 = y[i0]; y1 = y[i1]; }
+        row(d0, x0, y0);
+        row(d1, x1, y1);
+    }
+    if (r < M) {
+        const long i0 = r * ngrp + g;
+        const u4 d0 = dy[i0], x0 = x[i0];
+        u4 y0 = d0;
+        if (RELU) y0 = y[i0];
+        row(d0, x0, y0);
     }
     block_reduce_store<2>(acc, C, g, rr, rpb, part);
 }
@@ -280,11 +305,89 @@ __global__ __launch_bounds__(BN_BLK) void bn_bwd_apply_kernel(const u4 *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 3, stride 2, padding 1) of the stem (torchvision resnet18 children[3], cvae.py:431-435) on NHWC bf16 maps, with the
+// window position of the maximum kept as one byte per output so that the backward is a GATHER (every input looks at the <= 4 windows
+// that contain it): no atomics, deterministic, one coalesced pass.  First maximum in (kh, kw) scan order wins (strict >), like
+// at::max_pool2d_with_indices.  The library's NHWC backward takes 107 us for the stem's 67 MB map; this pass is bandwidth-bound.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BN_BLK) void maxpool_fwd_kernel(const u4 *__restrict__ x, int N, int H, int W, int C, int OH, int OW,
+                                                             u4 *__restrict__ y, unsigned long long *__restrict__ idx)
+{
+    const int ngrp = C / 8;
+    const long total = (long)N * OH * OW * ngrp;
+    for (long i = (long)blockIdx.x * BN_BLK + threadIdx.x; i < total; i += (long)gridDim.x * BN_BLK) {
+        const int g = (int)(i % ngrp);
+        long t = i / ngrp;
+        const int ow = (int)(t % OW);
+        t /= OW;
+        const int oh = (int)(t % OH), n = (int)(t / OH);
+        float best[8];
+        unsigned char bi[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { best[k] = -INFINITY; bi[k] = 0; }
+        bool first = true;
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+            for (int kw = 0; kw < 3; kw++) {
+                const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+                if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+                float f[8];
+                unpack8(x[(((long)n * H + ih) * W + iw) * ngrp + g], f);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (first || f[k] > best[k] || f[k] != f[k]) { best[k] = f[k]; bi[k] = (unsigned char)(kh * 3 + kw); }
+                first = false;
+            }
+        y[i] = pack8(best);
+        unsigned long long pk = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) pk |= (unsigned long long)bi[k] << (8 * k);
+        idx[i] = pk;
+    }
+}
+
+__global__ __launch_bounds__(BN_BLK) void maxpool_bwd_kernel(const u4 *__restrict__ dy, const unsigned long long *__restrict__ idx, int N, int H,
+                                                             int W, int C, int OH, int OW, u4 *__restrict__ dx)
+{
+    const int ngrp = C / 8;
+    const long total = (long)N * H * W * ngrp;
+    for (long i = (long)blockIdx.x * BN_BLK + threadIdx.x; i < total; i += (long)gridDim.x * BN_BLK) {
+        const int g = (int)(i % ngrp);
+        long t = i / ngrp;
+        const int iw = (int)(t % W);
+        t /= W;
+        const int ih = (int)(t % H), n = (int)(t / H);
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = 0.0f;
+        // windows that contain (ih, iw): oh with oh*2 - 1 <= ih <= oh*2 + 1
+        const int oh0 = ih >> 1, ow0 = iw >> 1;                 // and oh0 + 1 / ow0 + 1 when the coordinate is odd
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const int oh = oh0 + a, ow = ow0 + b;
+                if ((a && !(ih & 1)) || (b && !(iw & 1)) || oh >= OH || ow >= OW) continue;
+                const int pos = (ih - (oh * 2 - 1)) * 3 + (iw - (ow * 2 - 1));
+                const long o = (((long)n * OH + oh) * OW + ow) * ngrp + g;
+                const unsigned long long pk = idx[o];
+                float d[8];
+                unpack8(dy[o], d);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if ((int)((pk >> (8 * k)) & 0xff) == pos) acc[k] += d[k];
+            }
+        dx[i] = pack8(acc);
+    }
+}
+
 int bn_blocks(long M, int C)
 {
     const int rpb = BN_BLK / (C / 8);
     long need = (M + rpb - 1) / rpb;
-    long nb = need < 512 ? need : 512;            // two blocks per CU: enough loads in flight for a bandwidth-bound pass, few partials to sum
+    long nb = need < 512 ? need : 512;            // two blocks per CU, four rows in flight per thread: 32 KB of loads in flight per CU
     return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -350,5 +453,31 @@ extern "C" int psi_bn_backward(const void *dy, const void *x, const void *y, con
 #undef PSI_BN_BAPPLY
     PSI_CHECK_LAUNCH("bn_bwd_apply_kernel");
     psi_mark("bn_bwd_apply_kernel", st);
+    return 0;
+}
+
+extern "C" int psi_maxpool3x3s2_forward(const void *x, int N, int H, int W, int C, void *y, void *idx, void *stream)
+{
+    PSI_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "bad arguments (C must be a multiple of 8)");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long total = (long)N * OH * OW * (C / 8);
+    const int grid = (int)((total + BN_BLK - 1) / BN_BLK < 4096 ? (total + BN_BLK - 1) / BN_BLK : 4096);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid), dim3(BN_BLK), 0, (hipStream_t)stream, (const u4 *)x, N, H, W, C, OH, OW, (u4 *)y,
+                       (unsigned long long *)idx);
+    PSI_CHECK_LAUNCH("maxpool_fwd_kernel");
+    psi_mark("maxpool_fwd_kernel", (hipStream_t)stream);
+    return 0;
+}
+
+extern "C" int psi_maxpool3x3s2_backward(const void *dy, const void *idx, int N, int H, int W, int C, void *dx, void *stream)
+{
+    PSI_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "bad arguments (C must be a multiple of 8)");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long total = (long)N * H * W * (C / 8);
+    const int grid = (int)((total + BN_BLK - 1) / BN_BLK < 4096 ? (total + BN_BLK - 1) / BN_BLK : 4096);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid), dim3(BN_BLK), 0, (hipStream_t)stream, (const u4 *)dy, (const unsigned long long *)idx, N, H, W,
+                       C, OH, OW, (u4 *)dx);
+    PSI_CHECK_LAUNCH("maxpool_bwd_kernel");
+    psi_mark("maxpool_bwd_kernel", (hipStream_t)stream);
     return 0;
 }

@@ -80,9 +80,11 @@ def run_trunk(trunk, x):
     """forward of ``scene_trunk`` (an nn.Sequential, so that the state_dict keys stay ``resnet.0.weight``, ``resnet.1.*`` ...) with the
     stem's BN + ReLU fused when the fused kernels apply."""
     if _use_hip_bn(trunk[1], x):
-        from .ops import bn_act
+        from .ops import bn_act, maxpool3x3s2
         x = bn_act(trunk[0](x), trunk[1], relu=True)
-        for i in range(3, len(trunk)):
+        mp = trunk[3]
+        x = maxpool3x3s2(x) if (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False) else mp(x)
+        for i in range(4, len(trunk)):
             x = trunk[i](x)
         return x
     return trunk(x)

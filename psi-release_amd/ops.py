@@ -409,3 +409,33 @@ def bn_act(x, bn, relu=True, residual=None):
     if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape):
         raise ValueError('bn_act: residual must match x')
     return _BNAct.apply(x, bn.weight, bn.bias, residual, bn, relu)
+
+
+class _MaxPool3x3s2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        xc = x.contiguous(memory_format=torch.channels_last)
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(N, C, OH, OW, device=x.device, dtype=x.dtype).contiguous(memory_format=torch.channels_last)
+        idx = torch.empty(N * OH * OW * C, device=x.device, dtype=torch.uint8)
+        hip.check(hip.lib().psi_maxpool3x3s2_forward(_ptr_cl(xc), N, H, W, C, _ptr_cl(y), hip.ptr(idx), hip.stream()), 'psi_maxpool3x3s2_forward')
+        ctx.save_for_backward(idx)
+        ctx.dims = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, = ctx.saved_tensors
+        N, C, H, W = ctx.dims
+        dyc = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty(N, C, H, W, device=dy.device, dtype=dy.dtype).contiguous(memory_format=torch.channels_last)
+        hip.check(hip.lib().psi_maxpool3x3s2_backward(_ptr_cl(dyc), hip.ptr(idx), N, H, W, C, _ptr_cl(dx), hip.stream()), 'psi_maxpool3x3s2_backward')
+        return dx
+
+
+def maxpool3x3s2(x):
+    """``nn.MaxPool2d(kernel_size=3, stride=2, padding=1)`` (the trunk's stem) on a bf16 channels_last map: one gather pass each way."""
+    if x.dtype != torch.bfloat16 or not x.is_cuda or x.dim() != 4 or x.shape[1] % 8:
+        raise ValueError('maxpool3x3s2: expected a 4-D bf16 CUDA tensor with a multiple of 8 channels')
+    return _MaxPool3x3s2.apply(x)

@@ -63,6 +63,22 @@ def test_bn_act_matches_fp32_reference(shape, relu, with_res):
         assert float((res.grad.float() - rr.grad).abs().max()) <= 2 ** -7 * float(rr.grad.abs().max())
 
 
+@pytest.mark.parametrize('shape', [(4, 64, 64, 64), (2, 64, 9, 7), (3, 128, 16, 16), (1, 8, 1, 1)])
+def test_maxpool3x3s2_equals_torch(shape):
+    """ops.maxpool3x3s2 == F.max_pool2d(x, 3, 2, 1) on bf16 channels_last maps, values and gradient, bit for bit — on ReLU outputs,
+    i.e. with many exact ties inside the windows (the first maximum in scan order takes the gradient in both)."""
+    torch.manual_seed(sum(shape))
+    x = torch.relu(torch.randn(shape, device=DEV)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    xr = x.detach().clone().requires_grad_()
+    y = ops.maxpool3x3s2(x)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    assert y.shape == yr.shape and torch.equal(y, yr)
+    g = torch.randn(yr.shape, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y.backward(g)
+    yr.backward(g)
+    assert torch.equal(x.grad, xr.grad)
+
+
 def test_trunk_with_fused_bn_is_as_close_to_fp32_as_the_library_path():
     """BodyGlobalPoseVAE scene feature (trunk + conv + fc) in training mode, three ways on the same weights and input: fp32 (no
     autocast: the reference's arithmetic, cvae.py:427-455), bf16 autocast with the library BN (MIOpen), bf16 autocast with the fused
