@@ -588,16 +588,28 @@ def bench_train_s2(args):
             if d is not None:
                 batches.append(d)
         # matrix-core flops of one step (forward + backward of the PyTorch trunk; the HIP body/scene operators are not GEMMs)
+        # (counted with the hand-written convolution / dense / BN ops switched off: the flop counter only sees aten operators, and the
+        # arithmetic of the model is the same on either path)
         flops = None
+        saved_env = {k: os.environ.get(k) for k in ('PSI_HIP_CONV', 'PSI_HIP_LINEAR', 'PSI_HIP_BN')}
         try:
             from torch.utils.flop_counter import FlopCounterMode
+            os.environ.update(PSI_HIP_CONV='0', PSI_HIP_LINEAR='0', PSI_HIP_BN='0')
+            running = {k: v.clone() for k, v in op.model_h.state_dict().items() if 'running_' in k or 'num_batches' in k}
             with FlopCounterMode(display=False) as fc:
                 op.optimizer_h.zero_grad(set_to_none=True)
                 sum(op._losses_from_batch(batches[0], 9)).backward()
             flops = float(fc.get_total_flops())
             op.optimizer_h.zero_grad(set_to_none=True)
+            op.model_h.load_state_dict(running, strict=False)
         except Exception:
             pass
+        finally:
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         cnt = [0]
 
         def run_steps(k):
@@ -620,8 +632,12 @@ def bench_train_s2(args):
         res['roofline'] = {'bound': 'mfma', 'kernel': 'whole optimiser step (CVAE trunk GEMMs/convs, forward + backward)', 'achieved': round(ach, 2),
                            'peak': PEAK_BF16_TFLOPS if args.bf16 else PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': round(ach / (PEAK_BF16_TFLOPS if args.bf16 else PEAK_FP32_TFLOPS), 5), 'flops_per_step': flops, 'traffic': None,
-                           'note': 'matrix-core flops counted by torch.utils.flop_counter over one forward+backward; a step is a chain of small '
-                                   '(128-row) GEMMs/convs and elementwise glue, bound by launch count and activation traffic, not by the MFMA pipe'}
+                           'note': 'matrix-core flops counted by torch.utils.flop_counter over one forward+backward (library path; the hand-written '
+                                   'conv / dense kernels do the same arithmetic); a step is a chain of small (128-row) GEMMs/convs and elementwise '
+                                   'passes, bound by launch count and activation traffic, not by the MFMA pipe',
+                           'hand_written': 'conv3x3 forward + input gradient (conv.hip), dense layers forward + backward (linear.hip), BatchNorm + ReLU + '
+                                           'skip (bnorm.hip), stem max-pool, body decode / NN / SDF operators; library: 7x7 stem and strided convolutions, '
+                                           'convolution weight gradients'}
     return res
 
 

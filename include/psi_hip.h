@@ -280,6 +280,19 @@ int psi_bn_backward(const void *dy, const void *x, const void *y, const float *g
                     const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
                     float *ws, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 3x3 convolution, stride 1, padding 1 (nn.Conv2d(C, C', 3, 1, 1)) of the scene trunk on the bf16 matrix cores — replaces the library
+ * convolution for layer1 / layer2 of the ResNet-18 prefix (cvae.py:427-435) and the 128 -> 128 head convolution (net_layers.py:160-164),
+ * forward and input gradient (the input gradient is the same convolution of dY with the weight rotated by 180 degrees and its channel
+ * axes swapped: psi_conv3x3_rotate_weight).  x [N,H,W,Cin] bf16 (NHWC), w [Cout][3][3][Cin] bf16 (a channels_last Conv2d weight),
+ * bias [Cout] fp32 or NULL, y [N,H,W,Cout] bf16; fp32 accumulation.  Covered shapes (psi_conv3x3_supported != 0):
+ * Cin = 64 with Cout % 64 == 0, H % 8 == 0, W % 32 == 0;  Cin = 128 with Cout % 128 == 0, H % 8 == 0, W % 16 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int psi_conv3x3_supported(int Cin, int Cout, int H, int W);
+int psi_conv3x3_forward(const void *x, const void *w, const float *bias, int N, int H, int W, int Cin, int Cout, void *y, void *stream);
+/* w [Cout][3][3][Cin] -> wt [Cin][3][3][Cout] with wt[ci][kh][kw][co] = w[co][2-kh][2-kw][ci]:  dX = psi_conv3x3_forward(dY, wt) */
+int psi_conv3x3_rotate_weight(const void *w, int Cin, int Cout, void *wt, void *stream);
+
 /* MaxPool2d(kernel_size=3, stride=2, padding=1) of the trunk's stem (torchvision resnet18 children[3]; cvae.py:431-435) on an NHWC bf16 map
  * x [N,H,W,C] -> y [N,OH,OW,C], OH = (H - 1) / 2 + 1; idx [N,OH,OW,C] uint8 = position kh * 3 + kw of the maximum inside its window (first
  * maximum in scan order, like at::max_pool2d_with_indices).  Backward: dx [N,H,W,C] bf16 (OVERWRITTEN) gathers dy through idx. */

@@ -523,7 +523,7 @@ struct ContactSkinSrc {
 // vertices of one body each; gather-latency-bound).  As two launches they ran back to back (23 + 18 us); they depend on the same
 // inputs only, so in one grid their waves share the SIMDs and hide each other's stalls.
 __global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, const float *__restrict__ As, const float *__restrict__ v_posed,
-                                                           psikd::KdDev T, int n_kd, int nqb, int rows, float gscale)
+                                                           psikd::KdDev T, int n_kd, int nqb, int rows, float gscale, int skin_first)
 {
     extern __shared__ int smem_i[];
 #ifdef PSI_HEAD_STOPS
@@ -534,8 +534,15 @@ __global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, c
     // The NN-search workgroups come FIRST in the grid: they are the long ones.  Measured with the skinning workgroups first the launch
     // takes 43.6 us instead of 36.6 (HIP-event), with the two kinds spread evenly through the grid 45.8.
     int bid = blockIdx.x;
-    const bool is_kd = bid < n_kd;
-    if (!is_kd) bid -= n_kd;
+    bool is_kd;
+    if (skin_first) {                                         // the LONGER kind of workgroup is dispatched first (see the comment above)
+        const int n_sk = (int)gridDim.x - n_kd;
+        is_kd = bid >= n_sk;
+        if (is_kd) bid -= n_sk;
+    } else {
+        is_kd = bid < n_kd;
+        if (!is_kd) bid -= n_kd;
+    }
     if (is_kd) {
         const int b = bid / nqb, bx = bid % nqb;
         psikd::kd_query_body<true, false>(T, ContactSkinSrc{f, m, As, v_posed, nullptr}, f.n_c, (float *)nullptr, (int *)nullptr, f.cconst, gscale,
@@ -1004,6 +1011,7 @@ struct psi_fit_engine {
     char *blob;
     float *stats_local;           // engine-owned stats buffer (single-GPU path)
     bool merged_scene;            // skinning + SDF and the NN search in one launch (kd-tree mode, J <= 56, 4 lanes per query)
+    bool scene_skin_first;        // block order inside that launch: skinning + SDF workgroups before the NN-search workgroups
     hipGraph_t graph, graphN;     // one iteration / GRAPH_UNROLL iterations
     hipGraphExec_t graph_exec, graphN_exec;
     bool graph_ready, graphN_ready;
@@ -1067,7 +1075,7 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
         const psikd::KdDev T = psi_nn_index_dev(e->nn_index);
         const int nqb = f.nfp, n_kd = nqb * f.B;
         hipLaunchKernelGGL(fwd_scene_kernel, dim3(n_kd + f.nsdfblk * f.B), dim3(256), psikd::kd_lds_bytes(T.rows), st, f, e->lv.m, e->lv.A,
-                           e->lv.v_posed, T, n_kd, nqb, T.rows, gscale);
+                           e->lv.v_posed, T, n_kd, nqb, T.rows, gscale, e->scene_skin_first ? 1 : 0);
         PSI_CHECK_LAUNCH("fwd_scene_kernel");
         psi_mark("fwd_scene_kernel", st);
         if (local) return 0;
@@ -1245,6 +1253,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     // 0.3922 at 128; at 256 and above both parts are throughput-bound and the shared launch is 1-2 % slower); PSI_SPLIT_SCENE=1: two launches
     e->merged_scene = cfg->nn_mode == 1 && J <= PSI_JP - 8 && psikd::LPQ == 4 && cfg->B <= 128 &&
                       !(getenv("PSI_SPLIT_SCENE") && getenv("PSI_SPLIT_SCENE")[0] == '1');
+    e->scene_skin_first = getenv("PSI_SCENE_ORDER") && getenv("PSI_SCENE_ORDER")[0] == '1';
     hipLaunchKernelGGL(contact_weight_table_kernel, dim3(psi_cdiv((long)f.n_c * PSI_JP, 256)), dim3(256), 0, 0, e->lv.m.WT, e->lv.m.Vpad, f.vid,
                        f.n_c, J, (float *)f.Wct);
     f.sdf_brick = nullptr;

@@ -58,6 +58,9 @@ SIGNATURES = {
     'psi_bn_workspace_floats': (c_size_t, [c_long, c_int]),
     'psi_bn_forward': (c_int, [c_void_p] * 7 + [c_long, c_int, c_int, c_float, c_float] + [c_void_p] * 5),
     'psi_bn_backward': (c_int, [c_void_p] * 6 + [c_long, c_int, c_int] + [c_void_p] * 6),
+    'psi_conv3x3_supported': (c_int, [c_int] * 4),
+    'psi_conv3x3_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'psi_conv3x3_rotate_weight': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'psi_maxpool3x3s2_forward': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'psi_maxpool3x3s2_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'psi_dp_unique_id': (c_int, [c_void_p]),

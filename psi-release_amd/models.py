@@ -61,18 +61,30 @@ class _BasicBlock(nn.Module):
             # of the library's three launches per BN and separate ReLU / add launches — same arithmetic, same running-statistics update
             from .ops import bn_act
             identity = x if self.downsample is None else bn_act(self.downsample[0](x), self.downsample[1], relu=False)
-            out = bn_act(self.conv1(x), self.bn1, relu=True)
-            return bn_act(self.conv2(out), self.bn2, relu=True, residual=identity)
+            out = bn_act(_conv(self.conv1, x), self.bn1, relu=True)
+            return bn_act(_conv(self.conv2, out), self.bn2, relu=True, residual=identity)
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
+        out = self.relu(self.bn1(_conv(self.conv1, x)))
+        out = self.bn2(_conv(self.conv2, out))
         return self.relu(out + identity)
+
+
+def _conv(conv, x):
+    """A trunk convolution under bf16 autocast: the hand-written implicit-GEMM kernel where it applies (3x3, stride 1: ops.conv3x3;
+    PSI_HIP_CONV=0 keeps the library), the library otherwise (the 7x7 stem, the two strided convolutions)."""
+    import os
+    if (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            and os.environ.get('PSI_HIP_CONV', '1') != '0'):
+        from . import ops
+        if ops.conv3x3_supported(conv, x):
+            return ops.conv3x3(x, conv)
+    return conv(x)
 
 
 def _use_hip_bn(bn, x):
     """The fused BN kernels cover the training-mode trunk under bf16 autocast (PSI_HIP_BN=0 keeps the library path)."""
     import os
-    return (bn.training and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+    return (bn.training and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
             and bn.num_features % 8 == 0 and os.environ.get('PSI_HIP_BN', '1') != '0')
 
 
@@ -154,7 +166,7 @@ class _SceneCond(nn.Module):
                 self._nhwc = True
             scene = scene.contiguous(memory_format=torch.channels_last)
             with torch.autocast('cuda', dtype=torch.bfloat16):
-                f = self.conv(run_trunk(self.resnet, scene))
+                f = _conv(self.conv, run_trunk(self.resnet, scene))
                 if _use_hip_linear(self, scene):
                     # the 8192 / 32768 -> num_hidden layer: the bf16 feature map goes straight into the MFMA kernel, the fp32 master
                     # weight (up to 33.5 MB) is read once and rounded on load instead of being cast by a separate kernel every step

@@ -417,7 +417,7 @@ class _MaxPool3x3s2(Function):
         N, C, H, W = x.shape
         xc = x.contiguous(memory_format=torch.channels_last)
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = torch.empty(N, C, OH, OW, device=x.device, dtype=x.dtype).contiguous(memory_format=torch.channels_last)
+        y = torch.empty((N, C, OH, OW), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
         idx = torch.empty(N * OH * OW * C, device=x.device, dtype=torch.uint8)
         hip.check(hip.lib().psi_maxpool3x3s2_forward(_ptr_cl(xc), N, H, W, C, _ptr_cl(y), hip.ptr(idx), hip.stream()), 'psi_maxpool3x3s2_forward')
         ctx.save_for_backward(idx)
@@ -429,7 +429,7 @@ class _MaxPool3x3s2(Function):
         idx, = ctx.saved_tensors
         N, C, H, W = ctx.dims
         dyc = dy.contiguous(memory_format=torch.channels_last)
-        dx = torch.empty(N, C, H, W, device=dy.device, dtype=dy.dtype).contiguous(memory_format=torch.channels_last)
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=dy.dtype, memory_format=torch.channels_last)
         hip.check(hip.lib().psi_maxpool3x3s2_backward(_ptr_cl(dyc), hip.ptr(idx), N, H, W, C, _ptr_cl(dx), hip.stream()), 'psi_maxpool3x3s2_backward')
         return dx
 
@@ -439,3 +439,63 @@ def maxpool3x3s2(x):
     if x.dtype != torch.bfloat16 or not x.is_cuda or x.dim() != 4 or x.shape[1] % 8:
         raise ValueError('maxpool3x3s2: expected a 4-D bf16 CUDA tensor with a multiple of 8 channels')
     return _MaxPool3x3s2.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# 3x3 / stride 1 / padding 1 convolutions of the trunk on the hand-written implicit-GEMM kernel (csrc/conv.hip)
+# ------------------------------------------------------------------------------------------------------------------
+class _Conv3x3(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        xc = x.contiguous(memory_format=torch.channels_last)
+        wb = weight.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)          # [Cout,3,3,Cin]: a view for a channels_last weight
+        y = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        b = bias.detach().float().contiguous() if bias is not None else None
+        hip.check(hip.lib().psi_conv3x3_forward(_ptr_cl(xc), hip.ptr(wb), hip.ptr(b), N, H, W, Cin, Cout, _ptr_cl(y), hip.stream()),
+                  'psi_conv3x3_forward')
+        ctx.save_for_backward(xc, wb)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wb = ctx.saved_tensors
+        N, Cin, H, W = xc.shape
+        Cout = wb.shape[0]
+        dyc = dy.contiguous(memory_format=torch.channels_last)
+        L = hip.lib()
+        dx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if L.psi_conv3x3_supported(Cout, Cin, H, W):
+                wt = torch.empty(Cin, 3, 3, Cout, device=dy.device, dtype=torch.bfloat16)
+                hip.check(L.psi_conv3x3_rotate_weight(hip.ptr(wb), Cin, Cout, hip.ptr(wt), hip.stream()), 'psi_conv3x3_rotate_weight')
+                dx = torch.empty((N, Cin, H, W), device=dy.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+                hip.check(L.psi_conv3x3_forward(_ptr_cl(dyc), hip.ptr(wt), None, N, H, W, Cout, Cin, _ptr_cl(dx), hip.stream()),
+                          'psi_conv3x3_forward (input gradient)')
+            else:
+                dx = torch.ops.aten.convolution_backward(dyc, xc, wb.permute(0, 3, 1, 2), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            # the weight gradient (a reduction over all N*H*W pixels) stays with the library
+            gw = torch.ops.aten.convolution_backward(dyc, xc, wb.permute(0, 3, 1, 2), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     (False, True, False))[1].float()
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = dyc.float().sum((0, 2, 3))
+        return dx, gw, gb
+
+
+def conv3x3_supported(conv, x):
+    """True when ``conv`` (an nn.Conv2d) applied to the bf16 CUDA map ``x`` is covered by the hand-written kernel."""
+    return (x.is_cuda and x.dim() == 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros'
+            and bool(hip.lib().psi_conv3x3_supported(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3])))
+
+
+def conv3x3(x, conv):
+    """``conv(x)`` for a 3x3 / stride 1 / padding 1 ``nn.Conv2d`` on a bf16 map: hand-written bf16-MFMA implicit GEMM, forward and input
+    gradient (csrc/conv.hip); output bf16 channels_last."""
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)
+    return _Conv3x3.apply(x, conv.weight, conv.bias)
