@@ -290,6 +290,11 @@ int psi_bn_backward(const void *dy, const void *x, const void *y, const float *g
  * ------------------------------------------------------------------------------------------- */
 int psi_conv3x3_supported(int Cin, int Cout, int H, int W);
 int psi_conv3x3_forward(const void *x, const void *w, const float *bias, int N, int H, int W, int Cin, int Cout, void *y, void *stream);
+/* Weight gradient of the same convolution: gw [Cout][3][3][Cin] fp32 (OVERWRITTEN) = sum over all pixels of dY (x) X per filter tap; covered
+ * when the image width is 16 or 32, H % (128 / W) == 0 and both channel counts are multiples of 64.  ws: psi_conv3x3_wrw_workspace_floats()
+ * floats (per-split partial results, summed in a fixed order: deterministic, unlike the library's atomic split-K kernels). */
+size_t psi_conv3x3_wrw_workspace_floats(int N, int H, int W, int Cin, int Cout);
+int psi_conv3x3_weight_grad(const void *x, const void *dy, int N, int H, int W, int Cin, int Cout, float *gw, float *ws, void *stream);
 /* w [Cout][3][3][Cin] -> wt [Cin][3][3][Cout] with wt[ci][kh][kw][co] = w[co][2-kh][2-kw][ci]:  dX = psi_conv3x3_forward(dY, wt) */
 int psi_conv3x3_rotate_weight(const void *w, int Cin, int Cout, void *wt, void *stream);
 

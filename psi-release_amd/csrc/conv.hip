@@ -172,6 +172,125 @@ int launch_conv(const void *x, const void *w, const float *bias, void *y, int N,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient  dW[co][kh][kw][ci] = sum_{n,oy,ox} dY[n,oy,ox,co] * X[n, oy+kh-1, ox+kw-1, ci]   (fp32 output).
+// The contraction runs over PIXELS, along which neither operand is contiguous (channels are fastest), so both tiles are transposed on
+// their way into LDS: dYt[co][pixel], Xt[kw][ci][pixel] — the input tile is kept in THREE copies, shifted by one column each, so that
+// the eight consecutive pixels an MFMA lane reads for tap column kw are a 16-byte ALIGNED run in copy kw (the row shift kh is a multiple
+// of the row length and keeps the alignment).  A stage is TR output rows of one image (128 pixels); a workgroup owns a 64 (co) x 64 (ci)
+// tile of dW for all nine taps — wave (ct, it) one 32 x 32 quadrant, nine accumulators — and walks the stages s = split, split + S, ...;
+// the S partial results are summed in split order by conv_wrw_reduce_kernel (deterministic; the library's split-K kernels use atomics).
+// ------------------------------------------------------------------------------------------------
+template <int TW>                                            // image width == tile width (16 or 32); TR = 128 / TW output rows per stage
+__global__ __launch_bounds__(256) void conv3x3_wrw_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy, float *__restrict__ part,
+                                                          int N, int H, int CIN, int COUT, int nsplit)
+{
+    constexpr int TR = 128 / TW, PXP = 128 + 8, XR = (TR + 2) * TW, XP = XR + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 (*dYt)[PXP] = (__bf16 (*)[PXP])smem;                                    // [64 co][128 px]
+    __bf16 (*Xt)[64][XP] = (__bf16 (*)[64][XP])(smem + (size_t)64 * PXP * 2);       // [3 kw][64 ci][(TR+2) * TW]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ct = wv & 1, it = wv >> 1;
+    const int li = lane & 31, kb = (lane >> 5) * 8, h = lane >> 5;
+    const int split = blockIdx.x, co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+    const int stages_per_img = H / TR, nstage = N * stages_per_img;
+    // the border columns of the shifted copies are never written: zero everything once
+    for (int i = threadIdx.x; i < 3 * 64 * XP / 2; i += 256) ((unsigned *)&Xt[0][0][0])[i] = 0u;
+    f16v acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[tp][i] = 0.0f;
+    for (int stg = split; stg < nstage; stg += nsplit) {
+        const int n = stg / stages_per_img, oy0 = (stg % stages_per_img) * TR;
+        __syncthreads();                                     // previous stage's MFMAs are done with LDS (and the zero fill is visible)
+        // ---- dY tile: 128 px x 64 co = 1024 16-byte pieces, 4 per thread, transposed into dYt[co][px]
+        u4 dv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = threadIdx.x + 256 * i, px = idx >> 3, c = idx & 7;
+            dv[i] = *(const u4 *)(dy + (((size_t)n * H + oy0 + px / TW) * TW + px % TW) * COUT + co0 + c * 8);
+        }
+        // ---- X tile with one halo row above and below: (TR + 2) * TW px x 64 ci, XLD pieces per thread
+        constexpr int XPC = XR * 8, XLD = (XPC + 255) / 256;
+        u4 xv[XLD];
+#pragma unroll
+        for (int i = 0; i < XLD; i++) {
+            const int idx = threadIdx.x + 256 * i, px = idx >> 3, c = idx & 7;
+            const int iy = oy0 - 1 + px / TW;
+            xv[i] = (u4){0u, 0u, 0u, 0u};
+            if (idx < XPC && iy >= 0 && iy < H) xv[i] = *(const u4 *)(x + (((size_t)n * H + iy) * TW + px % TW) * CIN + ci0 + c * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = threadIdx.x + 256 * i, px = idx >> 3, c = idx & 7;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                ((unsigned short *)&dYt[c * 8 + 2 * e][px])[0] = (unsigned short)(dv[i][e] & 0xffffu);
+                ((unsigned short *)&dYt[c * 8 + 2 * e + 1][px])[0] = (unsigned short)(dv[i][e] >> 16);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < XLD; i++) {
+            const int idx = threadIdx.x + 256 * i, px = idx >> 3, c = idx & 7;
+            if (idx < XPC) {
+                const int col = px % TW, rowbase = px - col;
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++) {
+                    const int cc = col - kw + 1;              // copy kw holds x[.., c' + kw - 1] at column c'
+                    if (cc >= 0 && cc < TW) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            ((unsigned short *)&Xt[kw][c * 8 + 2 * e][rowbase + cc])[0] = (unsigned short)(xv[i][e] & 0xffffu);
+                            ((unsigned short *)&Xt[kw][c * 8 + 2 * e + 1][rowbase + cc])[0] = (unsigned short)(xv[i][e] >> 16);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k0 = 0; k0 < 128; k0 += 16) {
+            const bf16x8 a = *(const bf16x8 *)&dYt[ct * 32 + li][k0 + kb];
+            const int r = k0 / TW, c0 = k0 % TW;
+#pragma unroll
+            for (int tp = 0; tp < 9; tp++) {
+                const bf16x8 b = *(const bf16x8 *)&Xt[tp % 3][it * 32 + li][(r + tp / 3) * TW + c0 + kb];
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tp], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial tile: D[row = co][col = ci] per tap -> part[split][co][tap][ci]
+    float *po = part + (size_t)split * COUT * 9 * CIN;
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = co0 + ct * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            po[((size_t)co * 9 + tp) * CIN + ci0 + it * 32 + li] = acc[tp][r];
+        }
+}
+
+__global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(const float *__restrict__ part, int nsplit, long n, float *__restrict__ gw)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int s = 0;
+    for (; s + 7 < nsplit; s += 8) {                          // eight loads in flight; fixed order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = part[(size_t)(s + u) * n + i];
+        a0 += v[0] + v[4];
+        a1 += v[1] + v[5];
+        a2 += v[2] + v[6];
+        a3 += v[3] + v[7];
+    }
+    for (; s < nsplit; s++) a0 += part[(size_t)s * n + i];
+    gw[i] = (a0 + a1) + (a2 + a3);
+}
+
 // weight re-layout for the input gradient: W[co][kh][kw][ci] -> Wt[ci][2-kh][2-kw][co]
 __global__ void conv_weight_rot_kernel(const __bf16 *__restrict__ w, __bf16 *__restrict__ wt, int COUT, int CIN)
 {
@@ -205,5 +324,46 @@ extern "C" int psi_conv3x3_rotate_weight(const void *w, int Cin, int Cout, void 
     const int total = Cout * 9 * Cin;
     hipLaunchKernelGGL(conv_weight_rot_kernel, dim3(psi_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)w, (__bf16 *)wt, Cout, Cin);
     PSI_CHECK_LAUNCH("conv_weight_rot_kernel");
+    return 0;
+}
+
+// splits of the pixel range for the weight gradient: about one workgroup per compute unit
+static int wrw_splits(int N, int H, int W, int Cin, int Cout)
+{
+    const int TR = 128 / W, nstage = N * (H / TR), tiles = (Cin / 64) * (Cout / 64);
+    int S = 256 / tiles;
+    if (S > nstage) S = nstage;
+    return S < 1 ? 1 : S;
+}
+
+extern "C" size_t psi_conv3x3_wrw_workspace_floats(int N, int H, int W, int Cin, int Cout)
+{
+    if (!(W == 16 || W == 32) || H % (128 / W) || Cin % 64 || Cout % 64) return 0;
+    return (size_t)wrw_splits(N, H, W, Cin, Cout) * Cout * 9 * Cin;
+}
+
+extern "C" int psi_conv3x3_weight_grad(const void *x, const void *dy, int N, int H, int W, int Cin, int Cout, float *gw, float *ws, void *stream)
+{
+    PSI_REQUIRE(x && dy && gw && ws && N > 0, "null pointer");
+    PSI_REQUIRE((W == 16 || W == 32) && H % (128 / W) == 0 && Cin % 64 == 0 && Cout % 64 == 0, "shape not covered: W 16 or 32, H % (128 / W) == 0, channels % 64 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    const int S = wrw_splits(N, H, W, Cin, Cout);
+    const int TR = 128 / W;
+    const size_t lds = ((size_t)64 * (128 + 8) + (size_t)3 * 64 * ((TR + 2) * W + 8)) * 2;
+    dim3 grid(S, Cout / 64, Cin / 64);
+    if (W == 32) {
+        static bool a32 = false;
+        if (!a32) { PSI_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wrw_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a32 = true; }
+        hipLaunchKernelGGL(conv3x3_wrw_kernel<32>, grid, dim3(256), lds, st, (const __bf16 *)x, (const __bf16 *)dy, ws, N, H, Cin, Cout, S);
+    } else {
+        static bool a16 = false;
+        if (!a16) { PSI_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wrw_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a16 = true; }
+        hipLaunchKernelGGL(conv3x3_wrw_kernel<16>, grid, dim3(256), lds, st, (const __bf16 *)x, (const __bf16 *)dy, ws, N, H, Cin, Cout, S);
+    }
+    PSI_CHECK_LAUNCH("conv3x3_wrw_kernel");
+    psi_mark("conv3x3_wrw_kernel", st);
+    const long n = (long)Cout * 9 * Cin;
+    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(psi_cdiv(n, 256)), dim3(256), 0, st, ws, S, n, gw);
+    PSI_CHECK_LAUNCH("conv_wrw_reduce_kernel");
     return 0;
 }

@@ -60,6 +60,8 @@ SIGNATURES = {
     'psi_bn_backward': (c_int, [c_void_p] * 6 + [c_long, c_int, c_int] + [c_void_p] * 6),
     'psi_conv3x3_supported': (c_int, [c_int] * 4),
     'psi_conv3x3_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'psi_conv3x3_wrw_workspace_floats': (c_size_t, [c_int] * 5),
+    'psi_conv3x3_weight_grad': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'psi_conv3x3_rotate_weight': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'psi_maxpool3x3s2_forward': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'psi_maxpool3x3s2_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -478,9 +478,17 @@ class _Conv3x3(Function):
                 dx = torch.ops.aten.convolution_backward(dyc, xc, wb.permute(0, 3, 1, 2), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                          (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            # the weight gradient (a reduction over all N*H*W pixels) stays with the library
-            gw = torch.ops.aten.convolution_backward(dyc, xc, wb.permute(0, 3, 1, 2), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                     (False, True, False))[1].float()
+            nws = L.psi_conv3x3_wrw_workspace_floats(N, H, W, Cin, Cout) if os.environ.get('PSI_HIP_CONV_WRW', '1') != '0' else 0
+            if nws:
+                # hand-written split-K weight gradient (fp32, deterministic summation order)
+                gw4 = torch.empty(Cout, 3, 3, Cin, device=dy.device, dtype=torch.float32)
+                ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
+                hip.check(L.psi_conv3x3_weight_grad(_ptr_cl(xc), _ptr_cl(dyc), N, H, W, Cin, Cout, hip.ptr(gw4), hip.ptr(ws), hip.stream()),
+                          'psi_conv3x3_weight_grad')
+                gw = gw4.permute(0, 3, 1, 2)                         # [Cout,Cin,3,3] view (channels_last strides, like the parameter)
+            else:
+                gw = torch.ops.aten.convolution_backward(dyc, xc, wb.permute(0, 3, 1, 2), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (False, True, False))[1].float()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = dyc.float().sum((0, 2, 3))
         return dx, gw, gb
