@@ -175,79 +175,78 @@ int launch_conv(const void *x, const void *w, const float *bias, void *y, int N,
 // ------------------------------------------------------------------------------------------------
 // Weight gradient  dW[co][kh][kw][ci] = sum_{n,oy,ox} dY[n,oy,ox,co] * X[n, oy+kh-1, ox+kw-1, ci]   (fp32 output).
 // The contraction runs over PIXELS, along which neither operand is contiguous (channels are fastest), so both tiles are transposed on
-// their way into LDS: dYt[co][pixel], Xt[kw][ci][pixel] — the input tile is kept in THREE copies, shifted by one column each, so that
-// the eight consecutive pixels an MFMA lane reads for tap column kw are a 16-byte ALIGNED run in copy kw (the row shift kh is a multiple
-// of the row length and keeps the alignment).  A stage is TR output rows of one image (128 pixels); a workgroup owns a 64 (co) x 64 (ci)
-// tile of dW for all nine taps — wave (ct, it) one 32 x 32 quadrant, nine accumulators — and walks the stages s = split, split + S, ...;
-// the S partial results are summed in split order by conv_wrw_reduce_kernel (deterministic; the library's split-K kernels use atomics).
+// their way into LDS: dYt[co][pixel], Xt[ci][row][8 zeros | TW pixels | 8 zeros].  A thread loads the 16-byte channel pieces of TWO
+// adjacent pixels and stores one 32-bit {pixel, pixel + 1} pair per channel (the first version stored single bf16 values into three
+// column-shifted copies of the input tile: 176 conflicting 2-byte LDS stores per thread and stage, 38 us per layer).  The MFMA operand of
+// tap column kw is the run of eight pixels starting at ox + kw - 1: for kw = 1 an aligned 16-byte LDS read, for kw = 0 / 2 the same run
+// shifted by one pixel, assembled in registers from the aligned chunk and its left / right neighbour with five v_alignbit — the zero
+// columns left and right of a row are the convolution's padding.  The row shift kh moves by whole rows and keeps the alignment.
+// A stage is TR output rows of one image (128 pixels); a workgroup owns a 64 (co) x 64 (ci) tile of dW for all nine taps — wave (ct, it)
+// one 32 x 32 quadrant, nine accumulators — and walks the stages s = split, split + S, ...; the S partial results are summed in split
+// order by conv_wrw_reduce_kernel (deterministic; the library's split-K kernels use atomics).
 // ------------------------------------------------------------------------------------------------
 template <int TW>                                            // image width == tile width (16 or 32); TR = 128 / TW output rows per stage
 __global__ __launch_bounds__(256) void conv3x3_wrw_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy, float *__restrict__ part,
                                                           int N, int H, int CIN, int COUT, int nsplit)
 {
-    constexpr int TR = 128 / TW, PXP = 128 + 8, XR = (TR + 2) * TW, XP = XR + 8;
+    constexpr int TR = 128 / TW, PXP = 128 + 8, RP = TW + 16, XP = (TR + 2) * RP + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 (*dYt)[PXP] = (__bf16 (*)[PXP])smem;                                    // [64 co][128 px]
-    __bf16 (*Xt)[64][XP] = (__bf16 (*)[64][XP])(smem + (size_t)64 * PXP * 2);       // [3 kw][64 ci][(TR+2) * TW]
+    __bf16 (*Xt)[XP] = (__bf16 (*)[XP])(smem + (size_t)64 * PXP * 2);               // [64 ci][(TR + 2) rows of RP]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ct = wv & 1, it = wv >> 1;
     const int li = lane & 31, kb = (lane >> 5) * 8, h = lane >> 5;
     const int split = blockIdx.x, co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
     const int stages_per_img = H / TR, nstage = N * stages_per_img;
-    // the border columns of the shifted copies are never written: zero everything once
-    for (int i = threadIdx.x; i < 3 * 64 * XP / 2; i += 256) ((unsigned *)&Xt[0][0][0])[i] = 0u;
+    for (int i = threadIdx.x; i < 64 * XP / 2; i += 256) ((unsigned *)&Xt[0][0])[i] = 0u;      // the padding columns are never written again
     f16v acc[9];
 #pragma unroll
     for (int tp = 0; tp < 9; tp++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[tp][i] = 0.0f;
+    // item = (pixel pair q, channel piece c); consecutive lanes take consecutive PAIRS of one piece: their 32-bit LDS stores fall on
+    // consecutive banks, and the eight pieces of a pixel are still requested by one load instruction of the wave
+    constexpr int DP = 64, DLD = DP * 8 / 256;                    // dY: 64 pairs x 8 pieces = 512 items, 2 per thread
+    constexpr int XPR = (TR + 2) * TW / 2, XIT = XPR * 8, XLD = (XIT + 255) / 256;
     for (int stg = split; stg < nstage; stg += nsplit) {
         const int n = stg / stages_per_img, oy0 = (stg % stages_per_img) * TR;
         __syncthreads();                                     // previous stage's MFMAs are done with LDS (and the zero fill is visible)
-        // ---- dY tile: 128 px x 64 co = 1024 16-byte pieces, 4 per thread, transposed into dYt[co][px]
-        u4 dv[4];
+        u4 dv[DLD][2], xv[XLD][2];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int idx = threadIdx.x + 256 * i, px = idx >> 3, c = idx & 7;
-            dv[i] = *(const u4 *)(dy + (((size_t)n * H + oy0 + px / TW) * TW + px % TW) * COUT + co0 + c * 8);
+        for (int i = 0; i < DLD; i++) {
+            const int idx = threadIdx.x + 256 * i, q = idx % DP, c = idx / DP, px = 2 * q;
+            const __bf16 *src = dy + (((size_t)n * H + oy0 + px / TW) * TW + px % TW) * COUT + co0 + c * 8;
+            dv[i][0] = *(const u4 *)src;
+            dv[i][1] = *(const u4 *)(src + COUT);
         }
-        // ---- X tile with one halo row above and below: (TR + 2) * TW px x 64 ci, XLD pieces per thread
-        constexpr int XPC = XR * 8, XLD = (XPC + 255) / 256;
-        u4 xv[XLD];
 #pragma unroll
         for (int i = 0; i < XLD; i++) {
-            const int idx = threadIdx.x + 256 * i, px = idx >> 3, c = idx & 7;
+            const int idx = threadIdx.x + 256 * i, q = idx % XPR, c = idx / XPR, px = 2 * q;
             const int iy = oy0 - 1 + px / TW;
-            xv[i] = (u4){0u, 0u, 0u, 0u};
-            if (idx < XPC && iy >= 0 && iy < H) xv[i] = *(const u4 *)(x + (((size_t)n * H + iy) * TW + px % TW) * CIN + ci0 + c * 8);
+            xv[i][0] = xv[i][1] = (u4){0u, 0u, 0u, 0u};
+            if (idx < XIT && iy >= 0 && iy < H) {
+                const __bf16 *src = x + (((size_t)n * H + iy) * TW + px % TW) * CIN + ci0 + c * 8;
+                xv[i][0] = *(const u4 *)src;
+                xv[i][1] = *(const u4 *)(src + CIN);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int idx = threadIdx.x + 256 * i, px = idx >> 3, c = idx & 7;
+        auto scatter = [&](const u4 &p0, const u4 &p1, __bf16 *row0, int pitch) {     // 8 channels x {pixel, pixel + 1} -> 8 rows, one dword each
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                ((unsigned short *)&dYt[c * 8 + 2 * e][px])[0] = (unsigned short)(dv[i][e] & 0xffffu);
-                ((unsigned short *)&dYt[c * 8 + 2 * e + 1][px])[0] = (unsigned short)(dv[i][e] >> 16);
+                *(unsigned *)(row0 + (size_t)(2 * e) * pitch) = (p0[e] & 0xffffu) | (p1[e] << 16);
+                *(unsigned *)(row0 + (size_t)(2 * e + 1) * pitch) = (p0[e] >> 16) | (p1[e] & 0xffff0000u);
             }
+        };
+#pragma unroll
+        for (int i = 0; i < DLD; i++) {
+            const int idx = threadIdx.x + 256 * i, q = idx % DP, c = idx / DP;
+            scatter(dv[i][0], dv[i][1], &dYt[c * 8][2 * q], PXP);
         }
 #pragma unroll
         for (int i = 0; i < XLD; i++) {
-            const int idx = threadIdx.x + 256 * i, px = idx >> 3, c = idx & 7;
-            if (idx < XPC) {
-                const int col = px % TW, rowbase = px - col;
-#pragma unroll
-                for (int kw = 0; kw < 3; kw++) {
-                    const int cc = col - kw + 1;              // copy kw holds x[.., c' + kw - 1] at column c'
-                    if (cc >= 0 && cc < TW) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            ((unsigned short *)&Xt[kw][c * 8 + 2 * e][rowbase + cc])[0] = (unsigned short)(xv[i][e] & 0xffffu);
-                            ((unsigned short *)&Xt[kw][c * 8 + 2 * e + 1][rowbase + cc])[0] = (unsigned short)(xv[i][e] >> 16);
-                        }
-                    }
-                }
-            }
+            const int idx = threadIdx.x + 256 * i, q = idx % XPR, c = idx / XPR, px = 2 * q;
+            if (idx < XIT) scatter(xv[i][0], xv[i][1], &Xt[c * 8][(px / TW) * RP + 8 + px % TW], XP);
         }
         __syncthreads();
 #pragma unroll
@@ -255,9 +254,21 @@ __global__ __launch_bounds__(256) void conv3x3_wrw_kernel(const __bf16 *__restri
             const bf16x8 a = *(const bf16x8 *)&dYt[ct * 32 + li][k0 + kb];
             const int r = k0 / TW, c0 = k0 % TW;
 #pragma unroll
-            for (int tp = 0; tp < 9; tp++) {
-                const bf16x8 b = *(const bf16x8 *)&Xt[tp % 3][it * 32 + li][(r + tp / 3) * TW + c0 + kb];
-                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tp], 0, 0, 0);
+            for (int kh = 0; kh < 3; kh++) {
+                const __bf16 *mid = &Xt[it * 32 + li][(r + kh) * RP + 8 + c0 + kb];
+                const u4 L = *(const u4 *)(mid - 8), M = *(const u4 *)mid, R = *(const u4 *)(mid + 8);
+                u4 s0, s2;                                    // the run shifted one pixel to the left (kw = 0) / right (kw = 2)
+                s0[0] = __builtin_amdgcn_alignbit(M[0], L[3], 16);
+                s0[1] = __builtin_amdgcn_alignbit(M[1], M[0], 16);
+                s0[2] = __builtin_amdgcn_alignbit(M[2], M[1], 16);
+                s0[3] = __builtin_amdgcn_alignbit(M[3], M[2], 16);
+                s2[0] = s0[1];
+                s2[1] = s0[2];
+                s2[2] = s0[3];
+                s2[3] = __builtin_amdgcn_alignbit(R[0], M[3], 16);
+                acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, s0), acc[kh * 3 + 0], 0, 0, 0);
+                acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, M), acc[kh * 3 + 1], 0, 0, 0);
+                acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, s2), acc[kh * 3 + 2], 0, 0, 0);
             }
         }
     }
@@ -349,7 +360,7 @@ extern "C" int psi_conv3x3_weight_grad(const void *x, const void *dy, int N, int
     hipStream_t st = (hipStream_t)stream;
     const int S = wrw_splits(N, H, W, Cin, Cout);
     const int TR = 128 / W;
-    const size_t lds = ((size_t)64 * (128 + 8) + (size_t)3 * 64 * ((TR + 2) * W + 8)) * 2;
+    const size_t lds = ((size_t)64 * (128 + 8) + (size_t)64 * ((TR + 2) * (W + 16) + 8)) * 2;
     dim3 grid(S, Cout / 64, Cin / 64);
     if (W == 32) {
         static bool a32 = false;
