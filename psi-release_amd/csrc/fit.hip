@@ -1151,8 +1151,15 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     PSI_REQUIRE(!(f.indep && cfg->world_size > 1), "independent bodies have no cross-rank coupling: use world_size 1");
     f.w_rec = cfg->w_rec; f.w_vp = cfg->w_vposer; f.w_contact = cfg->w_contact; f.w_col = cfg->w_collision; f.cconst = cfg->contact_const;
     f.lr = cfg->lr; f.beta1 = cfg->beta1; f.beta2 = cfg->beta2; f.eps = cfg->eps;
-    f.nfp = cfg->nn_mode == 1 ? psi_nn_index_fparts(f.n_c) : psi_nn_contact_fparts(f.n_c);
+    // one launch for both scene terms up to B = 128 (measured: 0.1695 -> 0.1611 ms per iteration at B = 32, 0.2342 -> 0.2258 at 64, 0.3957 ->
+    // 0.3922 at 128; at 256 and above both parts are throughput-bound and the shared launch is 1-2 % slower); PSI_SPLIT_SCENE=1: two launches.
+    // (Round 3 also tried the opposite arrangement — no search workgroups at all, every skinning workgroup answering the contact queries of
+    // its own 256 vertices from LDS after the SDF lookup: 1312 workgroups = one occupancy round instead of two, no second skinning of the
+    // query vertices.  It measured 42 us against 33: the search became a serial tail of every workgroup instead of running beside them.)
+    e->merged_scene = cfg->nn_mode == 1 && J <= PSI_JP - 8 && psikd::LPQ == 4 && cfg->B <= 128 &&
+                      !(getenv("PSI_SPLIT_SCENE") && getenv("PSI_SPLIT_SCENE")[0] == '1');
     f.nsdfblk = psi_cdiv(V, 256);
+    f.nfp = cfg->nn_mode == 1 ? psi_nn_index_fparts(f.n_c) : psi_nn_contact_fparts(f.n_c);
     f.max_hist = cfg->max_history > 0 ? cfg->max_history : 1024;
     // workgroups per body in the head / tail kernels: enough to put ~256 workgroups on the chip, none once the bodies alone do
     {
@@ -1249,10 +1256,6 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
         if (rcv) { (void)hipFree(e->blob); delete e; return rcv; }
     }
     f.Wct = F(o_wct);
-    // one launch for both scene terms up to B = 128 (measured: 0.1695 -> 0.1611 ms per iteration at B = 32, 0.2342 -> 0.2258 at 64, 0.3957 ->
-    // 0.3922 at 128; at 256 and above both parts are throughput-bound and the shared launch is 1-2 % slower); PSI_SPLIT_SCENE=1: two launches
-    e->merged_scene = cfg->nn_mode == 1 && J <= PSI_JP - 8 && psikd::LPQ == 4 && cfg->B <= 128 &&
-                      !(getenv("PSI_SPLIT_SCENE") && getenv("PSI_SPLIT_SCENE")[0] == '1');
     e->scene_skin_first = getenv("PSI_SCENE_ORDER") && getenv("PSI_SCENE_ORDER")[0] == '1';
     hipLaunchKernelGGL(contact_weight_table_kernel, dim3(psi_cdiv((long)f.n_c * PSI_JP, 256)), dim3(256), 0, 0, e->lv.m.WT, e->lv.m.Vpad, f.vid,
                        f.n_c, J, (float *)f.Wct);

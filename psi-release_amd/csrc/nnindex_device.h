@@ -111,12 +111,31 @@ struct KdQueryFromMemory {
     }
 };
 
-// body of the search for workgroup (bx, b) of an (nbx, B) grid; smem_i: QPB * rows * 8 bytes of LDS for the traversal stacks
-template <bool CONTACT, bool MULTI, class QSrc>
-__device__ __forceinline__ void kd_query_body(KdDev T0, QSrc qsrc, int n, float *__restrict__ dist, int *__restrict__ idx, float cconst,
-                                              float gscale, float *__restrict__ gq, float *__restrict__ fpart, int *__restrict__ hint,
-                                              int rows, const KdDev *__restrict__ tab, const int *__restrict__ slot, int bx, int b, int nbx,
-                                              int *smem_i)
+// sum of the per-group contact terms over the workgroup (fixed order) -> *out
+__device__ __forceinline__ void kd_block_fsum(float fval, float *__restrict__ out)
+{
+    __shared__ float wsum[QBLK / 64];
+    const int tid = threadIdx.x;
+    float v = fval;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_down(v, o2, 64);
+    if ((tid & 63) == 0) wsum[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < QBLK / 64; w++) t += wsum[w];
+        *out = t;
+    }
+}
+
+// One round of the search: the workgroup's QPB lane groups answer one query each.  (qx,qy,qz): the group's query (the same values in
+// all LPQ lanes of the group), active: the group has a query, o: its output slot (dist / idx / hint / gq index).  Returns the contact
+// term s / (s + c) of the query in lane 0 of its group (0 elsewhere) when CONTACT.  No barriers inside: groups are independent.
+template <bool CONTACT>
+__device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float qy, float qz, bool active, size_t o, float *__restrict__ dist,
+                                                int *__restrict__ idx, float cconst, float gscale, float *__restrict__ gq, int *__restrict__ hint,
+                                                int rows, int *smem_i)
 {
 #pragma clang fp contract(off)    // the distance expression (PSI_SQ3) must not be re-contracted in translation units built with contraction on
     const int tid = threadIdx.x;
@@ -124,13 +143,6 @@ __device__ __forceinline__ void kd_query_body(KdDev T0, QSrc qsrc, int n, float 
     const int g = tid / LPQ;                                  // query group inside the workgroup
     int *stk_n = smem_i + (size_t)g * rows * 2;               // [rows] child references
     float *stk_d = (float *)(stk_n + rows);                   // [rows] box distances
-    const KdDev T = MULTI ? tab[slot[b]] : T0;
-    const int j = bx * QPB + g;
-    const bool active = j < n;
-    const size_t o = (size_t)b * n + (active ? j : 0);
-    float qx = 0, qy = 0, qz = 0;
-    qsrc.prepare(b);
-    qsrc.point(b, active ? j : 0, c, qx, qy, qz);                // every lane of the group ends up with the same point
     kd_key bestk = kd_pack(INFINITY, 0x7fffffff);
     float best = INFINITY;                                    // == kd_key_d(bestk)
     if (active && hint) {
@@ -280,22 +292,28 @@ __device__ __forceinline__ void kd_query_body(KdDev T0, QSrc qsrc, int n, float 
             gq[o * 3 + 2] = gg * (qz - w.z);
         }
     }
-    if (CONTACT) {
-        __shared__ float wsum[QBLK / 64];
-        float v = fval;
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_down(v, o2, 64);
-        if ((tid & 63) == 0) wsum[tid >> 6] = v;
-        __syncthreads();
-        if (tid == 0) {
-            float t = 0.0f;
-#pragma unroll
-            for (int w = 0; w < QBLK / 64; w++) t += wsum[w];
-            fpart[(size_t)b * nbx + bx] = t;
-        }
-    }
+    return fval;
 }
 
+// body of the search for workgroup (bx, b) of an (nbx, B) grid; smem_i: QPB * rows * 8 bytes of LDS for the traversal stacks
+template <bool CONTACT, bool MULTI, class QSrc>
+__device__ __forceinline__ void kd_query_body(KdDev T0, QSrc qsrc, int n, float *__restrict__ dist, int *__restrict__ idx, float cconst,
+                                              float gscale, float *__restrict__ gq, float *__restrict__ fpart, int *__restrict__ hint,
+                                              int rows, const KdDev *__restrict__ tab, const int *__restrict__ slot, int bx, int b, int nbx,
+                                              int *smem_i)
+{
+    const int tid = threadIdx.x;
+    const int c = tid & (LPQ - 1), g = tid / LPQ;
+    const KdDev T = MULTI ? tab[slot[b]] : T0;
+    const int j = bx * QPB + g;
+    const bool active = j < n;
+    const size_t o = (size_t)b * n + (active ? j : 0);
+    float qx = 0, qy = 0, qz = 0;
+    qsrc.prepare(b);
+    qsrc.point(b, active ? j : 0, c, qx, qy, qz);                // every lane of the group ends up with the same point
+    const float fval = kd_query_round<CONTACT>(T, qx, qy, qz, active, o, dist, idx, cconst, gscale, gq, hint, rows, smem_i);
+    if (CONTACT) kd_block_fsum(fval, fpart + (size_t)b * nbx + bx);
+}
 
 static inline size_t kd_lds_bytes(int rows) { return (size_t)QPB * rows * 8; }
 
