@@ -418,17 +418,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // One output per thread, ALL of its slices requested before the first add (the partials were just written by other XCDs'
 // workgroups: every dependent round of loads is a ~2 us trip to memory; measured 10 us with 4 loads in flight, and 15 us
 // when 32 workgroups did the whole 7.5 MB themselves).
+// RSPL threads share one output: thread s of the group adds slices s, s + RSPL, ... (all requested before the first add) and the group is
+// combined in lane order with shuffles — four times as many workgroups pulling the fresh partials (they were just written by other XCDs'
+// workgroups: a CU gets only ~15 GB/s of such data, so the kernel is bound by how many CUs pull at once, not by arithmetic).
+constexpr int RSPL = 4;
 template <int MAXS>
-__device__ __forceinline__ float sum_slices(const float *__restrict__ p, size_t stride, int n)
+__device__ __forceinline__ float sum_slices_split(const float *__restrict__ p, size_t stride, int n, int s0)
 {
     float v[MAXS];
 #pragma unroll
-    for (int sl = 0; sl < MAXS; sl++) v[sl] = sl < n ? p[(size_t)sl * stride] : 0.0f;
-    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int k = 0; k < MAXS; k++) {
+        const int sl = s0 + k * RSPL;
+        v[k] = sl < n ? p[(size_t)sl * stride] : 0.0f;
+    }
+    float a0 = 0, a1 = 0;
 #pragma unroll
-    for (int sl = 0; sl < MAXS; sl += 4) { a0 += v[sl]; a1 += v[sl + 1]; a2 += v[sl + 2]; a3 += v[sl + 3]; }
-    float r = (a0 + a1) + (a2 + a3);
-    for (int sl = MAXS; sl < n; sl++) r += p[(size_t)sl * stride];
+    for (int k = 0; k < MAXS; k += 2) { a0 += v[k]; a1 += v[k + 1]; }
+    float r = a0 + a1;
+    for (int sl = s0 + MAXS * RSPL; sl < n; sl += RSPL) r += p[(size_t)sl * stride];
+    // lanes s0 = 0..3 of the group -> ((r0 + r1) + (r2 + r3)), the same value in all four lanes
+    r += __shfl_xor(r, 1, 64);
+    r += __shfl_xor(r, 2, 64);
     return r;
 }
 
@@ -439,16 +449,21 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int Kpad, c
                                                               float *__restrict__ g_transl)
 {
     const long nA = (long)B * JP * 16, nF = (long)B * Kpad, nT = (long)B * 4;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = t / RSPL;
+    const int s0 = (int)(t % RSPL);
     if (i < nA) {
-        gA[i] = sum_slices<48>(gA_part + i, (size_t)nA, nsv);
+        const float r = sum_slices_split<12>(gA_part + i, (size_t)nA, nsv, s0);
+        if (s0 == 0) gA[i] = r;
     } else if (i < nA + nF) {
-        long k = i - nA;
-        gfeat[k] = sum_slices<32>(gfeat_part + k, (size_t)nF, nsn);
+        const long k = i - nA;
+        const float r = sum_slices_split<8>(gfeat_part + k, (size_t)nF, nsn, s0);
+        if (s0 == 0) gfeat[k] = r;
     } else if (i < nA + nF + nT) {
-        long k = i - nA - nF;
-        int b = (int)(k >> 2), c = (int)(k & 3);
-        if (c < 3 && g_transl) g_transl[(size_t)b * 3 + c] = sum_slices<48>(gt_part + (size_t)b * 4 + c, (size_t)B * 4, nvb);
+        const long k = i - nA - nF;
+        const int b = (int)(k >> 2), c = (int)(k & 3);
+        const float r = sum_slices_split<12>(gt_part + (size_t)b * 4 + (c < 3 ? c : 0), (size_t)B * 4, nvb, s0);
+        if (s0 == 0 && c < 3 && g_transl) g_transl[(size_t)b * 3 + c] = r;
     }
 }
 
@@ -753,7 +768,7 @@ static int lbs_launch_bwd_joint_parts(const LbsDev &m, const WsLayout &L, int B,
 static int lbs_launch_reduce(const LbsDev &m, const WsLayout &L, int B, float *ws, float *g_transl, hipStream_t st)
 {
     long nred = (long)B * JP * 16 + (long)B * m.Kpad + (long)B * 4;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(psi_cdiv(nred, 256)), dim3(256), 0, st, B, m.Kpad, ws + L.gA_part, L.nsv,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(psi_cdiv(nred * RSPL, 256)), dim3(256), 0, st, B, m.Kpad, ws + L.gA_part, L.nsv,
                        ws + L.gfeat_part, L.nsn, ws + L.gt_part, L.nvb, ws + L.gA, ws + L.gfeat, g_transl);
     PSI_CHECK_LAUNCH("reduce_partials_kernel");
     psi_mark("reduce_partials_kernel", st);

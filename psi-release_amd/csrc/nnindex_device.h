@@ -129,13 +129,25 @@ __device__ __forceinline__ void kd_block_fsum(float fval, float *__restrict__ ou
     }
 }
 
+// The warm-start candidate of a query: last iteration's winner (hint[o], -1 = none) and its coordinates.  Two dependent loads that need
+// nothing but the query's slot — callers issue them first and compute the query point while they are in flight.
+__device__ __forceinline__ int kd_warm_candidate(const KdDev &T, const int *__restrict__ hint, bool active, size_t o, float4 &hp)
+{
+    hp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!(active && hint)) return -1;
+    const int h = hint[o];
+    if (h < 0 || h >= T.m) return -1;
+    hp = T.opts[h];
+    return h;
+}
+
 // One round of the search: the workgroup's QPB lane groups answer one query each.  (qx,qy,qz): the group's query (the same values in
 // all LPQ lanes of the group), active: the group has a query, o: its output slot (dist / idx / hint / gq index).  Returns the contact
 // term s / (s + c) of the query in lane 0 of its group (0 elsewhere) when CONTACT.  No barriers inside: groups are independent.
 template <bool CONTACT>
 __device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float qy, float qz, bool active, size_t o, float *__restrict__ dist,
                                                 int *__restrict__ idx, float cconst, float gscale, float *__restrict__ gq, int *__restrict__ hint,
-                                                int rows, int *smem_i)
+                                                int rows, int *smem_i, int h, const float4 &hp)
 {
 #pragma clang fp contract(off)    // the distance expression (PSI_SQ3) must not be re-contracted in translation units built with contraction on
     const int tid = threadIdx.x;
@@ -145,16 +157,13 @@ __device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float 
     float *stk_d = (float *)(stk_n + rows);                   // [rows] box distances
     kd_key bestk = kd_pack(INFINITY, 0x7fffffff);
     float best = INFINITY;                                    // == kd_key_d(bestk)
-    if (active && hint) {
-        // warm start: the target that won for this query last time is evaluated first (an ordinary candidate, so the
-        // result is unchanged); a good initial `best` prunes almost every sibling on the way down
-        int h = hint[o];
-        if (h >= 0 && h < T.m) {
-            const float4 p = T.opts[h];
-            float x2 = p.x - qx, y2 = p.y - qy, z2 = p.z - qz;
-            best = PSI_SQ3(x2, y2, z2);
-            bestk = kd_pack(best, h);
-        }
+    if (h >= 0) {
+        // warm start: the target that won for this query last time (fetched by the caller, kd_warm_candidate, BEFORE it produced the query
+        // point, so the two dependent loads overlap that work) is evaluated first — an ordinary candidate, so the result is unchanged;
+        // a good initial `best` prunes almost every sibling on the way down
+        float x2 = hp.x - qx, y2 = hp.y - qy, z2 = hp.z - qz;
+        best = PSI_SQ3(x2, y2, z2);
+        bestk = kd_pack(best, h);
     }
     int sp = 0;
     int cur = T.root;
@@ -309,9 +318,11 @@ __device__ __forceinline__ void kd_query_body(KdDev T0, QSrc qsrc, int n, float 
     const bool active = j < n;
     const size_t o = (size_t)b * n + (active ? j : 0);
     float qx = 0, qy = 0, qz = 0;
+    float4 hp;
+    const int h = kd_warm_candidate(T, hint, active, o, hp);   // in flight while the query point is produced
     qsrc.prepare(b);
     qsrc.point(b, active ? j : 0, c, qx, qy, qz);                // every lane of the group ends up with the same point
-    const float fval = kd_query_round<CONTACT>(T, qx, qy, qz, active, o, dist, idx, cconst, gscale, gq, hint, rows, smem_i);
+    const float fval = kd_query_round<CONTACT>(T, qx, qy, qz, active, o, dist, idx, cconst, gscale, gq, hint, rows, smem_i, h, hp);
     if (CONTACT) kd_block_fsum(fval, fpart + (size_t)b * nbx + bx);
 }
 
