@@ -1084,6 +1084,11 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
         psi_mark("loss_finalize_kernel", st);
         return 0;
     }
+    // (Round 3 tried the dense blend of this kernel on the matrix cores at large batches — v_mfma_f32_16x16x4_f32 tiles of 16 vertices with
+    // the weights as the register-resident B operand and a body's transforms as the LDS-staged A operand, bit-identical results — on the
+    // grounds that the kernel is vector-ALU bound at B = 512 (805 VALU instructions per wave, 660 of them the blend; profiles/
+    // r03_pmc_skin_fwd_sdf_b512.txt).  It measured 191 us against 165: the fp32 MFMA runs at the vector FLOP rate and, as far as these timings
+    // show, does not overlap the other waves' vector instructions, so the blend's cycles moved but did not disappear.)
     hipLaunchKernelGGL(psi_skin_fwd_kernel<SdfPenEpilogue>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A, e->lv.v_posed,
                            f.transl, f.cam, f.B, f.verts, SdfPenEpilogue{f, 0.0f, 0.0f});
     PSI_CHECK_LAUNCH("skin_fwd_sdf_kernel");

@@ -119,3 +119,4 @@ __device__ __forceinline__ float psi_trilinear_bricked(const float *__restrict__
     }
     return c0 * wx0 + c1 * wx1;
 }
+

@@ -304,3 +304,4 @@ def test_head_cluster_widths_agree_and_repeat_exactly(smplx_data, vposer_sd, mon
         short[hc] = op.fitting(dict(bodies)).detach().cpu().numpy().copy()
     for hc in (2, 4, 8):
         assert np.abs(short[hc] - short[1]).max() < 1e-4, (hc, np.abs(short[hc] - short[1]).max())
+
