@@ -1028,6 +1028,7 @@ struct psi_fit_engine {
     const void *dp_comm;
     const float *dp_stats;
     bool dp_warm;                 // the communicator has run a collective for this engine outside capture
+    bool dp_no_graph;             // capturing the RCCL collective failed once on this engine: the loop stays on eager launches (still from C)
 };
 
 // head / tail launches: grid = B bodies x hc workgroups per body (template instance per cluster width)
@@ -1476,16 +1477,29 @@ extern "C" int psi_fit_iterate_dp(psi_fit_engine *e, psi_dp_comm *comm, int n_it
         e->dp_ready[slot] = true;
         return 0;
     };
-    if (n_iter - done >= GRAPH_UNROLL) {
-        if (!e->dp_ready[1]) {
-            int rc = capture(GRAPH_UNROLL, 1);
+    // A collective that cannot be captured (an RCCL build without graph support, a transport that needs host work per call) must not
+    // cost the run: the first failed capture switches this engine to eager launches of the same sequence — every rank takes the same
+    // decision at the same iteration, because they run the same code on the same communicator
+    auto eager_rest = [&]() -> int {
+        for (; done < n_iter; done++) {
+            int rc = one();
             if (rc) return rc;
+        }
+        return 0;
+    };
+    if (e->dp_no_graph) return eager_rest();
+    if (n_iter - done >= GRAPH_UNROLL) {
+        if (!e->dp_ready[1] && capture(GRAPH_UNROLL, 1)) {
+            (void)hipGetLastError();
+            e->dp_no_graph = true;
+            return eager_rest();
         }
         for (; done + GRAPH_UNROLL <= n_iter; done += GRAPH_UNROLL) PSI_CHECK_HIP(hipGraphLaunch(e->ge_dp[1], st));
     }
-    if (done < n_iter && !e->dp_ready[0]) {
-        int rc = capture(1, 0);
-        if (rc) return rc;
+    if (done < n_iter && !e->dp_ready[0] && capture(1, 0)) {
+        (void)hipGetLastError();
+        e->dp_no_graph = true;
+        return eager_rest();
     }
     for (; done < n_iter; done++) PSI_CHECK_HIP(hipGraphLaunch(e->ge_dp[0], st));
     return 0;
