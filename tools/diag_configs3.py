@@ -5,6 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.p
 import numpy as np, torch
 import torch.multiprocessing as mp
 import test_configs_gpu as tc
+import test_configs_dp_gpu as tcd
 from psi_release_amd import fitting, synth
 import psi_oracle as O
 
@@ -36,7 +37,7 @@ def main():
         print('   losses gpu', L[it], 'oracle', rec[it])
     if len(sys.argv) > 2:
         port = tc._free_port(); tmp = '/tmp/diagc3'; os.makedirs(tmp, exist_ok=True)
-        mp.spawn(tc._rank_worker, args=(2, port, tmp), nprocs=2, join=True)
+        mp.spawn(tcd._rank_worker, args=(2, port, tmp), nprocs=2, join=True)
         xg = np.concatenate([np.load(tmp + '/x%d.npy' % r) for r in range(2)])
         e = np.abs(xg - x1); bad = np.argwhere(e > 2e-3)
         print('dp2x32 vs single64: max', e.max(), 'n>2e-3', len(bad), 'cols', sorted(set(bad[:, 1].tolist()))[:30])
