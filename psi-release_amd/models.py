@@ -85,7 +85,8 @@ def _use_hip_bn(bn, x):
     """The fused BN kernels cover the training-mode trunk under bf16 autocast (PSI_HIP_BN=0 keeps the library path)."""
     import os
     return (bn.training and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
-            and bn.num_features % 8 == 0 and os.environ.get('PSI_HIP_BN', '1') != '0')
+            and bn.affine and bn.track_running_stats and bn.momentum is not None          # what the kernels implement (nn.BatchNorm2d defaults)
+            and bn.num_features in (8, 16, 32, 64, 128, 256) and os.environ.get('PSI_HIP_BN', '1') != '0')
 
 
 def run_trunk(trunk, x):
