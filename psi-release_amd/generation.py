@@ -97,14 +97,16 @@ class TestOP:
         ``repeat_cams``: the Habitat drivers store the cameras repeated to [n,...] in every pkl (test_habitat_s2.py:216-217), the
         PROX-E drivers store the single [1,4,4] / [1,3,3] (test_proxe_s1.py:120-128)."""
         n = n_samples or self.n_samples
-        xs_n = torch.cat([depth, seg], dim=1).repeat(n, 1, 1, 1)
+        # the reference feeds the trunk n copies of the view (xs.repeat(n_samples, 1, 1, 1), test_habitat_s2.py:192); the model is in eval
+        # mode, so the one view is encoded ONCE and its feature row shared by the n samples (models._SceneCond._scene_feature)
+        xs_1 = torch.cat([depth, seg], dim=1)
         cam_int_b, cam_ext_b, max_d_b = cam_int.repeat(n, 1, 1), cam_ext.repeat(n, 1, 1), max_d.view(1).repeat(n)
         if latents is None:
-            xhnr_gen = self.model_h.sample(xs_n)
+            xhnr_gen = self.model_h.sample(xs_1, rows=n)
         elif self.stage == 's1':
-            xhnr_gen = self.model_h.sample(xs_n, eps=latents)
+            xhnr_gen = self.model_h.sample(xs_1, eps=latents, rows=n)
         else:
-            xhnr_gen = self.model_h.sample(xs_n, eps_g=latents[0], eps_l=latents[1], use_eps=True)
+            xhnr_gen = self.model_h.sample(xs_1, eps_g=latents[0], eps_l=latents[1], use_eps=True, rows=n)
         xhn_gen = GeometryTransformer.convert_to_3D_rot(xhnr_gen)
         xh_gen = GeometryTransformer.recover_global_T(xhn_gen, cam_int_b, max_d_b)
         body_param_list = BodyParamParser.body_params_encapsulate(xh_gen)

@@ -158,7 +158,14 @@ def _reparam(mu, logvar, eps=None):
 class _SceneCond(nn.Module):
     """Shared shape of the three scene-conditioned VAEs: trunk -> conv -> fc."""
 
-    def _scene_feature(self, scene):
+    def _scene_feature(self, scene, rows=None):
+        """Scene feature z_s [b, num_hidden].  ``rows``: the generation drivers condition n samples on ONE view and feed the trunk n copies
+        of it (test_habitat_s2.py:192-195: ``xs.repeat(self.n_samples, 1, 1, 1)``); in eval mode every row of the trunk's output depends on
+        its own input only (BatchNorm on running statistics), so the single view is encoded once and the feature row repeated."""
+        if rows is not None and rows != scene.size(0):
+            if scene.size(0) != 1 or self.training:
+                raise ValueError('rows=%d needs ONE scene view and a model in eval mode (got %d views, training=%s)' % (rows, scene.size(0), self.training))
+            return self._scene_feature(scene).expand(rows, -1)
         b = scene.size(0)
         if getattr(self, 'autocast_bf16', False) and scene.is_cuda:
             if not getattr(self, '_nhwc', False):           # MIOpen's bf16 implicit-GEMM convs are NHWC: keep weights and
@@ -195,10 +202,10 @@ class BodyGlobalPoseVAE(_SceneCond):
         self.log_var_linear = nn.Linear(2 * num_hidden, zdim)
         self.decode = nn.Sequential(nn.Linear(num_hidden + zdim, f_dim), ResBlock(f_dim), ResBlock(f_dim), nn.Linear(f_dim, 3))
 
-    def forward(self, scene, torso=None, eps=None):
-        z_s = self._scene_feature(scene)
+    def forward(self, scene, torso=None, eps=None, rows=None):
+        z_s = self._scene_feature(scene, rows)
         if self.test:
-            z = torch.randn(scene.size(0), self.zdim, device=scene.device) if eps is None else eps
+            z = torch.randn(z_s.size(0), self.zdim, device=scene.device) if eps is None else eps
             return self.decode(torch.cat([z, z_s], dim=1))
         feature = self.encode(torch.cat((z_s, self.torso_linear(torso)), dim=1))            # net_layers.py:118
         mean, log_var = self.mean_linear(feature), self.log_var_linear(feature)
@@ -224,11 +231,11 @@ class BodyLocalPoseVAE(_SceneCond):
         self.log_var_linear = nn.Linear(3 * num_hidden, zdim)
         self.decode = nn.Sequential(nn.Linear(2 * num_hidden + zdim, f_dim), ResBlock(f_dim), ResBlock(f_dim), nn.Linear(f_dim, 72))
 
-    def forward(self, scene, torso=None, pose=None, eps=None):
-        z_s = self._scene_feature(scene)
+    def forward(self, scene, torso=None, pose=None, eps=None, rows=None):
+        z_s = self._scene_feature(scene, rows)
         z_g = self.torso_linear(torso)
         if self.test:
-            z = torch.randn(scene.size(0), self.zdim, device=scene.device) if eps is None else eps
+            z = torch.randn(z_s.size(0), self.zdim, device=scene.device) if eps is None else eps
             return self.decode(torch.cat([z, z_g, z_s], dim=1))
         feature = self.encode(torch.cat([self.pose_linear(pose), z_g, z_s], dim=1))         # net_layers.py:220
         mean, log_var = self.mean_linear(feature), self.log_var_linear(feature)
@@ -256,9 +263,10 @@ class HumanCVAES2(nn.Module):
         x_l_rec, mu_l, lv_l = self.pose_vae(x_s, x_g_rec, x_l, eps=eps_l if use_eps else None)
         return torch.cat([x_g_rec, x_l_rec], dim=1), mu_g, lv_g, mu_l, lv_l
 
-    def sample(self, x_s, eps_g=None, eps_l=None, use_eps=False):
-        x_g = self.trans_vae(x_s, eps=eps_g if use_eps else None)
-        x_l = self.pose_vae(x_s, x_g, eps=eps_l if use_eps else None)
+    def sample(self, x_s, eps_g=None, eps_l=None, use_eps=False, rows=None):
+        """``rows``: number of samples to draw for ONE view ``x_s [1,2,128,128]`` (the view is encoded once, see _scene_feature)."""
+        x_g = self.trans_vae(x_s, eps=eps_g if use_eps else None, rows=rows)
+        x_l = self.pose_vae(x_s, x_g, eps=eps_l if use_eps else None, rows=rows)
         return torch.cat([x_g, x_l], dim=1)
 
 
@@ -290,14 +298,14 @@ class HumanCVAES1(_SceneCond):
         z_h = self.linear_latent(_reparam(mu, logvar, eps))
         return self.linear_out(self.human_decoder(torch.cat([z_h, z_s], dim=1))), mu, logvar   # cvae.py:488
 
-    def _decode_latent(self, x_s, eps):
-        z_s = self._scene_feature(x_s)
+    def _decode_latent(self, x_s, eps, rows=None):
+        z_s = self._scene_feature(x_s, rows)
         return self.linear_out(self.human_decoder(torch.cat([self.linear_latent(eps), z_s], dim=1)))
 
-    def sample(self, x_s, eps=None, **kwargs):
+    def sample(self, x_s, eps=None, rows=None, **kwargs):
         if eps is None:
-            eps = torch.randn(x_s.shape[0], self.eps_d, dtype=torch.float32, device=x_s.device)
-        return self._decode_latent(x_s, eps)
+            eps = torch.randn(rows or x_s.shape[0], self.eps_d, dtype=torch.float32, device=x_s.device)
+        return self._decode_latent(x_s, eps, rows)
 
     def sample_line(self, x_s, **kwargs):
         """cvae.py:516-534: latent swept along the diagonal from -3 to 3."""
