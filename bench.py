@@ -638,7 +638,42 @@ def bench_train_s2(args):
                            'hand_written': 'conv3x3 forward + input gradient (conv.hip), dense layers forward + backward (linear.hip), BatchNorm + ReLU + '
                                            'skip (bnorm.hip), stem max-pool, body decode / NN / SDF operators; library: 7x7 stem and strided convolutions, '
                                            'convolution weight gradients'}
+    try:
+        res['conv_kernel_roofline'] = conv_kernel_roofline(dev, B)
+    except Exception as e:
+        res['conv_kernel_roofline'] = {'error': repr(e)}
     return res
+
+
+def conv_kernel_roofline(dev, N):
+    """The matrix-core kernel that carries most of the trunk's flops — conv3x3_kernel (csrc/conv.hip) at the layer1 shape of the step
+    (N x 32 x 32 x 64 -> 64, cvae.py:427-435) — timed alone with HIP events on its launch stream: achieved bf16 TFLOP/s against the dense
+    MFMA peak."""
+    import torch
+    from psi_release_amd import hip
+    H = W = 32
+    C = 64
+    x = torch.randn(N, H, W, C, device=dev).to(torch.bfloat16)
+    w = (torch.randn(C, 3, 3, C, device=dev) * 0.05).to(torch.bfloat16)
+    y = torch.empty(N, H, W, C, device=dev, dtype=torch.bfloat16)
+    L = hip.lib()
+    st = torch.cuda.current_stream()
+    call = lambda: hip.check(L.psi_conv3x3_forward(x.data_ptr(), w.data_ptr(), None, N, H, W, C, C, y.data_ptr(), st.cuda_stream), 'psi_conv3x3_forward')
+    for _ in range(10):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 50
+    e0.record(st)
+    for _ in range(reps):
+        call()
+    e1.record(st)
+    e1.synchronize()
+    t = e0.elapsed_time(e1) / reps * 1e-3
+    flops = 2.0 * N * H * W * C * C * 9
+    return {'bound': 'mfma', 'kernel': 'conv3x3_kernel<64> (layer1: %d x 32 x 32 x 64 -> 64, bf16 MFMA 32x32x16, fp32 accumulate)' % N,
+            'achieved': round(flops / t * 1e-12, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(flops / t * 1e-12 / PEAK_BF16_TFLOPS, 4),
+            'avg_launch_ms': round(t * 1e3, 4), 'flops_per_launch': flops,
+            'traffic': None, 'counters': 'profiles/r03_pmc_mfma_conv3x3_kernel.txt (SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA per launch)'}
 
 
 def main():
