@@ -108,22 +108,28 @@ __global__ __launch_bounds__(BN_BLK) void bn_stats_kernel(const u4 *__restrict__
     block_reduce_store<2>(acc, C, g, rr, rpb, part);
 }
 
-// Sum of the per-block partials for every (quantity, channel) output by ONE block of 1024 threads: output o = q * C + c is handled by
-// 1024 / (2C) threads, thread slice s adding partials s, s + nsl, ... with four independent accumulators (the loads of a 512-partial
-// column issued by one thread would be 512 dependent-latency steps), the slices are then combined in slice order: deterministic.
-__device__ __forceinline__ void sum_partials(const float *__restrict__ part, int nblk, int C, double *sh /* [1024] */, double &s_out, double &q_out)
+// Sum of the per-block partials.  A block of 1024 threads takes BN_FIN_CH channels (both quantities): output o = q * Cb + c is handled
+// by 1024 / (2 Cb) threads, thread slice s adding partials s, s + nsl, ... with four independent accumulators, the slices are then
+// combined in slice order: deterministic.  The kernel is pure latency (the partials were written by other compute units a moment ago,
+// every dependent round of loads is a trip to L2 / memory): with 16 channels per block a thread's share of 512 partials is ONE round of
+// 16 loads (one block for all channels needed four rounds at C = 64: 8.1 us per launch, 80 launches per train_s2 step).
+constexpr int BN_FIN_CH = 16;
+__host__ __device__ inline int bn_fin_blocks(int C) { return C > BN_FIN_CH ? C / BN_FIN_CH : 1; }
+
+__device__ __forceinline__ void sum_partials(const float *__restrict__ part, int nblk, int C, double *sh /* [1024] */, double &s_out, double &q_out,
+                                             int &c_out)
 {
-    const int t = threadIdx.x, no = 2 * C, nsl = 1024 / no;
+    const int Cb = C > BN_FIN_CH ? BN_FIN_CH : C, c_lo = blockIdx.x * Cb;
+    const int t = threadIdx.x, no = 2 * Cb, nsl = 1024 / no;
     const int o = t % no, sl = t / no;
+    const int col = (o / Cb) * C + c_lo + (o % Cb);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (sl < nsl) {
-        // sixteen loads requested before the first add: the partials were written by other compute units a moment ago, every dependent
-        // round is a trip to L2 / memory (the 4-deep version of this loop took 11 us for 512 partials; the kernel is pure latency)
+    {
         int b = sl;
         for (; b + 15 * nsl < nblk; b += 16 * nsl) {
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = part[(size_t)(b + u * nsl) * no + o];
+            for (int u = 0; u < 16; u++) v[u] = part[(size_t)(b + u * nsl) * (2 * C) + col];
 #pragma unroll
             for (int u = 0; u < 16; u += 4) {
                 a0 += (double)v[u];
@@ -132,20 +138,21 @@ __device__ __forceinline__ void sum_partials(const float *__restrict__ part, int
                 a3 += (double)v[u + 3];
             }
         }
-        for (; b < nblk; b += nsl) a0 += (double)part[(size_t)b * no + o];
+        for (; b < nblk; b += nsl) a0 += (double)part[(size_t)b * (2 * C) + col];
     }
     sh[t] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     s_out = q_out = 0.0;
-    if (t < C) {
+    c_out = t < Cb ? c_lo + t : -1;
+    if (t < Cb) {
         for (int k = 0; k < nsl; k++) {
             s_out += sh[k * no + t];
-            q_out += sh[k * no + C + t];
+            q_out += sh[k * no + Cb + t];
         }
     }
 }
 
-// one block: sums the per-block partials in order; mean / invstd / scale / shift; running statistics (nn.BatchNorm2d semantics:
+// sums the per-block partials in order (16 channels per block); mean / invstd / scale / shift; running statistics (nn.BatchNorm2d semantics:
 // running = (1 - momentum) * running + momentum * batch, the variance unbiased) and the batch counter
 __global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(const float *__restrict__ part, int nblk, long M, int C, const float *__restrict__ gamma,
                                                                  const float *__restrict__ beta, float eps, float momentum,
@@ -154,11 +161,11 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(const float *__re
                                                                  float *__restrict__ save_invstd, float *__restrict__ scale_shift)
 {
     __shared__ double shd[1024];
-    const int c = threadIdx.x;
-    if (c == 0 && num_batches) *num_batches += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
     double s, q;
-    sum_partials(part, nblk, C, shd, s, q);
-    if (c >= C) return;
+    int c;
+    sum_partials(part, nblk, C, shd, s, q, c);
+    if (c < 0) return;
     const double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -256,10 +263,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
                                                                  float *__restrict__ coef)
 {
     __shared__ double shd[1024];
-    const int c = threadIdx.x;
     double s, q;
-    sum_partials(part, nblk, C, shd, s, q);
-    if (c >= C) return;
+    int c;
+    sum_partials(part, nblk, C, shd, s, q, c);
+    if (c < 0) return;
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)q;
     const float a = gamma[c] * invstd[c];
@@ -407,7 +414,7 @@ extern "C" int psi_bn_forward(const void *x, const void *residual, const float *
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(BN_BLK), 0, st, (const u4 *)x, M, C, part);
     PSI_CHECK_LAUNCH("bn_stats_kernel");
     psi_mark("bn_stats_kernel", st);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nb, M, C, gamma, beta, eps, momentum, running_mean, running_var,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(bn_fin_blocks(C)), dim3(1024), 0, st, part, nb, M, C, gamma, beta, eps, momentum, running_mean, running_var,
                        num_batches_tracked, save_mean, save_invstd, ss);
     PSI_CHECK_LAUNCH("bn_fwd_finalize_kernel");
     const long n16 = M * (C / 8);
@@ -441,7 +448,7 @@ extern "C" int psi_bn_backward(const void *dy, const void *x, const void *y, con
                            save_invstd, part);
     PSI_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     psi_mark("bn_bwd_reduce_kernel", st);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nb, M, C, gamma, save_invstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(bn_fin_blocks(C)), dim3(1024), 0, st, part, nb, M, C, gamma, save_invstd, dgamma, dbeta, coef);
     PSI_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long n16 = M * (C / 8);
     const int ga = (int)((n16 + BN_BLK - 1) / BN_BLK < 2048 ? (n16 + BN_BLK - 1) / BN_BLK : 2048);
