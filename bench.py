@@ -62,6 +62,9 @@ def parse(argv=None):
     ap.add_argument('--m', type=int, default=32768, help='scene points')
     ap.add_argument('--nc', type=int, default=2048, help='contact vertices')
     ap.add_argument('--D', type=int, default=256, help='SDF grid dimension')
+    ap.add_argument('--weight-nnz', type=int, default=0,
+                    help='fitting: non-zero skinning weights per vertex of the synthetic body model (0 = dense random rows, the headline since round 1; '
+                         '4 = the sparsity of the released SMPL-X model: compressed-row skinning kernels)')
     ap.add_argument('--engine', default=os.environ.get('PSI_ENGINE', 'auto'), choices=['auto', 'fused', 'modular'])
     ap.add_argument('--workload', default='fitting', choices=['fitting', 'fitting_habitat', 'train_s2'],
                     help="'fitting' = BASELINE metric (configs[1]/[3]); 'fitting_habitat' = configs[4]; 'train_s2' = configs[2]")
@@ -181,7 +184,7 @@ LOSS = {'weight_loss_rec': 1, 'weight_loss_vposer': 0.01, 'weight_contact': 0.1,
 
 def make_op(args, rank, device, scene_seed=0, habitat=False, assets=None):
     from psi_release_amd import fitting, synth
-    smplx, vposer = assets if assets else (synth.make_smplx(7), synth.make_vposer_state(3))
+    smplx, vposer = assets if assets else (synth.make_smplx(7, weight_nnz=getattr(args, 'weight_nnz', 0)), synth.make_vposer_state(3))
     scene = synth.make_scene(scene_seed, args.m, args.D, args.nc)
     cfg = {'scene_verts_path': None, 'scene_sdf_path': None, 'human_model_path': None, 'vposer_ckpt_path': None,
            'init_lr_h': 0.1, 'num_iter': 1, 'batch_size': args.batch, 'device': device,
@@ -228,7 +231,8 @@ def kernel_work(args):
     B, V, J, nc, m = args.batch, 10475, 55, args.nc, args.m
     K, N = 506, 3 * V                       # feat = [10 betas + 10 expression | 54 x 9 rotation entries]; columns = 3 V
     dirs = K * N * 4.0                      # shapedirs + posedirs as one [K, 3V] matrix: 63.6 MB
-    W = J * V * 4.0                         # skinning weights 2.3 MB
+    nnz = getattr(args, 'weight_nnz', 0)
+    W = J * V * 4.0 if not nnz else nnz * V * 5.0      # skinning weights: dense rows 2.3 MB, or nnz (weight, joint byte) pairs per vertex
     vt = N * 4.0                            # v_template
     w = {
         'nn_partial_kernel': ('flop', 8.0 * B * nc * m, 'brute-force NN: 8 flop per query/target pair, fp32 VALU (no FMA contraction)'),
@@ -462,7 +466,7 @@ def bench_fitting(args):
         out = {
             'metric': metric, 'value': round(world / (med / args.steps), 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': wl, 'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'engine': args.engine_resolved,
+            'config': {'workload': wl, 'skinning_weight_nnz': args.weight_nnz or 'dense', 'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'engine': args.engine_resolved,
                        'nn': op.nn_mode, 'parallelism': 'dp%d (rows sharded, one 6-float all-reduce per iteration)' % world,
                        'rccl_world_size': rccl_world, 'backend': backend if world > 1 else 'none (single process)',
                        'launcher': 'bench.py self-spawn' if os.environ.get('PSI_BENCH_SPAWNED') == '1' else ('torchrun' if world > 1 else 'direct'),
