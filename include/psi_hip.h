@@ -304,6 +304,27 @@ int psi_conv3x3_rotate_weight(const void *w, int Cin, int Cout, void *wt, void *
 int psi_maxpool3x3s2_forward(const void *x, int N, int H, int W, int C, void *y, void *idx, void *stream);
 int psi_maxpool3x3s2_backward(const void *dy, const void *idx, int N, int H, int W, int C, void *dx, void *stream);
 
+/* ---- body-vector glue of a CVAE training step (train_s1.py:95-133 / train_s2.py:102-139 cal_loss) ------------------------------
+ * psi_cvae_target: out75[b] = convert_to_6D_rot(normalize_global_T(xh72[b], cam_int[b], max_d[b]))   (cvae.py:176-199 + 118-127, the
+ *   torchgeometry 0.1.2 angle_axis_to_rotation_matrix with its first-order branch at theta^2 <= 1e-6): [B,72] -> [B,75].
+ * psi_cvae_losses_forward: xh_rec75 = recover_global_T(rec75, cam_int, max_d) (cvae.py:153-172; only the translation changes) and
+ *   losses5 = { w_rec (0.5 L1(rec[:, :3], target[:, :3]) + 0.5 L1(xh_rec[:, :3], xh[:, :3])),  w_rec L1(rec[:, 3:], target[:, 3:]),
+ *               KL of latent 0, KL of latent 1 (fca^2 w_kl 0.5 mean(exp(logvar) + mu^2 - 1 - logvar); 0 when mu == NULL),
+ *               w_vposer mean(xh_rec[:, 19:51]^2) }                                            (train_s2.py:122-139)
+ *   fca: the KL annealing factor, read from fca_dev (a device float, so that a captured step can change it) when that is not NULL.
+ * psi_cvae_losses_backward: gradients of  sum_k g_losses5[k] * losses5[k]  +  <g_xh_rec75, xh_rec75>  (g_xh_rec75 may be NULL) with
+ *   respect to rec75, mu, logvar (all OVERWRITTEN).  All tensors fp32, contiguous, device memory. */
+int psi_cvae_target(const float *xh72, const float *cam_int, const float *max_d, int B, float *out75, void *stream);
+int psi_cvae_losses_forward(const float *rec75, const float *target75, const float *xh72, const float *cam_int, const float *max_d,
+                            const float *mu0, const float *logvar0, int nz0, const float *mu1, const float *logvar1, int nz1, int B,
+                            float w_rec, float w_kl, float w_vposer, float fca, const float *fca_dev, float *xh_rec75, float *losses5,
+                            void *stream);
+int psi_cvae_losses_backward(const float *rec75, const float *target75, const float *xh72, const float *cam_int, const float *max_d,
+                             const float *mu0, const float *logvar0, int nz0, const float *mu1, const float *logvar1, int nz1, int B,
+                             float w_rec, float w_kl, float w_vposer, float fca, const float *fca_dev, const float *xh_rec75,
+                             const float *g_losses5, const float *g_xh_rec75, float *g_rec75, float *g_mu0, float *g_logvar0,
+                             float *g_mu1, float *g_logvar1, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,8 @@ COMMON = ['-O3', '-std=c++17', '--offload-arch=' + ARCH, '-fPIC', '-fno-gpu-rdc'
           '-munsafe-fp-atomics']
 # -fno-slp-vectorize: hipcc's SLP pass packs the distance arithmetic into a v_pk/SGPR-shuffle mix that measured
 # 21% slower on MI355X than the plain stream (gpurun t1: 0.393 vs 0.324 ms at B=32, n=2048, m=32768)
-PER_FILE = {'chamfer.hip': ['-ffp-contract=off', '-fno-slp-vectorize'], 'nnindex.hip': ['-ffp-contract=off']}
+PER_FILE = {'chamfer.hip': ['-ffp-contract=off', '-fno-slp-vectorize'], 'nnindex.hip': ['-ffp-contract=off'],
+            'cvae_loss.hip': ['-ffp-contract=off']}     # the operator sequence of geometry.py, association for association
 
 
 def sources():

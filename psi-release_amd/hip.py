@@ -65,6 +65,11 @@ SIGNATURES = {
     'psi_conv3x3_rotate_weight': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'psi_maxpool3x3s2_forward': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'psi_maxpool3x3s2_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'psi_cvae_target': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'psi_cvae_losses_forward': (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float,
+                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    'psi_cvae_losses_backward': (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'psi_dp_unique_id': (c_int, [c_void_p]),
     'psi_dp_comm_create': (c_int, [c_void_p, c_void_p, c_int, c_int]),
     'psi_dp_comm_destroy': (None, [c_void_p]),

@@ -507,3 +507,75 @@ def conv3x3(x, conv):
     if x.dtype != torch.bfloat16:
         x = x.to(torch.bfloat16)
     return _Conv3x3.apply(x, conv.weight, conv.bias)
+
+
+# ------------------------------------------------------------------------------------------
+# Body-vector glue of a CVAE training step (csrc/cvae_loss.hip): target representation, reconstruction / KL / VPoser losses
+# ------------------------------------------------------------------------------------------
+def _f32c(t):
+    return None if t is None else t.detach().contiguous().float()
+
+
+def cvae_target(xh, cam_int, max_d):
+    """``GeometryTransformer.convert_to_6D_rot(GeometryTransformer.normalize_global_T(xh, cam_int, max_d))`` (cvae.py:118-127, 176-199) in
+    one launch: [B,72] -> [B,75].  The training target of the CVAE; a function of the batch only (no gradient)."""
+    B = xh.shape[0]
+    if xh.dim() != 2 or xh.shape[1] != 72 or tuple(cam_int.shape) != (B, 3, 3) or max_d.numel() != B:
+        raise ValueError('cvae_target: xh [B,72], cam_int [B,3,3], max_d [B] expected, got %s / %s / %s'
+                         % (tuple(xh.shape), tuple(cam_int.shape), tuple(max_d.shape)))
+    out = torch.empty(B, 75, device=xh.device)
+    hip.check(hip.lib().psi_cvae_target(hip.ptr(_f32c(xh)), hip.ptr(_f32c(cam_int)), hip.ptr(_f32c(max_d)), B, hip.ptr(out), hip.stream()),
+              'psi_cvae_target')
+    return out
+
+
+class _CvaeLosses(Function):
+    @staticmethod
+    def forward(ctx, rec, target, xh, cam_int, max_d, mu0, lv0, mu1, lv1, fca, w_rec, w_kl, w_vposer):
+        B = rec.shape[0]
+        if rec.dim() != 2 or rec.shape[1] != 75 or tuple(target.shape) != (B, 75) or tuple(xh.shape) != (B, 72):
+            raise ValueError('cvae_losses: rec / target [B,75] and xh [B,72] expected, got %s / %s / %s'
+                             % (tuple(rec.shape), tuple(target.shape), tuple(xh.shape)))
+        t = [_f32c(v) for v in (rec, target, xh, cam_int, max_d, mu0, lv0, mu1, lv1)]
+        fca_t = fca if torch.is_tensor(fca) else None
+        ctx.fca = 0.0 if fca_t is not None else float(fca)
+        ctx.w = (float(w_rec), float(w_kl), float(w_vposer))
+        ctx.nz = (0 if mu0 is None else mu0.shape[1], 0 if mu1 is None else mu1.shape[1])
+        xh_rec = torch.empty(B, 75, device=rec.device)
+        losses = torch.empty(5, device=rec.device)
+        hip.check(hip.lib().psi_cvae_losses_forward(*[hip.ptr(v) for v in t[:7]], ctx.nz[0], hip.ptr(t[7]), hip.ptr(t[8]), ctx.nz[1], B,
+                                                    *ctx.w, ctx.fca, hip.ptr(_f32c(fca_t)), hip.ptr(xh_rec), hip.ptr(losses), hip.stream()),
+                  'psi_cvae_losses_forward')
+        ctx.has = (mu0 is not None, mu1 is not None)
+        ctx.fca_t = _f32c(fca_t)
+        ctx.save_for_backward(*[v for v in t if v is not None], xh_rec)
+        return xh_rec, losses
+
+    @staticmethod
+    def backward(ctx, g_xh_rec, g_losses):
+        saved = list(ctx.saved_tensors)
+        xh_rec = saved.pop()
+        rec, target, xh, cam_int, max_d = saved[:5]
+        rest = saved[5:]
+        mu0, lv0 = (rest[0], rest[1]) if ctx.has[0] else (None, None)
+        mu1, lv1 = (rest[-2], rest[-1]) if ctx.has[1] else (None, None)
+        B = rec.shape[0]
+        dev = rec.device
+        gl = _f32c(g_losses) if g_losses is not None else torch.zeros(5, device=dev)
+        g_rec = torch.empty_like(rec)
+        g = [torch.empty_like(v) if v is not None else None for v in (mu0, lv0, mu1, lv1)]
+        hip.check(hip.lib().psi_cvae_losses_backward(hip.ptr(rec), hip.ptr(target), hip.ptr(xh), hip.ptr(cam_int), hip.ptr(max_d), hip.ptr(mu0),
+                                                     hip.ptr(lv0), ctx.nz[0], hip.ptr(mu1), hip.ptr(lv1), ctx.nz[1], B, *ctx.w, ctx.fca,
+                                                     hip.ptr(ctx.fca_t), hip.ptr(xh_rec), hip.ptr(gl), hip.ptr(_f32c(g_xh_rec)), hip.ptr(g_rec),
+                                                     hip.ptr(g[0]), hip.ptr(g[1]), hip.ptr(g[2]), hip.ptr(g[3]), hip.stream()),
+                  'psi_cvae_losses_backward')
+        return (g_rec, None, None, None, None, g[0], g[1], g[2], g[3], None, None, None, None)
+
+
+def cvae_losses(rec, target, xh, cam_int, max_d, mu0, logvar0, mu1=None, logvar1=None, fca=1.0, w_rec=1.0, w_kl=1.0, w_vposer=1.0):
+    """The body-vector losses of ``cal_loss`` (train_s1.py:113-133, train_s2.py:119-139) in one launch per direction.
+
+    rec = xhnr_rec [B,75] (the CVAE's reconstruction, 6D global rotation), target = cvae_target(xh, ...), xh [B,72] the ground truth.
+    -> xh_rec [B,75] = recover_global_T(rec, cam_int, max_d) and losses [5] = (rec_t, rec_p, KL of latent 0, KL of latent 1 (0 without
+    one), vposer).  ``fca``: the KL annealing factor, a float or a 0-dim device tensor (captured steps change it between replays)."""
+    return _CvaeLosses.apply(rec, target, xh, cam_int, max_d, mu0, logvar0, mu1, logvar1, fca, w_rec, w_kl, w_vposer)

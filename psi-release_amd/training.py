@@ -80,11 +80,12 @@ class _TrainBase:
             self._vid = torch.tensor(np.asarray(vid).astype(np.int64), device=self.device)
         return self._vid
 
-    def _scene_losses(self, xh_rec, cam_ext, scene_verts, s_grid_min_batch, s_grid_max_batch, s_grid_sdf_batch, ep):
+    def _scene_losses(self, xh_rec, cam_ext, scene_verts, s_grid_min_batch, s_grid_max_batch, s_grid_sdf_batch, ep, loss_vposer=None):
         """Shared tail of cal_loss: VPoser prior, contact (const 1.0) and penetration terms (train_s1.py:136-205)."""
         fused = xh_rec.shape[1] == 75                                            # 75-D: 6D global rotation, decoded by the fused op
-        latent = xh_rec[:, 19:51] if fused else xh_rec[:, 16:48]
-        loss_vposer = self.weight_loss_vposer * torch.mean(latent ** 2)
+        if loss_vposer is None:                                                  # (the fused glue op has it already)
+            latent = xh_rec[:, 19:51] if fused else xh_rec[:, 16:48]
+            loss_vposer = self.weight_loss_vposer * torch.mean(latent ** 2)
         if not ep > 0.75 * self.epoch and getattr(self, 'skip_gated_losses', True):
             # train_s1.py:171-173,197-199 multiply both scene terms by 0 for the first 75% of the epochs; their value and
             # gradient are exactly 0 there, so the body mesh, NN search and SDF lookup are not evaluated at all.
@@ -119,6 +120,12 @@ class _TrainBase:
         pen = psi_dist.penetration_loss_global(body_sdf) if psi_dist.is_dist() else ops.penetration_loss(body_sdf)
         loss_sdf_pene = gate * self.weight_collision * pen
         return loss_contact, loss_vposer, loss_sdf_pene
+
+    def _fused_glue(self, xh):
+        """The [B,75] body-vector glue of cal_loss as three HIP launches (ops.cvae_target / ops.cvae_losses) instead of ~190 elementwise
+        operators: the 75-D (6D rotation) layout on the GPU; PSI_HIP_GLUE=0 keeps the operator sequence."""
+        return (self.fused_decode and self.use_cont_rot and xh.is_cuda and xh.shape[1] == 72 and not xh.requires_grad
+                and os.environ.get('PSI_HIP_GLUE', '1') != '0')
 
     def _fca(self, ep):
         if not self.loss_weight_anealing:
@@ -308,6 +315,15 @@ class TrainOP(_TrainBase):
 
     def cal_loss(self, xs, xh, cam_ext, cam_int, max_d, scene_verts, scene_face, s_grid_min_batch, s_grid_max_batch,
                  s_grid_sdf_batch, ep, eps=None):
+        if self._fused_glue(xh):
+            xhnr = ops.cvae_target(xh, cam_int, max_d)
+            xhnr_rec, mu, logsigma2 = self.model_h(xhnr, xs, eps=eps)
+            xh_rec, L = ops.cvae_losses(xhnr_rec, xhnr, xh, cam_int, max_d, mu, logsigma2, fca=self._fca(ep) if self._fca_t is None else self._fca_t,
+                                        w_rec=self.weight_loss_rec_h, w_kl=self.weight_loss_kl, w_vposer=self.weight_loss_vposer)
+            loss_rec_t, loss_rec_p, loss_KL, _, loss_vposer = L.unbind(0)
+            loss_contact, loss_vposer, loss_sdf_pene = self._scene_losses(xh_rec, cam_ext, scene_verts, s_grid_min_batch, s_grid_max_batch,
+                                                                          s_grid_sdf_batch, ep, loss_vposer=loss_vposer)
+            return [loss_rec_t, loss_rec_p, loss_KL, loss_contact, loss_vposer, loss_sdf_pene]
         xhn = GeometryTransformer.normalize_global_T(xh, cam_int, max_d)
         xhnr = GeometryTransformer.convert_to_6D_rot(xhn)
         xhnr_rec, mu, logsigma2 = self.model_h(xhnr, xs, eps=eps)
@@ -343,6 +359,16 @@ class TrainOPS2(_TrainBase):
 
     def cal_loss(self, xs, xh, eps_g, eps_l, cam_ext, cam_int, max_d, scene_verts, scene_face, s_grid_min_batch,
                  s_grid_max_batch, s_grid_sdf_batch, ep, use_eps=False):
+        if self._fused_glue(xh):
+            xhnr = ops.cvae_target(xh, cam_int, max_d)
+            xhnr_rec, mu_g, lv_g, mu_l, lv_l = self.model_h(xhnr, eps_g, eps_l, xs, use_eps=use_eps)
+            xh_rec, L = ops.cvae_losses(xhnr_rec, xhnr, xh, cam_int, max_d, mu_g, lv_g, mu_l, lv_l,
+                                        fca=self._fca(ep) if self._fca_t is None else self._fca_t,
+                                        w_rec=self.weight_loss_rec_h, w_kl=self.weight_loss_kl, w_vposer=self.weight_loss_vposer)
+            loss_rec_t, loss_rec_p, loss_KL_g, loss_KL_l, loss_vposer = L.unbind(0)
+            loss_contact, loss_vposer, loss_sdf_pene = self._scene_losses(xh_rec, cam_ext, scene_verts, s_grid_min_batch, s_grid_max_batch,
+                                                                          s_grid_sdf_batch, ep, loss_vposer=loss_vposer)
+            return loss_rec_t, loss_rec_p, loss_KL_g, loss_KL_l, loss_contact, loss_vposer, loss_sdf_pene
         xhn = GeometryTransformer.normalize_global_T(xh, cam_int, max_d)
         xhnr = GeometryTransformer.convert_to_6D_rot(xhn)
         xhnr_rec, mu_g, lv_g, mu_l, lv_l = self.model_h(xhnr, eps_g, eps_l, xs, use_eps=use_eps)
