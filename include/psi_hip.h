@@ -325,6 +325,21 @@ int psi_cvae_losses_backward(const float *rec75, const float *target75, const fl
                              const float *g_losses5, const float *g_xh_rec75, float *g_rec75, float *g_mu0, float *g_logvar0,
                              float *g_mu1, float *g_logvar1, void *stream);
 
+/* ---- tail of the two scene losses of a training step (train_s1.py:156-204 / train_s2.py:159-202) ----------------------------------
+ * forward : losses2[0] = gate w_contact mean(s / (s + 1)), s = sqrt(dist + 1e-4) over the n_contact = B * n_c body->scene distances;
+ *           losses2[1] = gate w_collision * (mean |sdf| over the negative ones of the n_sdf = B * V values, 0 if there is none);
+ *           stats2 = { sum |sdf| over sdf < 0, their count } (input of the backward).  ws: psi_scene_losses_workspace_floats() floats.
+ * backward: g_verts [B,V,3] (OVERWRITTEN) = d(g_losses2[0] losses2[0] + g_losses2[1] losses2[1]) / d body vertices, given xyz1 [B,n_c,3] =
+ *           the contact vertices that were queried (rows vid [n_c] of the body), their nearest scene points verts_table[slot[b]][idx[b,j]]
+ *           (verts_table [S,m,3], chamfer.cu:155-174) and sdf_grad [B,V,3] = d sdf / d vertex (psi_sdf_sample_forward's out_grad). */
+size_t psi_scene_losses_workspace_floats(void);
+int psi_scene_losses_forward(const float *dist, long n_contact, const float *sdf_vals, long n_sdf, float w_contact, float w_collision,
+                             float gate, float *ws, float *losses2, float *stats2, void *stream);
+int psi_scene_losses_backward(const float *g_losses2, const float *stats2, const float *dist, const float *xyz1, const int32_t *idx,
+                              const int32_t *slot, const float *verts_table, long m, const int32_t *vid, const float *sdf_vals,
+                              const float *sdf_grad, int B, int V, int n_c, float w_contact, float w_collision, float gate,
+                              float *g_verts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

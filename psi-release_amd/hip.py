@@ -70,6 +70,10 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_void_p]),
     'psi_cvae_losses_backward': (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'psi_scene_losses_workspace_floats': (c_size_t, []),
+    'psi_scene_losses_forward': (c_int, [c_void_p, c_long, c_void_p, c_long, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'psi_scene_losses_backward': (c_int, [c_void_p] * 7 + [c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float,
+                                          c_void_p, c_void_p]),
     'psi_dp_unique_id': (c_int, [c_void_p]),
     'psi_dp_comm_create': (c_int, [c_void_p, c_void_p, c_int, c_int]),
     'psi_dp_comm_destroy': (None, [c_void_p]),

@@ -579,3 +579,54 @@ def cvae_losses(rec, target, xh, cam_int, max_d, mu0, logvar0, mu1=None, logvar1
     -> xh_rec [B,75] = recover_global_T(rec, cam_int, max_d) and losses [5] = (rec_t, rec_p, KL of latent 0, KL of latent 1 (0 without
     one), vposer).  ``fca``: the KL annealing factor, a float or a 0-dim device tensor (captured steps change it between replays)."""
     return _CvaeLosses.apply(rec, target, xh, cam_int, max_d, mu0, logvar0, mu1, logvar1, fca, w_rec, w_kl, w_vposer)
+
+
+# ------------------------------------------------------------------------------------------
+# Contact + penetration losses of a training step from the body mesh (csrc/scene_loss.hip)
+# ------------------------------------------------------------------------------------------
+class _SceneLosses(Function):
+    @staticmethod
+    def forward(ctx, verts, vid, scenes, slot, sdf, gmin, gmax, align_corners, w_contact, w_collision, gate, vid32):
+        verts = verts.detach().contiguous().float()
+        B, V, _ = verts.shape
+        L = hip.lib()
+        xyz1 = verts.index_select(1, vid)                                   # [B,n_c,3] contact vertices (train_s1.py:161)
+        n_c = xyz1.shape[1]
+        dist, idx = scenes.query(xyz1, slot)                                # exact body->scene NN (chamfer dist1 / idx1)
+        S, D = sdf.shape[0], sdf.shape[1]
+        vals = torch.empty(B, V, device=verts.device)
+        og = torch.empty(B, V, 3, device=verts.device)
+        hip.check(L.psi_sdf_sample_forward(hip.ptr(sdf), hip.ptr(slot), hip.ptr(gmin), hip.ptr(gmax), hip.ptr(verts), B, V, D, S,
+                                           int(bool(align_corners)), hip.ptr(vals), hip.ptr(og), hip.stream()), 'psi_sdf_sample_forward')
+        ws = torch.empty(L.psi_scene_losses_workspace_floats(), device=verts.device)
+        losses = torch.empty(2, device=verts.device)
+        stats = torch.empty(2, device=verts.device)
+        ctx.w = (float(w_contact), float(w_collision), float(gate))
+        hip.check(L.psi_scene_losses_forward(hip.ptr(dist), B * n_c, hip.ptr(vals), B * V, *ctx.w, hip.ptr(ws), hip.ptr(losses), hip.ptr(stats),
+                                             hip.stream()), 'psi_scene_losses_forward')
+        ctx.scenes = scenes
+        ctx.save_for_backward(dist, xyz1, idx, slot, vid32 if vid32 is not None else vid.to(torch.int32), vals, og, stats)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        dist, xyz1, idx, slot, vid32, vals, og, stats = ctx.saved_tensors
+        B, V = vals.shape
+        table = ctx.scenes.verts_table
+        g_verts = torch.empty(B, V, 3, device=vals.device)
+        hip.check(hip.lib().psi_scene_losses_backward(hip.ptr(g.contiguous().float()), hip.ptr(stats), hip.ptr(dist), hip.ptr(xyz1), hip.ptr(idx),
+                                                      hip.ptr(slot), hip.ptr(table), table.shape[1], hip.ptr(vid32), hip.ptr(vals), hip.ptr(og), B,
+                                                      V, xyz1.shape[1], *ctx.w, hip.ptr(g_verts), hip.stream()), 'psi_scene_losses_backward')
+        return (g_verts,) + (None,) * 11
+
+
+def scene_losses(body_verts, vid, scenes: SceneSet, slot, sdf, grid_min, grid_max, align_corners, w_contact, w_collision, gate=1.0, vid32=None):
+    """(loss_contact, loss_sdf_pene) of ``cal_loss`` (train_s1.py:156-204) from the camera-frame body mesh [B,V,3]: the contact rows ``vid``
+    against each body's scene (``scenes`` / ``slot`` as in chamfer_to_scenes), every vertex against its scene's SDF volume (sdf [S,D,D,D],
+    grid_min / grid_max [S,3], the same ``slot``).  Two exact-NN / SDF kernels and two small reduction kernels forward, two kernels
+    backward — the operator form of the same expressions is chamfer_to_scenes + sdf_sample + penetration_loss plus ~40 elementwise launches.
+    ``vid``: int64 [n_c] device; ``vid32``: the same as int32 when the caller keeps one (saves a cast launch per step)."""
+    assert slot.dtype == torch.int32 and slot.is_contiguous()
+    out = _SceneLosses.apply(body_verts, vid, scenes, slot, sdf.contiguous().float(), grid_min.reshape(-1, 3).contiguous().float(),
+                             grid_max.reshape(-1, 3).contiguous().float(), align_corners, w_contact, w_collision, gate, vid32)
+    return out[0], out[1]

@@ -78,6 +78,7 @@ class _TrainBase:
                 vid, _ = GeometryTransformer.get_contact_id(body_segments_folder=self.contact_id_folder,
                                                             contact_body_parts=self.contact_part)
             self._vid = torch.tensor(np.asarray(vid).astype(np.int64), device=self.device)
+            self._vid32 = self._vid.to(torch.int32)
         return self._vid
 
     def _scene_losses(self, xh_rec, cam_ext, scene_verts, s_grid_min_batch, s_grid_max_batch, s_grid_sdf_batch, ep, loss_vposer=None):
@@ -101,12 +102,19 @@ class _TrainBase:
             joint_rot_batch = self.vposer.decode(body_param_rec['body_pose_vp'], output_type='aa').view(xh_rec.shape[0], -1)
             body_param_ = {k: v for k, v in body_param_rec.items() if k != 'body_pose_vp'}
             body_verts_batch = self.body_mesh_model(return_verts=True, body_pose=joint_rot_batch, cam_ext=cam_ext, **body_param_).vertices
+        gate = 1.0 if ep > 0.75 * self.epoch else 0.0                           # train_s1.py:171-173,197-199
+        if (isinstance(s_grid_sdf_batch, tuple) and len(s_grid_sdf_batch) == 5 and getattr(self, 'use_scene_index', True)
+                and not psi_dist.is_dist() and os.environ.get('PSI_HIP_GLUE', '1') != '0'):
+            # both scene terms and their vertex gradient as one op (ops.scene_losses): 6 launches forward, 2 backward
+            sdf_t, sid, gmin_t, gmax_t, scenes = s_grid_sdf_batch
+            loss_contact, loss_sdf_pene = ops.scene_losses(body_verts_batch, self._contact_ids(), scenes, sid, sdf_t, gmin_t, gmax_t,
+                                                           self.align_corners, self.weight_contact, self.weight_collision, gate, vid32=self._vid32)
+            return loss_contact, loss_vposer, loss_sdf_pene
         body_verts_contact_batch = body_verts_batch[:, self._contact_ids(), :]
         if isinstance(s_grid_sdf_batch, tuple) and len(s_grid_sdf_batch) == 5 and getattr(self, 'use_scene_index', True):
             contact_dist = ops.chamfer_to_scenes(body_verts_contact_batch.contiguous(), s_grid_sdf_batch[4], s_grid_sdf_batch[1])
         else:
             contact_dist, _ = self._chamfer(body_verts_contact_batch.contiguous(), scene_verts.contiguous())
-        gate = 1.0 if ep > 0.75 * self.epoch else 0.0                           # train_s1.py:171-173,197-199
         s = torch.sqrt(contact_dist + 1e-4)
         loss_contact = gate * self.weight_contact * torch.mean(s / (s + 1.0))
         if isinstance(s_grid_sdf_batch, tuple):                                 # (sdf_table, scene_id, gmin_table, gmax_table)
