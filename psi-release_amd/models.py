@@ -148,6 +148,24 @@ def _use_hip_linear(module, x):
     return os.environ.get('PSI_HIP_LINEAR', '1') != '0'
 
 
+def _linear(owner, layer, x):
+    """``layer(x)`` for an nn.Linear of a model in the bf16 mode: the hand-written MFMA kernels when the layer's shape is covered (both
+    widths multiples of 16 — the latent heads and the decoders' input layers), the library otherwise (3-, 72-, 75-wide layers)."""
+    if _use_hip_linear(owner, x) and layer.in_features % 16 == 0 and layer.out_features % 16 == 0:
+        from .ops import linear_act
+        return linear_act(x, layer.weight, layer.bias)
+    return layer(x)
+
+
+def _decode(owner, seq, x):
+    """``seq(x)`` for the decoders ``nn.Sequential(Linear, ResBlock, ResBlock, Linear)`` (net_layers.py:88-93, 181-186): the first layer through
+    ``_linear`` (the state_dict keys stay ``decode.0.weight`` ...)."""
+    x = _linear(owner, seq[0], x)
+    for i in range(1, len(seq)):
+        x = seq[i](x)
+    return x
+
+
 def _reparam(mu, logvar, eps=None):
     std = torch.exp(0.5 * logvar)
     if eps is None:
@@ -206,11 +224,11 @@ class BodyGlobalPoseVAE(_SceneCond):
         z_s = self._scene_feature(scene, rows)
         if self.test:
             z = torch.randn(z_s.size(0), self.zdim, device=scene.device) if eps is None else eps
-            return self.decode(torch.cat([z, z_s], dim=1))
+            return _decode(self, self.decode, torch.cat([z, z_s], dim=1))
         feature = self.encode(torch.cat((z_s, self.torso_linear(torso)), dim=1))            # net_layers.py:118
-        mean, log_var = self.mean_linear(feature), self.log_var_linear(feature)
+        mean, log_var = _linear(self, self.mean_linear, feature), _linear(self, self.log_var_linear, feature)
         z = _reparam(mean, log_var, eps)
-        return self.decode(torch.cat([z, z_s], dim=1)), mean, log_var                       # net_layers.py:131
+        return _decode(self, self.decode, torch.cat([z, z_s], dim=1)), mean, log_var        # net_layers.py:131
 
 
 class BodyLocalPoseVAE(_SceneCond):
@@ -236,11 +254,11 @@ class BodyLocalPoseVAE(_SceneCond):
         z_g = self.torso_linear(torso)
         if self.test:
             z = torch.randn(z_s.size(0), self.zdim, device=scene.device) if eps is None else eps
-            return self.decode(torch.cat([z, z_g, z_s], dim=1))
+            return _decode(self, self.decode, torch.cat([z, z_g, z_s], dim=1))
         feature = self.encode(torch.cat([self.pose_linear(pose), z_g, z_s], dim=1))         # net_layers.py:220
-        mean, log_var = self.mean_linear(feature), self.log_var_linear(feature)
+        mean, log_var = _linear(self, self.mean_linear, feature), _linear(self, self.log_var_linear, feature)
         z = _reparam(mean, log_var, eps)
-        return self.decode(torch.cat([z, z_g, z_s], dim=1)), mean, log_var                  # net_layers.py:231
+        return _decode(self, self.decode, torch.cat([z, z_g, z_s], dim=1)), mean, log_var   # net_layers.py:231
 
 
 class HumanCVAES2(nn.Module):
@@ -294,13 +312,13 @@ class HumanCVAES1(_SceneCond):
     def forward(self, x_body, x_s, eps=None):
         z_s = self._scene_feature(x_s)
         z_hs = self.human_encoder(torch.cat([self.linear_in(x_body), z_s], dim=1))         # cvae.py:480
-        mu, logvar = self.mu_enc(z_hs), self.logvar_enc(z_hs)
-        z_h = self.linear_latent(_reparam(mu, logvar, eps))
+        mu, logvar = _linear(self, self.mu_enc, z_hs), _linear(self, self.logvar_enc, z_hs)
+        z_h = _linear(self, self.linear_latent, _reparam(mu, logvar, eps))
         return self.linear_out(self.human_decoder(torch.cat([z_h, z_s], dim=1))), mu, logvar   # cvae.py:488
 
     def _decode_latent(self, x_s, eps, rows=None):
         z_s = self._scene_feature(x_s, rows)
-        return self.linear_out(self.human_decoder(torch.cat([self.linear_latent(eps), z_s], dim=1)))
+        return self.linear_out(self.human_decoder(torch.cat([_linear(self, self.linear_latent, eps), z_s], dim=1)))
 
     def sample(self, x_s, eps=None, rows=None, **kwargs):
         if eps is None:
