@@ -297,6 +297,9 @@ size_t psi_conv3x3_wrw_workspace_floats(int N, int H, int W, int Cin, int Cout);
 int psi_conv3x3_weight_grad(const void *x, const void *dy, int N, int H, int W, int Cin, int Cout, float *gw, float *ws, void *stream);
 /* w [Cout][3][3][Cin] -> wt [Cin][3][3][Cout] with wt[ci][kh][kw][co] = w[co][2-kh][2-kw][ci]:  dX = psi_conv3x3_forward(dY, wt) */
 int psi_conv3x3_rotate_weight(const void *w, int Cin, int Cout, void *wt, void *stream);
+/* fp32 master weight w32 [Cout][3][3][Cin] (the channels_last memory of an nn.Conv2d weight) -> bf16 in both layouts in one launch:
+ * wb [Cout][3][3][Cin] (rounded to nearest even, what autocast's cast produces) and, when wt != NULL, wt = the rotated layout above. */
+int psi_conv3x3_prepare_weight(const float *w32, int Cin, int Cout, void *wb, void *wt, void *stream);
 
 /* MaxPool2d(kernel_size=3, stride=2, padding=1) of the trunk's stem (torchvision resnet18 children[3]; cvae.py:431-435) on an NHWC bf16 map
  * x [N,H,W,C] -> y [N,OH,OW,C], OH = (H - 1) / 2 + 1; idx [N,OH,OW,C] uint8 = position kh * 3 + kw of the maximum inside its window (first
@@ -314,11 +317,12 @@ int psi_maxpool3x3s2_backward(const void *dy, const void *idx, int N, int H, int
  *   fca: the KL annealing factor, read from fca_dev (a device float, so that a captured step can change it) when that is not NULL.
  * psi_cvae_losses_backward: gradients of  sum_k g_losses5[k] * losses5[k]  +  <g_xh_rec75, xh_rec75>  (g_xh_rec75 may be NULL) with
  *   respect to rec75, mu, logvar (all OVERWRITTEN).  All tensors fp32, contiguous, device memory. */
+size_t psi_cvae_losses_workspace_floats(void);      /* ws of psi_cvae_losses_forward */
 int psi_cvae_target(const float *xh72, const float *cam_int, const float *max_d, int B, float *out75, void *stream);
 int psi_cvae_losses_forward(const float *rec75, const float *target75, const float *xh72, const float *cam_int, const float *max_d,
                             const float *mu0, const float *logvar0, int nz0, const float *mu1, const float *logvar1, int nz1, int B,
-                            float w_rec, float w_kl, float w_vposer, float fca, const float *fca_dev, float *xh_rec75, float *losses5,
-                            void *stream);
+                            float w_rec, float w_kl, float w_vposer, float fca, const float *fca_dev, float *ws, float *xh_rec75,
+                            float *losses5, void *stream);
 int psi_cvae_losses_backward(const float *rec75, const float *target75, const float *xh72, const float *cam_int, const float *max_d,
                              const float *mu0, const float *logvar0, int nz0, const float *mu1, const float *logvar1, int nz1, int B,
                              float w_rec, float w_kl, float w_vposer, float fca, const float *fca_dev, const float *xh_rec75,

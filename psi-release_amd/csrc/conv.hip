@@ -311,7 +311,29 @@ __global__ void conv_weight_rot_kernel(const __bf16 *__restrict__ w, __bf16 *__r
     wt[i] = w[((size_t)co * 9 + (8 - tap)) * CIN + ci];
 }
 
+// fp32 master weight -> bf16 in BOTH layouts at once: W[co][kh][kw][ci] for the forward, Wt[ci][2-kh][2-kw][co] for the input gradient
+// (one launch per layer and step instead of a cast and a re-layout)
+__global__ void conv_weight_prepare_kernel(const float *__restrict__ w32, __bf16 *__restrict__ wb, __bf16 *__restrict__ wt, int COUT, int CIN)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, total = COUT * 9 * CIN;
+    if (i >= total) return;
+    const int ci = i % CIN, tap = (i / CIN) % 9, co = i / (CIN * 9);
+    const __bf16 v = (__bf16)w32[i];
+    wb[i] = v;
+    if (wt) wt[((size_t)ci * 9 + (8 - tap)) * COUT + co] = v;
+}
+
 }  // namespace
+
+extern "C" int psi_conv3x3_prepare_weight(const float *w32, int Cin, int Cout, void *wb, void *wt, void *stream)
+{
+    PSI_REQUIRE(w32 && wb && Cin > 0 && Cout > 0, "bad arguments");
+    const int total = Cout * 9 * Cin;
+    hipLaunchKernelGGL(conv_weight_prepare_kernel, dim3(psi_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w32, (__bf16 *)wb, (__bf16 *)wt, Cout,
+                       Cin);
+    PSI_CHECK_LAUNCH("conv_weight_prepare_kernel");
+    return 0;
+}
 
 extern "C" int psi_conv3x3_supported(int Cin, int Cout, int H, int W)
 {

@@ -1,4 +1,4 @@
-// The body-vector glue around the CVAE in a training step, as three launches instead of ~190 elementwise ones, gfx950.
+// The body-vector glue around the CVAE in a training step, as four launches instead of ~190 elementwise ones, gfx950.
 //
 // Per optimiser step the trainers (train_s1.py:95-133, train_s2.py:102-139 `cal_loss`) run, on [B, 72..75] tensors:
 //   target   : xhnr = convert_to_6D_rot(normalize_global_T(xh, cam_int, max_d))                      cvae.py:118-127, 176-199
@@ -12,12 +12,10 @@
 // Each of these is a handful of flops per element; as PyTorch operators they are ~55 (target), ~45 (losses) and ~90 (autograd) launches
 // of 4-5 us each inside the captured step.  The arithmetic below follows the operator sequence of psi_release_amd/geometry.py (same
 // association, no FMA contraction: this file is compiled with -ffp-contract=off), so results agree with the operator path to the last
-// bits of the transcendental functions; the reductions are fixed-order (one block).
+// bits of the transcendental functions; the reductions are fixed-order (per-block partials, summed in block order).
 #include "psi_internal.h"
 
 namespace {
-
-constexpr int CL_BLK = 1024;
 
 struct CvaeLossDev {
     const float *rec, *tgt, *xh, *cam_int, *max_d;     // [B,75] (grad), [B,75], [B,72], [B,9], [B]
@@ -86,33 +84,16 @@ __global__ void cvae_target_kernel(const float *__restrict__ xh, const float *__
     out[i] = v;
 }
 
-// fixed-order block sum of NQ quantities: lanes by shuffle, waves by thread 0 in wave order
-template <int NQ>
-__device__ __forceinline__ void block_sums(float (&a)[NQ], float (*sh)[CL_BLK / 64])
-{
-#pragma unroll
-    for (int q = 0; q < NQ; q++)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_down(a[q], o, 64);
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int q = 0; q < NQ; q++) sh[q][threadIdx.x >> 6] = a[q];
-    __syncthreads();
-    if (threadIdx.x == 0)
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            float s = 0.0f;
-            for (int w = 0; w < CL_BLK / 64; w++) s += sh[q][w];
-            a[q] = s;
-        }
-}
+// Forward in two launches: CL_GRID blocks leave fixed partial sums of the six quantities (and write xh_rec), one small block adds them in
+// block order.  (One 1024-thread block doing all of it took 27 us at batch 128: 64 dependent rounds of loads per thread.)
+constexpr int CL_GRID = 64;
 
-__global__ __launch_bounds__(CL_BLK) void cvae_losses_fwd_kernel(CvaeLossDev a)
+__global__ __launch_bounds__(256) void cvae_losses_partial_kernel(CvaeLossDev a, float *__restrict__ part /* [CL_GRID][6] */)
 {
-    __shared__ float sh[6][CL_BLK / 64];
+    __shared__ float sh[6][4];
     float acc[6] = {0, 0, 0, 0, 0, 0};          // |rec - tgt| over [:, :3], |xh_rec - xh| over [:, :3], |rec - tgt| over [:, 3:], KL0, KL1, latent^2
-    const int n = a.B * 75;
-    for (int i = threadIdx.x; i < n; i += CL_BLK) {
+    const int n = a.B * 75, stride = CL_GRID * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+    for (int i = t0; i < n; i += stride) {
         const int b = i / 75, j = i % 75;
         const float r = a.rec[i];
         const float d = fabsf(r - a.tgt[i]);
@@ -138,19 +119,40 @@ __global__ __launch_bounds__(CL_BLK) void cvae_losses_fwd_kernel(CvaeLossDev a)
     for (int k = 0; k < 2; k++)
         if (a.mu[k]) {
             const int nk = a.B * a.nz[k];
-            for (int i = threadIdx.x; i < nk; i += CL_BLK) {
+            for (int i = t0; i < nk; i += stride) {
                 const float m = a.mu[k][i], l = a.lv[k][i];
                 acc[3 + k] += expf(l) + m * m - 1.0f - l;
             }
         }
-    block_sums<6>(acc, sh);
-    if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 6; q++) sh[q][threadIdx.x >> 6] = acc[q];
+    __syncthreads();
+    if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(64) void cvae_losses_finalize_kernel(CvaeLossDev a, const float *__restrict__ part)
+{
+    const int t = threadIdx.x;
+    float v[CL_GRID];
+#pragma unroll
+    for (int b = 0; b < CL_GRID; b++) v[b] = t < 6 ? part[b * 6 + t] : 0.0f;      // all loads first, then the sum in block order
+    float s = 0.0f;
+#pragma unroll
+    for (int b = 0; b < CL_GRID; b++) s += v[b];
+    float acc[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) acc[q] = __shfl(s, q, 64);
+    if (t == 0) {
         const float fB = (float)a.B;
         const float fca = a.fca_dev ? *a.fca_dev : a.fca;
         *a.loss[0] = a.w_rec * (0.5f * (acc[0] / (3.0f * fB)) + 0.5f * (acc[1] / (3.0f * fB)));
         *a.loss[1] = a.w_rec * (acc[2] / (72.0f * fB));
-        for (int k = 0; k < 2; k++)
-            if (a.loss[2 + k]) *a.loss[2 + k] = a.mu[k] ? fca * fca * a.w_kl * 0.5f * (acc[3 + k] / (fB * (float)a.nz[k])) : 0.0f;
+        for (int k = 0; k < 2; k++) *a.loss[2 + k] = a.mu[k] ? fca * fca * a.w_kl * 0.5f * (acc[3 + k] / (fB * (float)a.nz[k])) : 0.0f;
         *a.loss[4] = a.w_vp * (acc[5] / (32.0f * fB));
     }
 }
@@ -227,20 +229,24 @@ static int cvae_fill(CvaeLossDev &a, const float *rec75, const float *target75, 
     return 0;
 }
 
+extern "C" size_t psi_cvae_losses_workspace_floats(void) { return (size_t)CL_GRID * 6; }
+
 extern "C" int psi_cvae_losses_forward(const float *rec75, const float *target75, const float *xh72, const float *cam_int, const float *max_d,
                                        const float *mu0, const float *logvar0, int nz0, const float *mu1, const float *logvar1, int nz1, int B,
-                                       float w_rec, float w_kl, float w_vposer, float fca, const float *fca_dev, float *xh_rec75, float *losses5,
-                                       void *stream)
+                                       float w_rec, float w_kl, float w_vposer, float fca, const float *fca_dev, float *ws, float *xh_rec75,
+                                       float *losses5, void *stream)
 {
     CvaeLossDev a = {};
     int rc = cvae_fill(a, rec75, target75, xh72, cam_int, max_d, mu0, logvar0, nz0, mu1, logvar1, nz1, B, w_rec, w_kl, w_vposer, fca, fca_dev);
     if (rc) return rc;
-    PSI_REQUIRE(xh_rec75 && losses5, "null output");
+    PSI_REQUIRE(xh_rec75 && losses5 && ws, "null output / workspace");
     a.xh_rec = xh_rec75;
     for (int k = 0; k < 5; k++) a.loss[k] = losses5 + k;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(cvae_losses_fwd_kernel, dim3(1), dim3(CL_BLK), 0, st, a);
-    PSI_CHECK_LAUNCH("cvae_losses_fwd_kernel");
+    hipLaunchKernelGGL(cvae_losses_partial_kernel, dim3(CL_GRID), dim3(256), 0, st, a, ws);
+    PSI_CHECK_LAUNCH("cvae_losses_partial_kernel");
+    hipLaunchKernelGGL(cvae_losses_finalize_kernel, dim3(1), dim3(64), 0, st, a, (const float *)ws);
+    PSI_CHECK_LAUNCH("cvae_losses_finalize_kernel");
     return 0;
 }
 

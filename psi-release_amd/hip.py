@@ -63,11 +63,13 @@ SIGNATURES = {
     'psi_conv3x3_wrw_workspace_floats': (c_size_t, [c_int] * 5),
     'psi_conv3x3_weight_grad': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'psi_conv3x3_rotate_weight': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'psi_conv3x3_prepare_weight': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'psi_maxpool3x3s2_forward': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'psi_maxpool3x3s2_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'psi_cvae_target': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'psi_cvae_losses_workspace_floats': (c_size_t, []),
     'psi_cvae_losses_forward': (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float,
-                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'psi_cvae_losses_backward': (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'psi_scene_losses_workspace_floats': (c_size_t, []),

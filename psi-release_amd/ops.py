@@ -450,18 +450,27 @@ class _Conv3x3(Function):
         N, Cin, H, W = x.shape
         Cout = weight.shape[0]
         xc = x.contiguous(memory_format=torch.channels_last)
-        wb = weight.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)          # [Cout,3,3,Cin]: a view for a channels_last weight
+        w4 = weight.detach().permute(0, 2, 3, 1)                                           # [Cout,3,3,Cin]: a view for a channels_last weight
+        wt = None
+        if w4.dtype == torch.float32 and w4.is_contiguous():
+            # master weight -> bf16, forward layout and (when the input needs a gradient) the rotated layout of the backward: one launch
+            wb = torch.empty(Cout, 3, 3, Cin, device=x.device, dtype=torch.bfloat16)
+            if ctx.needs_input_grad[0] and hip.lib().psi_conv3x3_supported(Cout, Cin, H, W):
+                wt = torch.empty(Cin, 3, 3, Cout, device=x.device, dtype=torch.bfloat16)
+            hip.check(hip.lib().psi_conv3x3_prepare_weight(hip.ptr(w4), Cin, Cout, hip.ptr(wb), hip.ptr(wt), hip.stream()), 'psi_conv3x3_prepare_weight')
+        else:
+            wb = w4.contiguous().to(torch.bfloat16)
         y = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
         b = bias.detach().float().contiguous() if bias is not None else None
         hip.check(hip.lib().psi_conv3x3_forward(_ptr_cl(xc), hip.ptr(wb), hip.ptr(b), N, H, W, Cin, Cout, _ptr_cl(y), hip.stream()),
                   'psi_conv3x3_forward')
-        ctx.save_for_backward(xc, wb)
+        ctx.save_for_backward(xc, wb, wt)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xc, wb = ctx.saved_tensors
+        xc, wb, wt = ctx.saved_tensors
         N, Cin, H, W = xc.shape
         Cout = wb.shape[0]
         dyc = dy.contiguous(memory_format=torch.channels_last)
@@ -469,8 +478,9 @@ class _Conv3x3(Function):
         dx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if L.psi_conv3x3_supported(Cout, Cin, H, W):
-                wt = torch.empty(Cin, 3, 3, Cout, device=dy.device, dtype=torch.bfloat16)
-                hip.check(L.psi_conv3x3_rotate_weight(hip.ptr(wb), Cin, Cout, hip.ptr(wt), hip.stream()), 'psi_conv3x3_rotate_weight')
+                if wt is None:
+                    wt = torch.empty(Cin, 3, 3, Cout, device=dy.device, dtype=torch.bfloat16)
+                    hip.check(L.psi_conv3x3_rotate_weight(hip.ptr(wb), Cin, Cout, hip.ptr(wt), hip.stream()), 'psi_conv3x3_rotate_weight')
                 dx = torch.empty((N, Cin, H, W), device=dy.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
                 hip.check(L.psi_conv3x3_forward(_ptr_cl(dyc), hip.ptr(wt), None, N, H, W, Cout, Cin, _ptr_cl(dx), hip.stream()),
                           'psi_conv3x3_forward (input gradient)')
@@ -543,8 +553,10 @@ class _CvaeLosses(Function):
         ctx.nz = (0 if mu0 is None else mu0.shape[1], 0 if mu1 is None else mu1.shape[1])
         xh_rec = torch.empty(B, 75, device=rec.device)
         losses = torch.empty(5, device=rec.device)
+        ws = torch.empty(hip.lib().psi_cvae_losses_workspace_floats(), device=rec.device)
         hip.check(hip.lib().psi_cvae_losses_forward(*[hip.ptr(v) for v in t[:7]], ctx.nz[0], hip.ptr(t[7]), hip.ptr(t[8]), ctx.nz[1], B,
-                                                    *ctx.w, ctx.fca, hip.ptr(_f32c(fca_t)), hip.ptr(xh_rec), hip.ptr(losses), hip.stream()),
+                                                    *ctx.w, ctx.fca, hip.ptr(_f32c(fca_t)), hip.ptr(ws), hip.ptr(xh_rec), hip.ptr(losses),
+                                                    hip.stream()),
                   'psi_cvae_losses_forward')
         ctx.has = (mu0 is not None, mu1 is not None)
         ctx.fca_t = _f32c(fca_t)
