@@ -252,12 +252,15 @@ int psi_fit_copy_buffer(psi_fit_engine *engine, const char *name, float *d_out, 
  * needs its sign.  ws: psi_linear_workspace_floats(M,N,K) floats (0 for small layers; split-K partials for large weights).
  * Backward: gy [M,N] = dL/dy; act_out as saved by the forward (NULL when act == 0); outputs gx [M,K] (dtype of x; nullable),
  * gW [N,K] fp32 and gbias [N] fp32 (nullable), all OVERWRITTEN.  The residual's gradient is gy itself (caller adds it).
+ * ws of the backward: psi_linear_backward_workspace_floats(M,N,K) floats (0 for small layers; partial dX of the n-slices otherwise;
+ * may be NULL when gx is NULL).  Partials of either direction are summed in slice order: deterministic.
  * ------------------------------------------------------------------------------------------- */
 size_t psi_linear_workspace_floats(int M, int N, int K);
 int psi_linear_forward(const void *x, int x_is_bf16, const float *W, const float *bias, const float *residual, int M, int N, int K,
                        int act, float slope, float *y, float *act_out, float *ws, void *stream);
+size_t psi_linear_backward_workspace_floats(int M, int N, int K);
 int psi_linear_backward(const float *gy, const float *act_out, const void *x, int x_is_bf16, const float *W, int M, int N, int K,
-                        float slope, void *gx, float *gW, float *gbias, void *stream);
+                        float slope, void *gx, float *gW, float *gbias, float *ws, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batch normalisation of the scene trunk with its ReLU and skip connection fused in — replaces, inside the BasicBlocks and the stem of

@@ -237,12 +237,13 @@ constexpr int DXP = DXN + 8;             // LDS pitch (elements): 16-byte aligne
 template <typename XT>
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restrict__ gy, const float *__restrict__ act_out,
                                                             const float *__restrict__ W, int M, int N, int K, float slope,
-                                                            XT *__restrict__ gx)
+                                                            XT *__restrict__ gx, int nchunk, float *__restrict__ part)
 {
     __shared__ __attribute__((aligned(16))) __bf16 Gs[2][128][DXP];
     __shared__ __attribute__((aligned(16))) __bf16 Wt[2][DXK][DXP];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int k0 = blockIdx.x * DXK, mblk = blockIdx.y * 128, m0 = mblk + w * TM;
+    const int n_begin = blockIdx.z * nchunk, n_end = min(N, n_begin + nchunk);      // this workgroup's slice of the contraction
     const int li = lane & 31, kb = (lane >> 5) * 8;
     f16v acc[2];
 #pragma unroll
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restr
 #pragma unroll
         for (int i = 0; i < 8; i++) {                       // G: 128 rows x 64 n = 2048 float4, 8 per thread, a wave covers 4 whole rows
             const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
-            const bool ok = mblk + row < M && n0 + c < N;
+            const bool ok = mblk + row < M && n0 + c < n_end;
             const size_t o = (size_t)(mblk + row) * N + n0 + c;
             gr[i] = ok ? *(const f4 *)(gy + o) : (f4){0, 0, 0, 0};
             if (act_out) mr[i] = ok ? *(const f4 *)(act_out + o) : (f4){1, 1, 1, 1};
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restr
 #pragma unroll
         for (int i = 0; i < 4; i++) {                       // W: 64 n-rows x 64 k = 1024 float4, 4 per thread
             const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
-            const bool ok = n0 + row < N && k0 + c < K;
+            const bool ok = n0 + row < n_end && k0 + c < K;
             wr[i] = ok ? *(const f4 *)(W + (size_t)(n0 + row) * K + k0 + c) : (f4){0, 0, 0, 0};
         }
     };
@@ -282,12 +283,12 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restr
             for (int e = 0; e < 4; e++) Wt[buf][c + e][row] = (__bf16)wr[i][e];
         }
     };
-    load_tiles(0);
+    load_tiles(n_begin);
     store_tiles(0);
     __syncthreads();
     int buf = 0;
-    for (int n0 = 0; n0 < N; n0 += DXN, buf ^= 1) {
-        const bool more = n0 + DXN < N;
+    for (int n0 = n_begin; n0 < n_end; n0 += DXN, buf ^= 1) {
+        const bool more = n0 + DXN < n_end;
         if (more) load_tiles(n0 + DXN);                     // next tile's global loads in flight during this tile's MFMAs
 #pragma unroll
         for (int st = 0; st < DXN / TK; st++) {
@@ -309,9 +310,23 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restr
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int i = m0 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-            if (i < M) gx[(size_t)i * K + col] = (XT)acc[t][r];
+            if (i >= M) continue;
+            if (part) part[((size_t)blockIdx.z * M + i) * K + col] = acc[t][r];
+            else gx[(size_t)i * K + col] = (XT)acc[t][r];
         }
     }
+}
+
+// sum of the n-slices of dX in slice order (deterministic), converted to the gradient's type
+template <typename XT>
+__global__ __launch_bounds__(256) void linear_dx_reduce_kernel(const float *__restrict__ part, int S, size_t MK, XT *__restrict__ gx)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= MK) return;
+    f4 a = *(const f4 *)(part + i);
+    for (int s = 1; s < S; s++) a += *(const f4 *)(part + (size_t)s * MK + i);
+#pragma unroll
+    for (int e = 0; e < 4; e++) gx[i + e] = (XT)a[e];
 }
 
 // dW[N,K] = G^T[N,M] X[M,K] (+ gbias[n] = sum_m G[m][n]): workgroup = 32 n-rows x 128 k-columns (wave w: k tile w), contraction over m in
@@ -434,13 +449,22 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float *__restr
 
 int pick_ksplit(int M, int N, int K)
 {
-    // enough workgroups to stream a large weight from HBM with every CU; small layers stay single-pass (latency-bound anyway)
+    // M is the batch (128): these GEMMs are weight streams and latency chains, not matrix-pipe work.  A single pass has N / 32 workgroups
+    // walking all of K in 64-wide tiles with a barrier each (32 workgroups x 16 dependent tiles for a 1024 x 1024 layer: 14.5 us for 4 MB);
+    // the contraction is split until the launch has about one workgroup per compute unit, at least two tiles per workgroup.
     const long tiles = (long)psi_cdiv(N, TN) * psi_cdiv(M, 128);
-    if ((long)N * K < (1L << 21)) return 1;                     // weight < 8 MB
     int s = (int)(256 / tiles);
-    while (s > 1 && (K / s) < 256) s >>= 1;
-    if (s < 1) s = 1;
-    return s;
+    if (s > K / (2 * BK)) s = K / (2 * BK);
+    return s < 1 ? 1 : s;
+}
+
+// dX: K / 64 workgroups per 128 rows (16 for a 1024 x 1024 layer) each walking all of N; same treatment over n
+int pick_nsplit(int M, int N, int K)
+{
+    const long tiles = (long)psi_cdiv(K, DXK) * psi_cdiv(M, 128);
+    int s = (int)(256 / tiles);
+    if (s > N / (2 * DXN)) s = N / (2 * DXN);
+    return s < 1 ? 1 : s;
 }
 
 }  // namespace
@@ -483,19 +507,40 @@ extern "C" int psi_linear_forward(const void *x, int x_is_bf16, const float *W, 
     return 0;
 }
 
+extern "C" size_t psi_linear_backward_workspace_floats(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int s = pick_nsplit(M, N, K);
+    return s > 1 ? (size_t)s * M * K : 0;
+}
+
 extern "C" int psi_linear_backward(const float *gy, const float *act_out, const void *x, int x_is_bf16, const float *W, int M, int N, int K,
-                                   float slope, void *gx, float *gW, float *gbias, void *stream)
+                                   float slope, void *gx, float *gW, float *gbias, float *ws, void *stream)
 {
     PSI_REQUIRE(gy && x && W, "null pointer");
     PSI_REQUIRE(M > 0 && N > 0 && K > 0 && N % 16 == 0 && K % 4 == 0, "N must be a positive multiple of 16 and K of 4");
     hipStream_t st = (hipStream_t)stream;
     if (gx) {
-        dim3 grid(psi_cdiv(K, DXK), psi_cdiv(M, 128));
+        int S = pick_nsplit(M, N, K), nchunk = N;
+        if (S > 1) {
+            PSI_REQUIRE(ws, "this shape is split over n: pass psi_linear_backward_workspace_floats() floats of workspace");
+            nchunk = psi_cdiv(psi_cdiv(N, S), DXN) * DXN;
+            S = psi_cdiv(N, nchunk);
+        }
+        float *part = S > 1 ? ws : nullptr;
+        dim3 grid(psi_cdiv(K, DXK), psi_cdiv(M, 128), S);
         if (x_is_bf16)
-            hipLaunchKernelGGL(linear_bwd_dx_kernel<__bf16>, grid, dim3(256), 0, st, gy, act_out, W, M, N, K, slope, (__bf16 *)gx);
+            hipLaunchKernelGGL(linear_bwd_dx_kernel<__bf16>, grid, dim3(256), 0, st, gy, act_out, W, M, N, K, slope, (__bf16 *)gx, nchunk, part);
         else
-            hipLaunchKernelGGL(linear_bwd_dx_kernel<float>, grid, dim3(256), 0, st, gy, act_out, W, M, N, K, slope, (float *)gx);
+            hipLaunchKernelGGL(linear_bwd_dx_kernel<float>, grid, dim3(256), 0, st, gy, act_out, W, M, N, K, slope, (float *)gx, nchunk, part);
         PSI_CHECK_LAUNCH("linear_bwd_dx_kernel");
+        if (S > 1) {
+            const size_t MK = (size_t)M * K;
+            const dim3 rg((unsigned)psi_cdiv((long)(MK / 4), 256));
+            if (x_is_bf16) hipLaunchKernelGGL(linear_dx_reduce_kernel<__bf16>, rg, dim3(256), 0, st, (const float *)part, S, MK, (__bf16 *)gx);
+            else hipLaunchKernelGGL(linear_dx_reduce_kernel<float>, rg, dim3(256), 0, st, (const float *)part, S, MK, (float *)gx);
+            PSI_CHECK_LAUNCH("linear_dx_reduce_kernel");
+        }
     }
     if (gW) {
         dim3 grid(psi_cdiv(K, DWK), psi_cdiv(N, TM));

@@ -335,8 +335,10 @@ class _LinearAct(Function):
         gx = torch.empty(M, K, device=gy.device, dtype=torch.bfloat16 if ctx.xb else torch.float32) if need_x else None
         gw = torch.empty(N, K, device=gy.device) if (need_w or need_b) else None         # gbias is produced by the dW kernel
         gb = torch.empty(N, device=gy.device) if need_b else None
+        nws = hip.lib().psi_linear_backward_workspace_floats(M, N, K) if need_x else 0
+        ws = torch.empty(nws, device=gy.device) if nws else None
         hip.check(hip.lib().psi_linear_backward(hip.ptr(gy), hip.ptr(a_out) if ctx.act else None, hip.ptr(xc), int(ctx.xb), hip.ptr(w), M, N, K,
-                                                ctx.slope, hip.ptr(gx), hip.ptr(gw), hip.ptr(gb), hip.stream()), 'psi_linear_backward')
+                                                ctx.slope, hip.ptr(gx), hip.ptr(gw), hip.ptr(gb), hip.ptr(ws), hip.stream()), 'psi_linear_backward')
         return gx, gw if need_w else None, gb, gy if (ctx.has_res and ctx.needs_input_grad[3]) else None, None, None
 
 

@@ -15,9 +15,10 @@ for name, M, N, K in shapes:
     x = torch.randn(M, K, device=DEV); W = torch.randn(N, K, device=DEV) / K ** 0.5
     gy = torch.randn(M, N, device=DEV); a_out = torch.randn(M, N, device=DEV)
     gx = torch.empty(M, K, device=DEV); gw = torch.empty(N, K, device=DEV); gb = torch.empty(N, device=DEV)
+    wsb = torch.empty(max(L.psi_linear_backward_workspace_floats(M, N, K), 1), device=DEV)
     def hip_bwd():
         hip.check(L.psi_linear_backward(hip.ptr(gy), hip.ptr(a_out), hip.ptr(x), 0, hip.ptr(W), M, N, K, 0.01, hip.ptr(gx), hip.ptr(gw), hip.ptr(gb),
-                                        hip.stream()), 'psi_linear_backward')
+                                        hip.ptr(wsb), hip.stream()), 'psi_linear_backward')
     def lib_bwd():
         g = torch.where(a_out > 0, gy, gy * 0.01)
         gb16 = g.to(torch.bfloat16)
