@@ -11,4 +11,4 @@ d=json.loads([l for l in open('gpurun_out/final3b/bench_default.json') if l.star
 print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'], d['secondary']['train_s2']['ms_per_step'], d['secondary']['train_s2'].get('conv_kernel_roofline'), d['cpu_baseline']['value'])
 PY
 timeout 300 python tools/time_generation.py > $O/gen.log 2>&1; cp gpurun_out/generation_times.json $O/ 2>/dev/null; tail -2 $O/gen.log
-timeout 1400 python -m pytest tests -m gpu -x -q 2>&1 | grep -v Warning | tail -3 | tee $O/pytest_gpu_tail.log
+timeout 1400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; grep -E " passed| failed" $O/pytest_gpu.log
