@@ -561,6 +561,7 @@ class _CvaeLosses(Function):
                                                     hip.stream()),
                   'psi_cvae_losses_forward')
         ctx.has = (mu0 is not None, mu1 is not None)
+        ctx.dtypes = tuple(None if v is None else v.dtype for v in (rec, mu0, lv0, mu1, lv1))
         ctx.fca_t = _f32c(fca_t)
         ctx.save_for_backward(*[v for v in t if v is not None], xh_rec)
         return xh_rec, losses
@@ -583,7 +584,10 @@ class _CvaeLosses(Function):
                                                      hip.ptr(ctx.fca_t), hip.ptr(xh_rec), hip.ptr(gl), hip.ptr(_f32c(g_xh_rec)), hip.ptr(g_rec),
                                                      hip.ptr(g[0]), hip.ptr(g[1]), hip.ptr(g[2]), hip.ptr(g[3]), hip.stream()),
                   'psi_cvae_losses_backward')
-        return (g_rec, None, None, None, None, g[0], g[1], g[2], g[3], None, None, None, None)
+        cast = lambda v, dt: v if (v is None or v.dtype == dt) else v.to(dt)            # gradients in the dtype of their inputs
+        dt = ctx.dtypes
+        return (cast(g_rec, dt[0]), None, None, None, None, cast(g[0], dt[1]), cast(g[1], dt[2]), cast(g[2], dt[3]), cast(g[3], dt[4]),
+                None, None, None, None)
 
 
 def cvae_losses(rec, target, xh, cam_int, max_d, mu0, logvar0, mu1=None, logvar1=None, fca=1.0, w_rec=1.0, w_kl=1.0, w_vposer=1.0):
@@ -601,6 +605,7 @@ def cvae_losses(rec, target, xh, cam_int, max_d, mu0, logvar0, mu1=None, logvar1
 class _SceneLosses(Function):
     @staticmethod
     def forward(ctx, verts, vid, scenes, slot, sdf, gmin, gmax, align_corners, w_contact, w_collision, gate, vid32):
+        ctx.verts_dtype = verts.dtype
         verts = verts.detach().contiguous().float()
         B, V, _ = verts.shape
         L = hip.lib()
@@ -631,7 +636,7 @@ class _SceneLosses(Function):
         hip.check(hip.lib().psi_scene_losses_backward(hip.ptr(g.contiguous().float()), hip.ptr(stats), hip.ptr(dist), hip.ptr(xyz1), hip.ptr(idx),
                                                       hip.ptr(slot), hip.ptr(table), table.shape[1], hip.ptr(vid32), hip.ptr(vals), hip.ptr(og), B,
                                                       V, xyz1.shape[1], *ctx.w, hip.ptr(g_verts), hip.stream()), 'psi_scene_losses_backward')
-        return (g_verts,) + (None,) * 11
+        return (g_verts if ctx.verts_dtype == g_verts.dtype else g_verts.to(ctx.verts_dtype),) + (None,) * 11
 
 
 def scene_losses(body_verts, vid, scenes: SceneSet, slot, sdf, grid_min, grid_max, align_corners, w_contact, w_collision, gate=1.0, vid32=None):
