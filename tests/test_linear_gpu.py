@@ -26,7 +26,8 @@ def _case(M, N, K, seed, xb=False):
     return x, W, b, res, gy
 
 
-@pytest.mark.parametrize('M,N,K', [(128, 512, 512), (128, 768, 768), (4, 32, 32), (100, 48, 64), (128, 256, 8192), (128, 256, 32768), (130, 128, 544)])
+@pytest.mark.parametrize('M,N,K', [(128, 512, 512), (128, 768, 768), (4, 32, 32), (100, 48, 64), (128, 256, 8192), (128, 256, 32768), (130, 128, 544),
+                                   (128, 1536, 1536), (128, 32, 1024), (200, 1024, 1024)])
 @pytest.mark.parametrize('mode', ['plain', 'leaky', 'leaky_res'])
 @pytest.mark.parametrize('bwd', ['hip', 'library'])
 def test_linear_act_forward_backward(M, N, K, mode, bwd, monkeypatch):
