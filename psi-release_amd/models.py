@@ -220,8 +220,9 @@ class BodyGlobalPoseVAE(_SceneCond):
         self.log_var_linear = nn.Linear(2 * num_hidden, zdim)
         self.decode = nn.Sequential(nn.Linear(num_hidden + zdim, f_dim), ResBlock(f_dim), ResBlock(f_dim), nn.Linear(f_dim, 3))
 
-    def forward(self, scene, torso=None, eps=None, rows=None):
-        z_s = self._scene_feature(scene, rows)
+    def forward(self, scene, torso=None, eps=None, rows=None, z_s=None):
+        if z_s is None:                                       # (HumanCVAES2 may have computed it on a second stream)
+            z_s = self._scene_feature(scene, rows)
         if self.test:
             z = torch.randn(z_s.size(0), self.zdim, device=scene.device) if eps is None else eps
             return _decode(self, self.decode, torch.cat([z, z_s], dim=1))
@@ -249,8 +250,9 @@ class BodyLocalPoseVAE(_SceneCond):
         self.log_var_linear = nn.Linear(3 * num_hidden, zdim)
         self.decode = nn.Sequential(nn.Linear(2 * num_hidden + zdim, f_dim), ResBlock(f_dim), ResBlock(f_dim), nn.Linear(f_dim, 72))
 
-    def forward(self, scene, torso=None, pose=None, eps=None, rows=None):
-        z_s = self._scene_feature(scene, rows)
+    def forward(self, scene, torso=None, pose=None, eps=None, rows=None, z_s=None):
+        if z_s is None:
+            z_s = self._scene_feature(scene, rows)
         z_g = self.torso_linear(torso)
         if self.test:
             z = torch.randn(z_s.size(0), self.zdim, device=scene.device) if eps is None else eps
@@ -277,8 +279,26 @@ class HumanCVAES2(nn.Module):
 
     def forward(self, x_body, eps_g, eps_l, x_s, use_eps=False):
         x_g, x_l = x_body[:, :3], x_body[:, 3:]
-        x_g_rec, mu_g, lv_g = self.trans_vae(x_s, x_g, eps=eps_g if use_eps else None)
-        x_l_rec, mu_l, lv_l = self.pose_vae(x_s, x_g_rec, x_l, eps=eps_l if use_eps else None)
+        z_s_l = None
+        import os
+        if x_s.is_cuda and self.training and os.environ.get('PSI_TRUNK_STREAMS', '1') != '0':
+            # The two scene trunks read the same view and meet only after their scene features: the local VAE's trunk runs on a second
+            # stream beside the global VAE's (autograd replays each backward on its forward's stream, so the two backward halves overlap
+            # too; inside a captured step the two become parallel branches of the graph).  Their many small launches — BN finalize, weight
+            # re-layout, split-K reductions — no longer queue behind each other.
+            cur = torch.cuda.current_stream(x_s.device)
+            side = getattr(self, '_side_stream', None)
+            if side is None or side.device != x_s.device:
+                side = self._side_stream = torch.cuda.Stream(x_s.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                z_s_l = self.pose_vae._scene_feature(x_s)
+            x_g_rec, mu_g, lv_g = self.trans_vae(x_s, x_g, eps=eps_g if use_eps else None)
+            cur.wait_stream(side)
+            z_s_l.record_stream(cur)
+        else:
+            x_g_rec, mu_g, lv_g = self.trans_vae(x_s, x_g, eps=eps_g if use_eps else None)
+        x_l_rec, mu_l, lv_l = self.pose_vae(x_s, x_g_rec, x_l, eps=eps_l if use_eps else None, z_s=z_s_l)
         return torch.cat([x_g_rec, x_l_rec], dim=1), mu_g, lv_g, mu_l, lv_l
 
     def sample(self, x_s, eps_g=None, eps_l=None, use_eps=False, rows=None):
