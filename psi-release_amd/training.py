@@ -52,6 +52,10 @@ class _TrainBase:
         if self.device.type != 'cuda':
             raise RuntimeError('TrainOP runs on the GPU (HIP operators); there is no CPU path')
         os.makedirs(self.save_dir, exist_ok=True)        # every rank of a torchrun job constructs TrainOP on the same save_dir
+        if os.environ.get('PSI_MIOPEN_FIND', '1') != '0':
+            # the convolutions that stay with the library (7x7 stem, the strided ones, the 128 -> 32 head): let MIOpen MEASURE its solvers
+            # once per shape instead of taking the heuristic pick (train_s2 step 4.22 -> 4.00 ms; the search runs in the first steps)
+            torch.backends.cudnn.benchmark = True
         n_dim_body = 72 + 3 if self.use_cont_rot else 72
         self.model_h_latentD = 256
         self.model_h = self._make_model(n_dim_body)
