@@ -263,6 +263,9 @@ class BodyLocalPoseVAE(_SceneCond):
         return _decode(self, self.decode, torch.cat([z, z_g, z_s], dim=1)), mean, log_var   # net_layers.py:231
 
 
+_SIDE_STREAMS = {}            # device index -> second stream of HumanCVAES2.forward
+
+
 class HumanCVAES2(nn.Module):
     """cvae.py:341-400.  ``eps_g`` / ``eps_l`` of the reference signature are unused there (cvae.py:369-385); here they are
     honoured only when ``use_eps=True`` (tests), otherwise noise is drawn internally like the reference does."""
@@ -287,9 +290,9 @@ class HumanCVAES2(nn.Module):
             # too; inside a captured step the two become parallel branches of the graph).  Their many small launches — BN finalize, weight
             # re-layout, split-K reductions — no longer queue behind each other.
             cur = torch.cuda.current_stream(x_s.device)
-            side = getattr(self, '_side_stream', None)
-            if side is None or side.device != x_s.device:
-                side = self._side_stream = torch.cuda.Stream(x_s.device)
+            side = _SIDE_STREAMS.get(x_s.device.index)          # (kept outside the module: streams do not pickle / deep-copy)
+            if side is None:
+                side = _SIDE_STREAMS[x_s.device.index] = torch.cuda.Stream(x_s.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 z_s_l = self.pose_vae._scene_feature(x_s)
