@@ -119,3 +119,26 @@ def test_synthetic_smplx_sparse_weight_rows():
         assert all((par[j] in js) or any(par[c] == j for c in js) for j in js)
     d = np.asarray(synth.make_smplx(7).weights)
     assert (d != 0).sum(1).min() > synth.J_SMPLX - 8               # the default stays dense (more than PSI_WNZ = 8 non-zeros everywhere)
+
+
+def test_workspace_queries_are_host_functions(built_lib):
+    """The *_workspace_floats() / *_blocks() queries run on the host (callers size buffers before any launch).  Their values pin the
+    launch shapes of the batch-sized dense layers: the contraction is split until a launch has about one workgroup per compute unit."""
+    from psi_release_amd import hip
+    L = hip.lib()
+    M = 128
+    # forward split-K: N / 32 column tiles, S = min(256 / tiles, K / 128) slices of [M, N] partial sums
+    assert L.psi_linear_workspace_floats(M, 1024, 1024) == 8 * M * 1024
+    assert L.psi_linear_workspace_floats(M, 32, 1024) == 8 * M * 32            # a 32-wide latent head: 1 tile, 8 slices of 128
+    assert L.psi_linear_workspace_floats(M, 512, 32768) == 16 * M * 512        # the 32768 -> 512 scene-feature layer: 16 tiles x 16 slices
+    assert L.psi_linear_workspace_floats(M, 32, 32) == 0 and L.psi_linear_workspace_floats(M, 128, 128) == 0
+    # dX split over n: K / 64 column tiles, S = min(256 / tiles, N / 128) slices of [M, K]
+    assert L.psi_linear_backward_workspace_floats(M, 1024, 1024) == 8 * M * 1024
+    assert L.psi_linear_backward_workspace_floats(M, 512, 32768) == 0          # 512 column tiles fill the chip on their own
+    assert L.psi_linear_backward_workspace_floats(M, 32, 1024) == 0            # one 64-wide tile of n: nothing to split
+    assert L.psi_linear_workspace_floats(0, 8, 8) == 0 and L.psi_linear_backward_workspace_floats(M, 0, 8) == 0
+    assert L.psi_cvae_losses_workspace_floats() == 64 * 6 and L.psi_scene_losses_workspace_floats() == 128 * 3
+    # conv3x3 weight gradient: one 64 x 64 tile of dW for a 64 -> 64 layer, split over 256 pixel-stage groups
+    assert L.psi_conv3x3_wrw_workspace_floats(128, 32, 32, 64, 64) == 256 * 64 * 9 * 64
+    assert L.psi_conv3x3_wrw_workspace_floats(128, 30, 30, 64, 64) == 0        # shape not covered -> 0 (callers fall back to the library)
+    assert L.psi_conv3x3_supported(64, 64, 32, 32) == 1 and L.psi_conv3x3_supported(64, 32, 32, 32) == 0
