@@ -639,9 +639,10 @@ def bench_train_s2(args):
                            'note': 'matrix-core flops counted by torch.utils.flop_counter over one forward+backward (library path; the hand-written '
                                    'conv / dense kernels do the same arithmetic); a step is a chain of small (128-row) GEMMs/convs and elementwise '
                                    'passes, bound by launch count and activation traffic, not by the MFMA pipe',
-                           'hand_written': 'conv3x3 forward + input gradient (conv.hip), dense layers forward + backward (linear.hip), BatchNorm + ReLU + '
-                                           'skip (bnorm.hip), stem max-pool, body decode / NN / SDF operators; library: 7x7 stem and strided convolutions, '
-                                           'convolution weight gradients'}
+                           'hand_written': 'conv3x3 forward + input gradient + weight gradient (conv.hip), dense layers forward + backward (linear.hip), '
+                                           'BatchNorm + ReLU + skip (bnorm.hip), stem max-pool, the loss glue of cal_loss (cvae_loss.hip, scene_loss.hip), '
+                                           'body decode / NN / SDF operators; library (MIOpen, measured solver search): 7x7 stem, strided 3x3 and 1x1 '
+                                           'convolutions, the 128 -> 32 head convolution'}
     try:
         res['conv_kernel_roofline'] = conv_kernel_roofline(dev, B)
     except Exception as e:
