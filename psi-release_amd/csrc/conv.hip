@@ -4,7 +4,7 @@
 // Conv2d(64,64,3,1,1), layer2 = Conv2d(128,128,3,1,1) x 3 behind the strided first one) and the 128 -> 128 head convolution of
 // BodyLocalPoseVAE (net_layers.py:160-164), the library convolution in BOTH directions that are convolutions: the forward pass and the
 // input gradient (dX = conv(dY, W rotated by 180 degrees with its channel axes swapped) — the same kernel on a re-laid-out weight).
-// The weight gradient stays with the library.
+// The weight gradient is the third kernel of this file (conv3x3_wrw_kernel: contraction over pixels, split-K with an ordered reduce).
 //
 // Layout: activations NHWC bf16 (torch channels_last), weights [Cout][kh][kw][Cin] bf16 (a channels_last Conv2d weight), fp32 accumulate,
 // bf16 output (+ optional fp32 bias).  GEMM view: D[co][pixel] = sum_{tap, ci} W[co][tap][ci] * X[pixel + tap][ci]; with channels fastest,
