@@ -13,7 +13,7 @@
 // a plain bandwidth-bound pass is ~6 us.
 //   forward : stats (read x) -> finalize (C values) -> apply (read x [+ residual], write y)
 //   backward: reduce (read dy, y|x) -> finalize -> apply (read dy, x, y, write dx [, d_residual])
-// The reductions are deterministic: fixed per-block partials, summed in order by the one-block finalize kernels (double precision
+// The reductions are deterministic: fixed per-block partials, summed in order by the finalize kernels (16 channels per block; double precision
 // for the variance, so E[x^2] - mean^2 does not cancel).
 #include "psi_internal.h"
 #include <hip/hip_bf16.h>
