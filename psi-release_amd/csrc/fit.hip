@@ -438,37 +438,55 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(FitDev f, PsiLbsView lv)
 // vertex is still in registers; per workgroup it leaves sum(-sdf) and the count over penetrating vertices, per vertex
 // the SDF gradient masked to sdf < 0.
 struct SdfPenEpilogue {
-    FitDev f;
-    float s, c;
+    PsiSdfGrid G;             // sampling constants of the bricked volume (G.brick == nullptr: the plain volume below)
+    const float *sdf, *gmin, *gmax;
+    float *og, *penpart;
+    int D, align_corners, V;
+    float s;
+    bool neg;
     __device__ __forceinline__ void vertex(int b, int v, float x, float y, float z, bool live)
     {
-        float g[3] = {0, 0, 0};
-        float val = 0.0f;
-        if (live)
-            val = f.sdf_brick ? psi_trilinear_bricked(f.sdf_brick, f.gmin, f.gmax, x, y, z, f.D, f.align_corners, g)
-                              : psi_trilinear(f.sdf, f.gmin, f.gmax, x, y, z, f.D, f.align_corners, g);
-        const bool neg = live && val < 0.0f;
-        if (live) {
-            float *o = f.og + ((size_t)b * f.V + v) * 3;
-            o[0] = neg ? g[0] : 0.0f;
-            o[1] = neg ? g[1] : 0.0f;
-            o[2] = neg ? g[2] : 0.0f;
+        s = 0.0f;
+        neg = false;
+        if (!live) return;
+        float g[3];
+        if (G.brick) {
+            bool in[3];
+            const float val = psi_sdf_sample_fast(G, x, y, z, g, in);
+            neg = val < 0.0f;
+#pragma unroll
+            for (int a = 0; a < 3; a++) g[a] = (neg && in[a]) ? g[a] : 0.0f;
+            s = neg ? -val : 0.0f;
+        } else {
+            const float val = psi_trilinear(sdf, gmin, gmax, x, y, z, D, align_corners, g);
+            neg = val < 0.0f;
+#pragma unroll
+            for (int a = 0; a < 3; a++) g[a] = neg ? g[a] : 0.0f;
+            s = neg ? -val : 0.0f;
         }
-        s = neg ? -val : 0.0f;
-        c = neg ? 1.0f : 0.0f;
+        psi_st(og + (size_t)b * V * 3, (unsigned)v * 12u, psi_p3{g[0], g[1], g[2]});
     }
     __device__ __forceinline__ void finish(int b, int vblock, int nvb)
     {
-        __shared__ float red[4];
-        float ss = block_sum(s, red);
-        float cc = block_sum(c, red);
+        // per workgroup: sum(-sdf) over the penetrating vertices by DPP adds, their count from the lane mask (scalar popcount)
+        __shared__ psi_f2 red[PSI_SKIN_BLK / 64];
+        const float ws = psi_wave_sum(s);
+        const float wc = (float)(int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(neg));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (psi_f2){ws, wc};
+        __syncthreads();
         if (threadIdx.x == 0) {
-            size_t o = ((size_t)b * nvb + vblock) * 2;
-            f.penpart[o] = ss;
-            f.penpart[o + 1] = cc;
+            psi_f2 a = red[0];
+#pragma unroll
+            for (int w = 1; w < PSI_SKIN_BLK / 64; w++) a += red[w];
+            *(psi_f2 *)(penpart + ((size_t)b * nvb + vblock) * 2) = a;
         }
     }
 };
+
+static inline SdfPenEpilogue make_sdf_epilogue(const FitDev &f, const PsiSdfGrid &G)
+{
+    return SdfPenEpilogue{G, f.sdf, f.gmin, f.gmax, f.og, f.penpart, f.D, f.align_corners, f.V, 0.0f, false};
+}
 
 // ------------------------------------------------------------------------------------------------
 // Query source of the NN search inside the fused forward launch: the contact vertex is SKINNED HERE, by the query's own lane group,
@@ -523,7 +541,7 @@ struct ContactSkinSrc {
 // vertices of one body each; gather-latency-bound).  As two launches they ran back to back (23 + 18 us); they depend on the same
 // inputs only, so in one grid their waves share the SIMDs and hide each other's stalls.
 __global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, const float *__restrict__ As, const float *__restrict__ v_posed,
-                                                           psikd::KdDev T, int n_kd, int nqb, int rows, float gscale, int skin_first)
+                                                           psikd::KdDev T, int n_kd, int nqb, int rows, float gscale, int skin_first, SdfPenEpilogue epi)
 {
     extern __shared__ int smem_i[];
 #ifdef PSI_HEAD_STOPS
@@ -549,7 +567,6 @@ __global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, c
                                           f.gq, f.fpart, f.nn_hint, rows, (const psikd::KdDev *)nullptr, (const int *)nullptr, bx, b, nqb, smem_i);
     } else {
         const int i = bid;
-        SdfPenEpilogue epi{f, 0.0f, 0.0f};
         psi_skin_fwd_body(m, As, v_posed, f.transl, f.cam, f.B, f.verts, epi, i % f.nsdfblk, i / f.nsdfblk, f.nsdfblk);
     }
 }
@@ -614,11 +631,11 @@ struct FitGradSource {
     __device__ __forceinline__ Pre issue(int b, int v, bool live)
     {
         Pre p;
-        p.cw = live ? f.cs_first[v] : 0;
+        p.cw = live ? psi_ld<int>(f.cs_first, (unsigned)v * 4u) : 0;
         for (int e = 0; e < 3; e++) { p.og[e] = 0.0f; p.q[e] = 0.0f; }
         if (live) {
-            const size_t o = ((size_t)b * f.V + v) * 3;
-            p.og[0] = f.og[o + 0]; p.og[1] = f.og[o + 1]; p.og[2] = f.og[o + 2];
+            const psi_p3 o = psi_ld<psi_p3>(f.og + (size_t)b * f.V * 3, (unsigned)v * 12u);      // body row base + lane offset: one 12-byte load
+            p.og[0] = o.x; p.og[1] = o.y; p.og[2] = o.z;
         }
         pp_valid = LOCAL && !f.indep;
         if (pp_valid) {
@@ -634,8 +651,8 @@ struct FitGradSource {
     __device__ __forceinline__ void issue_late(Pre &p, int b) const
     {
         if (p.cw >> 24) {
-            const float *q = f.gq + ((size_t)b * f.n_c + (p.cw & 0xffffff)) * 3;
-            p.q[0] = q[0]; p.q[1] = q[1]; p.q[2] = q[2];
+            const psi_p3 q = psi_ld<psi_p3>(f.gq + (size_t)b * f.n_c * 3, (unsigned)(p.cw & 0xffffff) * 12u);
+            p.q[0] = q.x; p.q[1] = q.y; p.q[2] = q.z;
         }
     }
     __device__ __forceinline__ void take(const Pre &p, int b, int v, float &gx, float &gy, float &gz) const
@@ -1003,6 +1020,7 @@ constexpr int GRAPH_UNROLL = 10;
 
 struct psi_fit_engine {
     FitDev d;
+    PsiSdfGrid grid;              // sampling constants of the bricked SDF volume (sdf_device.h)
     const psi_lbs_model *lbs;
     psi_nn_index *nn_index;
     float *lbs_ws;
@@ -1076,7 +1094,7 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
         const psikd::KdDev T = psi_nn_index_dev(e->nn_index);
         const int nqb = f.nfp, n_kd = nqb * f.B;
         hipLaunchKernelGGL(fwd_scene_kernel, dim3(n_kd + f.nsdfblk * f.B), dim3(256), psikd::kd_lds_bytes(T.rows), st, f, e->lv.m, e->lv.A,
-                           e->lv.v_posed, T, n_kd, nqb, T.rows, gscale, e->scene_skin_first ? 1 : 0);
+                           e->lv.v_posed, T, n_kd, nqb, T.rows, gscale, e->scene_skin_first ? 1 : 0, make_sdf_epilogue(f, e->grid));
         PSI_CHECK_LAUNCH("fwd_scene_kernel");
         psi_mark("fwd_scene_kernel", st);
         if (local) return 0;
@@ -1091,7 +1109,7 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
     // r03_pmc_skin_fwd_sdf_b512.txt).  It measured 191 us against 165: the fp32 MFMA runs at the vector FLOP rate and, as far as these timings
     // show, does not overlap the other waves' vector instructions, so the blend's cycles moved but did not disappear.)
     hipLaunchKernelGGL(psi_skin_fwd_kernel<SdfPenEpilogue>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A, e->lv.v_posed,
-                           f.transl, f.cam, f.B, f.verts, SdfPenEpilogue{f, 0.0f, 0.0f});
+                           f.transl, f.cam, f.B, f.verts, make_sdf_epilogue(f, e->grid));
     PSI_CHECK_LAUNCH("skin_fwd_sdf_kernel");
     psi_mark("skin_fwd_sdf_kernel", st);
     if (e->nn_index)
@@ -1222,7 +1240,8 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
            o_gt = take((size_t)B * 3 * 4), o_gr = take((size_t)B * J * 9 * 4), o_hist = take((size_t)f.max_hist * 4 * 4), o_stats = take(256), o_hint = take((size_t)B * f.n_c * 4);
     size_t o_hxo = take((size_t)B * f.hc * 128 * 8), o_hxg = take((size_t)B * f.hc * NH * 8), o_hxc = take((size_t)2 * B * 4);
     size_t o_wct = take((size_t)f.n_c * PSI_JP * 4);
-    const bool bricks = (cfg->D % 4 == 0) && !(getenv("PSI_SDF_LINEAR") && getenv("PSI_SDF_LINEAR")[0] == '1');
+    // (the bricked copy is addressed with 32-bit byte offsets: 512 bytes x (D / 4)^3 must stay below 4 GB, D <= 800)
+    const bool bricks = (cfg->D % 4 == 0) && cfg->D <= 800 && !(getenv("PSI_SDF_LINEAR") && getenv("PSI_SDF_LINEAR")[0] == '1');
     size_t o_brick = bricks ? take((size_t)(f.D / 4) * (f.D / 4) * (f.D / 4) * PSI_BRICK_FLOATS * 4) : 0;
     size_t lbs_floats = psi_lbs_workspace_floats(lbs, B);
     size_t o_lws = take(lbs_floats * 4), o_nws = take(psi_nn_ws_bytes(B, f.n_c, f.m));
@@ -1271,6 +1290,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
         hipLaunchKernelGGL(sdf_to_bricks_kernel, dim3((unsigned)psi_cdiv((long)n, 256)), dim3(256), 0, 0, d_sdf, F(o_brick), f.D);
         f.sdf_brick = F(o_brick);
     }
+    e->grid = psi_sdf_grid_make(f.sdf_brick, h_gmin, h_gmax, f.D, f.align_corners);
     err = hipDeviceSynchronize();                                // the two one-off layout kernels above ran on the NULL stream
     if (err == hipSuccess) err = hipGetLastError();
     if (err != hipSuccess) {

@@ -399,11 +399,41 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
 typedef float psi_f2 __attribute__((ext_vector_type(2)));
 constexpr int PSI_SKIN_BLK = 256;
 
+// Sum over the 64 lanes of a wave, returned in every lane.  Data-parallel primitives instead of shuffles: a `__shfl_down` is a
+// ds_bpermute plus its lane-address arithmetic (4-5 vector instructions per step and an LDS round trip); a DPP-modified add is ONE
+// instruction.  Fixed order (xor 1, xor 2, rotate 4, rotate 8 inside each row of 16, then the rows), so results repeat bit for bit.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float psi_dpp(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWS, 0xf, false));
+}
 __device__ __forceinline__ float psi_wave_sum(float x)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-    return x;
+    x += psi_dpp<0xB1, 0xf>(x);      // quad_perm [1,0,3,2]
+    x += psi_dpp<0x4E, 0xf>(x);      // quad_perm [2,3,0,1]
+    x += psi_dpp<0x124, 0xf>(x);     // row_ror 4
+    x += psi_dpp<0x128, 0xf>(x);     // row_ror 8: every lane holds its row's total
+    x += psi_dpp<0x142, 0xa>(x);     // row_bcast 15 into rows 1 and 3
+    x += psi_dpp<0x143, 0xc>(x);     // row_bcast 31 into rows 2 and 3: lane 63 holds the wave's total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
+// Addressing of the per-vertex streams of the skinning kernels: address = a wave-uniform base (row / body offset added in SCALAR
+// arithmetic) + ONE 32-bit unsigned lane offset, which the compiler turns into the `global_load v, v_off, s[base]` form.  A
+// `p[(size_t)row * stride + v]` access costs a 64-bit vector add per load instead (55 of them in the dense blend, plus 64-bit
+// multiplies for the [B, V, 3] rows).  (The raw-buffer builtins would do the same with a scalar offset operand, but the b64 / b96
+// forms are miscompiled by this toolchain's demanded-elements narrowing — element 0 is returned for every element — so only
+// the 32-bit form is used anywhere in this library.)
+struct psi_p3 { float x, y, z; };                               // 12-byte record: one global_load / global_store_dwordx3
+template <class T>
+__device__ __forceinline__ T psi_ld(const void *uniform_base, unsigned lane_off)
+{
+    return *(const T *)((const char *)uniform_base + lane_off);
+}
+template <class T>
+__device__ __forceinline__ void psi_st(void *uniform_base, unsigned lane_off, const T &val)
+{
+    *(T *)((char *)uniform_base + lane_off) = val;
 }
 
 // Blend the body's joint transforms with this lane's skinning weights: T = sum_j w_j A_j (3x4 as six float pairs).
@@ -427,10 +457,13 @@ struct PsiBlend {
                 const int idx = threadIdx.x + q * PSI_SKIN_BLK;
                 st[q] = idx < m.J * 6 ? *(const psi_f2 *)(As + ((size_t)b * m.J) * 12 + idx * 2) : (psi_f2){0.0f, 0.0f};
             }
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)m.Wc, 0, PSI_WNZ * m.Vpad * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc((void *)m.Wj, 0, PSI_WNZ / 4 * m.Vpad * 4, 0x00020000);
 #pragma unroll
-            for (int k = 0; k < PSI_WNZ; k++) wk[k] = m.Wc[(size_t)k * m.Vpad + v];
+            for (int k = 0; k < PSI_WNZ; k++)
+                wk[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (unsigned)v * 4u, (unsigned)(k * m.Vpad) * 4u, 0));
 #pragma unroll
-            for (int k = 0; k < PSI_WNZ / 4; k++) jk[k] = m.Wj[(size_t)k * m.Vpad + v];
+            for (int k = 0; k < PSI_WNZ / 4; k++) jk[k] = __builtin_amdgcn_raw_buffer_load_b32(rj, (unsigned)v * 4u, (unsigned)(k * m.Vpad) * 4u, 0);
         }
     }
     __device__ __forceinline__ psi_f2 (*commit(const LbsDev &m))[6]
@@ -440,7 +473,7 @@ struct PsiBlend {
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int idx = threadIdx.x + q * PSI_SKIN_BLK;
-            if (idx < m.J * 6) sA[idx / 6][idx % 6] = st[q];
+            if (idx < m.J * 6) (&sA[0][0])[idx] = st[q];             // [joint][6] pairs = the rows as they lie in memory
         }
         __syncthreads();
         return sA;
@@ -470,15 +503,56 @@ struct PsiBlend {
         // the skinning kernels: 26 k cycles per CU = 11 us for the 20 resident waves).  (Requesting the next joint's transform by hand before the
         // current one is used measured slower than the compiler's own three 16-byte scalar loads per joint.)
         const psi_f2 *Ab = (const psi_f2 *)As_b;
+        // weights through a buffer descriptor: the row offset j * Vpad * 4 is a scalar operand of the load, the lane offset v * 4 one
+        // register shared by all joints (a `WT[(size_t)j * Vpad + v]` access was a 64-bit vector add per joint).  Groups of
+        // PSI_DENSE_UNROLL joints: the next group's weights are requested before the current group is accumulated.
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)m.WT, 0, PSI_JP * m.Vpad * 4, 0x00020000);
+        const unsigned v4 = (unsigned)v * 4u, rowb = (unsigned)m.Vpad * 4u;
 #ifndef PSI_DENSE_UNROLL
 #define PSI_DENSE_UNROLL 11
 #endif
-#pragma unroll PSI_DENSE_UNROLL
-        for (int j = 0; j < m.J; j++) {
-            float wj = m.WT[(size_t)j * m.Vpad + v];
-            psi_f2 w2 = {wj, wj};
+        constexpr int GJ = PSI_DENSE_UNROLL;
+        float wa[GJ], wb[GJ];                                      // two register groups, filled and used alternately (no copies)
+        auto request = [&](float (&w)[GJ], int j0) {
+            unsigned ro = (unsigned)j0 * rowb;                      // rows J .. PSI_JP - 1 are zero, and the descriptor's range check returns 0 beyond them
 #pragma unroll
-            for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, Ab[j * 6 + e], T2[e]);
+            for (int k = 0; k < GJ; k++, ro += rowb) w[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, v4, ro, 0));
+        };
+        // A last group that runs past J is padded, not guarded: its weights come from the zero rows of WT and its transforms from the
+        // rows behind the body's (the next body's, or the padding rows psi_lbs_view leaves behind the last body), so the extra terms
+        // add 0 * finite = 0 (J = 55 = 5 groups of 11: no padding at all).  The transforms arrive through the scalar cache, one base
+        // address per group and immediate offsets per joint; a scheduling fence every PSI_DENSE_AHEAD joints bounds how many of those
+        // loads are in flight (left alone, the scheduler requests two groups' worth — 264 scalar registers — and spills 37 of them
+        // through v_writelane / v_readlane inside the loop).
+#ifndef PSI_DENSE_AHEAD
+#define PSI_DENSE_AHEAD 4
+#endif
+        auto accumulate = [&](const float (&w)[GJ], int j0) {
+            const psi_f2 *Ag = Ab + j0 * 6;
+#pragma unroll
+            for (int k = 0; k < GJ; k++) {
+                if (k % PSI_DENSE_AHEAD == 0) __builtin_amdgcn_sched_barrier(0);
+                psi_f2 w2 = {w[k], w[k]};
+#pragma unroll
+                for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, Ag[k * 6 + e], T2[e]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        request(wa, 0);
+        int j0 = 0;
+#pragma nounroll
+        for (; j0 + 2 * GJ < m.J; j0 += 2 * GJ) {                  // two whole groups, and another one behind them
+            request(wb, j0 + GJ);
+            accumulate(wa, j0);
+            request(wa, j0 + 2 * GJ);
+            accumulate(wb, j0 + GJ);
+        }
+        if (m.J - j0 > GJ) {                                        // wa holds group j0; one or two groups are left
+            request(wb, j0 + GJ);
+            accumulate(wa, j0);
+            accumulate(wb, j0 + GJ);
+        } else {
+            accumulate(wa, j0);
         }
     }
 };
@@ -511,39 +585,33 @@ __device__ __forceinline__ void psi_skin_fwd_body(const LbsDev &m, const float *
 {
     const int v = vblock * PSI_SKIN_BLK + threadIdx.x;
     const bool live = v < m.V;
-    // all first loads in one go: transforms to stage, weight row, posed vertex
+    const unsigned v12 = (unsigned)v * 12u;                     // lane offset of every [.., V, 3] stream of this kernel
+    // all first loads in one go: transforms to stage, weight row, posed vertex (one 12-byte load; rows are padded to Npad >= 3 Vpad)
     PsiBlend bl;
     bl.issue(m, As, b, v);
-    float px = 0, py = 0, pz = 0;
-    if (live) {
-        const float *vp = v_posed + (size_t)b * m.Npad + (size_t)v * 3;
-        px = vp[0]; py = vp[1]; pz = vp[2];
-    }
+    const psi_p3 pp = psi_ld<psi_p3>(v_posed + (size_t)b * m.Npad, v12);
+    const float px = pp.x, py = pp.y, pz = pp.z;
     psi_f2 T2[6];
     bl.blend(m, bl.commit(m), v, T2);
-    float x = 0, y = 0, z = 0;
-    if (live) {
-        x = psi_dot3p(T2[0].x, T2[0].y, T2[1].x, T2[1].y, px, py, pz);
-        y = psi_dot3p(T2[2].x, T2[2].y, T2[3].x, T2[3].y, px, py, pz);
-        z = psi_dot3p(T2[4].x, T2[4].y, T2[5].x, T2[5].y, px, py, pz);
-        if (transl) {
-            x += transl[(size_t)b * 3 + 0];
-            y += transl[(size_t)b * 3 + 1];
-            z += transl[(size_t)b * 3 + 2];
-        }
-        if (cam_ext) {   // cvae.py:141-149: [v,1] @ cam_ext^T, drop w
-            const float *C = cam_ext + (size_t)b * 16;
-            float X = psi_dot3p(C[0], C[1], C[2], C[3], x, y, z);
-            float Y = psi_dot3p(C[4], C[5], C[6], C[7], x, y, z);
-            float Z = psi_dot3p(C[8], C[9], C[10], C[11], x, y, z);
-            x = X; y = Y; z = Z;
-        }
+    float x = psi_dot3p(T2[0].x, T2[0].y, T2[1].x, T2[1].y, px, py, pz);
+    float y = psi_dot3p(T2[2].x, T2[2].y, T2[3].x, T2[3].y, px, py, pz);
+    float z = psi_dot3p(T2[4].x, T2[4].y, T2[5].x, T2[5].y, px, py, pz);
+    if (transl) {
+        x += transl[(size_t)b * 3 + 0];
+        y += transl[(size_t)b * 3 + 1];
+        z += transl[(size_t)b * 3 + 2];
+    }
+    if (cam_ext) {   // cvae.py:141-149: [v,1] @ cam_ext^T, drop w
+        const float *C = cam_ext + (size_t)b * 16;
+        float X = psi_dot3p(C[0], C[1], C[2], C[3], x, y, z);
+        float Y = psi_dot3p(C[4], C[5], C[6], C[7], x, y, z);
+        float Z = psi_dot3p(C[8], C[9], C[10], C[11], x, y, z);
+        x = X; y = Y; z = Z;
     }
     epi.vertex(b, v, x, y, z, live);
     if (live) {
         // stored AFTER the epilogue's lookups: a wait for a load also waits for the wave's earlier stores (one counter on gfx950)
-        float *o = verts + ((size_t)b * m.V + v) * 3;
-        o[0] = x; o[1] = y; o[2] = z;
+        psi_st(verts + (size_t)b * m.V * 3, v12, psi_p3{x, y, z});
     }
     epi.finish(b, vblock, nvb);
 }
@@ -614,12 +682,11 @@ __global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_bwd_v_kernel(LbsDev 
         }
     }
     {
-        float *o = gl + (size_t)b * m.Npad + (size_t)v * 3;
-        o[0] = lx; o[1] = ly; o[2] = lz;
-        float *p = g_vp + (size_t)b * m.Npad + (size_t)v * 3;   // T_R^T g_local (rotation part of T, row-major 3x3)
-        p[0] = psi_dot3(T2[0].x, T2[2].x, T2[4].x, lx, ly, lz);
-        p[1] = psi_dot3(T2[0].y, T2[2].y, T2[4].y, lx, ly, lz);
-        p[2] = psi_dot3(T2[1].x, T2[3].x, T2[5].x, lx, ly, lz);
+        // wave-uniform row base + the 32-bit lane offset v * 12: two 12-byte stores
+        psi_st(gl + (size_t)b * m.Npad, (unsigned)v * 12u, psi_p3{lx, ly, lz});
+        psi_st(g_vp + (size_t)b * m.Npad, (unsigned)v * 12u,      // T_R^T g_local (rotation part of T, row-major 3x3)
+               psi_p3{psi_dot3(T2[0].x, T2[2].x, T2[4].x, lx, ly, lz), psi_dot3(T2[0].y, T2[2].y, T2[4].y, lx, ly, lz),
+                      psi_dot3(T2[1].x, T2[3].x, T2[5].x, lx, ly, lz)});
     }
     float sx = psi_wave_sum(lx), sy = psi_wave_sum(ly), sz = psi_wave_sum(lz);
     if ((threadIdx.x & 63) == 0) {

@@ -120,3 +120,80 @@ __device__ __forceinline__ float psi_trilinear_bricked(const float *__restrict__
     return c0 * wx0 + c1 * wx1;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same lookup for the fused fitting engine's skinning epilogue, written for the instruction count (the fused skinning + SDF
+// kernel is vector-ALU bound at large batches: profiles/r04_pmc_skin_fwd_sdf_b512.txt).  What differs from psi_trilinear_bricked:
+//   * the world -> grid map is ONE subtract and ONE multiply per axis, u = (x - o) * k, with constants prepared on the host in double
+//     precision (k = (D - 1) / (max - min), o = min with align_corners; k = D / (max - min), o = min + 0.5 / k without) instead of
+//     the reference's divide-by-extent chain (fitting_proxe.py:147 + grid_sample's unnormalise: two IEEE divides per axis, ~20
+//     instructions each).  u differs from the reference's fp32 chain by a few ulp — the reference's own chain is as far from the
+//     exact value — i.e. by 1e-5 of a voxel;
+//   * clamp / floor / fraction are v_med3 / v_cvt / v_fract; the border rule's zero gradient is a lane mask that the caller
+//     combines with its sdf < 0 mask in scalar registers;
+//   * brick and in-brick offsets are 24-bit multiply-adds into ONE 32-bit byte offset from a wave-uniform base (no 64-bit vector
+//     arithmetic); the four corner pairs are that offset + 0 / 20 / 100 / 120 bytes as instruction immediates;
+//   * the interpolation works on the loaded z-pairs as packed values: lerp along y, then x (both z-ends at once), then z — the
+//     differences it forms are the gradient's operands: 14 instructions for value and gradient, a + w (b - a) form.
+// Returns the value; g[] = d value / d (x, y, z) BEFORE the border mask, in[] = lane strictly inside (0, D - 1) per axis.
+// ------------------------------------------------------------------------------------------------
+typedef float psi_f2v __attribute__((ext_vector_type(2)));
+struct PsiSdfGrid {
+    const float *brick;       // apron-brick volume (above)
+    float o[3], ku[3];        // grid origin (see above), grid units per world unit
+    float dm1;                // D - 1
+    unsigned nbr;             // bricks per axis
+};
+
+static inline PsiSdfGrid psi_sdf_grid_make(const float *brick, const float *h_gmin, const float *h_gmax, int D, int align_corners)
+{
+    PsiSdfGrid g;
+    g.brick = brick;
+    for (int a = 0; a < 3; a++) {
+        const double k = (double)(align_corners ? D - 1 : D) / ((double)h_gmax[a] - (double)h_gmin[a]);
+        g.ku[a] = (float)k;
+        g.o[a] = (float)((double)h_gmin[a] + (align_corners ? 0.0 : 0.5 / k));
+    }
+    g.dm1 = (float)(D - 1);
+    g.nbr = (unsigned)(D >> 2);
+    return g;
+}
+
+__device__ __forceinline__ unsigned psi_mad24(unsigned a, unsigned b_uniform, unsigned c)
+{
+    unsigned r;                                                   // full-rate 24-bit multiply-add (the compiler picks v_mul_lo_u32, a quarter-rate op)
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ float psi_sdf_sample_fast(const PsiSdfGrid &G, float x, float y, float z, float (&g)[3], bool (&in)[3])
+{
+    const float u[3] = {(x - G.o[0]) * G.ku[0], (y - G.o[1]) * G.ku[1], (z - G.o[2]) * G.ku[2]};
+    float w[3];
+    unsigned i[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        in[a] = u[a] > 0.0f && u[a] < G.dm1;                     // border: a clipped coordinate has zero gradient
+        const float uc = __builtin_amdgcn_fmed3f(u[a], 0.0f, G.dm1);
+        w[a] = __builtin_amdgcn_fractf(uc);                      // uc - floor(uc), exact
+        i[a] = (unsigned)(int)uc;                                // uc >= 0: truncation is floor
+    }
+    // voxel (i, i + 1) is voxel (l, l + 1) of brick i >> 2, l = i & 3 (the apron repeats the last voxel beyond the volume)
+    const unsigned brick = psi_mad24(psi_mad24(i[0] >> 2, G.nbr, i[1] >> 2), G.nbr, i[2] >> 2);
+    const unsigned local = __umul24(i[0] & 3, 100) + __umul24(i[1] & 3, 20) + ((i[2] << 2) & 12);
+    const unsigned off = (brick << 9) + local;                  // bytes: 512 per brick, strides 100 / 20 / 4
+    const char *vb = (const char *)G.brick;                     // wave-uniform base + 32-bit lane offset (+ immediates)
+    const psi_f2v q00 = *(const psi_f2u *)(vb + off), q01 = *(const psi_f2u *)(vb + (off + 20u));           // (z0, z1) pairs at (x0, y0), (x0, y1)
+    const psi_f2v q10 = *(const psi_f2u *)(vb + (off + 100u)), q11 = *(const psi_f2u *)(vb + (off + 120u)); //                  (x1, y0), (x1, y1)
+    const psi_f2v wy2 = {w[1], w[1]}, wx2 = {w[0], w[0]};
+    const psi_f2v e0 = q01 - q00, e1 = q11 - q10;                                        // d/dy on the two x faces, at z0 and z1
+    const psi_f2v r0 = __builtin_elementwise_fma(wy2, e0, q00), r1 = __builtin_elementwise_fma(wy2, e1, q10);
+    const psi_f2v ex = r1 - r0;                                                          // d/dx at z0 and z1
+    const psi_f2v r = __builtin_elementwise_fma(wx2, ex, r0);                            // value at z0 and z1
+    const psi_f2v ey = __builtin_elementwise_fma(wx2, e1 - e0, e0);                      // d/dy at z0 and z1
+    const float gz = r.y - r.x;
+    g[0] = __builtin_fmaf(w[2], ex.y - ex.x, ex.x) * G.ku[0];
+    g[1] = __builtin_fmaf(w[2], ey.y - ey.x, ey.x) * G.ku[1];
+    g[2] = gz * G.ku[2];
+    return __builtin_fmaf(w[2], gz, r.x);
+}
