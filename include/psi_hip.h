@@ -107,7 +107,8 @@ int psi_sdf_sample_backward(const float *grad_sdf, const float *out_grad, int B,
                             float *grad_verts, void *stream);
 /* Penetration statistics of fitting_proxe.py:155-158 without the .item() host sync:
  * stats[0] = sum_{sdf<0} |sdf|, stats[1] = count(sdf<0) (as float, exact below 2^24), over n values.
- * stats must be zeroed by the caller (it is accumulated with atomics). */
+ * stats must be zeroed by the caller (the result is ADDED to it; per-block partial sums combined in block order: no atomics,
+ * run-to-run bit-identical). */
 int psi_sdf_penetration_stats(const float *sdf_vals, long n, float *stats, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -169,6 +170,9 @@ typedef struct psi_fit_config {
     int concurrent_engines;   /* how many engines the caller keeps in flight on this GPU at the same time (other streams; 0 or 1 = this one
                                  alone).  The per-body head / tail kernels spread a body over up to 8 workgroups so that a lone engine with
                                  few bodies still covers the chip; engines that share the chip are told not to (B x engines x width <= 256). */
+    double lr_d, beta1_d, beta2_d;   /* the Adam hyper-parameters as DOUBLES, the way torch.optim.Adam (fitting_proxe.py:73-74) holds them: it forms
+                                 1 - beta and the bias corrections 1 - beta^t in double precision before rounding to fp32 (1 - 0.999 -> 0.001f;
+                                 1.0f - 0.999f would be 0.00099998713f).  0 = use the fp32 fields above. */
 } psi_fit_config;
 int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, const psi_fit_config *cfg,
                    const float *h_w1, const float *h_b1, const float *h_w2, const float *h_b2,
@@ -338,14 +342,16 @@ int psi_cvae_losses_backward(const float *rec75, const float *target75, const fl
  *           stats2 = { sum |sdf| over sdf < 0, their count } (input of the backward).  ws: psi_scene_losses_workspace_floats() floats.
  * backward: g_verts [B,V,3] (OVERWRITTEN) = d(g_losses2[0] losses2[0] + g_losses2[1] losses2[1]) / d body vertices, given xyz1 [B,n_c,3] =
  *           the contact vertices that were queried (rows vid [n_c] of the body), their nearest scene points verts_table[slot[b]][idx[b,j]]
- *           (verts_table [S,m,3], chamfer.cu:155-174) and sdf_grad [B,V,3] = d sdf / d vertex (psi_sdf_sample_forward's out_grad). */
+ *           (verts_table [S,m,3], chamfer.cu:155-174) and sdf_grad [B,V,3] = d sdf / d vertex (psi_sdf_sample_forward's out_grad).
+ *           ws_chain: 2 * n_c ints of scratch (the slots of a vertex that is listed more than once, cvae.py:99-115, are chained in slot
+ *           order and added by one thread: no atomics, run-to-run bit-identical). */
 size_t psi_scene_losses_workspace_floats(void);
 int psi_scene_losses_forward(const float *dist, long n_contact, const float *sdf_vals, long n_sdf, float w_contact, float w_collision,
                              float gate, float *ws, float *losses2, float *stats2, void *stream);
 int psi_scene_losses_backward(const float *g_losses2, const float *stats2, const float *dist, const float *xyz1, const int32_t *idx,
                               const int32_t *slot, const float *verts_table, long m, const int32_t *vid, const float *sdf_vals,
                               const float *sdf_grad, int B, int V, int n_c, float w_contact, float w_collision, float gate,
-                              float *g_verts, void *stream);
+                              int32_t *ws_chain, float *g_verts, void *stream);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,9 @@ __device__ int psi_dbg_sstop;            // dev: leave the skinning / scene kern
 #endif
 #include "lbs_device.h"
 #include "sdf_device.h"
+#ifndef PSI_SDF_CELLS
+#define PSI_SDF_CELLS 1      // the engine's copy of the SDF volume: 1 = cell-major records (two 16-byte gathers per sample), 0 = apron bricks (four 8-byte)
+#endif
 #include "nnindex_device.h"
 #include <math.h>
 #include <stdlib.h>
@@ -60,6 +63,10 @@ struct FitDev {
     int indep;                                        // 1: the B bodies are B independent problems (per-body loss normalisers)
     float w_rec, w_vp, w_contact, w_col, cconst;
     float lr, beta1, beta2, eps;
+    // torch.optim.Adam takes its hyper-parameters as Python doubles: `mul_(beta2)` rounds beta2 to fp32, `value = 1 - beta2` is formed
+    // in DOUBLE and then rounded (0.001f, not 1.0f - 0.999f = 0.00099998713f), and the bias corrections 1 - beta^t are double arithmetic
+    float one_m_beta1, one_m_beta2;
+    double lr_d, beta1_d, beta2_d;
     // model constants
     const float *W1T, *b1, *W2T, *b2, *W3T, *b3;      // transposed [in][out] for the forward
     const float *W1, *W2, *W3;                        // original [out][in] for the backward
@@ -442,36 +449,43 @@ struct SdfPenEpilogue {
     const float *sdf, *gmin, *gmax;
     float *og, *penpart;
     int D, align_corners, V;
-    float s;
-    bool neg;
-    __device__ __forceinline__ void vertex(int b, int v, float x, float y, float z, bool live)
+    float s[2];
+    bool neg[2];                  // per body of the workgroup (the skinning kernel handles one or two)
+    __device__ __forceinline__ void vertex(int n, int b, int v, float x, float y, float z, bool live)
     {
-        s = 0.0f;
-        neg = false;
+        s[n] = 0.0f;
+        neg[n] = false;
         if (!live) return;
         float g[3];
         if (G.brick) {
             bool in[3];
+#if PSI_SDF_CELLS
+            const float val = psi_sdf_sample_cells(G, x, y, z, g, in);
+#else
             const float val = psi_sdf_sample_fast(G, x, y, z, g, in);
-            neg = val < 0.0f;
+#endif
+            neg[n] = val < 0.0f;
 #pragma unroll
-            for (int a = 0; a < 3; a++) g[a] = (neg && in[a]) ? g[a] : 0.0f;
-            s = neg ? -val : 0.0f;
+            for (int a = 0; a < 3; a++) g[a] = (neg[n] && in[a]) ? g[a] : 0.0f;
+            s[n] = neg[n] ? -val : 0.0f;
         } else {
             const float val = psi_trilinear(sdf, gmin, gmax, x, y, z, D, align_corners, g);
-            neg = val < 0.0f;
+            neg[n] = val < 0.0f;
 #pragma unroll
-            for (int a = 0; a < 3; a++) g[a] = neg ? g[a] : 0.0f;
-            s = neg ? -val : 0.0f;
+            for (int a = 0; a < 3; a++) g[a] = neg[n] ? g[a] : 0.0f;
+            s[n] = neg[n] ? -val : 0.0f;
         }
+#if PSI_EXP == 3
+        if (g[0] == 1234.5f)                                      // dev experiment: no gradient store
+#endif
         psi_st(og + (size_t)b * V * 3, (unsigned)v * 12u, psi_p3{g[0], g[1], g[2]});
     }
-    __device__ __forceinline__ void finish(int b, int vblock, int nvb)
+    __device__ __forceinline__ void finish(int n, int b, int vblock, int nvb)
     {
         // per workgroup: sum(-sdf) over the penetrating vertices by DPP adds, their count from the lane mask (scalar popcount)
         __shared__ psi_f2 red[PSI_SKIN_BLK / 64];
-        const float ws = psi_wave_sum(s);
-        const float wc = (float)(int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(neg));
+        const float ws = psi_wave_sum(s[n]);
+        const float wc = (float)(int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(neg[n]));
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (psi_f2){ws, wc};
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -485,7 +499,7 @@ struct SdfPenEpilogue {
 
 static inline SdfPenEpilogue make_sdf_epilogue(const FitDev &f, const PsiSdfGrid &G)
 {
-    return SdfPenEpilogue{G, f.sdf, f.gmin, f.gmax, f.og, f.penpart, f.D, f.align_corners, f.V, 0.0f, false};
+    return SdfPenEpilogue{G, f.sdf, f.gmin, f.gmax, f.og, f.penpart, f.D, f.align_corners, f.V, {0.0f, 0.0f}, {false, false}};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -540,6 +554,7 @@ struct ContactSkinSrc {
 // one body each; long, VALU-issue-bound pointer chases — dispatched first), the rest are the skinning + SDF workgroups (256
 // vertices of one body each; gather-latency-bound).  As two launches they ran back to back (23 + 18 us); they depend on the same
 // inputs only, so in one grid their waves share the SIMDs and hide each other's stalls.
+template <int NB>
 __global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, const float *__restrict__ As, const float *__restrict__ v_posed,
                                                            psikd::KdDev T, int n_kd, int nqb, int rows, float gscale, int skin_first, SdfPenEpilogue epi)
 {
@@ -567,7 +582,7 @@ __global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, c
                                           f.gq, f.fpart, f.nn_hint, rows, (const psikd::KdDev *)nullptr, (const int *)nullptr, bx, b, nqb, smem_i);
     } else {
         const int i = bid;
-        psi_skin_fwd_body(m, As, v_posed, f.transl, f.cam, f.B, f.verts, epi, i % f.nsdfblk, i / f.nsdfblk, f.nsdfblk);
+        psi_skin_fwd_body<NB, (NB > 1 ? 2 : PSI_DENSE_AHEAD)>(m, As, v_posed, f.transl, f.cam, f.B, f.verts, epi, i % f.nsdfblk, (i / f.nsdfblk) * NB, f.nsdfblk);
     }
 }
 
@@ -846,9 +861,9 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
             step = *f.step;
             // the bias corrections (double-precision pow: a few hundred instructions) are computed HERE, by waves that idle through
             // the pose backward, not at the end of the kernel's critical path
-            const double bc1 = 1.0 - pow((double)f.beta1, (double)step);
-            const double bc2 = 1.0 - pow((double)f.beta2, (double)step);
-            step_size = (float)((double)f.lr / bc1);
+            const double bc1 = 1.0 - pow(f.beta1_d, (double)step);
+            const double bc2 = 1.0 - pow(f.beta2_d, (double)step);
+            step_size = (float)(f.lr_d / bc1);
             bc2_sqrt = (float)sqrt(bc2);
         }
     }
@@ -981,8 +996,8 @@ __global__ __launch_bounds__(HB) void head_bwd_adam_kernel(FitDev f, PsiLbsView 
         if (ta >= 19 && ta < 19 + NZ) g += f.w_vp / (Bg * NZ) * 2.0f * sx[ta];
         // torch.optim.Adam (defaults: amsgrad False, weight_decay 0), fitting_proxe.py:73-74 (step_size, bc2_sqrt: top of the kernel)
         size_t o = (size_t)b * XD + ta;
-        float m = am * f.beta1 + (1.0f - f.beta1) * g;
-        float v = av * f.beta2 + (1.0f - f.beta2) * g * g;
+        float m = am * f.beta1 + f.one_m_beta1 * g;
+        float v = av * f.beta2 + f.one_m_beta2 * g * g;
         f.adam_m[o] = m;
         f.adam_v[o] = v;
         float denom = sqrtf(v) / bc2_sqrt + f.eps;
@@ -1005,6 +1020,20 @@ __global__ void sdf_to_bricks_kernel(const float *__restrict__ src, float *__res
         v = src[((size_t)ix * D + iy) * D + iz];
     }
     dst[i] = v;
+}
+
+// ... and into the cell-major order (sdf_device.h): one thread per stored float, [brick][lx][ly][lz][dx][dy][dz]
+__global__ void sdf_to_cells_kernel(const float *__restrict__ src, float *__restrict__ dst, int D)
+{
+    const int nbr = D >> 2;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)D * D * D * 8;
+    if (i >= n) return;
+    const int c = (int)(i & 7), l = (int)((i >> 3) & 63);
+    const size_t br = i >> 9;
+    const int bz = (int)(br % nbr), by = (int)((br / nbr) % nbr), bx = (int)(br / ((size_t)nbr * nbr));
+    const int ix = min(4 * bx + (l >> 4) + (c >> 2), D - 1), iy = min(4 * by + ((l >> 2) & 3) + ((c >> 1) & 1), D - 1),
+              iz = min(4 * bz + (l & 3) + (c & 1), D - 1);
+    dst[i] = src[((size_t)ix * D + iy) * D + iz];
 }
 
 __global__ void adam_reset_kernel(float *m, float *v, int *step, int n)
@@ -1030,6 +1059,7 @@ struct psi_fit_engine {
     float *stats_local;           // engine-owned stats buffer (single-GPU path)
     bool merged_scene;            // skinning + SDF and the NN search in one launch (kd-tree mode, J <= 56, 4 lanes per query)
     bool scene_skin_first;        // block order inside that launch: skinning + SDF workgroups before the NN-search workgroups
+    int skin_nb;                  // bodies per workgroup of the forward skinning + SDF kernel (1 or 2: lbs_device.h)
     hipGraph_t graph, graphN;     // one iteration / GRAPH_UNROLL iterations
     hipGraphExec_t graph_exec, graphN_exec;
     bool graph_ready, graphN_ready;
@@ -1093,8 +1123,12 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
         // skinning + SDF and the NN search of the contact vertices as ONE launch (fwd_scene_kernel)
         const psikd::KdDev T = psi_nn_index_dev(e->nn_index);
         const int nqb = f.nfp, n_kd = nqb * f.B;
-        hipLaunchKernelGGL(fwd_scene_kernel, dim3(n_kd + f.nsdfblk * f.B), dim3(256), psikd::kd_lds_bytes(T.rows), st, f, e->lv.m, e->lv.A,
-                           e->lv.v_posed, T, n_kd, nqb, T.rows, gscale, e->scene_skin_first ? 1 : 0, make_sdf_epilogue(f, e->grid));
+        if (e->skin_nb == 2)
+            hipLaunchKernelGGL(fwd_scene_kernel<2>, dim3(n_kd + f.nsdfblk * psi_cdiv(f.B, 2)), dim3(256), psikd::kd_lds_bytes(T.rows), st, f, e->lv.m,
+                               e->lv.A, e->lv.v_posed, T, n_kd, nqb, T.rows, gscale, e->scene_skin_first ? 1 : 0, make_sdf_epilogue(f, e->grid));
+        else
+            hipLaunchKernelGGL(fwd_scene_kernel<1>, dim3(n_kd + f.nsdfblk * f.B), dim3(256), psikd::kd_lds_bytes(T.rows), st, f, e->lv.m, e->lv.A,
+                               e->lv.v_posed, T, n_kd, nqb, T.rows, gscale, e->scene_skin_first ? 1 : 0, make_sdf_epilogue(f, e->grid));
         PSI_CHECK_LAUNCH("fwd_scene_kernel");
         psi_mark("fwd_scene_kernel", st);
         if (local) return 0;
@@ -1108,8 +1142,12 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
     // grounds that the kernel is vector-ALU bound at B = 512 (805 VALU instructions per wave, 660 of them the blend; profiles/
     // r03_pmc_skin_fwd_sdf_b512.txt).  It measured 191 us against 165: the fp32 MFMA runs at the vector FLOP rate and, as far as these timings
     // show, does not overlap the other waves' vector instructions, so the blend's cycles moved but did not disappear.)
-    hipLaunchKernelGGL(psi_skin_fwd_kernel<SdfPenEpilogue>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A, e->lv.v_posed,
-                           f.transl, f.cam, f.B, f.verts, make_sdf_epilogue(f, e->grid));
+    if (e->skin_nb == 2)
+        hipLaunchKernelGGL((psi_skin_fwd_kernel<SdfPenEpilogue, 2>), dim3(f.nsdfblk, psi_cdiv(f.B, 2)), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
+                           e->lv.v_posed, f.transl, f.cam, f.B, f.verts, make_sdf_epilogue(f, e->grid));
+    else
+        hipLaunchKernelGGL((psi_skin_fwd_kernel<SdfPenEpilogue, 1>), dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
+                           e->lv.v_posed, f.transl, f.cam, f.B, f.verts, make_sdf_epilogue(f, e->grid));
     PSI_CHECK_LAUNCH("skin_fwd_sdf_kernel");
     psi_mark("skin_fwd_sdf_kernel", st);
     if (e->nn_index)
@@ -1175,6 +1213,12 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     PSI_REQUIRE(!(f.indep && cfg->world_size > 1), "independent bodies have no cross-rank coupling: use world_size 1");
     f.w_rec = cfg->w_rec; f.w_vp = cfg->w_vposer; f.w_contact = cfg->w_contact; f.w_col = cfg->w_collision; f.cconst = cfg->contact_const;
     f.lr = cfg->lr; f.beta1 = cfg->beta1; f.beta2 = cfg->beta2; f.eps = cfg->eps;
+    // the hyper-parameters as the doubles the caller's optimiser holds (0: only the fp32 fields were filled in)
+    f.lr_d = cfg->lr_d != 0.0 ? cfg->lr_d : (double)cfg->lr;
+    f.beta1_d = cfg->beta1_d != 0.0 ? cfg->beta1_d : (double)cfg->beta1;
+    f.beta2_d = cfg->beta2_d != 0.0 ? cfg->beta2_d : (double)cfg->beta2;
+    f.one_m_beta1 = (float)(1.0 - f.beta1_d);
+    f.one_m_beta2 = (float)(1.0 - f.beta2_d);
     // one launch for both scene terms up to B = 128 (measured: 0.1695 -> 0.1611 ms per iteration at B = 32, 0.2342 -> 0.2258 at 64, 0.3957 ->
     // 0.3922 at 128; at 256 and above both parts are throughput-bound and the shared launch is 1-2 % slower); PSI_SPLIT_SCENE=1: two launches.
     // (Round 3 also tried the opposite arrangement — no search workgroups at all, every skinning workgroup answering the contact queries of
@@ -1241,8 +1285,12 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     size_t o_hxo = take((size_t)B * f.hc * 128 * 8), o_hxg = take((size_t)B * f.hc * NH * 8), o_hxc = take((size_t)2 * B * 4);
     size_t o_wct = take((size_t)f.n_c * PSI_JP * 4);
     // (the bricked copy is addressed with 32-bit byte offsets: 512 bytes x (D / 4)^3 must stay below 4 GB, D <= 800)
-    const bool bricks = (cfg->D % 4 == 0) && cfg->D <= 800 && !(getenv("PSI_SDF_LINEAR") && getenv("PSI_SDF_LINEAR")[0] == '1');
+    const bool bricks = (cfg->D % 4 == 0) && cfg->D <= (PSI_SDF_CELLS ? 480 : 800) && !(getenv("PSI_SDF_LINEAR") && getenv("PSI_SDF_LINEAR")[0] == '1');
+#if PSI_SDF_CELLS
+    size_t o_brick = bricks ? take((size_t)f.D * f.D * f.D * 32) : 0;             // D <= 480 keeps the byte offsets below 4 GB
+#else
     size_t o_brick = bricks ? take((size_t)(f.D / 4) * (f.D / 4) * (f.D / 4) * PSI_BRICK_FLOATS * 4) : 0;
+#endif
     size_t lbs_floats = psi_lbs_workspace_floats(lbs, B);
     size_t o_lws = take(lbs_floats * 4), o_nws = take(psi_nn_ws_bytes(B, f.n_c, f.m));
     hipError_t err = hipMalloc((void **)&e->blob, o);
@@ -1282,12 +1330,22 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     }
     f.Wct = F(o_wct);
     e->scene_skin_first = getenv("PSI_SCENE_ORDER") && getenv("PSI_SCENE_ORDER")[0] == '1';
+    // two bodies per skinning workgroup share one pass over the vertex's weight row: from the batch size at which the kernel is
+    // throughput-bound (its own launch, B > 128); PSI_SKIN_NB=1|2 overrides
+    // (compressed rows are read once per lane either way and measured 2-3 % slower with two bodies: 114.7 vs 112.3 us at B = 512)
+    e->skin_nb = cfg->B > 128 && !e->lv.m.Wc ? 2 : 1;
+    if (const char *nbv = getenv("PSI_SKIN_NB")) e->skin_nb = atoi(nbv) == 2 ? 2 : 1;
     hipLaunchKernelGGL(contact_weight_table_kernel, dim3(psi_cdiv((long)f.n_c * PSI_JP, 256)), dim3(256), 0, 0, e->lv.m.WT, e->lv.m.Vpad, f.vid,
                        f.n_c, J, (float *)f.Wct);
     f.sdf_brick = nullptr;
     if (bricks) {
+#if PSI_SDF_CELLS
+        const size_t n = (size_t)f.D * f.D * f.D * 8;
+        hipLaunchKernelGGL(sdf_to_cells_kernel, dim3((unsigned)psi_cdiv((long)n, 256)), dim3(256), 0, 0, d_sdf, F(o_brick), f.D);
+#else
         const size_t n = (size_t)(f.D / 4) * (f.D / 4) * (f.D / 4) * PSI_BRICK_FLOATS;
         hipLaunchKernelGGL(sdf_to_bricks_kernel, dim3((unsigned)psi_cdiv((long)n, 256)), dim3(256), 0, 0, d_sdf, F(o_brick), f.D);
+#endif
         f.sdf_brick = F(o_brick);
     }
     e->grid = psi_sdf_grid_make(f.sdf_brick, h_gmin, h_gmax, f.D, f.align_corners);

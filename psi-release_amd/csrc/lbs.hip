@@ -12,6 +12,8 @@
 //                        Shape and pose blendshapes are ONE contraction: v_posed = v_template + feat @ dirs,
 //                        feat[b] = [betas | (R_1..R_{J-1} - I)]  (lbs.py:81 and :94-99 fused; 64 MB streamed once).
 //   WT    [64][Vpad]     skinning weights transposed (coalesced per-vertex reads), zero padded.
+//   WTt   [Vpad/64][64][64]  the same weights tiled per wave: [vertex tile][joint][vertex in tile] — the dense skinning blend of a wave
+//                        walks ONE contiguous 16 KB tile, joint after joint (lbs_device.h)
 //   J_t [J][3], J_s [J][3][NB]   joint regressor pre-contracted with v_template / shapedirs (fp64 on the host):
 //                        J = J_t + J_s @ betas, algebraically lbs.py:85 without the V-long reduction per call.
 // Kernels:
@@ -222,6 +224,92 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// blend forward, column decomposition (round 4; the default): a WAVE owns 32 output columns (half a 64-column tile) and contracts ALL of
+// K for them, so there is no cross-wave reduction at all — no LDS, no barriers, no tile boundary at which the four waves of a workgroup
+// wait for each other (the K-split kernel above ends every tile with an LDS reduction and two barriers, and its waves have only two
+// 16 KB chunks in flight: 3.6 TB/s against the 5.2 TB/s the same matrix streams at in the backward).  B operand: each lane loads 8 bytes
+// (2 consecutive columns of one dirs row), 16 rows per 64-k chunk, FOUR chunks deep in a rolling register ring (48 loads = 24 KB per
+// wave in flight beside the chunk being multiplied); MFMA c of a k-step uses element c of that pair, so the 16 output columns of
+// accumulator c are n0 + 2 * (lane & 15) + c.  984 waves = one per SIMD on 246 CUs, the two halves of a tile in one workgroup.
+// The k order inside an accumulator is ascending for every (body, column) at every batch size.
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void blend_fwd_cols_kernel(LbsDev m, const float *__restrict__ feat, int B,
+                                                                                                float *__restrict__ v_posed)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 4 + w;                   // half-tile of this wave
+    if (gw >= m.Npad / 32) return;
+    const int tile = gw >> 1, h = gw & 1;
+    const int b0 = blockIdx.y * 16 * MT;
+    const int li = lane & 15, lk = lane >> 4;
+    const int Bpad = (B + 15) & ~15;
+    const int nch = m.Kpad / 64;                         // 64-k chunks (Kpad % 256 == 0)
+    // k order inside a chunk: lane group lk owns k = 64 ch + 16 lk + s (s = MFMA step 0..15); feat is stored as k-quads [Kpad/4][Bpad][4],
+    // so the A operands of four consecutive steps are ONE 16-byte load per lane
+    const float *brow = m.dirs + ((size_t)tile * m.Kpad + 16 * lk) * 64 + 32 * h + 2 * li;
+    const float *arow = feat + ((size_t)(4 * lk) * Bpad + b0 + li) * 4;
+    auto load_chunk = [&](int ch, psi_f2 (&q)[16], f4 (&a4)[MT][4]) {
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) a4[t][j] = *(const f4 *)(arow + ((size_t)(16 * ch + j) * Bpad + t * 16) * 4);
+        const float *bq = brow + (size_t)ch * 64 * 64;
+#pragma unroll
+        for (int sidx = 0; sidx < 16; sidx++) q[sidx] = *(const psi_f2 *)(bq + sidx * 64);
+    };
+    f4 acc[MT][2];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) acc[t][c] = (f4){0, 0, 0, 0};
+    auto mfma_chunk = [&](const psi_f2 (&q)[16], const f4 (&a4)[MT][4]) {
+#pragma unroll
+        for (int sidx = 0; sidx < 16; sidx++)
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t][sidx >> 2][sidx & 3], q[sidx][c], acc[t][c], 0, 0, 0);
+    };
+    psi_f2 q0[16], q1[16], q2[16], q3[16];
+    f4 a0[MT][4], a1[MT][4], a2[MT][4], a3[MT][4];
+    const psi_f2 vt = *(const psi_f2 *)(m.v_template + tile * 64 + 32 * h + 2 * li);
+    load_chunk(0, q0, a0);
+    if (nch > 1) load_chunk(1, q1, a1);
+    if (nch > 2) load_chunk(2, q2, a2);
+    for (int ch = 0; ch < nch; ch += 4) {
+        if (ch + 3 < nch) load_chunk(ch + 3, q3, a3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(q0, a0);
+        if (ch + 1 < nch) {
+            if (ch + 4 < nch) load_chunk(ch + 4, q0, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(q1, a1);
+        }
+        if (ch + 2 < nch) {
+            if (ch + 5 < nch) load_chunk(ch + 5, q1, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(q2, a2);
+        }
+        if (ch + 3 < nch) {
+            if (ch + 6 < nch) load_chunk(ch + 6, q2, a2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(q3, a3);
+        }
+    }
+    // D[row = 4 lk + e -> body][col = li -> columns 2 li, 2 li + 1]: one 8-byte store per body row
+    float *orow = v_posed + (size_t)tile * 64 + 32 * h + 2 * li;
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int b = b0 + t * 16 + lk * 4 + e;
+            if (b < B) *(psi_f2 *)(orow + (size_t)b * m.Npad) = (psi_f2){vt.x + acc[t][0][e], vt.y + acc[t][1][e]};
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -551,8 +639,12 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     for (int p = 0; p < d.P; p++)
         for (int n = 0; n < d.N; n++) dirs_at(NB + p, n) = h_posedirs[(size_t)p * d.N + n];
     memcpy(vt.data(), h_v_template, sizeof(float) * d.N);
+    std::vector<float> WTt((size_t)JP * d.Vpad, 0.0f);
     for (int v = 0; v < V; v++)
-        for (int j = 0; j < J; j++) WT[(size_t)j * d.Vpad + v] = h_weights[(size_t)v * J + j];
+        for (int j = 0; j < J; j++) {
+            WT[(size_t)j * d.Vpad + v] = h_weights[(size_t)v * J + j];
+            WTt[((size_t)(v >> 6) * JP + j) * 64 + (v & 63)] = h_weights[(size_t)v * J + j];
+        }
     std::vector<float> Jt((size_t)J * 3), Js((size_t)J * 3 * (NB > 0 ? NB : 1), 0.0f);
     {
         std::vector<double> acc((size_t)3 * (NB + 1));
@@ -601,14 +693,14 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     // one device blob
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
-    size_t o_dirs = take(dirs.size() * 4), o_vt = take(vt.size() * 4), o_wt = take(WT.size() * 4), o_jt = take(Jt.size() * 4),
+    size_t o_dirs = take(dirs.size() * 4), o_vt = take(vt.size() * 4), o_wt = take(WT.size() * 4), o_wtt = take(WTt.size() * 4), o_jt = take(Jt.size() * 4),
            o_js = take(Js.size() * 4), o_wc = take(Wc.size() * 4 + 4), o_wj = take(Wj.size() * 4 + 4), o_par = take(J * 4), o_lvl = take(J * 4), o_cp = take((J + 1) * 4), o_ci = take(cidx.size() * 4),
            o_jump = take(jump.size() * 4), o_sl = take(sub_list.size()), o_si = take(sub_item.size() * 4), o_sf = take(sub_first.size());
     char *blob = nullptr;
     PSI_CHECK_HIP(hipMalloc((void **)&blob, o));
     std::vector<int> par(h_parents, h_parents + J);
     struct { size_t off; const void *src; size_t bytes; } cp[] = {
-        {o_dirs, dirs.data(), dirs.size() * 4}, {o_vt, vt.data(), vt.size() * 4}, {o_wt, WT.data(), WT.size() * 4},
+        {o_dirs, dirs.data(), dirs.size() * 4}, {o_vt, vt.data(), vt.size() * 4}, {o_wt, WT.data(), WT.size() * 4}, {o_wtt, WTt.data(), WTt.size() * 4},
         {o_jt, Jt.data(), Jt.size() * 4}, {o_js, Js.data(), Js.size() * 4}, {o_wc, Wc.data(), Wc.size() * 4}, {o_wj, Wj.data(), Wj.size() * 4},
         {o_par, par.data(), (size_t)J * 4},
         {o_lvl, level.data(), (size_t)J * 4}, {o_cp, cptr.data(), (size_t)(J + 1) * 4}, {o_ci, cidx.data(), cidx.size() * 4},
@@ -626,6 +718,7 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     d.dirs = (const float *)(blob + o_dirs);
     d.v_template = (const float *)(blob + o_vt);
     d.WT = (const float *)(blob + o_wt);
+    d.WTt = (const float *)(blob + o_wtt);
     d.Wc = Wc.empty() ? nullptr : (const float *)(blob + o_wc);
     d.Wj = Wj.empty() ? nullptr : (const unsigned *)(blob + o_wj);
     d.J_t = (const float *)(blob + o_jt);
@@ -660,7 +753,17 @@ extern "C" size_t psi_lbs_workspace_floats(const psi_lbs_model *m, int B)
 
 static int lbs_launch_blend(const LbsDev &m, const WsLayout &L, int B, float *ws, hipStream_t st)
 {
-    {
+    static const bool ksplit = getenv("PSI_BLEND_FWD") && getenv("PSI_BLEND_FWD")[0] == '0';    // the round-1..3 K-split kernel (A/B)
+    if (!ksplit) {
+        const int bgroups = B > 32 ? psi_cdiv(B, 64) : 1;
+        const dim3 grid(psi_cdiv(m.Npad / 32, 4), bgroups);
+        if (B > 32)
+            hipLaunchKernelGGL(blend_fwd_cols_kernel<4>, grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
+        else if (B > 16)
+            hipLaunchKernelGGL(blend_fwd_cols_kernel<2>, grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
+        else
+            hipLaunchKernelGGL(blend_fwd_cols_kernel<1>, grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
+    } else {
         const int ntiles = m.Npad / 64;
         const int bgroups = B > 32 ? psi_cdiv(B, 64) : 1;
         int tpb = psi_cdiv((long)ntiles * bgroups, 256);          // ~one workgroup (1 wave/SIMD) per CU, single round

@@ -18,6 +18,7 @@ constexpr int PSI_WNZ = 8;          // compressed skinning rows are used when no
 struct LbsDev {
     int V, J, NB, P, K, Kpad, N, Npad, Vpad, maxlevel, njump;
     const float *dirs, *v_template, *WT, *J_t, *J_s;
+    const float *WTt;                                // the same weights as [Vpad/64][PSI_JP][64]: a wave's 64 vertices x all joints = one contiguous 16 KB tile
     const float *Wc;                                 // compressed rows [PSI_WNZ][Vpad]: the k-th non-zero weight of each vertex (ascending joint), or nullptr
     const unsigned *Wj;                              //                 [PSI_WNZ/4][Vpad]: their joint indices, one byte each (padding: weight 0, joint 0)
     const int *parents, *level, *child_ptr, *child_idx;
@@ -436,27 +437,60 @@ __device__ __forceinline__ void psi_st(void *uniform_base, unsigned lane_off, co
     *(T *)((char *)uniform_base + lane_off) = val;
 }
 
-// Blend the body's joint transforms with this lane's skinning weights: T = sum_j w_j A_j (3x4 as six float pairs).
-// The 55 transforms are staged in LDS once (2.6 KB); the j loop then has no scalar-load round trip per joint, the
-// per-lane weights are prefetched 11 joints ahead (unroll 11 of J = 55), and the accumulation is packed (v_pk_fma_f32).
+// Blend a body's joint transforms with this lane's skinning weights: T = sum_j w_j A_j (3x4 as six float pairs), packed
+// accumulation (v_pk_fma_f32), for NB bodies at once: the lane's weights are loaded ONCE and every body's transforms are blended
+// with them (NB = 2 halves the weight traffic — 2.7 MB per body from L2, what bounds the dense kernel at large batches — and the
+// number of skinning workgroups).
 //
 // The skinning kernels are latency-bound at the BASELINE batch, and what they read at the start — the transforms to stage, the
 // lane's weight row, its vertex / gradient operands — are independent of each other: PsiBlend splits the blend into issue() (all
 // the loads, to be called together with the caller's own first loads), commit() (LDS writes + barrier) and blend().  Requested
 // one after the other, as a staged-then-blend function does, these were three to six dependent L2 round trips per workgroup.
-struct PsiBlend {
-    psi_f2 st[2];                 // this thread's share of the body's transforms (J * 6 float pairs over 256 threads, J <= 85)
+//
+// Dense rows: the transforms are the same for every lane of the workgroup — read through the SCALAR cache (48 bytes per joint and
+// wave) instead of LDS broadcasts (3 KB per joint and wave: at 55 joints the LDS return path, 128 B/clk per CU, bounded the
+// skinning kernels: 26 k cycles per CU = 11 us for the 20 resident waves).  Weights come through a buffer descriptor: the row
+// offset j * Vpad * 4 is a scalar operand of the load and the lane offset v * 4 one register shared by all joints (a
+// `WT[(size_t)j * Vpad + v]` access was a 64-bit vector add per joint); rows from J on are outside the descriptor's range and read
+// as 0 without a memory access.  Joints are taken in groups of PSI_DENSE_UNROLL with the NEXT group's weights requested while the
+// current group is accumulated; a scheduling fence every PSI_DENSE_AHEAD joints bounds how many scalar loads are in flight (left
+// alone, the scheduler requests two groups' worth — 264 scalar registers — and spills through v_writelane / v_readlane inside
+// the loop).  PSI_DENSE_LOOP selects the loop form:
+//   1  compact: ONE group of code; a weight register is re-requested for the next group right after its joint has been accumulated
+//      (the last group's requests are out of range: no traffic).  Smallest instruction footprint — a cold instruction cache line is
+//      a trip to memory on the critical path of a 15 us kernel.
+//   0  ping-pong: two register groups filled and used alternately, two groups of code + tail.
+#ifndef PSI_EXP
+#define PSI_EXP 0            // dev: bound-isolating experiments of the skinning + SDF kernel (tools/gpu_call.sh); 0 in every shipped build
+#endif
+#ifndef PSI_DENSE_UNROLL
+#define PSI_DENSE_UNROLL 11
+#endif
+#ifndef PSI_DENSE_AHEAD
+#define PSI_DENSE_AHEAD 4
+#endif
+#ifndef PSI_DENSE_LOOP
+#define PSI_DENSE_LOOP 1
+#endif
+template <int NB>
+struct PsiBlendN {
+    psi_f2 st[NB][2];             // this thread's share of the bodies' transforms (J * 6 float pairs over 256 threads, J <= 85)
     float wk[PSI_WNZ];            // compressed weight row of the lane's vertex (when the model has one)
     unsigned jk[PSI_WNZ / 4];     // ... and its joint indices, a byte each
-    __device__ __forceinline__ void issue(const LbsDev &m, const float *__restrict__ As, int b, int v)
+    const float *As_b[NB];        // the bodies' transforms in global memory (set by issue)
+    typedef psi_f2 (*Staged)[PSI_JP][6];
+    __device__ __forceinline__ void issue(const LbsDev &m, const float *__restrict__ As, const int (&b)[NB], int v)
     {
-        As_b = As + (size_t)b * m.J * 12;
+#pragma unroll
+        for (int n = 0; n < NB; n++) As_b[n] = As + (size_t)b[n] * m.J * 12;
         if (m.Wc) {
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int idx = threadIdx.x + q * PSI_SKIN_BLK;
-                st[q] = idx < m.J * 6 ? *(const psi_f2 *)(As + ((size_t)b * m.J) * 12 + idx * 2) : (psi_f2){0.0f, 0.0f};
-            }
+            for (int n = 0; n < NB; n++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int idx = threadIdx.x + q * PSI_SKIN_BLK;
+                    st[n][q] = idx < m.J * 6 ? *(const psi_f2 *)(As_b[n] + idx * 2) : (psi_f2){0.0f, 0.0f};
+                }
             const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)m.Wc, 0, PSI_WNZ * m.Vpad * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc((void *)m.Wj, 0, PSI_WNZ / 4 * m.Vpad * 4, 0x00020000);
 #pragma unroll
@@ -466,23 +500,27 @@ struct PsiBlend {
             for (int k = 0; k < PSI_WNZ / 4; k++) jk[k] = __builtin_amdgcn_raw_buffer_load_b32(rj, (unsigned)v * 4u, (unsigned)(k * m.Vpad) * 4u, 0);
         }
     }
-    __device__ __forceinline__ psi_f2 (*commit(const LbsDev &m))[6]
+    __device__ __forceinline__ Staged commit(const LbsDev &m)
     {
-        __shared__ psi_f2 sA[PSI_JP][6];
+        __shared__ psi_f2 sA[NB][PSI_JP][6];
         if (!m.Wc) return sA;                                   // dense rows read the transforms through the scalar cache (blend)
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int idx = threadIdx.x + q * PSI_SKIN_BLK;
-            if (idx < m.J * 6) (&sA[0][0])[idx] = st[q];             // [joint][6] pairs = the rows as they lie in memory
-        }
+        for (int n = 0; n < NB; n++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int idx = threadIdx.x + q * PSI_SKIN_BLK;
+                if (idx < m.J * 6) (&sA[n][0][0])[idx] = st[n][q];     // [joint][6] pairs = the rows as they lie in memory
+            }
         __syncthreads();
         return sA;
     }
-    const float *As_b;            // this body's transforms in global memory (set by issue)
-    __device__ __forceinline__ void blend(const LbsDev &m, const psi_f2 (*sA)[6], int v, psi_f2 (&T2)[6]) const
+    template <int AH = PSI_DENSE_AHEAD>
+    __device__ __forceinline__ void blend(const LbsDev &m, Staged sA, int v, psi_f2 (&T2)[NB][6]) const
     {
 #pragma unroll
-        for (int e = 0; e < 6; e++) T2[e] = (psi_f2){0.0f, 0.0f};
+        for (int n = 0; n < NB; n++)
+#pragma unroll
+            for (int e = 0; e < 6; e++) T2[n][e] = (psi_f2){0.0f, 0.0f};
         if (m.Wc) {
             // compressed rows (real SMPL-X weight rows have a handful of non-zeros): the same sum with the exact zeros skipped,
             // in ascending joint order — bit-identical to the dense loop, 8 instead of 55 terms
@@ -494,47 +532,66 @@ struct PsiBlend {
                 psi_f2 w2 = {wk[k], wk[k]};
                 const int jj = (jk[k >> 2] >> (8 * (k & 3))) & 0xff;
 #pragma unroll
-                for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, sA[jj][e], T2[e]);
+                for (int n = 0; n < NB; n++)
+#pragma unroll
+                    for (int e = 0; e < 6; e++) T2[n][e] = __builtin_elementwise_fma(w2, sA[n][jj][e], T2[n][e]);
             }
             return;
         }
-        // dense rows: the transforms are the same for every lane of the workgroup — read through the SCALAR cache (48 bytes per joint
-        // and wave) instead of LDS broadcasts (3 KB per joint and wave: at 55 joints the LDS return path, 128 B/clk per CU, bounded
-        // the skinning kernels: 26 k cycles per CU = 11 us for the 20 resident waves).  (Requesting the next joint's transform by hand before the
-        // current one is used measured slower than the compiler's own three 16-byte scalar loads per joint.)
-        const psi_f2 *Ab = (const psi_f2 *)As_b;
-        // weights through a buffer descriptor: the row offset j * Vpad * 4 is a scalar operand of the load, the lane offset v * 4 one
-        // register shared by all joints (a `WT[(size_t)j * Vpad + v]` access was a 64-bit vector add per joint).  Groups of
-        // PSI_DENSE_UNROLL joints: the next group's weights are requested before the current group is accumulated.
-        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)m.WT, 0, PSI_JP * m.Vpad * 4, 0x00020000);
-        const unsigned v4 = (unsigned)v * 4u, rowb = (unsigned)m.Vpad * 4u;
-#ifndef PSI_DENSE_UNROLL
-#define PSI_DENSE_UNROLL 11
-#endif
-        constexpr int GJ = PSI_DENSE_UNROLL;
-        float wa[GJ], wb[GJ];                                      // two register groups, filled and used alternately (no copies)
-        auto request = [&](float (&w)[GJ], int j0) {
-            unsigned ro = (unsigned)j0 * rowb;                      // rows J .. PSI_JP - 1 are zero, and the descriptor's range check returns 0 beyond them
+        const psi_f2 *Ab[NB];
 #pragma unroll
-            for (int k = 0; k < GJ; k++, ro += rowb) w[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, v4, ro, 0));
-        };
-        // A last group that runs past J is padded, not guarded: its weights come from the zero rows of WT and its transforms from the
-        // rows behind the body's (the next body's, or the padding rows psi_lbs_view leaves behind the last body), so the extra terms
-        // add 0 * finite = 0 (J = 55 = 5 groups of 11: no padding at all).  The transforms arrive through the scalar cache, one base
-        // address per group and immediate offsets per joint; a scheduling fence every PSI_DENSE_AHEAD joints bounds how many of those
-        // loads are in flight (left alone, the scheduler requests two groups' worth — 264 scalar registers — and spills 37 of them
-        // through v_writelane / v_readlane inside the loop).
-#ifndef PSI_DENSE_AHEAD
-#define PSI_DENSE_AHEAD 4
+        for (int n = 0; n < NB; n++) Ab[n] = (const psi_f2 *)As_b[n];
+        // weights from the wave-tiled copy: descriptor base + the tile's scalar offset + lane * 4, the joint as an IMMEDIATE (k * 256 bytes)
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)m.WTt, 0, PSI_JP * m.Vpad * 4, 0x00020000);
+#if PSI_EXP != 2
+        const unsigned v4 = (unsigned)(v & 63) * 4u;
 #endif
-        auto accumulate = [&](const float (&w)[GJ], int j0) {
-            const psi_f2 *Ag = Ab + j0 * 6;
+        const unsigned tile_off = (unsigned)__builtin_amdgcn_readfirstlane(v >> 6) * (unsigned)(PSI_JP * 64 * 4);   // a wave = 64 consecutive vertices
+        constexpr int GJ = PSI_DENSE_UNROLL;
+        static_assert(GJ * 256 <= 4096, "joint offsets of a group must fit the load's 12-bit immediate");
+        auto fma6 = [&](float w, int j) {
+            psi_f2 w2 = {w, w};
+#pragma unroll
+            for (int n = 0; n < NB; n++)
+#pragma unroll
+                for (int e = 0; e < 6; e++) T2[n][e] = __builtin_elementwise_fma(w2, Ab[n][j * 6 + e], T2[n][e]);
+        };
+#if PSI_DENSE_LOOP == 1
+        float w[GJ];
+#if PSI_EXP == 2
+        const unsigned v4 = 0;                                       // dev experiment: every lane reads the tile's first weight (one line access per load)
+#endif
+        unsigned ro = tile_off;                                      // scalar offset of the group being requested
+#pragma unroll
+        for (int k = 0; k < GJ; k++) w[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, v4 + k * 256, ro, 0));
+        int j0 = 0;
+#pragma nounroll
+        for (; j0 + GJ <= m.J; j0 += GJ) {
+            ro += j0 + GJ < m.J ? GJ * 256 : 0;                      // the last trip re-requests its own rows (first-level cache hits, unused)
 #pragma unroll
             for (int k = 0; k < GJ; k++) {
-                if (k % PSI_DENSE_AHEAD == 0) __builtin_amdgcn_sched_barrier(0);
-                psi_f2 w2 = {w[k], w[k]};
+                if (k % AH == 0) __builtin_amdgcn_sched_barrier(0);
+                fma6(w[k], j0 + k);
+                w[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, v4 + k * 256, ro, 0));   // joint j0 + GJ + k, for the next trip
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-                for (int e = 0; e < 6; e++) T2[e] = __builtin_elementwise_fma(w2, Ag[k * 6 + e], T2[e]);
+        for (int k = 0; k < GJ; k++)                                 // J % GJ joints are left (none for J = 55)
+            if (j0 + k < m.J) fma6(w[k], j0 + k);
+#else
+        float wa[GJ], wb[GJ];                                      // two register groups, filled and used alternately (no copies)
+        auto request = [&](float (&w)[GJ], int j0) {
+            const unsigned ro = tile_off + (unsigned)j0 * 256u;     // rows J .. PSI_JP - 1 of a tile are zero
+#pragma unroll
+            for (int k = 0; k < GJ; k++) w[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, v4 + k * 256, ro, 0));
+        };
+        // a last group that runs past J is padded, not guarded: its weights read as 0 and its transforms are row J - 1's
+        auto accumulate = [&](const float (&w)[GJ], int j0, bool padded) {
+#pragma unroll
+            for (int k = 0; k < GJ; k++) {
+                if (k % AH == 0) __builtin_amdgcn_sched_barrier(0);
+                fma6(w[k], padded ? min(j0 + k, m.J - 1) : j0 + k);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -543,19 +600,21 @@ struct PsiBlend {
 #pragma nounroll
         for (; j0 + 2 * GJ < m.J; j0 += 2 * GJ) {                  // two whole groups, and another one behind them
             request(wb, j0 + GJ);
-            accumulate(wa, j0);
+            accumulate(wa, j0, false);
             request(wa, j0 + 2 * GJ);
-            accumulate(wb, j0 + GJ);
+            accumulate(wb, j0 + GJ, false);
         }
         if (m.J - j0 > GJ) {                                        // wa holds group j0; one or two groups are left
             request(wb, j0 + GJ);
-            accumulate(wa, j0);
-            accumulate(wb, j0 + GJ);
+            accumulate(wa, j0, false);
+            accumulate(wb, j0 + GJ, true);
         } else {
-            accumulate(wa, j0);
+            accumulate(wa, j0, true);
         }
+#endif
     }
 };
+typedef PsiBlendN<1> PsiBlend;
 
 // The per-vertex affine maps of the skinning kernels with an EXPLICIT operation order (fma chains), so that every instantiation
 // — one body or several per workgroup, dense or compressed rows — rounds identically (left to the compiler's contraction the
@@ -569,59 +628,83 @@ __device__ __forceinline__ float psi_dot3(float a, float b, float c, float x, fl
     return __builtin_fmaf(c, z, __builtin_fmaf(b, y, a * x));               // (a x + b y) + c z
 }
 
-// Epilogue hook of skin_fwd: vertex() sees every lane's final world-space vertex (live = false for padding lanes),
-// finish(b, vblock, nvb) runs once per workgroup (vertex block vblock of nvb, body b) with all threads present.
+// Epilogue hook of skin_fwd: vertex(n, b, v, ...) sees every lane's final world-space vertex of the workgroup's n-th body b (live = false
+// for padding lanes), finish(n, b, vblock, nvb) runs once per workgroup and body (vertex block vblock of nvb) with all threads present.
 struct PsiSkinNoEpilogue {
-    __device__ __forceinline__ void vertex(int, int, float, float, float, bool) {}
-    __device__ __forceinline__ void finish(int, int, int) {}
+    __device__ __forceinline__ void vertex(int, int, int, float, float, float, bool) {}
+    __device__ __forceinline__ void finish(int, int, int, int) {}
 };
 
 // verts = cam_ext * (sum_j W_j A_j [v_posed;1] + transl)      (lbs.py:108-116, cvae.py:141-149)
 // (a device function so that the fused fitting engine can run it inside a launch it shares with the NN search: fit.hip)
-template <class Epi>
+// NB bodies per workgroup (b0, b0 + 1, ...; a body index beyond B - 1 repeats the last body and stores nothing): every lane blends
+// its vertex for all of them with ONE pass over its weights, then runs transform + epilogue body by body.
+template <int NB, int AH, class Epi>
 __device__ __forceinline__ void psi_skin_fwd_body(const LbsDev &m, const float *__restrict__ As, const float *__restrict__ v_posed,
                                                   const float *__restrict__ transl, const float *__restrict__ cam_ext, int B,
-                                                  float *__restrict__ verts, Epi &epi, int vblock, int b, int nvb)
+                                                  float *__restrict__ verts, Epi &epi, int vblock, int b0, int nvb)
 {
     const int v = vblock * PSI_SKIN_BLK + threadIdx.x;
     const bool live = v < m.V;
     const unsigned v12 = (unsigned)v * 12u;                     // lane offset of every [.., V, 3] stream of this kernel
-    // all first loads in one go: transforms to stage, weight row, posed vertex (one 12-byte load; rows are padded to Npad >= 3 Vpad)
-    PsiBlend bl;
-    bl.issue(m, As, b, v);
-    const psi_p3 pp = psi_ld<psi_p3>(v_posed + (size_t)b * m.Npad, v12);
-    const float px = pp.x, py = pp.y, pz = pp.z;
-    psi_f2 T2[6];
-    bl.blend(m, bl.commit(m), v, T2);
-    float x = psi_dot3p(T2[0].x, T2[0].y, T2[1].x, T2[1].y, px, py, pz);
-    float y = psi_dot3p(T2[2].x, T2[2].y, T2[3].x, T2[3].y, px, py, pz);
-    float z = psi_dot3p(T2[4].x, T2[4].y, T2[5].x, T2[5].y, px, py, pz);
-    if (transl) {
-        x += transl[(size_t)b * 3 + 0];
-        y += transl[(size_t)b * 3 + 1];
-        z += transl[(size_t)b * 3 + 2];
+    int bs[NB];
+#pragma unroll
+    for (int n = 0; n < NB; n++) bs[n] = min(b0 + n, B - 1);
+    // all first loads in one go: transforms to stage, weight row, posed vertices (one 12-byte load each; rows are padded to Npad >= 3 Vpad)
+    PsiBlendN<NB> bl;
+    bl.issue(m, As, bs, v);
+    psi_p3 pp[NB];
+#pragma unroll
+    for (int n = 0; n < NB; n++) pp[n] = psi_ld<psi_p3>(v_posed + (size_t)bs[n] * m.Npad, v12);
+    psi_f2 T2[NB][6];
+    bl.template blend<AH>(m, bl.commit(m), v, T2);
+#pragma unroll
+    for (int n = 0; n < NB; n++) {
+        const int b = bs[n];
+        const bool on = n == 0 || b0 + n < B;                    // wave-uniform
+        const float px = pp[n].x, py = pp[n].y, pz = pp[n].z;
+        float x = psi_dot3p(T2[n][0].x, T2[n][0].y, T2[n][1].x, T2[n][1].y, px, py, pz);
+        float y = psi_dot3p(T2[n][2].x, T2[n][2].y, T2[n][3].x, T2[n][3].y, px, py, pz);
+        float z = psi_dot3p(T2[n][4].x, T2[n][4].y, T2[n][5].x, T2[n][5].y, px, py, pz);
+        if (transl) {
+            x += transl[(size_t)b * 3 + 0];
+            y += transl[(size_t)b * 3 + 1];
+            z += transl[(size_t)b * 3 + 2];
+        }
+        if (cam_ext) {   // cvae.py:141-149: [v,1] @ cam_ext^T, drop w
+            const float *C = cam_ext + (size_t)b * 16;
+            float X = psi_dot3p(C[0], C[1], C[2], C[3], x, y, z);
+            float Y = psi_dot3p(C[4], C[5], C[6], C[7], x, y, z);
+            float Z = psi_dot3p(C[8], C[9], C[10], C[11], x, y, z);
+            x = X; y = Y; z = Z;
+        }
+        epi.vertex(n, b, v, x, y, z, live && on);
+#if PSI_EXP == 3
+        if (live && on && x == 1234.5f)                          // dev experiment: no vertex store
+#else
+        if (live && on)   // stored AFTER the epilogue's lookups: a wait for a load also waits for the wave's earlier stores (one counter on gfx950)
+#endif
+            psi_st(verts + (size_t)b * m.V * 3, v12, psi_p3{x, y, z});
     }
-    if (cam_ext) {   // cvae.py:141-149: [v,1] @ cam_ext^T, drop w
-        const float *C = cam_ext + (size_t)b * 16;
-        float X = psi_dot3p(C[0], C[1], C[2], C[3], x, y, z);
-        float Y = psi_dot3p(C[4], C[5], C[6], C[7], x, y, z);
-        float Z = psi_dot3p(C[8], C[9], C[10], C[11], x, y, z);
-        x = X; y = Y; z = Z;
+#pragma unroll
+    for (int n = 0; n < NB; n++) {
+        if (n > 0) __syncthreads();                              // the previous body's reduction has been read
+        if (n == 0 || b0 + n < B) epi.finish(n, bs[n], vblock, nvb);
     }
-    epi.vertex(b, v, x, y, z, live);
-    if (live) {
-        // stored AFTER the epilogue's lookups: a wait for a load also waits for the wave's earlier stores (one counter on gfx950)
-        psi_st(verts + (size_t)b * m.V * 3, v12, psi_p3{x, y, z});
-    }
-    epi.finish(b, vblock, nvb);
 }
 
-template <class Epi>
+// (standalone kernel: scheduling fence every PSI_SKIN_FWD_AHEAD joints — with more transforms in flight this instantiation spills
+// scalar registers inside the blend loop, 12 lane moves per group)
+#ifndef PSI_SKIN_FWD_AHEAD
+#define PSI_SKIN_FWD_AHEAD 2
+#endif
+template <class Epi, int NB = 1>
 __global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_fwd_kernel(LbsDev m, const float *__restrict__ As, const float *__restrict__ v_posed,
                                                                      const float *__restrict__ transl, const float *__restrict__ cam_ext,
                                                                      int B, float *__restrict__ verts, Epi epi)
 {
-    psi_skin_fwd_body(m, As, v_posed, transl, cam_ext, B, verts, epi, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+    psi_skin_fwd_body<NB, (NB > 1 ? 1 : PSI_SKIN_FWD_AHEAD)>(m, As, v_posed, transl, cam_ext, B, verts, epi, (int)blockIdx.x, (int)blockIdx.y * NB,
+                                                              (int)gridDim.x);
 }
 
 // Gradient source of skin_bwd_v: where dL/dverts[b][v] comes from.
@@ -658,12 +741,14 @@ __global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_bwd_v_kernel(LbsDev 
     PSI_SSTOP(11);
     typename Src::Pre pre = src.issue(b, v, v < m.V);
     PsiBlend bl;
-    bl.issue(m, As, b, v);
+    const int bs1[1] = {b};
+    bl.issue(m, As, bs1, v);
     src.issue_late(pre, b);
     PSI_SSTOP(12);
     // the blend first (its weight loads run while the statistics inputs requested above are still in flight), then the statistics
-    psi_f2 T2[6];
-    bl.blend(m, bl.commit(m), v, T2);
+    psi_f2 T2n[1][6];
+    bl.blend(m, bl.commit(m), v, T2n);
+    const psi_f2 (&T2)[6] = T2n[0];
     PSI_SSTOP(13);
     src.prepare(b, 1);
     PSI_SSTOP(14);

@@ -6,8 +6,10 @@
 //     pene    = gate * w_collision * ( mean |sdf| over sdf < 0,  0 when no vertex penetrates )           train_s1.py:193-204
 // and the gradient of both with respect to the body vertices [B, V, 3]:
 //     penetration: -(gate w_collision / count) * [sdf < 0] * d sdf / d vertex        (every vertex: a dense write, no zero fill)
-//     contact    : (gate w_contact / (B n_c)) * 1 / (2 s (s + 1)^2) * 2 (x - nn(x))  scattered to the contact vertices' rows
-//                  (chamfer.cu:155-174, query side; atomics, so a vertex listed by two contact parts accumulates both)
+//     contact    : (gate w_contact / (B n_c)) * 1 / (2 s (s + 1)^2) * 2 (x - nn(x))  added to the contact vertices' rows
+//                  (chamfer.cu:155-174, query side).  A vertex listed by two contact parts accumulates both (cvae.py:99-115 keeps
+//                  duplicates): the slots of one vertex form a chain in ascending slot order, built by a small kernel per call, and the
+//                  FIRST slot's thread adds the whole chain to the row — no atomics, the same bits on every run
 // As PyTorch operators that is: a sqrt / add / div / mean chain and its autograd twin, torch.where pieces around the penetration mean,
 // an advanced-indexing gather for the neighbours, an index_put_(accumulate=True) for the contact rows (61 us at batch 128: it sorts), a
 // 16 MB zero fill and a 16 MB add of the two vertex gradients.
@@ -95,26 +97,50 @@ __global__ __launch_bounds__(SL_BLK) void scene_loss_bwd_dense_kernel(const floa
     g[2] = neg ? c * o[2] : 0.0f;
 }
 
-// contact part: thread = (body, contact slot); added to the vertex's row
+// chain[j] = the next contact slot (> j) that lists the same vertex as slot j, or -1; chain[n + j] = 1 when no earlier slot lists it
+__global__ __launch_bounds__(SL_BLK) void contact_chain_kernel(const int *__restrict__ vid, int n, int *__restrict__ chain)
+{
+    extern __shared__ int svid[];
+    for (int i = threadIdx.x; i < n; i += SL_BLK) svid[i] = vid[i];
+    __syncthreads();
+    const int j = blockIdx.x * SL_BLK + threadIdx.x;
+    if (j >= n) return;
+    const int my = svid[j];
+    int first = 1, next = -1;
+    for (int k = 0; k < j; k++) first &= svid[k] != my;
+    for (int k = n - 1; k > j; k--) next = svid[k] == my ? k : next;
+    chain[j] = next;
+    chain[n + j] = first;
+}
+
+// contact part: thread = (body, contact slot); the first slot of a vertex adds the terms of all of the vertex's slots to its row
 __global__ __launch_bounds__(SL_BLK) void scene_loss_bwd_contact_kernel(const float *__restrict__ g_losses, const float *__restrict__ dist,
                                                                         const float *__restrict__ xyz1, const int *__restrict__ idx,
                                                                         const int *__restrict__ slot, const float *__restrict__ table, long m,
-                                                                        const int *__restrict__ vid, int B, int n, int V, float w_contact,
-                                                                        float gate, float *__restrict__ g_verts)
+                                                                        const int *__restrict__ vid, const int *__restrict__ chain, int B, int n,
+                                                                        int V, float w_contact, float gate, float *__restrict__ g_verts)
 {
     const long i = (long)blockIdx.x * SL_BLK + threadIdx.x;
     if (i >= (long)B * n) return;
     const int b = (int)(i / n), j = (int)(i % n);
-    const float s = sqrtf(dist[i] + 1e-4f);
-    const float sp = s + 1.0f;
-    // d/d dist of mean(s / (s + 1)):  1 / (s + 1)^2 * 1 / (2 s) / (B n)
-    const float c = g_losses[0] * (gate * w_contact) / (float)((long)B * n) * (1.0f / (sp * sp)) * (0.5f / s);
-    const float *q = xyz1 + i * 3;
-    const float *p = table + ((size_t)slot[b] * m + idx[i]) * 3;
+    if (!chain[n + j]) return;
     float *g = g_verts + ((size_t)b * V + vid[j]) * 3;
-    atomicAdd(g + 0, 2.0f * c * (q[0] - p[0]));
-    atomicAdd(g + 1, 2.0f * c * (q[1] - p[1]));
-    atomicAdd(g + 2, 2.0f * c * (q[2] - p[2]));
+    float a0 = g[0], a1 = g[1], a2 = g[2];                    // the penetration part (scene_loss_bwd_dense_kernel, earlier on the stream)
+    const float k0 = g_losses[0] * (gate * w_contact) / (float)((long)B * n);
+    const float *pt = table + (size_t)slot[b] * m * 3;
+    for (int jj = j; jj >= 0; jj = chain[jj]) {
+        const long q_i = (long)b * n + jj;
+        const float s = sqrtf(dist[q_i] + 1e-4f);
+        const float sp = s + 1.0f;
+        // d/d dist of mean(s / (s + 1)):  1 / (s + 1)^2 * 1 / (2 s) / (B n)
+        const float c = k0 * (1.0f / (sp * sp)) * (0.5f / s);
+        const float *q = xyz1 + q_i * 3;
+        const float *p = pt + (size_t)idx[q_i] * 3;
+        a0 += 2.0f * c * (q[0] - p[0]);
+        a1 += 2.0f * c * (q[1] - p[1]);
+        a2 += 2.0f * c * (q[2] - p[2]);
+    }
+    g[0] = a0; g[1] = a1; g[2] = a2;
 }
 
 } // namespace
@@ -137,17 +163,20 @@ extern "C" int psi_scene_losses_forward(const float *dist, long n_contact, const
 extern "C" int psi_scene_losses_backward(const float *g_losses2, const float *stats2, const float *dist, const float *xyz1, const int32_t *idx,
                                          const int32_t *slot, const float *verts_table, long m, const int32_t *vid, const float *sdf_vals,
                                          const float *sdf_grad, int B, int V, int n_c, float w_contact, float w_collision, float gate,
-                                         float *g_verts, void *stream)
+                                         int32_t *ws_chain, float *g_verts, void *stream)
 {
-    PSI_REQUIRE(g_losses2 && stats2 && dist && xyz1 && idx && slot && verts_table && vid && sdf_vals && sdf_grad && g_verts, "null pointer");
+    PSI_REQUIRE(g_losses2 && stats2 && dist && xyz1 && idx && slot && verts_table && vid && sdf_vals && sdf_grad && ws_chain && g_verts, "null pointer");
     PSI_REQUIRE(B > 0 && V > 0 && n_c > 0 && m > 0, "bad sizes");
+    PSI_REQUIRE(n_c <= 16384, "more than 16384 contact slots");          // the slot table is staged in 64 KB of LDS
     hipStream_t st = (hipStream_t)stream;
     const long n_sdf = (long)B * V, n_q = (long)B * n_c;
     hipLaunchKernelGGL(scene_loss_bwd_dense_kernel, dim3((unsigned)psi_cdiv(n_sdf, (long)SL_BLK)), dim3(SL_BLK), 0, st, g_losses2, stats2, sdf_vals,
                        sdf_grad, n_sdf, w_collision, gate, g_verts);
     PSI_CHECK_LAUNCH("scene_loss_bwd_dense_kernel");
+    hipLaunchKernelGGL(contact_chain_kernel, dim3((unsigned)psi_cdiv(n_c, SL_BLK)), dim3(SL_BLK), (size_t)n_c * sizeof(int), st, vid, n_c, ws_chain);
+    PSI_CHECK_LAUNCH("contact_chain_kernel");
     hipLaunchKernelGGL(scene_loss_bwd_contact_kernel, dim3((unsigned)psi_cdiv(n_q, (long)SL_BLK)), dim3(SL_BLK), 0, st, g_losses2, dist, xyz1, idx,
-                       slot, verts_table, m, vid, B, n_c, V, w_contact, gate, g_verts);
+                       slot, verts_table, m, vid, ws_chain, B, n_c, V, w_contact, gate, g_verts);
     PSI_CHECK_LAUNCH("scene_loss_bwd_contact_kernel");
     return 0;
 }

@@ -54,7 +54,11 @@ __device__ __forceinline__ float wave_sum(float x)
     return x;
 }
 
-__global__ __launch_bounds__(BLK) void pen_stats_kernel(const float *__restrict__ vals, long n, float *stats)
+// per-block partial sums in a fixed grid, then ONE block adds them in block order: the same bits on every run (the first version added
+// the blocks' sums to stats[] with floating-point atomics, i.e. in arrival order)
+constexpr int PEN_BLOCKS = 256;
+
+__global__ __launch_bounds__(BLK) void pen_stats_partial_kernel(const float *__restrict__ vals, long n, float *__restrict__ part /* [PEN_BLOCKS][2] */)
 {
     float s = 0.0f, c = 0.0f;
     for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
@@ -79,9 +83,22 @@ __global__ __launch_bounds__(BLK) void pen_stats_kernel(const float *__restrict_
             ts += sh[0][i];
             tc += sh[1][i];
         }
-        unsafeAtomicAdd(&stats[0], ts);
-        unsafeAtomicAdd(&stats[1], tc);
+        part[blockIdx.x * 2 + 0] = ts;
+        part[blockIdx.x * 2 + 1] = tc;
     }
+}
+
+__global__ __launch_bounds__(64) void pen_stats_finalize_kernel(const float *__restrict__ part, int nblocks, float *__restrict__ stats)
+{
+    const int t = threadIdx.x;
+    if (t >= 2) return;
+    float v[PEN_BLOCKS];
+#pragma unroll
+    for (int b = 0; b < PEN_BLOCKS; b++) v[b] = b < nblocks ? part[b * 2 + t] : 0.0f;      // all loads first, then the sum in block order
+    float s = 0.0f;
+#pragma unroll
+    for (int b = 0; b < PEN_BLOCKS; b++) s += v[b];
+    stats[t] += s;                                                                          // the caller zeroes stats (historic contract)
 }
 
 }  // namespace
@@ -120,8 +137,12 @@ extern "C" int psi_sdf_penetration_stats(const float *sdf_vals, long n, float *s
     if (n == 0) return 0;
     PSI_REQUIRE(sdf_vals && stats, "null pointer");
     int blocks = psi_cdiv(n, BLK * 8);
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(pen_stats_kernel, dim3(blocks), dim3(BLK), 0, (hipStream_t)stream, sdf_vals, n, stats);
-    PSI_CHECK_LAUNCH("pen_stats_kernel");
+    if (blocks > PEN_BLOCKS) blocks = PEN_BLOCKS;
+    float *part = (float *)psi_scratch((size_t)PEN_BLOCKS * 2 * sizeof(float), (hipStream_t)stream);
+    PSI_REQUIRE(part != nullptr, "scratch allocation failed");
+    hipLaunchKernelGGL(pen_stats_partial_kernel, dim3(blocks), dim3(BLK), 0, (hipStream_t)stream, sdf_vals, n, part);
+    PSI_CHECK_LAUNCH("pen_stats_partial_kernel");
+    hipLaunchKernelGGL(pen_stats_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, blocks, stats);
+    PSI_CHECK_LAUNCH("pen_stats_finalize_kernel");
     return 0;
 }

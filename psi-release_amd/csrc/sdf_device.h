@@ -197,3 +197,54 @@ __device__ __forceinline__ float psi_sdf_sample_fast(const PsiSdfGrid &G, float 
     g[2] = gz * G.ku[2];
     return __builtin_fmaf(w[2], gz, r.x);
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// CELL-MAJOR layout (round 4; the fused engine's default, PSI_SDF_CELLS): every cell stores its OWN eight corner values, 32 contiguous
+// bytes [dx][dy][dz], cells in 4 x 4 x 4 bricks of 2 KB ([bx][by][bz][lx][ly][lz][8]); D cells per axis (the last cell repeats the
+// last voxel, so the border clamp needs no special case).  A sample is TWO 16-byte gathers into one aligned 32-byte record instead of
+// four 8-byte gathers spread over up to 124 bytes.  Why: counters of the fused skinning + SDF kernel at B = 512
+// (profiles/r04_pmc_skin_fwd_sdf_b512*.txt) show the first-level cache at 0.48 line accesses per clock and CU for the dense AND the
+// compressed-row body model — the kernel's time follows its L1 access count (45.9 M -> 158 us, 32.9 M -> 112 us), not its instruction
+// count (805 -> 459 vector instructions per wave moved the dense kernel by 4 %) — and a gather costs one access per LANE and
+// instruction: 4 x 64 (+ pairs that straddle a line) of a wave's ~390.  Eight times the plain volume (537 MB at 256^3; a body still
+// touches only the cells around it).
+// ------------------------------------------------------------------------------------------------
+constexpr int PSI_CELL_BRICK_BYTES = 2048;
+
+__device__ __forceinline__ float psi_sdf_sample_cells(const PsiSdfGrid &G, float x, float y, float z, float (&g)[3], bool (&in)[3])
+{
+    const float u[3] = {(x - G.o[0]) * G.ku[0], (y - G.o[1]) * G.ku[1], (z - G.o[2]) * G.ku[2]};
+    float w[3];
+    unsigned i[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        in[a] = u[a] > 0.0f && u[a] < G.dm1;                     // border: a clipped coordinate has zero gradient
+        const float uc = __builtin_amdgcn_fmed3f(u[a], 0.0f, G.dm1);
+        w[a] = __builtin_amdgcn_fractf(uc);
+        i[a] = (unsigned)(int)uc;                                // cell index 0 .. D - 1 (cell D - 1: both corners the last voxel, w = 0)
+    }
+    const unsigned brick = psi_mad24(psi_mad24(i[0] >> 2, G.nbr, i[1] >> 2), G.nbr, i[2] >> 2);
+    const unsigned local = ((i[0] & 3) << 9) | ((i[1] & 3) << 7) | ((i[2] & 3) << 5);
+#if PSI_EXP == 1
+    const unsigned off = 0 * ((brick << 11) + local);           // dev experiment: every lane reads record 0 (one line access per gather)
+#else
+    const unsigned off = (brick << 11) + local;                 // bytes
+#endif
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const char *vb = (const char *)G.brick;
+    const f4_t lo = *(const f4_t *)(vb + off), hi = *(const f4_t *)(vb + (off + 16u));       // x0 face, x1 face: (y0z0, y0z1, y1z0, y1z1)
+    const psi_f2v q00 = {lo.x, lo.y}, q01 = {lo.z, lo.w}, q10 = {hi.x, hi.y}, q11 = {hi.z, hi.w};
+    const psi_f2v wy2 = {w[1], w[1]}, wx2 = {w[0], w[0]};
+    const psi_f2v e0 = q01 - q00, e1 = q11 - q10;
+    const psi_f2v r0 = __builtin_elementwise_fma(wy2, e0, q00), r1 = __builtin_elementwise_fma(wy2, e1, q10);
+    const psi_f2v ex = r1 - r0;
+    const psi_f2v r = __builtin_elementwise_fma(wx2, ex, r0);
+    const psi_f2v ey = __builtin_elementwise_fma(wx2, e1 - e0, e0);
+    const float gz = r.y - r.x;
+    g[0] = __builtin_fmaf(w[2], ex.y - ex.x, ex.x) * G.ku[0];
+    g[1] = __builtin_fmaf(w[2], ey.y - ey.x, ey.x) * G.ku[1];
+    g[2] = gz * G.ku[2];
+    return __builtin_fmaf(w[2], gz, r.x);
+}
+

@@ -364,7 +364,7 @@ class FusedEngine:
                             align_corners=int(bool(op.align_corners)), world_size=world, num_pca_comps=lhc.shape[0],
                             max_history=4096, nn_mode=1 if op.nn_mode == 'kdtree' else 0, w_rec=op.weight_loss_rec, w_vposer=op.weight_loss_vposer,
                             w_contact=op.weight_contact, w_collision=op.weight_collision, contact_const=op.contact_const,
-                            lr=op.init_lr_h, beta1=0.9, beta2=0.999, eps=1e-8,
+                            lr=op.init_lr_h, beta1=0.9, beta2=0.999, eps=1e-8, lr_d=float(op.init_lr_h), beta1_d=0.9, beta2_d=0.999,
                             independent_bodies=int(bool(getattr(op, 'independent_bodies', False))),
                             concurrent_engines=int(getattr(op, 'concurrent_engines', 1)))
         self.concurrent_engines = int(getattr(op, 'concurrent_engines', 1))

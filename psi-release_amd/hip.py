@@ -76,7 +76,7 @@ SIGNATURES = {
     'psi_scene_losses_workspace_floats': (c_size_t, []),
     'psi_scene_losses_forward': (c_int, [c_void_p, c_long, c_void_p, c_long, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'psi_scene_losses_backward': (c_int, [c_void_p] * 7 + [c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float,
-                                          c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p]),
     'psi_dp_unique_id': (c_int, [c_void_p]),
     'psi_dp_comm_create': (c_int, [c_void_p, c_void_p, c_int, c_int]),
     'psi_dp_comm_destroy': (None, [c_void_p]),
@@ -98,7 +98,8 @@ class FitConfig(ctypes.Structure):
                 ('world_size', c_int), ('num_pca_comps', c_int), ('max_history', c_int), ('nn_mode', c_int),
                 ('w_rec', c_float), ('w_vposer', c_float), ('w_contact', c_float), ('w_collision', c_float),
                 ('contact_const', c_float), ('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float),
-                ('independent_bodies', c_int), ('concurrent_engines', c_int)]
+                ('independent_bodies', c_int), ('concurrent_engines', c_int),
+                ('lr_d', ctypes.c_double), ('beta1_d', ctypes.c_double), ('beta2_d', ctypes.c_double)]
 
 
 class PsiHipError(RuntimeError):

@@ -633,9 +633,11 @@ class _SceneLosses(Function):
         B, V = vals.shape
         table = ctx.scenes.verts_table
         g_verts = torch.empty(B, V, 3, device=vals.device)
+        chain = torch.empty(2 * xyz1.shape[1], dtype=torch.int32, device=vals.device)     # scratch: slots of a repeated contact vertex, chained
         hip.check(hip.lib().psi_scene_losses_backward(hip.ptr(g.contiguous().float()), hip.ptr(stats), hip.ptr(dist), hip.ptr(xyz1), hip.ptr(idx),
                                                       hip.ptr(slot), hip.ptr(table), table.shape[1], hip.ptr(vid32), hip.ptr(vals), hip.ptr(og), B,
-                                                      V, xyz1.shape[1], *ctx.w, hip.ptr(g_verts), hip.stream()), 'psi_scene_losses_backward')
+                                                      V, xyz1.shape[1], *ctx.w, hip.ptr(chain), hip.ptr(g_verts), hip.stream()),
+                  'psi_scene_losses_backward')
         return (g_verts if ctx.verts_dtype == g_verts.dtype else g_verts.to(ctx.verts_dtype),) + (None,) * 11
 
 

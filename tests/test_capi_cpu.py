@@ -97,7 +97,7 @@ def test_fit_config_struct_matches_header():
         ctype, names = decl.split(None, 1)
         for nm in names.split(','):
             fields.append((nm.strip(), ctype))
-    want = {'int': ctypes.c_int, 'float': ctypes.c_float}
+    want = {'int': ctypes.c_int, 'float': ctypes.c_float, 'double': ctypes.c_double}
     got = [(n, t) for n, t in hip.FitConfig._fields_]
     assert [n for n, _ in got] == [n for n, _ in fields]
     assert all(t is want[c] for (_, t), (_, c) in zip(got, fields))

@@ -1,8 +1,8 @@
 """BASELINE.json configs[3] at its per-rank shape against the ORACLE: "fitting_proxe.py batch=256 sharded 8xMI355X" = every rank holds 32
 bodies at the full scene size (n_c=2048, m=32768, 256^3 SDF) and the loss normalisers are global.  Here: 2 ranks x 32 bodies (gloo, both on
 the one GPU of the test box), 3 iterations; the gathered first-iteration gradient, the per-iteration loss values and the parameters must
-equal ``FittingOracle`` run on the GLOBAL batch of 64 (fitting_proxe.py:101-162,177-189 on 64 bodies) — see test_configs_gpu._check for
-what is compared exactly.  A separate module because it spawns processes: tests/conftest.py collects it after the single-process parity
+equal ``FittingOracle`` run on the GLOBAL batch of 64 (fitting_proxe.py:101-162,177-189 on 64 bodies), iteration by iteration from the
+ranks' own state, within bounds derived from the fp64 arbiter — see tests/arbiter.py for what is compared exactly.  A separate module because it spawns processes: tests/conftest.py collects it after the single-process parity
 modules."""
 import os
 import sys
@@ -13,7 +13,8 @@ import torch.multiprocessing as mp
 
 from conftest import ROOT
 from psi_release_amd import fitting, synth
-from test_configs_gpu import ITERS, LOSS, M, NC, D, _cfg, _check, _free_port, _oracle, _oracle_run, _run
+import arbiter
+from test_configs_gpu import ITERS, LOSS, M, NC, D, _cfg, _check, _free_port, _run
 
 pytestmark = pytest.mark.gpu
 
@@ -28,10 +29,8 @@ def _rank_worker(rank, world, port, tmp):
     bodies = synth.make_bodies(13, per * world)
     bodies['cam_ext'] = synth.make_cam_ext(9, per * world)
     op = fitting.FittingOP(_cfg(synth.make_smplx(7), synth.make_vposer_state(3), scene, per), dict(LOSS))
-    x, losses, m1 = _run(op, {k: v[rank * per:(rank + 1) * per] for k, v in bodies.items()})
-    np.save(os.path.join(tmp, 'x%d.npy' % rank), x)
-    np.save(os.path.join(tmp, 'l%d.npy' % rank), losses)
-    np.save(os.path.join(tmp, 'm%d.npy' % rank), m1)
+    trace = _run(op, {k: v[rank * per:(rank + 1) * per] for k, v in bodies.items()})
+    arbiter.save_trace(os.path.join(tmp, 'trace%d.npz' % rank), trace)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -40,12 +39,8 @@ def test_configs3_two_ranks_of_32_bodies_equal_the_oracle_on_64(tmp_path, smplx_
     world, per = 2, 32
     port = _free_port()
     mp.spawn(_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    x_gpu = np.concatenate([np.load(tmp_path / ('x%d.npy' % r)) for r in range(world)])
-    l0, l1 = np.load(tmp_path / 'l0.npy'), np.load(tmp_path / 'l1.npy')
-    assert np.array_equal(l0, l1)                   # every rank reports the GLOBAL loss values (one all-reduce per iteration)
+    trace = arbiter.load_traces([tmp_path / ('trace%d.npz' % r) for r in range(world)])     # rows concatenated; asserts the ranks' loss values agree
     scene = synth.make_scene(0, M, D, NC)
     bodies = synth.make_bodies(13, per * world)
     bodies['cam_ext'] = synth.make_cam_ext(9, per * world)
-    m_gpu = np.concatenate([np.load(tmp_path / ('m%d.npy' % r)) for r in range(world)])
-    fo = _oracle(smplx_data, vposer_sd, scene, per * world)
-    _check((x_gpu, l0, m_gpu), _oracle_run(fo, bodies, bodies['cam_ext']))
+    _check(trace, smplx_data, vposer_sd, scene, bodies, bodies['cam_ext'])

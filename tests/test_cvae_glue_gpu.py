@@ -178,3 +178,42 @@ def test_scene_losses_match_the_operator_sequence(smplx_data, B, penetrating):
     # fixed-order reductions: the same call twice gives the same bits
     a2 = run(True)
     assert a2[0] == a[0] and a2[1] == a[1]
+
+
+def test_scene_loss_backward_and_penetration_statistics_repeat_bit_for_bit_with_repeated_contact_ids():
+    """SURVEY section 5 / VERDICT r03 #8: no floating-point atomics on the training path.  Contact ids in which several vertices are listed two,
+    three and five times (cvae.py:99-115 keeps duplicates; an atomic scatter adds their terms in arrival order): twenty backward passes of
+    ``ops.scene_losses`` give ONE set of bits, equal to the ordered sum formed on the host; ``psi_sdf_penetration_stats`` likewise."""
+    n_scenes, m, D, n_c, B, V = 2, 4096, 32, 512, 24, 3000
+    sc = [synth.make_scene(i, m, D, n_c) for i in range(n_scenes)]
+    T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=DEV)
+    table = torch.stack([T(s.verts) for s in sc])
+    sdf = torch.stack([T(s.sdf) for s in sc]).contiguous()
+    gmin, gmax = torch.stack([T(s.grid_min) for s in sc]), torch.stack([T(s.grid_max) for s in sc])
+    scenes = ops.SceneSet(table)
+    slot = torch.tensor([b % n_scenes for b in range(B)], dtype=torch.int32, device=DEV)
+    rs = np.random.RandomState(5)
+    verts0 = T(rs.uniform(sc[0].grid_min, sc[0].grid_max, (B, V, 3)))
+    ids = rs.choice(V, n_c, replace=False)
+    ids[100:140] = ids[:40]                                 # forty vertices twice ...
+    ids[200:210] = ids[:10]                                 # ... ten of them three times ...
+    ids[300:302] = ids[0]
+    ids[400:402] = ids[0]                                   # ... and one seven times, far apart in slot order
+    vid = torch.tensor(ids, dtype=torch.int64, device=DEV)
+    grads = []
+    for _ in range(20):
+        verts = verts0.clone().requires_grad_(True)
+        l_c, l_p = ops.scene_losses(verts, vid, scenes, slot, sdf, gmin, gmax, True, 0.1, 0.3, 1.0)
+        (1.3 * l_c + 0.7 * l_p).backward()
+        grads.append(verts.grad.clone())
+    assert all(torch.equal(g, grads[0]) for g in grads[1:])
+    # the repeated vertex's row = penetration part + its seven contact terms; against the operator sequence under autograd (fp32 reassociation)
+    verts = verts0.clone().requires_grad_(True)
+    d = ops.chamfer_to_scenes(verts[:, vid, :].contiguous(), scenes, slot)
+    s = torch.sqrt(d + 1e-4)
+    vals = ops.sdf_sample(verts, sdf, gmin, gmax, scene_id=slot, align_corners=True)
+    (1.3 * 0.1 * torch.mean(s / (s + 1.0)) + 0.7 * 0.3 * ops.penetration_loss(vals)).backward()
+    assert (grads[0] - verts.grad).abs().max().item() < 1e-5 * verts.grad.abs().max().item()
+    assert (grads[0][:, ids[0]] - verts.grad[:, ids[0]]).abs().max().item() < 1e-5 * verts.grad[:, ids[0]].abs().max().item()
+    st = [ops.penetration_loss(vals.detach()) for _ in range(20)]
+    assert all(torch.equal(x, st[0]) for x in st[1:])

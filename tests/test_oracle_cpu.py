@@ -173,3 +173,77 @@ def test_fitting_golden(smplx_data, vposer_sd, tag):
     assert np.abs(np.array(rec) - g['traj_loss_' + tag]).max() < 2e-5
     assert rel_err(fo.xhr_rec.detach(), g['traj_final_xhr_' + tag]) < 1e-4
     assert np.abs(xh.detach().numpy() - g['traj_final_' + tag]).max() < 1e-3
+
+
+def test_arbiter_mode_bounds_the_fp32_oracle_and_the_reference(smplx_data, vposer_sd):
+    """``SMPLXOracle(dtype=float64)`` / ``FittingOracle`` on it = the ARBITER: the same restatement in double precision on the same
+    fp32-valued constants.  It is the yardstick of the GPU parity tests (|gpu - fp64| against |oracle_fp32 - fp64|); here it is held to
+    the reference's own recorded numbers: the reference's fp32 loss values and gradient (tests/golden/fitting_proxe.npz, recorded by
+    importing /root/reference) lie as close to the arbiter as this oracle's fp32 evaluation does."""
+    g = golden('fitting_proxe')
+    B, m, n_c, D = int(g['B']), int(g['m']), int(g['n_c']), int(g['D'])
+    sc = synth.make_scene(0, m, D, n_c)
+    vid = synth.contact_ids_from_parts(sc.contact_parts)
+    out = {}
+    for name, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        fo = O.FittingOracle(O.SMPLXOracle(smplx_data, dtype=dt), vposer_sd, sc.verts, sc.sdf, sc.grid_min, sc.grid_max, vid, B)
+        fo.xhr_rec.data = torch.tensor(g['xhr_rec0_ac1'], dtype=dt)
+        losses = fo.cal_loss(torch.tensor(g['xhr_ac1'], dtype=dt), torch.tensor(g['cam_ext'], dtype=dt))
+        assert all(l.dtype == dt for l in losses) and fo.last.verts.dtype == dt
+        sum(losses).backward()
+        out[name] = (np.array([float(l) for l in losses]), fo.xhr_rec.grad.numpy().astype(np.float64),
+                     fo.last.verts.detach().numpy().astype(np.float64))
+    l32, g32, v32 = out['f32']
+    l64, g64, v64 = out['f64']
+    # the fp32 oracle's own distance from the exact value: a few ulp of the operands
+    assert np.abs(l32 - l64).max() < 1e-6 and np.abs(v32 - v64).max() < 1e-5 and np.abs(g32 - g64).max() < 1e-5 * np.abs(g64).max()
+    # the reference's recorded fp32 numbers are no further from the arbiter than 4x that (different summation orders, same precision)
+    assert np.abs(g['loss0_ac1'] - l64).max() <= 4 * np.abs(l32 - l64).max() + 1e-7
+    assert np.abs(g['grad0_ac1'] - g64).max() <= 4 * np.abs(g32 - g64).max() + 1e-7 * np.abs(g64).max()
+    assert np.abs(g['verts0'] - v64).max() <= 4 * np.abs(v32 - v64).max() + 1e-7
+
+
+def test_arbiter_trace_check_accepts_the_fp32_oracle_and_rejects_a_perturbed_run(smplx_data, vposer_sd):
+    """tests/arbiter.py (the step-by-step check the GPU parity tests apply to the product) on a trace produced by the fp32 oracle's own
+    loop — it must pass — and on the same trace with one gradient entry of one iteration off by 1e-3 of the gradient scale, the Adam
+    update of another off by 1e-3, and one loss value off by 1e-4 — each must be rejected."""
+    import arbiter
+    B, m, n_c, D, iters = 12, 4096, 256, 64, 3
+    sc = synth.make_scene(0, m, D, n_c)
+    vid = synth.contact_ids_from_parts(sc.contact_parts)
+    bodies = synth.make_bodies(11, B)
+    cam = synth.make_cam_ext(5, B)
+    make = lambda dt: O.FittingOracle(O.SMPLXOracle(smplx_data, dtype=dt), vposer_sd, sc.verts, sc.sdf, sc.grid_min, sc.grid_max, vid, B)
+    fo = make(torch.float32)
+    xhr = O.convert_to_6d_rot(torch.as_tensor(synth.body_vector_72(bodies), dtype=torch.float32))
+    camt = torch.as_tensor(cam, dtype=torch.float32)
+    fo.xhr_rec.data = xhr.clone()
+    trace = []
+    f = lambda t: t.detach().numpy().astype(np.float64)
+    for it in range(iters):
+        st = fo.optimizer.state.get(fo.xhr_rec, {})
+        x0, m0, v0 = f(fo.xhr_rec), f(st.get('exp_avg', torch.zeros(B, 75))), f(st.get('exp_avg_sq', torch.zeros(B, 75)))
+        fo.optimizer.zero_grad()
+        ls = fo.cal_loss(xhr, camt)
+        sum(ls).backward()
+        fo.optimizer.step()
+        st = fo.optimizer.state[fo.xhr_rec]
+        trace.append(dict(x0=x0, m0=m0, v0=v0, x1=f(fo.xhr_rec), m1=f(st['exp_avg']), v1=f(st['exp_avg_sq']),
+                          losses=np.array([float(l.detach()) for l in ls])))
+    report = arbiter.check_trace(trace, make, np.asarray(cam, np.float64))
+    assert len(report) == iters and all(r['bodies_by_rule']['a'] == B for r in report), report     # the fp32 oracle against itself: rule (a)
+    import copy
+    gscale = np.abs(trace[1]['m1']).max() / 0.1
+    bad = copy.deepcopy(trace)
+    bad[1]['m1'][2, 40] += 0.1 * 1e-3 * gscale                       # the gradient of iteration 2, one entry, off by 1e-3 of the scale
+    with pytest.raises(AssertionError):
+        arbiter.check_trace(bad, make, np.asarray(cam, np.float64))
+    bad = copy.deepcopy(trace)
+    j = int(np.argmax(np.abs(trace[2]['m1'][1])))                     # a well-conditioned entry of body 1
+    bad[2]['x1'][1, j] += 1e-3
+    with pytest.raises(AssertionError):
+        arbiter.check_trace(bad, make, np.asarray(cam, np.float64))
+    bad = copy.deepcopy(trace)
+    bad[0]['losses'][3] += 1e-4
+    with pytest.raises(AssertionError):
+        arbiter.check_trace(bad, make, np.asarray(cam, np.float64))

@@ -9,13 +9,19 @@ line() {   # bench JSON line -> short summary
 import sys,json
 d=json.loads(sys.stdin.read()); kb=d.get('kernel_bandwidth',{}); print('$1', d['ms_per_step'], ' '.join('%s=%.1f/%.3f'%(k.replace('_kernel',''),v.get('us'),v.get('frac_hbm',0) or 0) for k,v in kb.items()))"
 }
-uselib() { if [ "$1" = default ]; then unset PSI_HIP_LIB; else export PSI_HIP_LIB=$GRAFT_REPO_ROOT/tools/_variants/$1.so; fi; }
+# a variant is <lib>[@VAR=value[@VAR=value]]: library build (default = the in-tree one) + environment switches for this run only
+uselib() {
+  local spec=$1 lib=${1%%@*}
+  for v in $PSI_CALL_VARS; do unset $v; done; PSI_CALL_VARS=""
+  if [ "$lib" = default ]; then unset PSI_HIP_LIB; else export PSI_HIP_LIB=$GRAFT_REPO_ROOT/tools/_variants/$lib.so; fi
+  if [ "$spec" != "$lib" ]; then IFS=@ read -ra kv <<< "${spec#*@}"; for e in "${kv[@]}"; do export "$e"; PSI_CALL_VARS="$PSI_CALL_VARS ${e%%=*}"; done; fi
+}
 for step in "$@"; do
   IFS=: read -r what a1 a2 <<< "$step"
   case $what in
     tests) ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; tail -4 $O/pytest.log ;;
     bench) ( time timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_default.json 2> $O/bench_default.err; tail -1 $O/bench_default.json | line default ;;
-    ab) for r in 1 2; do for l in ${a1//,/ }; do uselib $l; timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 $a2 2>>$O/ab.err | tail -1 | tee -a $O/ab_$l.json | line "$l [$a2]"; done; done; unset PSI_HIP_LIB ;;
+    ab) for r in 1 2; do for l in ${a1//,/ }; do uselib $l; timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 $a2 2>>$O/ab.err | tail -1 | tee -a "$O/ab_$l.json" | line "$l [$a2]"; done; done; uselib default ;;
     pmc512) args="--batch 512"; [ "$a1" = sparse ] && args="--batch 512 --weight-nnz 4"
       bash tools/pmc2.sh $TAG "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" ${a2:-psi_skin_fwd_kernel} python $GRAFT_REPO_ROOT/bench.py $args --steps 10 --warmup 3 --no-cpu-baseline --secondary 0 > $O/pmc_skin_fwd_sdf_b512_$a1.txt 2>&1; cat $O/pmc_skin_fwd_sdf_b512_$a1.txt ;;
     prof) rm -rf /tmp/prof_$TAG; ( cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 > $O/prof.log 2>&1 ); cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; head -12 $O/kernel_stats.csv | cut -c1-150 ;;

@@ -7,5 +7,5 @@ for o in $R/lib/obj/*.o; do b=$(basename $o .o); case $b in *_fma) continue;; es
 extra=""
 [ "$which" = "nnindex.hip" ] && extra="-ffp-contract=off"
 [ "$which" = "chamfer.hip" ] && extra="-ffp-contract=off -fno-slp-vectorize"
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -munsafe-fp-atomics -I$R/csrc $extra "$@" -c $src -o /tmp/var_$name.o && \
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -I$R/csrc $extra "$@" -c $src -o /tmp/var_$name.o && \
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/tools/_variants/$name.so $objs /tmp/var_$name.o && echo built tools/_variants/$name.so
