@@ -90,14 +90,21 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def rank_launch_command(n_gpus, argv, port=None, base_env=None):
+    """(command line, environment) with which `python bench.py --gpus N` starts its own N ranks: one process per GPU of ONE node under
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve), the caller's arguments passed through."""
+    env = dict(os.environ if base_env is None else base_env)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(n_gpus, 1) // 2)))
+    env['PSI_BENCH_SPAWNED'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port() if port is None else port), os.path.abspath(__file__)] + list(argv)
+    return cmd, env
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one per GPU, RCCL)."""
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC (RCCL across processes on this driver)
-    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1) // 2)))
-    env['PSI_BENCH_SPAWNED'] = '1'
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd, env = rank_launch_command(args.gpus, sys.argv[1:])
     return subprocess.call(cmd, env=env)
 
 
@@ -452,6 +459,27 @@ def bench_fitting(args):
         t[rank] = med / args.steps * 1e3
         torch.distributed.all_reduce(t)
         per_rank_ms = [round(float(x), 4) for x in t.tolist()]
+    # what RCCL ITSELF reports on every rank (ncclCommCount / ncclGetVersion through psi_dp_comm_info, all-gathered) and how each rank's
+    # loop was launched (psi_fit_dp_mode): a line produced on N GPUs shows N ranks that each saw N ranks, all on graphs — or says what else
+    # happened.  Single process: one entry, RCCL not loaded.
+    rccl_seen, rccl_version, dp_modes = [1], None, ['single process']
+    uses_rccl = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl' \
+        and args.engine_resolved == 'fused' and (world > 1 or os.environ.get('PSI_FORCE_DP_PATH') == '1')
+    if uses_rccl:
+        from psi_release_amd import dist as _pd
+        _, seen, ver = _pd.rccl_comm_info()
+        eng = (runners[0].eng if hasattr(runners[0], 'eng') else None)
+        mode = eng.dp_mode() if eng is not None else 0
+        t = torch.zeros(world, 3, device=device, dtype=torch.int64)
+        t[rank, 0], t[rank, 1], t[rank, 2] = seen, ver, mode
+        if world > 1:
+            torch.distributed.all_reduce(t)
+        rccl_seen = [int(x) for x in t[:, 0].tolist()]
+        rccl_version = int(t[0, 1])
+        dp_modes = [{0: 'python loop', 1: 'hipGraph (collective captured)', 2: 'eager from C (capture refused)'}.get(int(x), str(int(x))) for x in t[:, 2].tolist()]
+    elif world > 1:
+        dp_modes = ['python loop (%s collective)' % backend] * world
+        rccl_seen = [0] * world
 
     out = None
     if rank == 0:
@@ -468,7 +496,8 @@ def bench_fitting(args):
             'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': wl, 'skinning_weight_nnz': args.weight_nnz or 'dense', 'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'engine': args.engine_resolved,
                        'nn': op.nn_mode, 'parallelism': 'dp%d (rows sharded, one 6-float all-reduce per iteration)' % world,
-                       'rccl_world_size': rccl_world, 'backend': backend if world > 1 else 'none (single process)',
+                       'rccl_world_size': rccl_world, 'rccl_ranks_seen': rccl_seen, 'rccl_version': rccl_version, 'dp_launch_mode': dp_modes,
+                       'backend': backend if world > 1 else 'none (single process)',
                        'launcher': 'bench.py self-spawn' if os.environ.get('PSI_BENCH_SPAWNED') == '1' else ('torchrun' if world > 1 else 'direct'),
                        'protocol': 'median of %d blocks of %d steps (barrier + synchronize around each, max over ranks)' % (summ['repeats'], args.steps),
                        'final_losses': [round(float(x), 6) for x in losses]},

@@ -22,6 +22,7 @@ extern "C" {
 #endif
 
 #define PSI_EINVAL (-22)
+#define PSI_ETIMEOUT (-110)   /* psi_stream_wait: the stream was still busy at the bound */
 #define PSI_ENOMEM (-12)
 
 const char *psi_last_error(void);
@@ -232,6 +233,12 @@ int psi_dp_comm_info(const psi_dp_comm *comm, int *rank, int *world, int *rccl_v
  * training path's scalar reductions). */
 int psi_dp_allreduce_sum(psi_dp_comm *comm, float *d_buf, int n, void *stream);
 int psi_fit_iterate_dp(psi_fit_engine *engine, psi_dp_comm *comm, int n_iter, int use_graph, float *d_stats, void *stream);
+/* How this engine's data-parallel iterations have been launched so far: 0 = none yet, 1 = captured hipGraphs (the collective inside),
+ * 2 = eager launches from C (capturing the collective was refused once; results are the same). */
+int psi_fit_dp_mode(const psi_fit_engine *engine);
+/* Host-side wait for everything enqueued on `stream` with a bound (hipStreamQuery polls): 0 = done, PSI_ETIMEOUT = still busy after
+ * timeout_ms — the watchdog of the data-parallel loop (a collective that cannot complete becomes an error, not a hang). */
+int psi_stream_wait(void *stream, int timeout_ms);
 
 /* Per-kernel timing of one fitting iteration with HIP events on the launch stream (an event is recorded right after
  * every kernel launch of the sequence psi_fit_iterate runs; ungraphed), averaged over n_rep iterations.  Advances the

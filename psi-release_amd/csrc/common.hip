@@ -1,6 +1,8 @@
 // libpsi_hip.so: error reporting, device facts, growable scratch.
 #include "psi_internal.h"
 #include <stdarg.h>
+#include <chrono>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -96,3 +98,26 @@ extern "C" int psi_scratch_release(void *stream, int all)
 }
 
 thread_local PsiStageTimer *g_psi_timer = nullptr;
+
+// Host-side wait for everything enqueued on `stream`, with a bound: polls hipStreamQuery (no blocking synchronise) and gives up after
+// timeout_ms — a collective that never completes (a rank that died, ranks that disagree about how many collectives they issue) then
+// becomes an error the caller can report instead of a process that hangs for ever.  0: done; PSI_ETIMEOUT: still running at the bound.
+extern "C" int psi_stream_wait(void *stream, int timeout_ms)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long polls = 0;; polls++) {
+        hipError_t e = hipStreamQuery((hipStream_t)stream);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) {
+            psi_set_error("psi_stream_wait: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        const long ms = (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (timeout_ms >= 0 && ms >= timeout_ms) {
+            psi_set_error("psi_stream_wait: the stream was still busy after %d ms (a collective that cannot complete?)", timeout_ms);
+            return PSI_ETIMEOUT;
+        }
+        if (polls > 2000) std::this_thread::sleep_for(std::chrono::microseconds(200));    // the first ~ms spin, then back off
+    }
+}
+

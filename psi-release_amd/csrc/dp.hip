@@ -21,6 +21,8 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*GetVersion)(int *) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 };
 RcclApi g_rccl;
 std::mutex g_rccl_mu;
@@ -46,6 +48,8 @@ int rccl_load()
     a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
     a.GetVersion = (decltype(a.GetVersion))dlsym(h, "ncclGetVersion");
+    a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
+    a.CommUserRank = (decltype(a.CommUserRank))dlsym(h, "ncclCommUserRank");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
         psi_set_error("data parallel: librccl.so.1 lacks an expected symbol");
         return PSI_EINVAL;
@@ -113,8 +117,16 @@ extern "C" void psi_dp_comm_destroy(psi_dp_comm *c)
 extern "C" int psi_dp_comm_info(const psi_dp_comm *c, int *rank, int *world, int *rccl_version)
 {
     PSI_REQUIRE(c, "null communicator");
-    if (rank) *rank = c->rank;
-    if (world) *world = c->world;
+    // what RCCL itself says about the communicator (not what psi_dp_comm_create was told): a launcher that starts fewer ranks than
+    // it announces, or ranks that joined different communicators, show up here
+    if (rank) {
+        *rank = c->rank;
+        if (g_rccl.CommUserRank) PSI_CHECK_RCCL(g_rccl.CommUserRank(c->comm, rank));
+    }
+    if (world) {
+        *world = c->world;
+        if (g_rccl.CommCount) PSI_CHECK_RCCL(g_rccl.CommCount(c->comm, world));
+    }
     if (rccl_version) {
         *rccl_version = 0;
         if (g_rccl.GetVersion) (void)g_rccl.GetVersion(rccl_version);

@@ -59,7 +59,7 @@ constexpr int OS1 = HB / 8;             // output slices of W1^T (8 latent quads
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct FitDev {
-    int B, V, J, NB, n_c, m, D, align_corners, world, ncomp, nfp, nsdfblk;
+    int B, V, Vpad, J, NB, n_c, m, D, align_corners, world, ncomp, nfp, nsdfblk;
     int indep;                                        // 1: the B bodies are B independent problems (per-body loss normalisers)
     float w_rec, w_vp, w_contact, w_col, cconst;
     float lr, beta1, beta2, eps;
@@ -448,9 +448,11 @@ struct SdfPenEpilogue {
     PsiSdfGrid G;             // sampling constants of the bricked volume (G.brick == nullptr: the plain volume below)
     const float *sdf, *gmin, *gmax;
     float *og, *penpart;
-    int D, align_corners, V;
+    int D, align_corners, Vpad;
+    const int *contact_of;        // != nullptr: only the vertices that are contact queries (cs_first[v] != 0) are stored to `verts`
     float s[2];
     bool neg[2];                  // per body of the workgroup (the skinning kernel handles one or two)
+    __device__ __forceinline__ bool keeps_vertex(int v) const { return !contact_of || psi_ld<int>(contact_of, (unsigned)v * 4u) != 0; }
     __device__ __forceinline__ void vertex(int n, int b, int v, float x, float y, float z, bool live)
     {
         s[n] = 0.0f;
@@ -475,10 +477,9 @@ struct SdfPenEpilogue {
             for (int a = 0; a < 3; a++) g[a] = neg[n] ? g[a] : 0.0f;
             s[n] = neg[n] ? -val : 0.0f;
         }
-#if PSI_EXP == 3
-        if (g[0] == 1234.5f)                                      // dev experiment: no gradient store
-#endif
-        psi_st(og + (size_t)b * V * 3, (unsigned)v * 12u, psi_p3{g[0], g[1], g[2]});
+        // [B][Vpad][4]: one ALIGNED 16-byte store per lane, a wave = 1 KB = eight whole cache lines (a [B][V][3] row starts 4 bytes past a
+        // line boundary for every body but the first, and every wave's 768 bytes then end in two partially written lines)
+        psi_st(og + (size_t)b * Vpad * 4, (unsigned)v * 16u, f4{g[0], g[1], g[2], 0.0f});
     }
     __device__ __forceinline__ void finish(int n, int b, int vblock, int nvb)
     {
@@ -497,9 +498,10 @@ struct SdfPenEpilogue {
     }
 };
 
-static inline SdfPenEpilogue make_sdf_epilogue(const FitDev &f, const PsiSdfGrid &G)
+static inline SdfPenEpilogue make_sdf_epilogue(const FitDev &f, const PsiSdfGrid &G, bool contact_vertices_only = false)
 {
-    return SdfPenEpilogue{G, f.sdf, f.gmin, f.gmax, f.og, f.penpart, f.D, f.align_corners, f.V, {0.0f, 0.0f}, {false, false}};
+    return SdfPenEpilogue{G, f.sdf, f.gmin, f.gmax, f.og, f.penpart, f.D, f.align_corners, f.Vpad, contact_vertices_only ? f.cs_first : nullptr,
+                          {0.0f, 0.0f}, {false, false}};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -649,7 +651,7 @@ struct FitGradSource {
         p.cw = live ? psi_ld<int>(f.cs_first, (unsigned)v * 4u) : 0;
         for (int e = 0; e < 3; e++) { p.og[e] = 0.0f; p.q[e] = 0.0f; }
         if (live) {
-            const psi_p3 o = psi_ld<psi_p3>(f.og + (size_t)b * f.V * 3, (unsigned)v * 12u);      // body row base + lane offset: one 12-byte load
+            const f4 o = psi_ld<f4>(f.og + (size_t)b * f.Vpad * 4, (unsigned)v * 16u);         // body row base + lane offset: one aligned 16-byte load
             p.og[0] = o.x; p.og[1] = o.y; p.og[2] = o.z;
         }
         pp_valid = LOCAL && !f.indep;
@@ -790,8 +792,8 @@ struct FitGradSource {
     {
         const float Nb = sNb ? sNb[b - b0] : N;
         const float sp = Nb > 0.0f ? -f.w_col / Nb : 0.0f;     // d/d sdf_k of w * sum(-sdf)/N on the penetrating entries
-        const size_t o = ((size_t)b * f.V + v) * 3;
-        gx = sp * f.og[o + 0]; gy = sp * f.og[o + 1]; gz = sp * f.og[o + 2];
+        const f4 o = *(const f4 *)(f.og + ((size_t)b * f.Vpad + v) * 4);
+        gx = sp * o.x; gy = sp * o.y; gz = sp * o.z;
         for (int ci = f.cs_ptr[v]; ci < f.cs_ptr[v + 1]; ci++) {
             const float *q = f.gq + ((size_t)b * f.n_c + f.cs_idx[ci]) * 3;
             gx += q[0]; gy += q[1]; gz += q[2];
@@ -1058,6 +1060,8 @@ struct psi_fit_engine {
     char *blob;
     float *stats_local;           // engine-owned stats buffer (single-GPU path)
     bool merged_scene;            // skinning + SDF and the NN search in one launch (kd-tree mode, J <= 56, 4 lanes per query)
+    bool self_skin;               // the NN search can skin its own contact vertices (ContactSkinSrc): it does not read `verts`
+    bool keep_verts;              // the forward skinning kernel stores the camera-frame vertices (only needed when !self_skin)
     bool scene_skin_first;        // block order inside that launch: skinning + SDF workgroups before the NN-search workgroups
     int skin_nb;                  // bodies per workgroup of the forward skinning + SDF kernel (1 or 2: lbs_device.h)
     hipGraph_t graph, graphN;     // one iteration / GRAPH_UNROLL iterations
@@ -1123,11 +1127,13 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
         // skinning + SDF and the NN search of the contact vertices as ONE launch (fwd_scene_kernel)
         const psikd::KdDev T = psi_nn_index_dev(e->nn_index);
         const int nqb = f.nfp, n_kd = nqb * f.B;
+        FitDev fk = f;
+        if (!e->keep_verts) fk.verts = nullptr;
         if (e->skin_nb == 2)
-            hipLaunchKernelGGL(fwd_scene_kernel<2>, dim3(n_kd + f.nsdfblk * psi_cdiv(f.B, 2)), dim3(256), psikd::kd_lds_bytes(T.rows), st, f, e->lv.m,
+            hipLaunchKernelGGL(fwd_scene_kernel<2>, dim3(n_kd + f.nsdfblk * psi_cdiv(f.B, 2)), dim3(256), psikd::kd_lds_bytes(T.rows), st, fk, e->lv.m,
                                e->lv.A, e->lv.v_posed, T, n_kd, nqb, T.rows, gscale, e->scene_skin_first ? 1 : 0, make_sdf_epilogue(f, e->grid));
         else
-            hipLaunchKernelGGL(fwd_scene_kernel<1>, dim3(n_kd + f.nsdfblk * f.B), dim3(256), psikd::kd_lds_bytes(T.rows), st, f, e->lv.m, e->lv.A,
+            hipLaunchKernelGGL(fwd_scene_kernel<1>, dim3(n_kd + f.nsdfblk * f.B), dim3(256), psikd::kd_lds_bytes(T.rows), st, fk, e->lv.m, e->lv.A,
                                e->lv.v_posed, T, n_kd, nqb, T.rows, gscale, e->scene_skin_first ? 1 : 0, make_sdf_epilogue(f, e->grid));
         PSI_CHECK_LAUNCH("fwd_scene_kernel");
         psi_mark("fwd_scene_kernel", st);
@@ -1142,12 +1148,16 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
     // grounds that the kernel is vector-ALU bound at B = 512 (805 VALU instructions per wave, 660 of them the blend; profiles/
     // r03_pmc_skin_fwd_sdf_b512.txt).  It measured 191 us against 165: the fp32 MFMA runs at the vector FLOP rate and, as far as these timings
     // show, does not overlap the other waves' vector instructions, so the blend's cycles moved but did not disappear.)
+    // separate launches (large batches): the search reads its contact vertices from `verts` — letting its lane groups skin them
+    // themselves, as in the shared launch, measured 157 us against 113 for the search at B = 512 — so the skinning kernel stores those
+    // rows, and ONLY those (2048 of 10475: the rest of the 64 MB was written for nobody; PSI_KEEP_VERTS=1 stores all of them)
+    const bool all_verts = !e->nn_index || (getenv("PSI_KEEP_VERTS") && getenv("PSI_KEEP_VERTS")[0] == '1');
     if (e->skin_nb == 2)
         hipLaunchKernelGGL((psi_skin_fwd_kernel<SdfPenEpilogue, 2>), dim3(f.nsdfblk, psi_cdiv(f.B, 2)), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
-                           e->lv.v_posed, f.transl, f.cam, f.B, f.verts, make_sdf_epilogue(f, e->grid));
+                           e->lv.v_posed, f.transl, f.cam, f.B, f.verts, make_sdf_epilogue(f, e->grid, !all_verts));
     else
         hipLaunchKernelGGL((psi_skin_fwd_kernel<SdfPenEpilogue, 1>), dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
-                           e->lv.v_posed, f.transl, f.cam, f.B, f.verts, make_sdf_epilogue(f, e->grid));
+                           e->lv.v_posed, f.transl, f.cam, f.B, f.verts, make_sdf_epilogue(f, e->grid, !all_verts));
     PSI_CHECK_LAUNCH("skin_fwd_sdf_kernel");
     psi_mark("skin_fwd_sdf_kernel", st);
     if (e->nn_index)
@@ -1224,9 +1234,14 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     // (Round 3 also tried the opposite arrangement — no search workgroups at all, every skinning workgroup answering the contact queries of
     // its own 256 vertices from LDS after the SDF lookup: 1312 workgroups = one occupancy round instead of two, no second skinning of the
     // query vertices.  It measured 42 us against 33: the search became a serial tail of every workgroup instead of running beside them.)
-    e->merged_scene = cfg->nn_mode == 1 && J <= PSI_JP - 8 && psikd::LPQ == 4 && cfg->B <= 128 &&
-                      !(getenv("PSI_SPLIT_SCENE") && getenv("PSI_SPLIT_SCENE")[0] == '1');
+    e->self_skin = cfg->nn_mode == 1 && J <= PSI_JP - 8 && psikd::LPQ == 4;      // the search lanes can skin their own contact vertex
+    e->merged_scene = e->self_skin && cfg->B <= 128 && !(getenv("PSI_SPLIT_SCENE") && getenv("PSI_SPLIT_SCENE")[0] == '1');
+    // the vertices themselves are an output nobody reads when the search skins its own queries (the shared launch): not stored there
+    // (psi_fit_copy_buffer("verts") produces them on demand); with separate launches the search reads its contact rows, which are the
+    // only ones stored (fit_forward); PSI_KEEP_VERTS=1 stores all of them in every iteration
+    e->keep_verts = !e->merged_scene || (getenv("PSI_KEEP_VERTS") && getenv("PSI_KEEP_VERTS")[0] == '1');
     f.nsdfblk = psi_cdiv(V, 256);
+    f.Vpad = f.nsdfblk * 256;
     f.nfp = cfg->nn_mode == 1 ? psi_nn_index_fparts(f.n_c) : psi_nn_contact_fparts(f.n_c);
     f.max_hist = cfg->max_history > 0 ? cfg->max_history : 1024;
     // workgroups per body in the head / tail kernels: enough to put ~256 workgroups on the chip, none once the bodies alone do
@@ -1278,7 +1293,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     size_t o_x = take((size_t)B * XD * 4), o_xhr = take((size_t)B * XD * 4), o_cam = take((size_t)B * 16 * 4), o_am = take((size_t)B * XD * 4),
            o_av = take((size_t)B * XD * 4), o_step = take(256), o_h1 = take((size_t)B * NH * 4), o_h2 = take((size_t)B * NH * 4),
            o_o6 = take((size_t)B * 128 * 4), o_b20 = take((size_t)B * NB * 4), o_pose = take((size_t)B * J * 3 * 4), o_tr = take((size_t)B * 3 * 4),
-           o_verts = take((size_t)B * V * 3 * 4), o_og = take((size_t)B * V * 3 * 4),
+           o_verts = take((size_t)B * V * 3 * 4), o_og = take((size_t)B * psi_cdiv(V, 256) * 256 * 4 * 4),
            o_gq = take((size_t)B * f.n_c * 3 * 4), o_fp = take((size_t)B * f.nfp * 4), o_pp = take((size_t)B * f.nsdfblk * 2 * 4),
            o_rp = take((size_t)B * 4), o_vp = take((size_t)B * 4), o_gb = take((size_t)B * NB * 4), o_gp = take((size_t)B * J * 3 * 4),
            o_gt = take((size_t)B * 3 * 4), o_gr = take((size_t)B * J * 9 * 4), o_hist = take((size_t)f.max_hist * 4 * 4), o_stats = take(256), o_hint = take((size_t)B * f.n_c * 4);
@@ -1540,24 +1555,39 @@ extern "C" int psi_fit_iterate_dp(psi_fit_engine *e, psi_dp_comm *comm, int n_it
         e->dp_warm = true;
         if (!use_graph) return 0;
     }
+    // capture() = 0: graph ready; 1: the capture itself was refused (the stream's capture was invalidated by a call that is illegal under
+    // capture — an RCCL build / transport that needs host work per collective); anything else: a genuine error of the sequence, with the
+    // message of the call that failed, to be PROPAGATED (round 3 treated every failure as "cannot capture" and retried eagerly on a
+    // communicator that may already have been aborted, overwriting the error)
+    bool capture_refused = false;
     auto capture = [&](int iters, int slot) -> int {
         PSI_REQUIRE(st != nullptr, "graph capture needs a non-default stream");
         PSI_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
         int rc = 0;
         for (int i = 0; i < iters && !rc; i++) rc = one();
-        hipError_t ce = hipStreamEndCapture(st, &e->g_dp[slot]);
-        if (rc) {
-            if (ce == hipSuccess && e->g_dp[slot]) (void)hipGraphDestroy(e->g_dp[slot]);
+        hipGraph_t g = nullptr;
+        const hipError_t ce = hipStreamEndCapture(st, &g);
+        const bool invalidated = ce >= hipErrorStreamCaptureUnsupported && ce <= hipErrorStreamCaptureWrongThread;   // 900 .. 908
+        if (rc || ce != hipSuccess) {
+            if (g) (void)hipGraphDestroy(g);
+            if (invalidated) {
+                (void)hipGetLastError();
+                capture_refused = true;
+                return 1;
+            }
+            if (!rc) {
+                psi_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+                rc = (int)ce;
+            }
             return rc;
         }
-        PSI_CHECK_HIP(ce);
+        e->g_dp[slot] = g;
         PSI_CHECK_HIP(hipGraphInstantiate(&e->ge_dp[slot], e->g_dp[slot], nullptr, nullptr, 0));
         e->dp_ready[slot] = true;
         return 0;
     };
-    // A collective that cannot be captured (an RCCL build without graph support, a transport that needs host work per call) must not
-    // cost the run: the first failed capture switches this engine to eager launches of the same sequence — every rank takes the same
-    // decision at the same iteration, because they run the same code on the same communicator
+    // A collective that cannot be captured must not cost the run: the first refused capture switches this engine to eager launches of
+    // the same sequence — every rank takes the same decision at the same iteration, because they run the same code on the same communicator
     auto eager_rest = [&]() -> int {
         for (; done < n_iter; done++) {
             int rc = one();
@@ -1567,20 +1597,32 @@ extern "C" int psi_fit_iterate_dp(psi_fit_engine *e, psi_dp_comm *comm, int n_it
     };
     if (e->dp_no_graph) return eager_rest();
     if (n_iter - done >= GRAPH_UNROLL) {
-        if (!e->dp_ready[1] && capture(GRAPH_UNROLL, 1)) {
-            (void)hipGetLastError();
-            e->dp_no_graph = true;
-            return eager_rest();
+        if (!e->dp_ready[1]) {
+            const int rc = capture(GRAPH_UNROLL, 1);
+            if (rc && !capture_refused) return rc;
+            if (rc) {
+                e->dp_no_graph = true;
+                return eager_rest();
+            }
         }
         for (; done + GRAPH_UNROLL <= n_iter; done += GRAPH_UNROLL) PSI_CHECK_HIP(hipGraphLaunch(e->ge_dp[1], st));
     }
-    if (done < n_iter && !e->dp_ready[0] && capture(1, 0)) {
-        (void)hipGetLastError();
-        e->dp_no_graph = true;
-        return eager_rest();
+    if (done < n_iter && !e->dp_ready[0]) {
+        const int rc = capture(1, 0);
+        if (rc && !capture_refused) return rc;
+        if (rc) {
+            e->dp_no_graph = true;
+            return eager_rest();
+        }
     }
     for (; done < n_iter; done++) PSI_CHECK_HIP(hipGraphLaunch(e->ge_dp[0], st));
     return 0;
+}
+
+extern "C" int psi_fit_dp_mode(const psi_fit_engine *e)
+{
+    if (!e || !e->dp_warm) return 0;
+    return e->dp_no_graph ? 2 : 1;
 }
 
 // ---- differentiable body decode for the CVAE training losses (train_s1.py:136-170): the same head / LBS kernels, driven
@@ -1702,7 +1744,14 @@ extern "C" int psi_fit_copy_buffer(psi_fit_engine *e, const char *name, float *d
     FitDev &f = e->d;
     const float *src = nullptr;
     long cap = 0;
-    if (!strcmp(name, "verts")) { src = f.verts; cap = (long)f.B * f.V * 3; }
+    if (!strcmp(name, "verts")) {
+        src = f.verts; cap = (long)f.B * f.V * 3;
+        if (e->nn_index) {           // not (or only partly) stored by the iteration: skinned on demand from the last forward's v_posed and transforms
+            hipLaunchKernelGGL(psi_skin_fwd_kernel<PsiSkinNoEpilogue>, dim3(f.nsdfblk, f.B), dim3(PSI_SKIN_BLK), 0, (hipStream_t)stream, e->lv.m, e->lv.A,
+                               e->lv.v_posed, f.transl, f.cam, f.B, f.verts, PsiSkinNoEpilogue());
+            PSI_CHECK_LAUNCH("skin_fwd_kernel");
+        }
+    }
     else if (!strcmp(name, "pose")) { src = f.pose; cap = (long)f.B * f.J * 3; }
     else if (!strcmp(name, "g_pose")) { src = f.g_pose; cap = (long)f.B * f.J * 3; }
     else if (!strcmp(name, "g_rot")) { src = f.g_rot; cap = (long)f.B * f.J * 9; }

@@ -77,16 +77,37 @@ def rccl_comm():
         return _RCCL_COMM[key]
     L = hip.lib()
     buf = ctypes.create_string_buffer(128)
+    status = 0
     if dist.get_rank() == 0:
-        hip.check(L.psi_dp_unique_id(buf), 'psi_dp_unique_id')
-    box = [bytes(buf.raw)]
+        status = L.psi_dp_unique_id(buf)
+    # the id travels WITH rank 0's status: if drawing it failed, every rank raises here together (a rank 0 that raised before the
+    # broadcast left the others waiting in it for ever)
+    box = [(int(status), bytes(buf.raw), hip.last_error() if status else '')]
     if dist.get_world_size() > 1:
         dist.broadcast_object_list(box, src=0)
+    if box[0][0]:
+        raise RuntimeError('psi_dp_unique_id failed on rank 0 (%d): %s' % (box[0][0], box[0][2]))
     h = ctypes.c_void_p()
-    hip.check(L.psi_dp_comm_create(ctypes.byref(h), ctypes.create_string_buffer(box[0], 128), dist.get_rank(), dist.get_world_size()),
-              'psi_dp_comm_create')
+    rc = L.psi_dp_comm_create(ctypes.byref(h), ctypes.create_string_buffer(box[0][1], 128), dist.get_rank(), dist.get_world_size())
+    # ... and so does joining: a rank whose ncclCommInitRank failed tells the others before anybody issues a collective on it
+    ok = torch.tensor([0 if rc else 1], device='cuda', dtype=torch.int32)
+    if dist.get_world_size() > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    hip.check(rc, 'psi_dp_comm_create')
+    if int(ok.item()) == 0:
+        raise RuntimeError('psi_dp_comm_create failed on another rank')
     _RCCL_COMM[key] = h
     return h
+
+
+def rccl_comm_info(h=None):
+    """(rank, ranks, version) as RCCL itself reports them for the library-owned communicator (ncclCommUserRank / ncclCommCount /
+    ncclGetVersion): what bench.py prints per rank, so that a multi-GPU line shows how many ranks RCCL really saw."""
+    import ctypes
+    h = rccl_comm() if h is None else h
+    r, w, v = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(0)
+    hip.check(hip.lib().psi_dp_comm_info(h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(v)), 'psi_dp_comm_info')
+    return r.value, w.value, v.value
 
 
 def rccl_comm_release():

@@ -416,8 +416,22 @@ class FusedEngine:
                 tdist.all_reduce(self.stats, op=tdist.ReduceOp.SUM)           # the one collective of the data path
                 hip.check(L.psi_fit_backward_step(self.handle, hip.ptr(self.stats), int(bool(use_graph)), self.stream.cuda_stream), 'psi_fit_backward_step')
 
+    def dp_mode(self):
+        """How the data-parallel iterations of this engine were launched: 0 none yet / python loop, 1 hipGraphs with the collective
+        inside, 2 eager launches from C (psi_fit_dp_mode)."""
+        return int(hip.lib().psi_fit_dp_mode(self.handle))
+
+    def watchdog(self):
+        """Data-parallel runs: wait for the engine's stream with a bound (PSI_DP_WATCHDOG_S seconds, default 60) before a blocking read —
+        a collective that can never complete (a rank that died, ranks that issued different numbers of collectives) becomes an error
+        with a message instead of a process that hangs in hipStreamSynchronize for ever."""
+        if self.world > 1 or os.environ.get('PSI_FORCE_DP_PATH') == '1':
+            limit = float(os.environ.get('PSI_DP_WATCHDOG_S', '60'))
+            hip.check(hip.lib().psi_stream_wait(self.stream.cuda_stream, int(limit * 1000)), 'psi_stream_wait (data-parallel watchdog)')
+
     def read(self, n_hist=0):
         op = self.op
+        self.watchdog()
         x = torch.empty(op.batch_size, 75, device=op.device)
         hist = torch.empty(max(n_hist, 1), 4, device=op.device)
         step = ctypes.c_int(0)
@@ -429,6 +443,7 @@ class FusedEngine:
     def read_losses(self, adam_step):
         """The four loss values of Adam step ``adam_step`` (one 16-byte copy, not the whole history ring)."""
         out = torch.empty(4, device=self.op.device)
+        self.watchdog()
         hip.check(hip.lib().psi_fit_read_losses(self.handle, int(adam_step), hip.ptr(out), self.stream.cuda_stream), 'psi_fit_read_losses')
         self.stream.synchronize()
         return out

@@ -77,6 +77,8 @@ SIGNATURES = {
     'psi_scene_losses_forward': (c_int, [c_void_p, c_long, c_void_p, c_long, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'psi_scene_losses_backward': (c_int, [c_void_p] * 7 + [c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float,
                                           c_void_p, c_void_p, c_void_p]),
+    'psi_fit_dp_mode': (c_int, [c_void_p]),
+    'psi_stream_wait': (c_int, [c_void_p, c_int]),
     'psi_dp_unique_id': (c_int, [c_void_p]),
     'psi_dp_comm_create': (c_int, [c_void_p, c_void_p, c_int, c_int]),
     'psi_dp_comm_destroy': (None, [c_void_p]),
@@ -122,6 +124,10 @@ def lib():
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+def last_error() -> str:
+    return lib().psi_last_error().decode()
 
 
 def check(rc: int, what: str):

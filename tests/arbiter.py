@@ -19,8 +19,9 @@ Per iteration:
       (b) it is no further from the ARBITER than K_NOISE x the fp32 oracle's own distance from the arbiter in that body (the reference's
           rotation-matrix -> quaternion -> angle-axis chain, cvae.py:128-137, is ill-conditioned for some orientations: there the fp32
           oracle itself is 1e-3..1e-2 from the exact gradient, and an implementation that rounds differently must be allowed the same), or
-      (c) the body contains a vertex whose fp64 SDF value is within AMBIGUOUS of zero — the ``sdf < 0`` mask (fitting_proxe.py:155) is
-          discontinuous and a correct fp32 evaluation may count such a vertex either way — and (a) or (b) holds against the oracle /
+      (c) the body contains a vertex whose fp64 SDF value is within tau of zero, tau = K_NOISE x the largest |sdf_fp32 - sdf_fp64| the fp32
+          ORACLE itself shows over all vertices (>= AMBIGUOUS) — the ``sdf < 0`` mask (fitting_proxe.py:155) is discontinuous and a
+          correct fp32 evaluation may count such a vertex either way — and (a) or (b) holds against the oracle /
           arbiter evaluated with those vertices counted in or counted out (both are tried; bodies without such a vertex see the mask only
           through the global count N, a relative change of n_ambiguous / N that is added to their bounds);
     the test reports how many bodies needed (b) or (c);
@@ -33,7 +34,7 @@ import torch
 import psi_oracle as O
 
 K_NOISE = 4.0          # implementation-vs-arbiter may be this many times the fp32 oracle's own distance from the arbiter
-AMBIGUOUS = 1e-6       # |sdf_fp64| below this: the sdf < 0 decision of the vertex is not determined in fp32
+AMBIGUOUS = 1e-6       # floor of the ambiguity threshold tau (below): |sdf_fp64| < tau: the sdf < 0 decision of the vertex is not determined in fp32
 BETA1, BETA2, EPS = 0.9, 0.999, 1e-8    # torch.optim.Adam defaults (fitting_proxe.py:73-74)
 
 
@@ -117,14 +118,19 @@ def check_trace(trace, make_oracle, cam, lr=0.1, first_step=1):
     report = []
     for i, t in enumerate(trace):
         step = first_step + i
-        l32, g32, _ = _evaluate(f32, t['x0'], xhr, cam)
+        l32, g32, sdf32 = _evaluate(f32, t['x0'], xhr, cam)
         l64, g64, sdf64 = _evaluate(f64, t['x0'], xhr, cam)
-        amb = np.abs(sdf64) < AMBIGUOUS
+        # how far an fp32 evaluation of a vertex's SDF value is from the exact one (vertex coordinates of a few metres carry ~5e-7 m of
+        # rounding, times |grad sdf| ~ 1): measured on the fp32 oracle, not assumed
+        tau = max(AMBIGUOUS, K_NOISE * float(np.abs(sdf32 - sdf64).max()))
+        amb = np.abs(sdf64) < tau
         n_pen = max(int((sdf64 < 0).sum()), 1)
         scale = np.abs(g64).max()
         slack = (amb.sum() / n_pen) * scale                    # the global count N seen by bodies without an ambiguous vertex
         # --- loss values (continuous in the parameters: no event rule needed)
-        l_bound = K_NOISE * np.abs(l32 - l64) + 3e-6 * np.maximum(np.abs(l64), 1e-2) + amb.sum() * AMBIGUOUS / n_pen
+        # (a vertex counted the other way moves the penetration MEAN by about mean / N: the count changes by one, the sum by < AMBIGUOUS)
+        l_bound = K_NOISE * np.abs(l32 - l64) + 3e-6 * np.maximum(np.abs(l64), 1e-2)
+        l_bound[3] += amb.sum() * 1.5 * (np.abs(l64[3]) + tau) / n_pen
         assert np.all(np.abs(t['losses'] - l64) <= l_bound), (step, t['losses'], l64, l32, l_bound)
         # --- gradient, per body
         g_gpu = (t['m1'] - BETA1 * t['m0']) / (1 - BETA1)
@@ -158,5 +164,5 @@ def check_trace(trace, make_oracle, cam, lr=0.1, first_step=1):
                            grad_vs_oracle32_rel=float(np.median(bmax(g_gpu - g32)) / scale), grad_vs_oracle32_worst_rel=float(bmax(g_gpu - g32).max() / scale),
                            oracle32_vs_arbiter_worst_rel=float(bmax(g32 - g64).max() / scale),
                            bodies_by_rule=dict(a=int(ok_a.sum()), b_only=int((ok_b & ~ok_a).sum()), c_only=int((ok_c & ~ok_a & ~ok_b).sum())),
-                           ambiguous_vertices=int(amb.sum()), x_update_err=float(xerr.max())))
+                           ambiguous_vertices=int(amb.sum()), ambiguity_threshold=tau, x_update_err=float(xerr.max())))
     return report

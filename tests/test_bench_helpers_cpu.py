@@ -61,3 +61,17 @@ def test_rank_launcher_command_line(monkeypatch):
     cmd = ' '.join(seen['cmd'])
     assert rc == 0 and 'torch.distributed.run' in cmd and '--nproc-per-node 4' in cmd.replace('=', ' ') and '127.0.0.1' in cmd
     assert cmd.rstrip().endswith('--gpus 4 --steps 20 --warmup 5')
+
+
+def test_rank_launch_command_for_an_eight_gpu_node():
+    """The command line and environment with which `bench.py --gpus 8` starts its ranks (configs[3]: 8 x 32 bodies): eight processes on
+    one node under torch.distributed.run, loopback rendezvous, the caller's arguments passed through unchanged, dmabuf IPC for RCCL."""
+    argv = ['--gpus', '8', '--steps', '20', '--warmup', '5']
+    cmd, env = bench.rank_launch_command(8, argv, port=29555, base_env={'PATH': '/usr/bin'})
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '8'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '29555'
+    script = cmd.index(os.path.join(ROOT, 'bench.py'))
+    assert cmd[script + 1:] == argv                                             # bench.py then joins the job: RANK / WORLD_SIZE from the env
+    assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and env['PSI_BENCH_SPAWNED'] == '1' and int(env['OMP_NUM_THREADS']) >= 1
+    assert env['PATH'] == '/usr/bin'
