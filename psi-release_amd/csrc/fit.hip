@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, c
                                           f.gq, f.fpart, f.nn_hint, rows, (const psikd::KdDev *)nullptr, (const int *)nullptr, bx, b, nqb, smem_i);
     } else {
         const int i = bid;
-        psi_skin_fwd_body<NB, (NB > 1 ? 2 : PSI_DENSE_AHEAD)>(m, As, v_posed, f.transl, f.cam, f.B, f.verts, epi, i % f.nsdfblk, (i / f.nsdfblk) * NB, f.nsdfblk);
+        psi_skin_fwd_body<NB, PsiBlendCompact>(m, As, v_posed, f.transl, f.cam, f.B, f.verts, epi, i % f.nsdfblk, (i / f.nsdfblk) * NB, f.nsdfblk);
     }
 }
 
@@ -1176,7 +1176,12 @@ static int fit_backward(psi_fit_engine *e, float *stats, hipStream_t st, bool lo
 {
     FitDev &f = e->d;
     local = fit_use_local_stats(f, local);
-    const bool mb = f.B >= PSI_SKIN_MB_MIN_B;
+    // large batches: compressed rows keep the multi-body kernel (a lane's weights in registers, eight bodies per workgroup); DENSE rows
+    // take one body per workgroup with the pipelined scalar-cache blend — the multi-body kernel reads the transforms as LDS broadcasts
+    // and is bound by the LDS return path with 55-joint rows (PSI_BWDV_MB=1: the multi-body kernel for dense rows too)
+    static const bool dense_mb = getenv("PSI_BWDV_MB") && getenv("PSI_BWDV_MB")[0] == '1';
+    const bool big = f.B >= PSI_SKIN_MB_MIN_B;
+    const bool mb = big && (e->lv.m.Wc || dense_mb);
     const dim3 bgrid(f.nsdfblk, mb ? psi_cdiv(f.B, PSI_SKIN_MB) : f.B);
     if (local && mb)
         psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, FitGradSource<true>{f, stats, 0.0f, nullptr, 0, {}, false}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
@@ -1185,6 +1190,9 @@ static int fit_backward(psi_fit_engine *e, float *stats, hipStream_t st, bool lo
                            FitGradSource<true>{f, stats, 0.0f, nullptr, 0, {}, false}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
     else if (mb)
         psi_launch_skin_bwd_v_mb(e->lv.m, e->lv.A, FitGradSource<false>{f, stats, 0.0f, nullptr, 0, {}, false}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w, st);
+    else if (big)
+        hipLaunchKernelGGL((psi_skin_bwd_v_kernel<FitGradSource<false>, PsiBlendPipelined>), bgrid, dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
+                           FitGradSource<false>{f, stats, 0.0f, nullptr, 0, {}, false}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);
     else
         hipLaunchKernelGGL(psi_skin_bwd_v_kernel<FitGradSource<false>>, bgrid, dim3(PSI_SKIN_BLK), 0, st, e->lv.m, e->lv.A,
                            FitGradSource<false>{f, stats, 0.0f, nullptr, 0, {}, false}, f.cam, f.B, e->lv.gl, e->lv.g_vp, e->lv.gt_part_w);

@@ -855,6 +855,8 @@ static int lbs_launch_bwd_joint_parts(const LbsDev &m, const WsLayout &L, int B,
     int nbody = psi_cdiv(B, 256 / L.nsv > 0 ? 256 / L.nsv : 1);
     if (nbody > SKA_NBODY) nbody = SKA_NBODY;
     if (const char *ev = getenv("PSI_SKA_NBODY")) { int v = atoi(ev); if (v >= 1 && v <= SKA_NBODY) nbody = v; }
+    // (Round 4 measured the two halves as two launches of this kernel — stream workgroups, then the skin_bwd_A workgroups: 18.4 us each by
+    // rocprofv3 = 36.8 against 27.2 for the heterogeneous grid, profiles/r04_ab_blend_loop.txt.  One grid it stays.)
     const int grid = n_blend + L.nsv * psi_cdiv(B, nbody);
 #define PSI_LAUNCH_JOINT(MT_)                                                                                                      \
     hipLaunchKernelGGL(bwd_joint_kernel<MT_>, dim3(grid), dim3(256), 0, st, m, ws + L.g_vp, ws + L.gl, ws + L.v_posed, B, steps,     \

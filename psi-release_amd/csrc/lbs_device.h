@@ -449,29 +449,27 @@ __device__ __forceinline__ void psi_st(void *uniform_base, unsigned lane_off, co
 //
 // Dense rows: the transforms are the same for every lane of the workgroup — read through the SCALAR cache (48 bytes per joint and
 // wave) instead of LDS broadcasts (3 KB per joint and wave: at 55 joints the LDS return path, 128 B/clk per CU, bounded the
-// skinning kernels: 26 k cycles per CU = 11 us for the 20 resident waves).  Weights come through a buffer descriptor: the row
-// offset j * Vpad * 4 is a scalar operand of the load and the lane offset v * 4 one register shared by all joints (a
-// `WT[(size_t)j * Vpad + v]` access was a 64-bit vector add per joint); rows from J on are outside the descriptor's range and read
-// as 0 without a memory access.  Joints are taken in groups of PSI_DENSE_UNROLL with the NEXT group's weights requested while the
-// current group is accumulated; a scheduling fence every PSI_DENSE_AHEAD joints bounds how many scalar loads are in flight (left
-// alone, the scheduler requests two groups' worth — 264 scalar registers — and spills through v_writelane / v_readlane inside
-// the loop).  PSI_DENSE_LOOP selects the loop form:
-//   1  compact: ONE group of code; a weight register is re-requested for the next group right after its joint has been accumulated
-//      (the last group's requests are out of range: no traffic).  Smallest instruction footprint — a cold instruction cache line is
-//      a trip to memory on the critical path of a 15 us kernel.
-//   0  ping-pong: two register groups filled and used alternately, two groups of code + tail.
-#ifndef PSI_EXP
-#define PSI_EXP 0            // dev: bound-isolating experiments of the skinning + SDF kernel (tools/gpu_call.sh); 0 in every shipped build
-#endif
+// skinning kernels: 26 k cycles per CU = 11 us for the 20 resident waves).  Weights come from the wave-tiled copy WTt through a
+// buffer descriptor: tile offset (scalar) + lane * 4, the joint as an instruction IMMEDIATE (a `WT[(size_t)j * Vpad + v]` access was a
+// 64-bit vector add per joint, 55 of the kernel's 805 vector instructions per wave in round 3).  A weight register is re-requested
+// for the next group right after its joint has been accumulated (the last group re-requests its own rows: first-level cache hits).
+// Two forms of the joint loop (rocprofv3, profiles/r04_ab_blend_loop.txt):
+//   PsiBlendCompact    one group of 11 joints of code in a loop, no scheduling fences: the scheduler hoists a group's scalar loads
+//                      itself (a few scalar registers spill).  The smallest instruction footprint and the fewest scalar round trips in
+//                      a row — what the latency-bound BASELINE batch wants (skin_bwd_v 14.0 us; with a fence every 4 joints 15.2, every
+//                      2 joints 16.3; round 3's loop 14.7).
+//   PsiBlendPipelined  groups of 12 joints (J padded: the extra joints have zero weights and read the finite rows behind the body's
+//                      transforms) in sets of PS joints whose transforms sit in TWO alternating sets of scalar registers: the scalar
+//                      loads of set i + 1 are issued BEFORE set i is accumulated, so a wave hides them behind its own packed FMAs
+//                      instead of draining the scalar-load counter (it cannot count out-of-order returns: every wait is "all of
+//                      them") in front of every set.  SMPL-X's five groups are straight-line code: at a loop header the compiler waits
+//                      for EVERY outstanding weight load, i.e. for the two requested a few cycles earlier; in straight-line code its
+//                      waits are exact.  What the throughput-bound large batches want (skin_fwd_sdf at B = 512, dense rows: 136 us
+//                      against 150 for the same code as a loop and 158 for the compact form).
 #ifndef PSI_DENSE_UNROLL
 #define PSI_DENSE_UNROLL 11
 #endif
-#ifndef PSI_DENSE_AHEAD
-#define PSI_DENSE_AHEAD 4
-#endif
-#ifndef PSI_DENSE_LOOP
-#define PSI_DENSE_LOOP 1
-#endif
+enum PsiBlendForm { PsiBlendCompact = 0, PsiBlendPipelined = 1 };
 template <int NB>
 struct PsiBlendN {
     psi_f2 st[NB][2];             // this thread's share of the bodies' transforms (J * 6 float pairs over 256 threads, J <= 85)
@@ -514,7 +512,7 @@ struct PsiBlendN {
         __syncthreads();
         return sA;
     }
-    template <int AH = PSI_DENSE_AHEAD>
+    template <PsiBlendForm FORM = PsiBlendCompact>
     __device__ __forceinline__ void blend(const LbsDev &m, Staged sA, int v, psi_f2 (&T2)[NB][6]) const
     {
 #pragma unroll
@@ -541,77 +539,91 @@ struct PsiBlendN {
         const psi_f2 *Ab[NB];
 #pragma unroll
         for (int n = 0; n < NB; n++) Ab[n] = (const psi_f2 *)As_b[n];
-        // weights from the wave-tiled copy: descriptor base + the tile's scalar offset + lane * 4, the joint as an IMMEDIATE (k * 256 bytes)
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)m.WTt, 0, PSI_JP * m.Vpad * 4, 0x00020000);
-#if PSI_EXP != 2
         const unsigned v4 = (unsigned)(v & 63) * 4u;
-#endif
         const unsigned tile_off = (unsigned)__builtin_amdgcn_readfirstlane(v >> 6) * (unsigned)(PSI_JP * 64 * 4);   // a wave = 64 consecutive vertices
-        constexpr int GJ = PSI_DENSE_UNROLL;
-        static_assert(GJ * 256 <= 4096, "joint offsets of a group must fit the load's 12-bit immediate");
-        auto fma6 = [&](float w, int j) {
-            psi_f2 w2 = {w, w};
-#pragma unroll
-            for (int n = 0; n < NB; n++)
-#pragma unroll
-                for (int e = 0; e < 6; e++) T2[n][e] = __builtin_elementwise_fma(w2, Ab[n][j * 6 + e], T2[n][e]);
-        };
-#if PSI_DENSE_LOOP == 1
-        float w[GJ];
-#if PSI_EXP == 2
-        const unsigned v4 = 0;                                       // dev experiment: every lane reads the tile's first weight (one line access per load)
-#endif
+        auto wload = [&](int k, unsigned ro) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, v4 + k * 256, ro, 0)); };
         unsigned ro = tile_off;                                      // scalar offset of the group being requested
+        if (FORM == PsiBlendCompact) {
+            constexpr int GJ = PSI_DENSE_UNROLL;
+            static_assert(GJ * 256 <= 4096, "joint offsets of a group must fit the load's 12-bit immediate");
+            float w[GJ];
 #pragma unroll
-        for (int k = 0; k < GJ; k++) w[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, v4 + k * 256, ro, 0));
-        int j0 = 0;
+            for (int k = 0; k < GJ; k++) w[k] = wload(k, ro);
+            auto fma6 = [&](float wj, int j) {
+                psi_f2 w2 = {wj, wj};
+#pragma unroll
+                for (int n = 0; n < NB; n++)
+#pragma unroll
+                    for (int e = 0; e < 6; e++) T2[n][e] = __builtin_elementwise_fma(w2, Ab[n][j * 6 + e], T2[n][e]);
+            };
+            int j0 = 0;
 #pragma nounroll
-        for (; j0 + GJ <= m.J; j0 += GJ) {
-            ro += j0 + GJ < m.J ? GJ * 256 : 0;                      // the last trip re-requests its own rows (first-level cache hits, unused)
+            for (; j0 + GJ <= m.J; j0 += GJ) {
+                ro += j0 + GJ < m.J ? GJ * 256 : 0;
 #pragma unroll
-            for (int k = 0; k < GJ; k++) {
-                if (k % AH == 0) __builtin_amdgcn_sched_barrier(0);
-                fma6(w[k], j0 + k);
-                w[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, v4 + k * 256, ro, 0));   // joint j0 + GJ + k, for the next trip
+                for (int k = 0; k < GJ; k++) {
+                    fma6(w[k], j0 + k);
+                    w[k] = wload(k, ro);                             // joint j0 + GJ + k, for the next trip
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
 #pragma unroll
-        for (int k = 0; k < GJ; k++)                                 // J % GJ joints are left (none for J = 55)
-            if (j0 + k < m.J) fma6(w[k], j0 + k);
-#else
-        float wa[GJ], wb[GJ];                                      // two register groups, filled and used alternately (no copies)
-        auto request = [&](float (&w)[GJ], int j0) {
-            const unsigned ro = tile_off + (unsigned)j0 * 256u;     // rows J .. PSI_JP - 1 of a tile are zero
-#pragma unroll
-            for (int k = 0; k < GJ; k++) w[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, v4 + k * 256, ro, 0));
-        };
-        // a last group that runs past J is padded, not guarded: its weights read as 0 and its transforms are row J - 1's
-        auto accumulate = [&](const float (&w)[GJ], int j0, bool padded) {
-#pragma unroll
-            for (int k = 0; k < GJ; k++) {
-                if (k % AH == 0) __builtin_amdgcn_sched_barrier(0);
-                fma6(w[k], padded ? min(j0 + k, m.J - 1) : j0 + k);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        request(wa, 0);
-        int j0 = 0;
-#pragma nounroll
-        for (; j0 + 2 * GJ < m.J; j0 += 2 * GJ) {                  // two whole groups, and another one behind them
-            request(wb, j0 + GJ);
-            accumulate(wa, j0, false);
-            request(wa, j0 + 2 * GJ);
-            accumulate(wb, j0 + GJ, false);
-        }
-        if (m.J - j0 > GJ) {                                        // wa holds group j0; one or two groups are left
-            request(wb, j0 + GJ);
-            accumulate(wa, j0, false);
-            accumulate(wb, j0 + GJ, true);
+            for (int k = 0; k < GJ; k++)                             // J % GJ joints are left (none for J = 55)
+                if (j0 + k < m.J) fma6(w[k], j0 + k);
         } else {
-            accumulate(wa, j0, true);
+            constexpr int G2 = 12, PS = NB == 1 ? 2 : 1;
+            static_assert(G2 % (2 * PS) == 0, "a group is a whole number of set pairs");
+            float w[G2];
+#pragma unroll
+            for (int k = 0; k < G2; k++) w[k] = wload(k, ro);
+            psi_f2 P0[NB][PS][6], P1[NB][PS][6];
+            auto aload = [&](psi_f2 (&P)[NB][PS][6], int j) {
+#pragma unroll
+                for (int n = 0; n < NB; n++)
+#pragma unroll
+                    for (int q = 0; q < PS; q++)
+#pragma unroll
+                        for (int e = 0; e < 6; e++) P[n][q][e] = Ab[n][(j + q) * 6 + e];
+            };
+            auto fmas = [&](const psi_f2 (&P)[NB][PS][6], const float *wk) {
+#pragma unroll
+                for (int q = 0; q < PS; q++) {
+                    const psi_f2 w2 = {wk[q], wk[q]};
+#pragma unroll
+                    for (int n = 0; n < NB; n++)
+#pragma unroll
+                        for (int e = 0; e < 6; e++) T2[n][e] = __builtin_elementwise_fma(w2, P[n][q][e], T2[n][e]);
+                }
+            };
+            aload(P0, 0);
+            const int ngroups = (m.J + G2 - 1) / G2;
+            auto group = [&](int g) {
+                const int j0 = g * G2;
+                ro += g + 1 < ngroups ? G2 * 256 : 0;
+#pragma unroll
+                for (int k = 0; k < G2; k += 2 * PS) {
+                    aload(P1, j0 + k + PS);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fmas(P0, w + k);
+#pragma unroll
+                    for (int q = 0; q < PS; q++) w[k + q] = wload(k + q, ro);
+                    __builtin_amdgcn_sched_barrier(0);
+                    aload(P0, j0 + k + 2 * PS);                      // (the last one of the last group reads rows that are never used)
+                    __builtin_amdgcn_sched_barrier(0);
+                    fmas(P1, w + k + PS);
+#pragma unroll
+                    for (int q = 0; q < PS; q++) w[k + PS + q] = wload(k + PS + q, ro);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (ngroups == 5) {                                      // SMPL-X
+#pragma unroll
+                for (int g = 0; g < 5; g++) group(g);
+            } else {
+#pragma nounroll
+                for (int g = 0; g < ngroups; g++) group(g);
+            }
         }
-#endif
     }
 };
 typedef PsiBlendN<1> PsiBlend;
@@ -640,7 +652,7 @@ struct PsiSkinNoEpilogue {
 // (a device function so that the fused fitting engine can run it inside a launch it shares with the NN search: fit.hip)
 // NB bodies per workgroup (b0, b0 + 1, ...; a body index beyond B - 1 repeats the last body and stores nothing): every lane blends
 // its vertex for all of them with ONE pass over its weights, then runs transform + epilogue body by body.
-template <int NB, int AH, class Epi>
+template <int NB, PsiBlendForm FORM, class Epi>
 __device__ __forceinline__ void psi_skin_fwd_body(const LbsDev &m, const float *__restrict__ As, const float *__restrict__ v_posed,
                                                   const float *__restrict__ transl, const float *__restrict__ cam_ext, int B,
                                                   float *__restrict__ verts, Epi &epi, int vblock, int b0, int nvb)
@@ -658,7 +670,7 @@ __device__ __forceinline__ void psi_skin_fwd_body(const LbsDev &m, const float *
 #pragma unroll
     for (int n = 0; n < NB; n++) pp[n] = psi_ld<psi_p3>(v_posed + (size_t)bs[n] * m.Npad, v12);
     psi_f2 T2[NB][6];
-    bl.template blend<AH>(m, bl.commit(m), v, T2);
+    bl.template blend<FORM>(m, bl.commit(m), v, T2);
 #pragma unroll
     for (int n = 0; n < NB; n++) {
         const int b = bs[n];
@@ -692,18 +704,13 @@ __device__ __forceinline__ void psi_skin_fwd_body(const LbsDev &m, const float *
     }
 }
 
-// (standalone kernel: scheduling fence every PSI_SKIN_FWD_AHEAD joints — with more transforms in flight this instantiation spills
-// scalar registers inside the blend loop, 12 lane moves per group)
-#ifndef PSI_SKIN_FWD_AHEAD
-#define PSI_SKIN_FWD_AHEAD 2
-#endif
+// (its own launch = the throughput-bound large batches: the pipelined form of the dense blend)
 template <class Epi, int NB = 1>
 __global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_fwd_kernel(LbsDev m, const float *__restrict__ As, const float *__restrict__ v_posed,
                                                                      const float *__restrict__ transl, const float *__restrict__ cam_ext,
                                                                      int B, float *__restrict__ verts, Epi epi)
 {
-    psi_skin_fwd_body<NB, (NB > 1 ? 1 : PSI_SKIN_FWD_AHEAD)>(m, As, v_posed, transl, cam_ext, B, verts, epi, (int)blockIdx.x, (int)blockIdx.y * NB,
-                                                              (int)gridDim.x);
+    psi_skin_fwd_body<NB, PsiBlendPipelined>(m, As, v_posed, transl, cam_ext, B, verts, epi, (int)blockIdx.x, (int)blockIdx.y * NB, (int)gridDim.x);
 }
 
 // Gradient source of skin_bwd_v: where dL/dverts[b][v] comes from.
@@ -729,7 +736,7 @@ struct PsiGradFromMemory {
 };
 
 // per-vertex part of the skinning backward: g_local = R_c^T g_verts;  g_vposed = T_R^T g_local;  partial g_transl
-template <class Src>
+template <class Src, PsiBlendForm FORM = PsiBlendCompact>
 __global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_bwd_v_kernel(LbsDev m, const float *__restrict__ As, Src src,
                                                                        const float *__restrict__ cam_ext, int B, float *__restrict__ gl,
                                                                        float *__restrict__ g_vp, float *__restrict__ gt_part)
@@ -746,7 +753,7 @@ __global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_bwd_v_kernel(LbsDev 
     PSI_SSTOP(12);
     // the blend first (its weight loads run while the statistics inputs requested above are still in flight), then the statistics
     psi_f2 T2n[1][6];
-    bl.blend(m, bl.commit(m), v, T2n);
+    bl.template blend<FORM>(m, bl.commit(m), v, T2n);
     const psi_f2 (&T2)[6] = T2n[0];
     PSI_SSTOP(13);
     src.prepare(b, 1);

@@ -226,11 +226,7 @@ __device__ __forceinline__ float psi_sdf_sample_cells(const PsiSdfGrid &G, float
     }
     const unsigned brick = psi_mad24(psi_mad24(i[0] >> 2, G.nbr, i[1] >> 2), G.nbr, i[2] >> 2);
     const unsigned local = ((i[0] & 3) << 9) | ((i[1] & 3) << 7) | ((i[2] & 3) << 5);
-#if PSI_EXP == 1
-    const unsigned off = 0 * ((brick << 11) + local);           // dev experiment: every lane reads record 0 (one line access per gather)
-#else
     const unsigned off = (brick << 11) + local;                 // bytes
-#endif
     typedef float f4_t __attribute__((ext_vector_type(4)));
     const char *vb = (const char *)G.brick;
     const f4_t lo = *(const f4_t *)(vb + off), hi = *(const f4_t *)(vb + (off + 16u));       // x0 face, x1 face: (y0z0, y0z1, y1z0, y1z1)

@@ -24,6 +24,15 @@ for step in "$@"; do
     ab) for r in 1 2; do for l in ${a1//,/ }; do uselib $l; timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 $a2 2>>$O/ab.err | tail -1 | tee -a "$O/ab_$l.json" | line "$l [$a2]"; done; done; uselib default ;;
     pmc512) args="--batch 512"; [ "$a1" = sparse ] && args="--batch 512 --weight-nnz 4"
       bash tools/pmc2.sh $TAG "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" ${a2:-psi_skin_fwd_kernel} python $GRAFT_REPO_ROOT/bench.py $args --steps 10 --warmup 3 --no-cpu-baseline --secondary 0 > $O/pmc_skin_fwd_sdf_b512_$a1.txt 2>&1; cat $O/pmc_skin_fwd_sdf_b512_$a1.txt ;;
+    profab) for l in ${a1//,/ }; do uselib $l; rm -rf /tmp/pab; ( cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pab -o p -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 $a2 > "$O/profab_$l.log" 2>&1 )
+        f=$(find /tmp/pab -name "*kernel_stats.csv" | head -1); cp $f "$O/kernel_stats_$l.csv"
+        python - "$f" "$l" <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if int(r['Calls']) > 1000]
+rows.sort(key=lambda r: -float(r['TotalDurationNs']))
+print(sys.argv[2], 'sum %.1f us |' % sum(float(r['AverageNs']) for r in rows[:7]) ,' '.join('%s=%.2f' % (r['Name'].split('(')[0].split('<')[0][-22:], float(r['AverageNs']) / 1e3) for r in rows[:8]))
+PY
+      done; uselib default ;;
     prof) rm -rf /tmp/prof_$TAG; ( cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 > $O/prof.log 2>&1 ); cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; head -12 $O/kernel_stats.csv | cut -c1-150 ;;
     *) echo "unknown step $step" ;;
   esac
