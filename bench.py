@@ -50,7 +50,7 @@ PEAK_FP32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vec
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 ROOMS = 7                     # fitting_habitat.py:238-241: seven MP3D-R rooms
-PMC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json')
+PMC_FILES = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
 
 
 def parse(argv=None):
@@ -631,6 +631,19 @@ def bench_fitting(args):
                 out['secondary']['train_s2'] = sec
             except Exception as e:
                 out['secondary']['train_s2'] = {'error': repr(e)}
+            # the same step at the REFERENCE's precision (fp32 model, cvae.py:427-455): what `train_s1/s2.py` run out of the box (`--bf16 0` is
+            # their default: a drop-in must not change a checkpoint's arithmetic silently); the trunk then stays with MIOpen / hipBLASLt in
+            # fp32 — the hand-written convolution / BN / dense kernels are the bf16 mode's
+            try:
+                import contextlib
+                import io
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    sec = bench_train_s2(argparse.Namespace(**dict(vars(args), batch=128, steps=5, warmup=3, repeats=3, min_timed_s=0.2, bf16=0)))
+                sys.stderr.write(buf.getvalue())
+                out['secondary']['train_s2_fp32'] = sec
+            except Exception as e:
+                out['secondary']['train_s2_fp32'] = {'error': repr(e)}
         print(json.dumps(out))
         sys.stdout.flush()
     if torch.distributed.is_available() and torch.distributed.is_initialized():

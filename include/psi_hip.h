@@ -350,15 +350,18 @@ int psi_cvae_losses_backward(const float *rec75, const float *target75, const fl
  * backward: g_verts [B,V,3] (OVERWRITTEN) = d(g_losses2[0] losses2[0] + g_losses2[1] losses2[1]) / d body vertices, given xyz1 [B,n_c,3] =
  *           the contact vertices that were queried (rows vid [n_c] of the body), their nearest scene points verts_table[slot[b]][idx[b,j]]
  *           (verts_table [S,m,3], chamfer.cu:155-174) and sdf_grad [B,V,3] = d sdf / d vertex (psi_sdf_sample_forward's out_grad).
- *           ws_chain: 2 * n_c ints of scratch (the slots of a vertex that is listed more than once, cvae.py:99-115, are chained in slot
- *           order and added by one thread: no atomics, run-to-run bit-identical). */
+ *           chain: psi_contact_slot_chain(vid) — the slots of a vertex that is listed more than once (cvae.py:99-115 keeps duplicates) are
+ *           chained in slot order and added by one thread: no atomics, run-to-run bit-identical. */
 size_t psi_scene_losses_workspace_floats(void);
 int psi_scene_losses_forward(const float *dist, long n_contact, const float *sdf_vals, long n_sdf, float w_contact, float w_collision,
                              float gate, float *ws, float *losses2, float *stats2, void *stream);
 int psi_scene_losses_backward(const float *g_losses2, const float *stats2, const float *dist, const float *xyz1, const int32_t *idx,
                               const int32_t *slot, const float *verts_table, long m, const int32_t *vid, const float *sdf_vals,
                               const float *sdf_grad, int B, int V, int n_c, float w_contact, float w_collision, float gate,
-                              int32_t *ws_chain, float *g_verts, void *stream);
+                              const int32_t *chain, float *g_verts, void *stream);
+/* chain [2 * n_c] of a contact-id list vid [n_c] (device): chain[j] = the next slot > j that lists the same vertex as slot j (-1: none),
+ * chain[n_c + j] = 1 when no earlier slot lists it.  A constant of the list: build it once, pass it to every backward. */
+int psi_contact_slot_chain(const int32_t *vid, int n_c, int32_t *chain, void *stream);
 
 #ifdef __cplusplus
 }

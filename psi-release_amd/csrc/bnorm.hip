@@ -13,8 +13,11 @@
 // a plain bandwidth-bound pass is ~6 us.
 //   forward : stats (read x) -> finalize (C values) -> apply (read x [+ residual], write y)
 //   backward: reduce (read dy, y|x) -> finalize -> apply (read dy, x, y, write dx [, d_residual])
-// The reductions are deterministic: fixed per-block partials, summed in order by the finalize kernels (16 channels per block; double precision
-// for the variance, so E[x^2] - mean^2 does not cancel).
+// The reductions are deterministic: fixed per-block partials, summed in order by the finalize kernels (16 channels per block).  The partials
+// are fp32 sums of x and x^2; the finalize step combines them in double precision, which keeps the COMBINATION exact but not the partials:
+// for a channel whose |mean| is far above its standard deviation (mean 10, variance 0.01) E[x^2] - mean^2 loses the digits the fp32 partials
+// no longer hold and the variance can be off by about a percent, where the library's Welford pass is not.  Convolution outputs of this
+// trunk have |mean| of the order of their standard deviation (the parity tests against the library path hold to bf16 rounding).
 #include "psi_internal.h"
 #include <hip/hip_bf16.h>
 

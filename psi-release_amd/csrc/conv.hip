@@ -19,8 +19,22 @@
 // LDS are padded by 8 elements, which makes the 16-byte operand reads of 16 adjacent lanes fall on 16 different bank groups.
 // Output: a lane ends up with four consecutive output channels of one pixel per accumulator quarter -> 8-byte stores.
 #include "psi_internal.h"
+#include <atomic>
 
 namespace {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: set once per device (bit = device id), safely from any thread
+static inline hipError_t psi_set_max_lds(const void *kern, size_t lds, std::atomic<unsigned long long> &done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -160,11 +174,8 @@ int launch_conv(const void *x, const void *w, const float *bias, void *y, int N,
     constexpr int PX = WPX * 64, TH = PX / TW, COT = WCO * 64, P = CIN + 8;
     const size_t lds = ((size_t)(TH + 2) * (TW + 2) * P + (size_t)2 * COT * P) * 2;
     auto kern = conv3x3_kernel<CIN, WPX, WCO, TW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PSI_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_set{0};           // one bit per device: the attribute is per device, and forward / autograd threads race here
+    PSI_CHECK_HIP(psi_set_max_lds((const void *)kern, lds, attr_set));
     dim3 grid((unsigned)(N * (H / TH) * (W / TW)), (unsigned)(COUT / COT));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const __bf16 *)x, (const __bf16 *)w, bias, (__bf16 *)y, N, H, W, COUT);
     PSI_CHECK_LAUNCH("conv3x3_kernel");
@@ -385,12 +396,12 @@ extern "C" int psi_conv3x3_weight_grad(const void *x, const void *dy, int N, int
     const size_t lds = ((size_t)64 * (128 + 8) + (size_t)64 * ((TR + 2) * (W + 16) + 8)) * 2;
     dim3 grid(S, Cout / 64, Cin / 64);
     if (W == 32) {
-        static bool a32 = false;
-        if (!a32) { PSI_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wrw_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a32 = true; }
+        static std::atomic<unsigned long long> a32{0};
+        PSI_CHECK_HIP(psi_set_max_lds((const void *)conv3x3_wrw_kernel<32>, lds, a32));
         hipLaunchKernelGGL(conv3x3_wrw_kernel<32>, grid, dim3(256), lds, st, (const __bf16 *)x, (const __bf16 *)dy, ws, N, H, Cin, Cout, S);
     } else {
-        static bool a16 = false;
-        if (!a16) { PSI_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_wrw_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a16 = true; }
+        static std::atomic<unsigned long long> a16{0};
+        PSI_CHECK_HIP(psi_set_max_lds((const void *)conv3x3_wrw_kernel<16>, lds, a16));
         hipLaunchKernelGGL(conv3x3_wrw_kernel<16>, grid, dim3(256), lds, st, (const __bf16 *)x, (const __bf16 *)dy, ws, N, H, Cin, Cout, S);
     }
     PSI_CHECK_LAUNCH("conv3x3_wrw_kernel");

@@ -147,6 +147,17 @@ __global__ __launch_bounds__(SL_BLK) void scene_loss_bwd_contact_kernel(const fl
 
 extern "C" size_t psi_scene_losses_workspace_floats(void) { return (size_t)SL_GRID * 3; }
 
+// The slot chain of a contact-id list (a constant of the model: built once per list, 100 us for 2048 slots — every thread scans the list)
+extern "C" int psi_contact_slot_chain(const int32_t *vid, int n_c, int32_t *chain, void *stream)
+{
+    PSI_REQUIRE(vid && chain && n_c > 0, "bad arguments");
+    PSI_REQUIRE(n_c <= 16384, "more than 16384 contact slots");          // the slot table is staged in 64 KB of LDS
+    hipLaunchKernelGGL(contact_chain_kernel, dim3((unsigned)psi_cdiv(n_c, SL_BLK)), dim3(SL_BLK), (size_t)n_c * sizeof(int), (hipStream_t)stream, vid, n_c,
+                       chain);
+    PSI_CHECK_LAUNCH("contact_chain_kernel");
+    return 0;
+}
+
 extern "C" int psi_scene_losses_forward(const float *dist, long n_contact, const float *sdf_vals, long n_sdf, float w_contact, float w_collision,
                                         float gate, float *ws, float *losses2, float *stats2, void *stream)
 {
@@ -163,20 +174,17 @@ extern "C" int psi_scene_losses_forward(const float *dist, long n_contact, const
 extern "C" int psi_scene_losses_backward(const float *g_losses2, const float *stats2, const float *dist, const float *xyz1, const int32_t *idx,
                                          const int32_t *slot, const float *verts_table, long m, const int32_t *vid, const float *sdf_vals,
                                          const float *sdf_grad, int B, int V, int n_c, float w_contact, float w_collision, float gate,
-                                         int32_t *ws_chain, float *g_verts, void *stream)
+                                         const int32_t *chain, float *g_verts, void *stream)
 {
-    PSI_REQUIRE(g_losses2 && stats2 && dist && xyz1 && idx && slot && verts_table && vid && sdf_vals && sdf_grad && ws_chain && g_verts, "null pointer");
+    PSI_REQUIRE(g_losses2 && stats2 && dist && xyz1 && idx && slot && verts_table && vid && sdf_vals && sdf_grad && chain && g_verts, "null pointer");
     PSI_REQUIRE(B > 0 && V > 0 && n_c > 0 && m > 0, "bad sizes");
-    PSI_REQUIRE(n_c <= 16384, "more than 16384 contact slots");          // the slot table is staged in 64 KB of LDS
     hipStream_t st = (hipStream_t)stream;
     const long n_sdf = (long)B * V, n_q = (long)B * n_c;
     hipLaunchKernelGGL(scene_loss_bwd_dense_kernel, dim3((unsigned)psi_cdiv(n_sdf, (long)SL_BLK)), dim3(SL_BLK), 0, st, g_losses2, stats2, sdf_vals,
                        sdf_grad, n_sdf, w_collision, gate, g_verts);
     PSI_CHECK_LAUNCH("scene_loss_bwd_dense_kernel");
-    hipLaunchKernelGGL(contact_chain_kernel, dim3((unsigned)psi_cdiv(n_c, SL_BLK)), dim3(SL_BLK), (size_t)n_c * sizeof(int), st, vid, n_c, ws_chain);
-    PSI_CHECK_LAUNCH("contact_chain_kernel");
     hipLaunchKernelGGL(scene_loss_bwd_contact_kernel, dim3((unsigned)psi_cdiv(n_q, (long)SL_BLK)), dim3(SL_BLK), 0, st, g_losses2, dist, xyz1, idx,
-                       slot, verts_table, m, vid, ws_chain, B, n_c, V, w_contact, gate, g_verts);
+                       slot, verts_table, m, vid, chain, B, n_c, V, w_contact, gate, g_verts);
     PSI_CHECK_LAUNCH("scene_loss_bwd_contact_kernel");
     return 0;
 }

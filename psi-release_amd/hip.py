@@ -77,6 +77,7 @@ SIGNATURES = {
     'psi_scene_losses_forward': (c_int, [c_void_p, c_long, c_void_p, c_long, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'psi_scene_losses_backward': (c_int, [c_void_p] * 7 + [c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float,
                                           c_void_p, c_void_p, c_void_p]),
+    'psi_contact_slot_chain': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     'psi_fit_dp_mode': (c_int, [c_void_p]),
     'psi_stream_wait': (c_int, [c_void_p, c_int]),
     'psi_dp_unique_id': (c_int, [c_void_p]),

@@ -602,6 +602,23 @@ def cvae_losses(rec, target, xh, cam_int, max_d, mu0, logvar0, mu1=None, logvar1
 # ------------------------------------------------------------------------------------------
 # Contact + penetration losses of a training step from the body mesh (csrc/scene_loss.hip)
 # ------------------------------------------------------------------------------------------
+_CHAIN_CACHE = {}
+
+
+def _contact_chain(vid32):
+    """psi_contact_slot_chain of a contact-id tensor, cached per tensor (the ids are a constant of the model; the cache is keyed by storage
+    and version, so an id list that is modified in place gets a new chain)."""
+    key = (vid32.data_ptr(), vid32.numel(), vid32._version, vid32.device)
+    hit = _CHAIN_CACHE.get(key)
+    if hit is None:
+        chain = torch.empty(2 * vid32.numel(), dtype=torch.int32, device=vid32.device)
+        hip.check(hip.lib().psi_contact_slot_chain(hip.ptr(vid32), vid32.numel(), hip.ptr(chain), hip.stream()), 'psi_contact_slot_chain')
+        if len(_CHAIN_CACHE) > 64:
+            _CHAIN_CACHE.clear()
+        hit = _CHAIN_CACHE[key] = (vid32, chain)             # keeps the id tensor alive: its address cannot be reused while cached
+    return hit[1]
+
+
 class _SceneLosses(Function):
     @staticmethod
     def forward(ctx, verts, vid, scenes, slot, sdf, gmin, gmax, align_corners, w_contact, w_collision, gate, vid32):
@@ -633,7 +650,7 @@ class _SceneLosses(Function):
         B, V = vals.shape
         table = ctx.scenes.verts_table
         g_verts = torch.empty(B, V, 3, device=vals.device)
-        chain = torch.empty(2 * xyz1.shape[1], dtype=torch.int32, device=vals.device)     # scratch: slots of a repeated contact vertex, chained
+        chain = _contact_chain(vid32)                       # slots of a repeated contact vertex, chained in slot order (built once per id list)
         hip.check(hip.lib().psi_scene_losses_backward(hip.ptr(g.contiguous().float()), hip.ptr(stats), hip.ptr(dist), hip.ptr(xyz1), hip.ptr(idx),
                                                       hip.ptr(slot), hip.ptr(table), table.shape[1], hip.ptr(vid32), hip.ptr(vals), hip.ptr(og), B,
                                                       V, xyz1.shape[1], *ctx.w, hip.ptr(chain), hip.ptr(g_verts), hip.stream()),

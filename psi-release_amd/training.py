@@ -52,10 +52,11 @@ class _TrainBase:
         if self.device.type != 'cuda':
             raise RuntimeError('TrainOP runs on the GPU (HIP operators); there is no CPU path')
         os.makedirs(self.save_dir, exist_ok=True)        # every rank of a torchrun job constructs TrainOP on the same save_dir
-        if os.environ.get('PSI_MIOPEN_FIND', '1') != '0':
-            # the convolutions that stay with the library (7x7 stem, the strided ones, the 128 -> 32 head): let MIOpen MEASURE its solvers
-            # once per shape instead of taking the heuristic pick (train_s2 step 4.22 -> 4.00 ms; the search runs in the first steps)
-            torch.backends.cudnn.benchmark = True
+        # the convolutions that stay with the library (7x7 stem, the strided ones, the 128 -> 32 head): let MIOpen MEASURE its solvers once per
+        # shape instead of taking the heuristic pick (train_s2 step 4.22 -> 4.00 ms; the search runs in the first steps).  The flag is
+        # process-global in PyTorch: it is set for the duration of a training step only (train_step) and restored, so that a trainer in the
+        # process does not change how later convolutions of other components (generation, fitting, tests) pick their solvers
+        self.miopen_find = os.environ.get('PSI_MIOPEN_FIND', '1') != '0'
         n_dim_body = 72 + 3 if self.use_cont_rot else 72
         self.model_h_latentD = 256
         self.model_h = self._make_model(n_dim_body)
@@ -270,15 +271,21 @@ class _TrainBase:
 
     def train_step(self, train_data, ep):
         """One optimiser step on one batch (the body of the ``while batch_gen.has_next_batch()`` loop)."""
-        if self.use_graph:
-            return self._train_step_graph(train_data, ep)
-        self.optimizer_h.zero_grad()
-        losses = self._losses_from_batch(train_data, ep)
-        loss_h = sum(losses)
-        loss_h.backward()
-        self._allreduce_grads()
-        self.optimizer_h.step()
-        return losses
+        prev = torch.backends.cudnn.benchmark
+        if getattr(self, 'miopen_find', False):
+            torch.backends.cudnn.benchmark = True
+        try:
+            if self.use_graph:
+                return self._train_step_graph(train_data, ep)
+            self.optimizer_h.zero_grad()
+            losses = self._losses_from_batch(train_data, ep)
+            loss_h = sum(losses)
+            loss_h.backward()
+            self._allreduce_grads()
+            self.optimizer_h.step()
+            return losses
+        finally:
+            torch.backends.cudnn.benchmark = prev
 
     def _all_ranks_have(self, train_data):
         """Skip decision of the batch loop (batch_gen_hdf5.py:198-199,211-214 return None).  It must be COLLECTIVE: train_step

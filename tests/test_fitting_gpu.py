@@ -114,7 +114,7 @@ def test_fused_matches_modular(smplx_data, vposer_sd, B, cls, lr, graph):
     assert np.abs(res['fused'][0] - res['modular'][0]).max() < 1e-3
 
 
-@pytest.mark.parametrize('B', [40, 64, 136])          # 136: multi-body skinning kernels (B >= 128), ragged last group
+@pytest.mark.parametrize('B', [40, 64, 136, 137])     # 136 / 137: the large-batch kernels (B >= 128); 137 is odd: two-body skinning workgroups with a ragged last pair
 def test_fused_gradient_matches_modular_large_batch(smplx_data, vposer_sd, B):
     """B > 32 selects the 4-row-tile MFMA variants (blend_fwd<4>, bwd_joint<4>).  Compared on the FIRST-iteration gradient
     (Adam's first moment after one step = 0.1 * gradient in both engines): with 1/B normalisers some elements have
@@ -132,18 +132,24 @@ def test_fused_gradient_matches_modular_large_batch(smplx_data, vposer_sd, B):
     if B <= 64:
         assert d.max() < 2e-6 and d.max() < 1e-4 * np.abs(g['modular']).max(), (d.max(), np.abs(g['modular']).max())
         return
-    # B >= 128 (multi-body skinning backward, separate statistics kernel): both engines against the ORACLE's autograd gradient
-    fo = O.FittingOracle(O.SMPLXOracle(smplx_data), vposer_sd, scene.verts, scene.sdf, scene.grid_min, scene.grid_max,
-                         synth.contact_ids_from_parts(scene.contact_parts), B)
+    # B >= 128 (large-batch skinning kernels, separate statistics kernel): both engines against the ORACLE's autograd gradient — per body
+    # within 1e-4 of the largest entry of the fp32 oracle's gradient, or no further from the fp64 arbiter than 4 x the fp32 oracle itself is
+    # (a 24^3 SDF grid makes the gradient's cell-boundary jumps large: tests/arbiter.py explains the two rules)
     xh = torch.tensor(synth.body_vector_72(bodies))
-    xhr = O.convert_to_6d_rot(xh)
-    fo.xhr_rec.data = xhr.clone()
-    sum(fo.cal_loss(xhr, torch.tensor(bodies['cam_ext']))).backward()
-    ref = fo.xhr_rec.grad.numpy()
-    scale = np.abs(ref).max()
+    ref = {}
+    for name, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        fo = O.FittingOracle(O.SMPLXOracle(smplx_data, dtype=dt), vposer_sd, scene.verts, scene.sdf, scene.grid_min, scene.grid_max,
+                             synth.contact_ids_from_parts(scene.contact_parts), B)
+        xhr = O.convert_to_6d_rot(xh).to(dt)                 # the fp32 target in both precisions: the loop starts AT the target (|.| kink)
+        fo.xhr_rec.data = xhr.clone()
+        sum(fo.cal_loss(xhr, torch.tensor(bodies['cam_ext']).to(dt))).backward()
+        ref[name] = fo.xhr_rec.grad.numpy().astype(np.float64)
+    scale = np.abs(ref['f64']).max()
+    bmax = lambda a: np.abs(a).max(axis=1)
     for k in g:
-        assert np.abs(g[k] - ref).max() < 3e-4 * scale, (k, np.abs(g[k] - ref).max(), scale)
-    assert d.max() < 3e-4 * scale
+        ok = (bmax(g[k] - ref['f32']) <= 1e-4 * scale) | (bmax(g[k] - ref['f64']) <= 4 * bmax(ref['f32'] - ref['f64']) + 2e-6 * scale)
+        assert ok.all(), (k, np.nonzero(~ok)[0], bmax(g[k] - ref['f32'])[~ok] / scale, bmax(ref['f32'] - ref['f64'])[~ok] / scale)
+    assert np.median(bmax(d)) < 1e-5 * scale
 
 
 def test_nn_modes_agree(smplx_data, vposer_sd):

@@ -33,6 +33,18 @@ rows.sort(key=lambda r: -float(r['TotalDurationNs']))
 print(sys.argv[2], 'sum %.1f us |' % sum(float(r['AverageNs']) for r in rows[:7]) ,' '.join('%s=%.2f' % (r['Name'].split('(')[0].split('<')[0][-22:], float(r['AverageNs']) / 1e3) for r in rows[:8]))
 PY
       done; uselib default ;;
+    proftrain) rm -rf /tmp/ptr; ( cd /tmp; PSI_MIOPEN_FIND=${a1:-0} rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ptr -o p -- python $GRAFT_REPO_ROOT/bench.py --workload train_s2 --steps 40 --warmup 5 $a2 > $O/proftrain.log 2>&1 )
+      f=$(find /tmp/ptr -name "*kernel_stats.csv" | head -1); cp $f $O/train_s2_kernel_stats.csv; tail -1 $O/proftrain.log | cut -c1-400
+      python - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+rows.sort(key=lambda r: -float(r['TotalDurationNs']))
+print('total kernel time %.1f ms, %d kernels' % (tot / 1e6, len(rows)))
+for r in rows[:40]:
+    print('%5.1f%% calls %6s avg %8.1f us  %s' % (100 * float(r['TotalDurationNs']) / tot, r['Calls'], float(r['AverageNs']) / 1e3, r['Name'][:110]))
+PY
+      ;;
     prof) rm -rf /tmp/prof_$TAG; ( cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 > $O/prof.log 2>&1 ); cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; head -12 $O/kernel_stats.csv | cut -c1-150 ;;
     *) echo "unknown step $step" ;;
   esac
