@@ -107,6 +107,45 @@ def _adam(x0, m0, v0, g, t, lr):
     return x0 - lr / (1 - BETA1 ** t) * m / denom, m, v
 
 
+def check_gradient(g_gpu, f32, f64, x, xhr, cam):
+    """The gradient rules (a) / (b) / (c) of the module docstring for ONE evaluation point x ([B,75], 6D form): g_gpu [B,75] is the
+    implementation's gradient there, f32 / f64 the fp32 oracle and the fp64 arbiter (FittingOracle).  Asserts every body passes; returns
+    the evaluations and a summary."""
+    l32, g32, sdf32 = _evaluate(f32, x, xhr, cam)
+    l64, g64, sdf64 = _evaluate(f64, x, xhr, cam)
+    # how far an fp32 evaluation of a vertex's SDF value is from the exact one (vertex coordinates of a few metres carry ~5e-7 m of
+    # rounding, times |grad sdf| ~ 1): measured on the fp32 oracle, not assumed
+    tau = max(AMBIGUOUS, K_NOISE * float(np.abs(sdf32 - sdf64).max()))
+    amb = np.abs(sdf64) < tau
+    n_pen = max(int((sdf64 < 0).sum()), 1)
+    scale = np.abs(g64).max()
+    slack = (amb.sum() / n_pen) * scale                        # the global count N seen by bodies without an ambiguous vertex
+    bmax = lambda a: np.abs(a).max(axis=1)
+
+    def rules(r32, r64):
+        a = bmax(g_gpu - r32) <= 1e-4 * scale + slack
+        b = bmax(g_gpu - r64) <= K_NOISE * bmax(r32 - r64) + 2e-6 * scale + slack
+        return a, b
+    ok_a, ok_b = rules(g32, g64)
+    ok_c = np.zeros_like(ok_a)
+    bodies_amb = np.nonzero(amb.any(axis=1))[0]
+    if len(bodies_amb) and not np.all(ok_a | ok_b):
+        alts32 = [_evaluate(f32, x, xhr, cam, force=(amb, val))[1] for val in (True, False)]
+        alts64 = [_evaluate(f64, x, xhr, cam, force=(amb, val))[1] for val in (True, False)]
+        for r32 in alts32:
+            for r64 in alts64:
+                a, b = rules(r32, r64)
+                ok_c[bodies_amb] |= (a | b)[bodies_amb]
+    ok = ok_a | ok_b | ok_c
+    assert np.all(ok), (np.nonzero(~ok)[0].tolist(), (bmax(g_gpu - g32) / scale)[~ok], (bmax(g_gpu - g64) / scale)[~ok],
+                        (bmax(g32 - g64) / scale)[~ok], bodies_amb.tolist(), tau)
+    info = dict(grad_vs_oracle32_rel=float(np.median(bmax(g_gpu - g32)) / scale), grad_vs_oracle32_worst_rel=float(bmax(g_gpu - g32).max() / scale),
+                oracle32_vs_arbiter_worst_rel=float(bmax(g32 - g64).max() / scale),
+                bodies_by_rule=dict(a=int(ok_a.sum()), b_only=int((ok_b & ~ok_a).sum()), c_only=int((ok_c & ~ok_a & ~ok_b).sum())),
+                ambiguous_vertices=int(amb.sum()), ambiguity_threshold=tau)
+    return (l32, l64, amb, n_pen, tau), info
+
+
 def check_trace(trace, make_oracle, cam, lr=0.1, first_step=1):
     """``make_oracle(dtype)`` -> FittingOracle on the GLOBAL batch; cam [B,4,4].  The fixed 6D target ``xhr`` of the reconstruction loss is the
     implementation's own starting point (the loop starts AT the target, fitting_proxe.py:171-175, where |xhr - x| has its kink: the target
@@ -118,41 +157,13 @@ def check_trace(trace, make_oracle, cam, lr=0.1, first_step=1):
     report = []
     for i, t in enumerate(trace):
         step = first_step + i
-        l32, g32, sdf32 = _evaluate(f32, t['x0'], xhr, cam)
-        l64, g64, sdf64 = _evaluate(f64, t['x0'], xhr, cam)
-        # how far an fp32 evaluation of a vertex's SDF value is from the exact one (vertex coordinates of a few metres carry ~5e-7 m of
-        # rounding, times |grad sdf| ~ 1): measured on the fp32 oracle, not assumed
-        tau = max(AMBIGUOUS, K_NOISE * float(np.abs(sdf32 - sdf64).max()))
-        amb = np.abs(sdf64) < tau
-        n_pen = max(int((sdf64 < 0).sum()), 1)
-        scale = np.abs(g64).max()
-        slack = (amb.sum() / n_pen) * scale                    # the global count N seen by bodies without an ambiguous vertex
-        # --- loss values (continuous in the parameters: no event rule needed)
-        # (a vertex counted the other way moves the penetration MEAN by about mean / N: the count changes by one, the sum by < AMBIGUOUS)
+        g_gpu = (t['m1'] - BETA1 * t['m0']) / (1 - BETA1)
+        (l32, l64, amb, n_pen, tau), info = check_gradient(g_gpu, f32, f64, t['x0'], xhr, cam)
+        # --- loss values (continuous in the parameters: no event rule needed; a vertex counted the other way moves the penetration MEAN by
+        # about mean / N: the count changes by one, the sum by < tau)
         l_bound = K_NOISE * np.abs(l32 - l64) + 3e-6 * np.maximum(np.abs(l64), 1e-2)
         l_bound[3] += amb.sum() * 1.5 * (np.abs(l64[3]) + tau) / n_pen
         assert np.all(np.abs(t['losses'] - l64) <= l_bound), (step, t['losses'], l64, l32, l_bound)
-        # --- gradient, per body
-        g_gpu = (t['m1'] - BETA1 * t['m0']) / (1 - BETA1)
-        bmax = lambda a: np.abs(a).max(axis=1)
-
-        def rules(r32, r64):
-            a = bmax(g_gpu - r32) <= 1e-4 * scale + slack
-            b = bmax(g_gpu - r64) <= K_NOISE * bmax(r32 - r64) + 2e-6 * scale + slack
-            return a, b
-        ok_a, ok_b = rules(g32, g64)
-        ok_c = np.zeros_like(ok_a)
-        bodies_amb = np.nonzero(amb.any(axis=1))[0]
-        if len(bodies_amb) and not np.all(ok_a | ok_b):
-            alts32 = [_evaluate(f32, t['x0'], xhr, cam, force=(amb, val))[1] for val in (True, False)]
-            alts64 = [_evaluate(f64, t['x0'], xhr, cam, force=(amb, val))[1] for val in (True, False)]
-            for r32 in alts32:
-                for r64 in alts64:
-                    a, b = rules(r32, r64)
-                    ok_c[bodies_amb] |= (a | b)[bodies_amb]
-        ok = ok_a | ok_b | ok_c
-        assert np.all(ok), (step, np.nonzero(~ok)[0].tolist(), (bmax(g_gpu - g32) / scale)[~ok], (bmax(g_gpu - g64) / scale)[~ok],
-                            (bmax(g32 - g64) / scale)[~ok], bodies_amb.tolist())
         # --- Adam's update from the implementation's own state and gradient
         x_ref, m_ref, v_ref = _adam(t['x0'], t['m0'], t['v0'], g_gpu, step, lr)
         assert np.abs(t['m1'] - m_ref).max() <= 1e-6 * np.abs(m_ref).max(), (step, 'm')
@@ -161,8 +172,5 @@ def check_trace(trace, make_oracle, cam, lr=0.1, first_step=1):
         x_tol = 2e-5 * np.abs(x_ref - t['x0']) + 5e-7 * np.maximum(np.abs(x_ref), 1.0)
         assert np.all(xerr <= x_tol), (step, float((xerr / x_tol).max()), np.unravel_index(np.argmax(xerr / x_tol), xerr.shape))
         report.append(dict(step=step, loss_err=float(np.abs(t['losses'] - l64).max()), oracle32_loss_err=float(np.abs(l32 - l64).max()),
-                           grad_vs_oracle32_rel=float(np.median(bmax(g_gpu - g32)) / scale), grad_vs_oracle32_worst_rel=float(bmax(g_gpu - g32).max() / scale),
-                           oracle32_vs_arbiter_worst_rel=float(bmax(g32 - g64).max() / scale),
-                           bodies_by_rule=dict(a=int(ok_a.sum()), b_only=int((ok_b & ~ok_a).sum()), c_only=int((ok_c & ~ok_a & ~ok_b).sum())),
-                           ambiguous_vertices=int(amb.sum()), ambiguity_threshold=tau, x_update_err=float(xerr.max())))
+                           x_update_err=float(xerr.max()), **info))
     return report
