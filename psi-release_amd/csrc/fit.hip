@@ -30,6 +30,27 @@
 #ifdef PSI_HEAD_STOPS
 __device__ int psi_dbg_sstop;            // dev: leave the skinning / scene kernels at this point (tools/head_stops.sh)
 #define PSI_SSTOP(k) do { if (psi_dbg_sstop == (k)) return; } while (0)
+// dev (PSI_SKIN_STOP=9): the workgroup timeline of the LAST fwd_scene launch — {start, end} in 10 ns wall-clock ticks, the hardware id
+// words and the kind of workgroup, one record per workgroup (tools/timeline.py draws it)
+__device__ unsigned long long psi_dbg_tl[4 * 8192];
+struct PsiBlockTrace {
+    unsigned long long t0;
+    int kind;
+    __device__ PsiBlockTrace() : t0(wall_clock64()), kind(0) {}
+    __device__ ~PsiBlockTrace()
+    {
+        if (psi_dbg_sstop < 9 || threadIdx.x != 0 || blockIdx.x >= 8192) return;
+        unsigned long long *o = psi_dbg_tl + 4 * (size_t)blockIdx.x;
+        o[0] = t0;
+        o[1] = wall_clock64();
+        o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        o[3] = (unsigned long long)kind;
+    }
+};
+extern "C" int psi_dbg_timeline(unsigned long long *out, int nblocks)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psi_dbg_tl), sizeof(unsigned long long) * 4 * (size_t)(nblocks < 8192 ? nblocks : 8192));
+}
 #endif
 #include "lbs_device.h"
 #include "sdf_device.h"
@@ -516,25 +537,73 @@ struct ContactSkinSrc {
     LbsDev m;
     const float *As, *v_posed;
     psi_f2 (*sA)[6];
-    __device__ __forceinline__ void prepare(int b)
+    // The source's loads in TWO dependent rounds (round 3 had six in a row in front of the search: winner index, winner coordinates, two
+    // load -> LDS-store trips of the transform staging loop, then contact id + weight row, then posed vertex + translation + camera):
+    //   issue()   this thread's two pieces of the body's transforms, the slot's vertex id            (with the caller's hint load)
+    //             + one entry of the body's camera / translation per thread 128 .. 142
+    //   fetch()   the posed vertex (needs the id)                                                    (with the caller's winner coordinates)
+    //   prepare() transforms, camera, translation -> LDS, barrier;   point() the weight row (slot-indexed) and the arithmetic
+    // = two rounds + the weight row in front of the search where there were six (camera and translation come back from LDS: as per-lane
+    // loads the scheduler sank them behind the blend, as scalar loads the kernel spilled 221 registers).
+    psi_f2 st[2];
+    float ct;                     // threads 128 .. 142 of the workgroup: one entry of the body's camera (12) / translation (3), staged with the transforms
+    int v;
+    float px, py, pz;
+    float *sCT;
+#ifdef PSI_DBG_SHORT_BLEND
+    static constexpr int NWQ = 2, NWE = 2;                    // dev: timing bound only (wrong results)
+#else
+    static constexpr int NWQ = PSI_JP / 4 - 2, NWE = 10;
+#endif      // weight-row quads: 14 (56 joints); the first NWE are requested in fetch()
+    f4 wq[NWE];
+    int jslot;
+    __device__ __forceinline__ void issue(int b, int j)
+    {
+        jslot = j;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int idx = threadIdx.x + q * 256;
+            st[q] = idx < m.J * 6 ? psi_ld<psi_f2>(As + (size_t)b * m.J * 12, (unsigned)idx * 8u) : (psi_f2){0.0f, 0.0f};
+        }
+        const int k = (int)threadIdx.x - 128;                // (the second transform piece of these threads is beyond J: they have a load slot free)
+        ct = 0.0f;
+        if (k >= 0 && k < 12) ct = f.cam[(size_t)b * 16 + k];
+        else if (k >= 12 && k < 15) ct = f.transl[(size_t)b * 3 + (k - 12)];
+        v = f.vid[j];
+    }
+    __device__ __forceinline__ void fetch(int b)
+    {
+        const psi_p3 p = psi_ld<psi_p3>(v_posed + (size_t)b * m.Npad, (unsigned)v * 12u);
+        px = p.x; py = p.y; pz = p.z;
+        // ... and as much of the slot's weight row as the register budget holds (it depends on the slot only): in flight across the LDS
+        // staging and the barrier of prepare() instead of a round of its own behind them
+        const f4 *wrow = (const f4 *)(f.Wct + (size_t)jslot * PSI_JP);
+#pragma unroll
+        for (int q = 0; q < NWE; q++) wq[q] = wrow[q];
+    }
+    __device__ __forceinline__ void prepare(int)
     {
         __shared__ psi_f2 sA_[PSI_JP][6];
-        for (int idx = threadIdx.x; idx < PSI_JP * 6; idx += blockDim.x)
-            sA_[idx / 6][idx % 6] = idx < m.J * 6 ? *(const psi_f2 *)(As + ((size_t)b * m.J) * 12 + idx * 2) : (psi_f2){0.0f, 0.0f};
+        __shared__ float sCT_[16];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int idx = threadIdx.x + q * 256;
+            if (idx < PSI_JP * 6) (&sA_[0][0])[idx] = st[q];             // rows beyond J: zeros (issue)
+        }
+        const int k = (int)threadIdx.x - 128;
+        if (k >= 0 && k < 16) sCT_[k] = ct;
         __syncthreads();
         sA = sA_;
+        sCT = sCT_;
     }
     __device__ __forceinline__ void point(int b, int j, int c, float &qx, float &qy, float &qz) const
     {
         const int r = c < 2 ? c : 2;                          // lane 3 repeats row 2 (its result is not used)
-        const int v = f.vid[j];
         const f4 *wrow = (const f4 *)(f.Wct + (size_t)j * PSI_JP);
-        const float *vp = v_posed + (size_t)b * m.Npad + (size_t)v * 3;
-        const float px = vp[0], py = vp[1], pz = vp[2];
         psi_f2 T0 = {0.0f, 0.0f}, T1 = {0.0f, 0.0f};
 #pragma unroll
-        for (int q = 0; q < PSI_JP / 4 - 2; q++) {            // 56 joints: J = 55 (SMPL-X) + one zero row; psi_fit_create checks J <= 56
-            const f4 w4 = wrow[q];
+        for (int q = 0; q < NWQ; q++) {                        // 56 joints: J = 55 (SMPL-X) + one zero row; psi_fit_create checks J <= 56
+            const f4 w4 = q < NWE ? wq[q] : wrow[q];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const psi_f2 w2 = {w4[t], w4[t]};
@@ -542,16 +611,26 @@ struct ContactSkinSrc {
                 T1 = __builtin_elementwise_fma(w2, sA[q * 4 + t][2 * r + 1], T1);
             }
         }
-        float xr = psi_dot3p(T0.x, T0.y, T1.x, T1.y, px, py, pz) + f.transl[(size_t)b * 3 + r];
+        float xr = psi_dot3p(T0.x, T0.y, T1.x, T1.y, px, py, pz) + sCT[12 + r];
         const int base = (threadIdx.x & 63) & ~3;
         const float x = __shfl(xr, base, 64), y = __shfl(xr, base + 1, 64), z = __shfl(xr, base + 2, 64);
-        const float *C = f.cam + (size_t)b * 16;
+        const float *C = sCT;                                  // camera rows from LDS (broadcast reads)
         qx = psi_dot3p(C[0], C[1], C[2], C[3], x, y, z);
         qy = psi_dot3p(C[4], C[5], C[6], C[7], x, y, z);
         qz = psi_dot3p(C[8], C[9], C[10], C[11], x, y, z);
     }
 };
 
+#ifdef PSI_HEAD_STOPS
+extern "C" int psi_dbg_kd_mark(unsigned long long *out, int nblocks)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psi_kd_mark), sizeof(unsigned long long) * 4 * (size_t)(nblocks < 8192 ? nblocks : 8192));
+}
+extern "C" int psi_dbg_kd_stat(int *out, int nblocks)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psi_kd_stat), sizeof(int) * 4 * (size_t)(nblocks < 8192 ? nblocks : 8192));
+}
+#endif
 // ONE launch for the two scene terms of the forward pass: block ids [0, n_kd) are the NN-search workgroups (64 contact queries of
 // one body each; long, VALU-issue-bound pointer chases — dispatched first), the rest are the skinning + SDF workgroups (256
 // vertices of one body each; gather-latency-bound).  As two launches they ran back to back (23 + 18 us); they depend on the same
@@ -565,6 +644,9 @@ __global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, c
     if (psi_dbg_sstop == 1 && (int)blockIdx.x >= n_kd) return;      // NN-search workgroups only
     if (psi_dbg_sstop == 2 && (int)blockIdx.x < n_kd) return;       // skinning + SDF workgroups only
     if (psi_dbg_sstop == 3) return;                                  // neither: the launch itself
+    PsiBlockTrace trace;
+    if (threadIdx.x < 4 && blockIdx.x < 8192) psi_kd_stat[4 * blockIdx.x + threadIdx.x] = 0;     // (the search's atomics come after a barrier)
+    trace.kind = skin_first ? ((int)blockIdx.x >= (int)gridDim.x - n_kd) : ((int)blockIdx.x < n_kd);
 #endif
     // The NN-search workgroups come FIRST in the grid: they are the long ones.  Measured with the skinning workgroups first the launch
     // takes 43.6 us instead of 36.6 (HIP-event), with the two kinds spread evenly through the grid 45.8.
@@ -580,7 +662,7 @@ __global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, c
     }
     if (is_kd) {
         const int b = bid / nqb, bx = bid % nqb;
-        psikd::kd_query_body<true, false>(T, ContactSkinSrc{f, m, As, v_posed, nullptr}, f.n_c, (float *)nullptr, (int *)nullptr, f.cconst, gscale,
+        psikd::kd_query_body<true, false>(T, ContactSkinSrc{f, m, As, v_posed, nullptr, {}, 0.0f, 0, 0.0f, 0.0f, 0.0f, nullptr, {}, 0}, f.n_c, (float *)nullptr, (int *)nullptr, f.cconst, gscale,
                                           f.gq, f.fpart, f.nn_hint, rows, (const psikd::KdDev *)nullptr, (const int *)nullptr, bx, b, nqb, smem_i);
     } else {
         const int i = bid;

@@ -5,6 +5,7 @@
 // `+ transl` and PSI's verts_transform (cvae.py:141-149).
 //
 // Data layout in HBM (built once by psi_lbs_create, fp32):
+//   dirs_b [Npad/16][Kpad][16] the same matrix in 16-column tiles (the backward's copy)
 //   dirs  [Npad/64][Kpad][64]  column-tile-major: tile t holds columns 64t..64t+63 of the [Kpad][Npad] matrix whose rows
 //                        0..NB-1 = shapedirs^T and NB..NB+P-1 = posedirs (zero padded; N = 3V).  A workgroup's 64-column
 //                        strip is one contiguous 128 KB run, so the stream is sequential per CU instead of 256-byte
@@ -314,37 +315,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 // ------------------------------------------------------------------------------------------------
 // skinning backward, joint part (MFMA): gA[b][j][r*4+s] = sum_v W[v][j] * g_local[b][v][r] * [v_posed;1][s]
-// wave = one body x one 256-vertex slice x all 64 padded joints (4 accumulators).
 // ------------------------------------------------------------------------------------------------
-// NBODY bodies per workgroup: the weight tile of the slice (64 joints x 256 vertices = 64 KB, 16 registers x 16 B per lane) is
-// loaded ONCE and reused for every body (it was re-read from L2 per body: 86 MB per launch at B = 32), all bodies' operands are
-// requested up front and parked in LDS, and there are Vpad/256 * ceil(B/NBODY) workgroups (246 at B = 32) instead of 1312 — few
-// enough to be resident all at once beside the blend_bwd stream workgroups.  (In blend_fwd, requesting a tile's v_template slice
-// with its last chunk instead of after the reduction's barrier changed nothing: 21.9 us either way.)
+// One workgroup = one 256-vertex slice x NBODY bodies; it is ONE product  D[64 joints][12 NBODY] = W^T[64][256] P[256][12 NBODY]  with
+// P[v][12 bb + 4 r + s] = g_local[bb][v][r] [v_posed[bb][v]; 1][s]: the 12 (r, s) entries of consecutive bodies are packed side by side, so
+// the 16-wide MFMA tiles carry no padding (a tile per body carried four zero columns: a quarter of the instructions).  Wave w owns joint
+// tile w (joints 16 w .. 16 w + 15) for the WHOLE slice and all column tiles: nothing to reduce across waves — the previous form split
+// the slice's vertices over the waves and met in LDS behind two barriers per body, which behind the blend_bwd stream's MFMA bursts (the
+// two share the launch and each SIMD) cost 2.5 us per body (workgroup timeline: operands staged at 5.6 us, end at 22 — later than the
+// stream itself, profiles/r04_timeline_bwd_joint.txt).
+//   A operand: lane (li, lk) supplies joint 16 w + li, vertex 64 lk + st in step st: 64 consecutive floats of its weight row, a quad
+// (16 B) per four steps, each used for every column tile.  B operand: the same vertex, column 16 nt + li: a product of two LDS values; the
+// staged operands are kept component-major ([body][component][vertex], 64-vertex runs padded by 4) so that the four steps of a quad
+// are ONE 16-byte LDS read each for g_local and v_posed.
 constexpr int SKA_NBODY = 8;
+constexpr int SKA_ROW = 256 + 16;          // floats per staged (body, component) row: vertex v sits at v + 4 (v / 64)
+constexpr int SKA_MAXT = (12 * SKA_NBODY + 15) / 16;
+#ifdef PSI_HEAD_STOPS
+__device__ unsigned long long psi_dbg_ska_mark[2 * 2048];     // dev: skin_bwd_A workgroup — operands staged, first quad done
+#define PSI_SKA_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) psi_dbg_ska_mark[2 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+extern "C" int psi_dbg_ska_marks(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psi_dbg_ska_mark), sizeof(unsigned long long) * 2 * (size_t)(n < 2048 ? n : 2048)); }
+#else
+#define PSI_SKA_MARK(k)
+#endif
 
+// NT: column tiles of a full workgroup, (12 nbody + 15) / 16 — a compile-time count keeps the 16 quads straight-line code with all weight
+// quads in registers (a workgroup with fewer bodies than nbody repeats its last column in the spare tiles)
+template <int NT>
 __device__ __forceinline__ void skin_bwd_A_body(const LbsDev &m, const float *__restrict__ gl, const float *__restrict__ v_posed,
                                                 int B, float *__restrict__ part, int vslice, int b0, int nbody, f4 *smem)
 {
-    // workgroup = NBODY bodies x one 256-vertex slice; wave w contracts vertices [64w, 64w+64) of the slice (4 MFMA steps);
-    // the four waves are summed through LDS -> one partial per (slice, body).
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int vs = vslice * 256 + w * 64;
     const int li = lane & 15, lk = lane >> 4;
-    const int r = li >> 2, s = li & 3;
-    f4 wa[4][4];
-#pragma unroll
-    for (int st = 0; st < 4; st++)
-#pragma unroll
-        for (int jt = 0; jt < 4; jt++) wa[st][jt] = *(const f4 *)(m.WT + (size_t)(jt * 16 + li) * m.Vpad + vs + st * 16 + 4 * lk);
     const int nb = min(nbody, B - b0);
-    // ALL bodies' operands of this slice are requested up front, coalesced (768 consecutive floats of g_local and of v_posed per
-    // body: one 16-byte load each for threads 0..191), and parked in LDS; the MFMA operand order (component r / s of vertex
-    // 4*lk + t) is then a gather from LDS.  One memory round trip for the whole workgroup — it used to be one per body, of
-    // 32 four-byte loads per lane that fetched 48 useful bytes each, and behind the blend_bwd stream's traffic (the two share the
-    // launch) those six dependent round trips took as long as the stream itself.
-    f4 (*red)[4][64] = (f4 (*)[4][64])smem;                                     // [4][4][64] f4 = 16 KB
-    float *sg = (float *)(smem + 4 * 4 * 64);                                   // [SKA_NBODY][2][768]
+    const int ncol = 12 * nb;
+    // my weight row: joint 16 w + li, vertices 64 lk .. 64 lk + 63 of the slice — all 16 quads requested now (behind the stream's traffic
+    // a load takes ~2 us: requested two quads ahead of their use, they made every quad wait, 1 us per quad)
+    f4 wa[16];
+    {
+#ifdef PSI_SKA_WT        // dev: the joint-major copy (nothing else reads it between two launches of this kernel)
+        const f4 *wr = (const f4 *)(m.WT + (size_t)(w * 16 + li) * m.Vpad + (size_t)vslice * 256 + lk * 64);
+#else
+        // from the wave-tiled copy ([Vpad/64][64 joints][64 vertices]: the same 256 contiguous bytes per lane) — the copy skin_bwd_v streamed
+        // just before this launch, so most of it is still in L2 / MALL
+        const f4 *wr = (const f4 *)(m.WTt + (((size_t)vslice * 4 + lk) * PSI_JP + (w * 16 + li)) * 64);
+#endif
+#pragma unroll
+        for (int q = 0; q < 16; q++) wa[q] = wr[q];
+    }
+    // ALL bodies' operands of this slice are requested up front, coalesced (768 consecutive floats of g_local and of v_posed per body: one
+    // 16-byte load each for threads 0..191), and parked in LDS component-major
+    float *sG = (float *)smem;                                  // [SKA_NBODY][3][SKA_ROW]
+    float *sP = sG + SKA_NBODY * 3 * SKA_ROW;                   // [SKA_NBODY][3][SKA_ROW]
     {
         f4 og[SKA_NBODY], op[SKA_NBODY];
         const int t4 = threadIdx.x;
@@ -357,35 +378,54 @@ __device__ __forceinline__ void skin_bwd_A_body(const LbsDev &m, const float *__
 #pragma unroll
         for (int bb = 0; bb < SKA_NBODY; bb++)
             if (bb < nb && t4 < 192) {
-                *(f4 *)(sg + (bb * 2 + 0) * 768 + t4 * 4) = og[bb];
-                *(f4 *)(sg + (bb * 2 + 1) * 768 + t4 * 4) = op[bb];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = t4 * 4 + e, v = i / 3, comp = i - 3 * v;
+                    const int pos = (bb * 3 + comp) * SKA_ROW + v + 4 * (v >> 6);
+                    sG[pos] = og[bb][e];
+                    sP[pos] = op[bb][e];
+                }
             }
     }
     __syncthreads();
-    for (int bb = 0; bb < nb; bb++) {
-        const float *g_ = sg + (bb * 2 + 0) * 768 + (w * 64 + 4 * lk) * 3, *p_ = sg + (bb * 2 + 1) * 768 + (w * 64 + 4 * lk) * 3;
-        f4 acc[4];
+    PSI_SKA_MARK(0);
+    // my columns: tile nt -> column 16 nt + li = 12 bb + 4 r + s
+    int goff[NT], poff[NT];                                     // float offsets of my (body, r) / (body, s) rows + my 64-vertex run; poff < 0: s == 3
+    f4 acc[NT];
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = (f4){0, 0, 0, 0};
+    for (int nt = 0; nt < NT; nt++) {
+        const int c = min(16 * nt + li, ncol - 1);             // (columns past the last body repeat the last one; they are not stored)
+        const int bb = c / 12, rs = c - 12 * bb, r = rs >> 2, sx = rs & 3;
+        goff[nt] = (bb * 3 + r) * SKA_ROW + lk * 68;
+        poff[nt] = sx < 3 ? (bb * 3 + sx) * SKA_ROW + lk * 68 : -1;
+        acc[nt] = (f4){0, 0, 0, 0};
+    }
 #pragma unroll
-        for (int st = 0; st < 4; st++)
+    for (int q = 0; q < 16; q++) {
+        f4 bop[NT];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const float gv = (r < 3) ? g_[(st * 16 + t) * 3 + r] : 0.0f;
-                const float pv = (s < 3) ? p_[(st * 16 + t) * 3 + s] : 1.0f;
-                const float bop = gv * pv;
+        for (int nt = 0; nt < NT; nt++) {
+            const f4 g4 = *(const f4 *)(sG + goff[nt] + 4 * q);
+            const f4 p4 = *(const f4 *)(sP + max(poff[nt], 0) + 4 * q);
+            bop[nt] = poff[nt] >= 0 ? g4 * p4 : g4;
+        }
 #pragma unroll
-                for (int jt = 0; jt < 4; jt++) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[st][jt][t], bop, acc[jt], 0, 0, 0);
-            }
-        if (bb > 0) __syncthreads();             // the previous body's reduction has been read
+        for (int e = 0; e < 4; e++)
 #pragma unroll
-        for (int jt = 0; jt < 4; jt++) red[w][jt][lane] = acc[jt];
-        __syncthreads();
-        // wave w finishes joint tile w: D[row = lk*4+e -> joint][col = li -> r*4+s]
-        f4 o4 = red[0][w][lane] + red[1][w][lane] + red[2][w][lane] + red[3][w][lane];
-        float *o = part + ((size_t)vslice * B + b0 + bb) * JP * 16;
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[q][e], bop[nt][e], acc[nt], 0, 0, 0);
+        if (q == 0) PSI_SKA_MARK(1);
+        __builtin_amdgcn_sched_barrier(0);                      // (the scheduler otherwise hoists every quad's LDS reads to the top and spills)
+    }
+    // D[row = 4 lk + e -> joint 16 w + 4 lk + e][col = li -> column 16 nt + li]
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[(w * 16 + lk * 4 + e) * 16 + li] = o4[e];
+    for (int nt = 0; nt < NT; nt++) {
+        const int c = 16 * nt + li;
+        if (c < ncol) {
+            const int bb = c / 12, rs = c - 12 * bb;
+            float *o = part + (((size_t)vslice * B + b0 + bb) * JP + w * 16 + lk * 4) * 16 + rs;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e * 16] = acc[nt][e];
+        }
     }
 }
 
@@ -415,7 +455,11 @@ __device__ __forceinline__ void blend_bwd_body(const LbsDev &m, const float *__r
     for (int t = 0; t < MT; t++) grow[t] = g_vp + (size_t)min(b0 + t * 16 + li, B - 1) * m.Npad + 4 * lk;
     const float *drow[KT];
 #pragma unroll
-    for (int kt = 0; kt < KT; kt++) drow[kt] = m.dirs + (size_t)(k0 + kt * 16 + li) * 64 + 4 * lk;   // + tile base per step
+#ifdef PSI_BWD_DIRS_OLD
+    for (int kt = 0; kt < KT; kt++) drow[kt] = m.dirs + (size_t)(k0 + kt * 16 + li) * 64 + 4 * lk;
+#else
+    for (int kt = 0; kt < KT; kt++) drow[kt] = m.dirs_b + (size_t)(k0 + kt * 16 + li) * 16 + 4 * lk;   // + step base: a wave-load is 1 KB contiguous
+#endif
     // each wave owns steps s_begin+w, +4, ...; three steps' operands (3 x (MT + KT) 16-byte loads) are issued before the
     // first MFMA group waits, and the scheduler is fenced so it cannot sink them back next to their uses
     constexpr int PF = 3;
@@ -428,7 +472,11 @@ __device__ __forceinline__ void blend_bwd_body(const LbsDev &m, const float *__r
 #pragma unroll
             for (int t = 0; t < MT; t++) ga[p][t] = *(const f4 *)(grow[t] + n0);
 #pragma unroll
+#ifdef PSI_BWD_DIRS_OLD
             for (int kt = 0; kt < KT; kt++) db[p][kt] = *(const f4 *)(drow[kt] + (size_t)(n0 >> 6) * m.Kpad * 64 + (n0 & 63));
+#else
+            for (int kt = 0; kt < KT; kt++) db[p][kt] = *(const f4 *)(drow[kt] + (size_t)st * m.Kpad * 16);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -469,15 +517,48 @@ __device__ __forceinline__ void blend_bwd_body(const LbsDev &m, const float *__r
 // XCD-aware mapping of the stream part: workgroup `bid` runs on XCD bid % 8 (observed dispatch order) and every XCD has its
 // own L2, so the k-groups that share an n-slice — and therefore read the same g_vposed columns — are placed on ONE XCD: that
 // slice of g_vposed is fetched from memory once and served to the other k-groups from L2 (it used to be fetched by all 8 XCDs).
+#ifdef PSI_HEAD_STOPS
+// dev: workgroup timeline of the last bwd_joint launch ({start, end} in 10 ns ticks, hardware id, kind), tools/timeline.py
+__device__ unsigned long long psi_dbg_tl2[4 * 2048];
+struct PsiBlockTrace2 {
+    unsigned long long t0;
+    int kind;
+    __device__ PsiBlockTrace2() : t0(wall_clock64()), kind(0) {}
+    __device__ ~PsiBlockTrace2()
+    {
+        if (threadIdx.x != 0 || blockIdx.x >= 2048) return;
+        unsigned long long *o = psi_dbg_tl2 + 4 * (size_t)blockIdx.x;
+        o[0] = t0;
+        o[1] = wall_clock64();
+        o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        o[3] = (unsigned long long)kind;
+    }
+};
+extern "C" int psi_dbg_timeline2(unsigned long long *out, int nblocks)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psi_dbg_tl2), sizeof(unsigned long long) * 4 * (size_t)(nblocks < 2048 ? nblocks : 2048));
+}
+#endif
 template <int MT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void bwd_joint_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_joint_kernel(
     LbsDev m, const float *__restrict__ g_vp, const float *__restrict__ gl, const float *__restrict__ v_posed, int B, int steps_per_slice,
     float *__restrict__ gfeat_part, float *__restrict__ gA_part, int n_blend, int kgroups, int nslices, int nsv, int nbody)
 {
-    // blend_bwd: [4][KT][MT][64] f4; skin_bwd_A: [4][4][64] f4 for the reduction + SKA_NBODY bodies' staged operands (2 x 768 floats each)
-    constexpr int SMEM_A = 4 * 4 * 64 + SKA_NBODY * 2 * 768 / 4;
+    // blend_bwd: [4][KT][MT][64] f4; skin_bwd_A: SKA_NBODY bodies' staged operands (2 x 3 component rows each)
+    constexpr int SMEM_A = SKA_NBODY * 2 * 3 * SKA_ROW / 4;
     __shared__ f4 smem[4 * 4 * MT * 64 > SMEM_A ? 4 * 4 * MT * 64 : SMEM_A];
+#ifdef PSI_SKA_LAST       // dev: the previous grid order (stream workgroups first)
     const int bid = blockIdx.x;
+#else
+    // the skin_bwd_A workgroups come FIRST in the grid: a CU serves its workgroups' loads in order, and behind the 72 KB each stream wave
+    // requests at once the 100 KB of a skin_bwd_A workgroup arrived after 9.6 us (workgroup timeline) — in front of it they are short
+    const int n_ska = (int)gridDim.x - n_blend;
+    const int bid = (int)blockIdx.x >= n_ska ? (int)blockIdx.x - n_ska : (int)blockIdx.x + n_blend;
+#endif
+#ifdef PSI_HEAD_STOPS
+    PsiBlockTrace2 trace;
+    trace.kind = bid < n_blend;
+#endif
     if (bid < n_blend) {
         int kg, slice, bg;
         if ((nslices & 7) == 0) {
@@ -495,7 +576,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         blend_bwd_body<MT>(m, g_vp, B, steps_per_slice, gfeat_part, kg, slice, bg, smem);
     } else {
         const int i = bid - n_blend;
-        skin_bwd_A_body(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem);
+        switch ((12 * nbody + 15) >> 4) {
+        case 1: skin_bwd_A_body<1>(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem); break;
+        case 2: skin_bwd_A_body<2>(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem); break;
+        case 3: skin_bwd_A_body<3>(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem); break;
+        case 4: skin_bwd_A_body<4>(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem); break;
+        case 5: skin_bwd_A_body<5>(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem); break;
+        default: skin_bwd_A_body<SKA_MAXT>(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem); break;
+        }
     }
 }
 
@@ -541,7 +629,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int Kpad, c
     const long i = t / RSPL;
     const int s0 = (int)(t % RSPL);
     if (i < nA) {
-        const float r = sum_slices_split<12>(gA_part + i, (size_t)nA, nsv, s0);
+        // (entries 12..15 of a joint's 16 do not exist: skin_bwd_A writes the 3 x 4 gradient only, and nothing reads them)
+        const float r = (i & 15) < 12 ? sum_slices_split<12>(gA_part + i, (size_t)nA, nsv, s0) : 0.0f;
         if (s0 == 0) gA[i] = r;
     } else if (i < nA + nF) {
         const long k = i - nA;
@@ -632,12 +721,16 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
         d.n_items = (int)sub_item.size();
     }
     // host staging
-    std::vector<float> dirs((size_t)d.Kpad * d.Npad, 0.0f), vt(d.Npad, 0.0f), WT((size_t)JP * d.Vpad, 0.0f);
+    std::vector<float> dirs((size_t)d.Kpad * d.Npad, 0.0f), dirs_b((size_t)d.Kpad * d.Npad, 0.0f), vt(d.Npad, 0.0f), WT((size_t)JP * d.Vpad, 0.0f);
     auto dirs_at = [&](int k, int n) -> float & { return dirs[((size_t)(n >> 6) * d.Kpad + k) * 64 + (n & 63)]; };
     for (int l = 0; l < NB; l++)
         for (int n = 0; n < d.N; n++) dirs_at(l, n) = h_shapedirs[(size_t)n * NB + l];                  // [V,3,NB] -> row l
     for (int p = 0; p < d.P; p++)
         for (int n = 0; n < d.N; n++) dirs_at(NB + p, n) = h_posedirs[(size_t)p * d.N + n];
+    // the backward's copy, [Npad/16][Kpad][16]: blend_bwd contracts over n in steps of 16, and with 16-column tiles the 16 rows x 64 B a
+    // wave requests per load are ONE contiguous 1 KB (with the forward's 64-column tiles they were sixteen half cache lines)
+    for (int k = 0; k < d.Kpad; k++)
+        for (int n = 0; n < d.Npad; n++) dirs_b[((size_t)(n >> 4) * d.Kpad + k) * 16 + (n & 15)] = dirs_at(k, n);
     memcpy(vt.data(), h_v_template, sizeof(float) * d.N);
     std::vector<float> WTt((size_t)JP * d.Vpad, 0.0f);
     for (int v = 0; v < V; v++)
@@ -693,14 +786,14 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     // one device blob
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
-    size_t o_dirs = take(dirs.size() * 4), o_vt = take(vt.size() * 4), o_wt = take(WT.size() * 4), o_wtt = take(WTt.size() * 4), o_jt = take(Jt.size() * 4),
+    size_t o_dirs = take(dirs.size() * 4), o_dirs_b = take(dirs_b.size() * 4), o_vt = take(vt.size() * 4), o_wt = take(WT.size() * 4), o_wtt = take(WTt.size() * 4), o_jt = take(Jt.size() * 4),
            o_js = take(Js.size() * 4), o_wc = take(Wc.size() * 4 + 4), o_wj = take(Wj.size() * 4 + 4), o_par = take(J * 4), o_lvl = take(J * 4), o_cp = take((J + 1) * 4), o_ci = take(cidx.size() * 4),
            o_jump = take(jump.size() * 4), o_sl = take(sub_list.size()), o_si = take(sub_item.size() * 4), o_sf = take(sub_first.size());
     char *blob = nullptr;
     PSI_CHECK_HIP(hipMalloc((void **)&blob, o));
     std::vector<int> par(h_parents, h_parents + J);
     struct { size_t off; const void *src; size_t bytes; } cp[] = {
-        {o_dirs, dirs.data(), dirs.size() * 4}, {o_vt, vt.data(), vt.size() * 4}, {o_wt, WT.data(), WT.size() * 4}, {o_wtt, WTt.data(), WTt.size() * 4},
+        {o_dirs, dirs.data(), dirs.size() * 4}, {o_dirs_b, dirs_b.data(), dirs_b.size() * 4}, {o_vt, vt.data(), vt.size() * 4}, {o_wt, WT.data(), WT.size() * 4}, {o_wtt, WTt.data(), WTt.size() * 4},
         {o_jt, Jt.data(), Jt.size() * 4}, {o_js, Js.data(), Js.size() * 4}, {o_wc, Wc.data(), Wc.size() * 4}, {o_wj, Wj.data(), Wj.size() * 4},
         {o_par, par.data(), (size_t)J * 4},
         {o_lvl, level.data(), (size_t)J * 4}, {o_cp, cptr.data(), (size_t)(J + 1) * 4}, {o_ci, cidx.data(), cidx.size() * 4},
@@ -716,6 +809,7 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
         }
     }
     d.dirs = (const float *)(blob + o_dirs);
+    d.dirs_b = (const float *)(blob + o_dirs_b);
     d.v_template = (const float *)(blob + o_vt);
     d.WT = (const float *)(blob + o_wt);
     d.WTt = (const float *)(blob + o_wtt);

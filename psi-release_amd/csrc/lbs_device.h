@@ -17,7 +17,7 @@ constexpr int PSI_WNZ = 8;          // compressed skinning rows are used when no
 
 struct LbsDev {
     int V, J, NB, P, K, Kpad, N, Npad, Vpad, maxlevel, njump;
-    const float *dirs, *v_template, *WT, *J_t, *J_s;
+    const float *dirs, *dirs_b, *v_template, *WT, *J_t, *J_s;
     const float *WTt;                                // the same weights as [Vpad/64][PSI_JP][64]: a wave's 64 vertices x all joints = one contiguous 16 KB tile
     const float *Wc;                                 // compressed rows [PSI_WNZ][Vpad]: the k-th non-zero weight of each vertex (ascending joint), or nullptr
     const unsigned *Wj;                              //                 [PSI_WNZ/4][Vpad]: their joint indices, one byte each (padding: weight 0, joint 0)

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <cmath>
+#include <limits>
 #include <vector>
 
 #pragma clang fp contract(off)    // the distance expression is spelled out by PSI_SQ3 (psi_common.h) in both arithmetic modes
@@ -181,13 +182,56 @@ extern "C" int psi_nn_index_create(psi_nn_index **out, const float *h_points, in
             }
             return ((size_t)cc[0] * gn[1] + cc[1]) * gn[2] + cc[2];
         };
-        cell_start.assign(ncell + 1, 0);
+        // cell-ordered points, ascending original index inside a cell.  A point with the coordinates of a lower-index point can never
+        // win under the lowest-index-among-minima rule, so it is left out of the grid's list: what remains has no two entries at equal
+        // coordinates, which is what lets the scan's tie flag (nnindex_device.h) stay silent on clouds with duplicated vertices.
         std::vector<size_t> cid(m);
-        for (int i = 0; i < m; i++) { cid[i] = cell_of(i); cell_start[cid[i] + 1]++; }
+        for (int i = 0; i < m; i++) cid[i] = cell_of(i);
+        std::vector<int> ord(m);
+        for (int i = 0; i < m; i++) ord[i] = i;
+        auto coord_less = [&](int a, int b) {
+            for (int k = 0; k < 3; k++) {
+                const float u = h_points[(size_t)a * 3 + k], v = h_points[(size_t)b * 3 + k];
+                if (u < v) return true;
+                if (v < u) return false;
+            }
+            return a < b;
+        };
+        std::sort(ord.begin(), ord.end(), [&](int a, int b) { return cid[a] != cid[b] ? cid[a] < cid[b] : coord_less(a, b); });
+        std::vector<int> keep;
+        keep.reserve(m);
+        for (int k = 0; k < m; k++) {
+            const int i = ord[k];
+            bool dup = false;
+            if (k > 0 && cid[ord[k - 1]] == cid[i]) {
+                const int pi = ord[k - 1];                  // equal coordinates sort next to each other, lowest index first
+                dup = h_points[(size_t)pi * 3] == h_points[(size_t)i * 3] && h_points[(size_t)pi * 3 + 1] == h_points[(size_t)i * 3 + 1] &&
+                      h_points[(size_t)pi * 3 + 2] == h_points[(size_t)i * 3 + 2];
+                if (dup) ord[k] = pi;                       // a run of duplicates keeps comparing against its first member
+            }
+            if (!dup) keep.push_back(i);
+        }
+        std::sort(keep.begin(), keep.end(), [&](int a, int b) { return cid[a] != cid[b] ? cid[a] < cid[b] : a < b; });
+        cell_start.assign(ncell + 1, 0);
+        for (int i : keep) cell_start[cid[i] + 1]++;
         for (size_t c = 0; c < ncell; c++) cell_start[c + 1] += cell_start[c];
-        std::vector<int> fill(cell_start.begin(), cell_start.end() - 1);
-        gpts.resize(m);
-        for (int i = 0; i < m; i++) gpts[fill[cid[i]]++] = rec(i);                   // ascending original index inside a cell
+        // pair records (32 bytes): {x0,x1,y0,y1} {z0,z1,i0,i1} for list entries 2p, 2p+1 — the scan's packed arithmetic takes two points
+        // per instruction.  A scan reads whole pairs, GRID_PAIRS per round, so it may run one entry before its range and a round past it: those
+        // are real points of the cloud (ordinary candidates) or, past the end of the list, NaN records that no comparison accepts.
+        const size_t npair = (keep.size() + 1) / 2 + GRID_PAIRS;
+        const float nanf_ = std::numeric_limits<float>::quiet_NaN();
+        gpts.assign(npair * 2, make_float4(nanf_, nanf_, nanf_, nanf_));
+        for (size_t k = 0; k < keep.size(); k++) {
+            const float4 r = rec(keep[k]);
+            float4 &a = gpts[(k / 2) * 2], &b = gpts[(k / 2) * 2 + 1];
+            if (k & 1) { a.y = r.x; a.w = r.y; b.y = r.z; b.w = r.w; }
+            else       { a.x = r.x; a.z = r.y; b.x = r.z; b.z = r.w; }
+        }
+        const int none = 0x7fffffff;
+        for (size_t k = keep.size(); k < npair * 2; k++) {
+            float4 &b = gpts[(k / 2) * 2 + 1];
+            if (k & 1) memcpy(&b.w, &none, 4); else memcpy(&b.z, &none, 4);
+        }
     }
     size_t nb_nodes = bd.nodes.size() * sizeof(KdNode), nb_pts = pts.size() * sizeof(float4), nb_opts = opts.size() * sizeof(float4);
     size_t nb_cs = use_grid ? cell_start.size() * sizeof(int) : 0, nb_gp = gpts.size() * sizeof(float4);

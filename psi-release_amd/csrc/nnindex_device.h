@@ -6,6 +6,20 @@
 #include <math.h>
 #include "psi_common.h"
 
+#ifndef PSI_SSTOP
+#define PSI_SSTOP(k)
+#endif
+#ifdef PSI_HEAD_STOPS
+// dev: per workgroup {queries that took the tree walk, most node + leaf visits of one query, visits summed, grid points evaluated (max)}
+__device__ int psi_kd_stat[4 * 8192];
+__device__ unsigned long long psi_kd_mark[4 * 8192];   // wall clock (10 ns) of thread 0 at four points of the search body
+#define PSI_KD_STAT(what) what
+#define PSI_KD_MARK(k) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 8192 && psi_dbg_sstop >= 9) psi_kd_mark[4 * blockIdx.x + (k)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSI_KD_STAT(what)
+#define PSI_KD_MARK(k)
+#endif
+
 namespace psikd {
 
 constexpr int LEAF = 8;             // points per leaf; leaves are PADDED to exactly 8 records (copies of the last point)
@@ -45,14 +59,17 @@ struct KdDev {
     // Uniform grid over the same cloud, for WARM queries (ball_query below): cell (cx,cy,cz) holds gpts[cell_start[i] .. cell_start[i+1]),
     // i = (cx * gn[1] + cy) * gn[2] + cz — the cells of a z-run are one contiguous point range.  cell_start == nullptr: no grid.
     const int *cell_start;          // [gn0*gn1*gn2 + 1]
-    const float4 *gpts;             // cell-ordered {x,y,z,bitcast(orig index)}
+    const float4 *gpts;             // cell-ordered PAIR records {x0,x1,y0,y1} {z0,z1,bitcast(i0),bitcast(i1)}; NaN records past the end
     float gorg[3], ginv;            // cell of a point: clamp(floor((p - gorg) * ginv), 0, gn - 1), evaluated in fp32 exactly like this
     int gn[3];
 };
 
-constexpr int GRID_MAX_COLS = 3 * LPQ;      // (x,y) cell columns a warm query may touch (three per lane) ...
-constexpr int GRID_MAX_ZRUN = 4;            // ... and cells per column, before it takes the tree walk instead
-constexpr float GRID_EPS = 1e-3f;           // slack of the cell range in cell units: covers the rounding of (p - org) * inv on either side
+constexpr int GRID_COLS_PER_LANE = 3;       // (x,y) cell columns of the ball a lane scans (more columns than that: the tree walk) ...
+#ifndef PSI_KD_GRID_PAIRS
+#define PSI_KD_GRID_PAIRS 4
+#endif
+constexpr int GRID_PAIRS = PSI_KD_GRID_PAIRS;   // pair records a lane requests per round of its scan (nnindex.hip pads the list for the overshoot)
+constexpr int GRID_MAX_CAND = 64;           // ... out of at most this many columns in the ball's bounding rectangle
 
 // lane permutations inside an 8-lane group as DPP modifiers (no LDS traffic)
 template <int CTRL>
@@ -97,11 +114,16 @@ __device__ __forceinline__ kd_key group_min(kd_key k)
 // over 16 (8) queries, not 64.
 // Query source: where a query point comes from.  KdQueryFromMemory reads row qidx[j] (or j) of a [rows,3] table per body; the fused
 // fitting engine substitutes a source that SKINS the contact vertex on the spot (fit.hip), so the search does not have to wait for
-// the skinning kernel.  prepare(b) runs once per workgroup with all threads present (it may use LDS and barriers).
+// the skinning kernel.  Three phases, so that a source's loads travel in as few DEPENDENT rounds as possible (a round trip under the load
+// of the fused launch is ~2 us, and a search workgroup's life is a chain of them): issue(b, j) = loads that depend on nothing but the
+// query's slot, fetch(b) = loads that need issue()'s results (called after the caller has ALSO issued its own first loads), prepare(b)
+// = once per workgroup with all threads present (it may use LDS and barriers), point() = the query point.
 struct KdQueryFromMemory {
     const float *xyz1;
     const int *qidx;
     long qstride;
+    __device__ __forceinline__ void issue(int, int) {}
+    __device__ __forceinline__ void fetch(int) {}
     __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ void point(int b, int j, int, float &qx, float &qy, float &qz) const
     {
@@ -130,12 +152,12 @@ __device__ __forceinline__ void kd_block_fsum(float fval, float *__restrict__ ou
 }
 
 // The warm-start candidate of a query: last iteration's winner (hint[o], -1 = none) and its coordinates.  Two dependent loads that need
-// nothing but the query's slot — callers issue them first and compute the query point while they are in flight.
-__device__ __forceinline__ int kd_warm_candidate(const KdDev &T, const int *__restrict__ hint, bool active, size_t o, float4 &hp)
+// nothing but the query's slot, as two calls: callers issue the first together with their own first loads and the second together with
+// their own dependent loads, and compute the query point while it is in flight.
+__device__ __forceinline__ int kd_warm_hint(const int *__restrict__ hint, bool active, size_t o) { return (active && hint) ? hint[o] : -1; }
+__device__ __forceinline__ int kd_warm_candidate(const KdDev &T, int h, float4 &hp)
 {
     hp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (!(active && hint)) return -1;
-    const int h = hint[o];
     if (h < 0 || h >= T.m) return -1;
     hp = T.opts[h];
     return h;
@@ -169,59 +191,111 @@ __device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float 
     int cur = T.root;
     float curd = 0.0f;
     bool have = active;
+    PSI_KD_STAT(int nvis = 0; int ngp = 0;)
     // Warm query (a candidate from the previous iteration is known): the winner can only lie in the ball of radius sqrt(best) around
     // the query, so instead of walking the tree — ~8 DEPENDENT node / leaf loads — every point of the grid cells that ball touches is
-    // evaluated: two dependent rounds of independent loads (cell ranges, then points).  Exact for the same reason the tree is: a point
-    // p with computed d(p) <= best has |p - q| <= sqrt(best) (1 + 3e-7) on every axis, the cell range below covers that interval with
-    // GRID_EPS cells of slack against the rounding of the cell formula, every point in range is evaluated with the identical distance
-    // expression and the (d, index) key keeps the lowest index among minima.  A ball that touches too many cells (a body far from
-    // the scene) takes the tree walk.  The decision is uniform over the lanes of a group (they hold the same query and bound).
+    // evaluated: two dependent rounds of independent loads (cell ranges, then points).
+    //   Which cells: in cell units u = (p - org) * ginv the cell of a point is clamp(floor(u)) per axis, the query sits at uq and the
+    // ball has radius ru (inflated by 1e-4 relative + 0.01 cell: far above the rounding of u, of the distance expression and of the
+    // square root below).  Column (cx, cy) can hold a point of the ball only if its (x,y) rectangle — the unit square at (cx, cy),
+    // open-ended on the sides where the grid ends, since the cell formula clamps — is within ru of uq; if it is, the ball reaches
+    // hz = sqrt(ru^2 - dxy^2) along z in that column, i.e. cells floor(uz - hz) .. floor(uz + hz).  The lanes of the group enumerate
+    // the columns of the ball's bounding rectangle, the surviving ones are numbered with a ballot and handed out round-robin through
+    // the group's (idle) stack rows, so every lane scans at most GRID_COLS_PER_LANE z-runs, each one contiguous point range.
+    //   Exact for the same reason the tree is: every point with computed d <= best lies in a scanned cell, every scanned point is
+    // evaluated with the identical distance expression, and the lowest index among minima wins — inside a lane by scan order (a
+    // strictly smaller distance replaces; an EQUAL one raises the tie flag, and a group with a flagged lane re-does the query with
+    // the tree walk and its (d, index) keys), across lanes and against the warm candidate by the key.  A ball with too many columns
+    // (a body far from the scene) takes the tree walk as well.  All decisions are uniform over the lanes of a group.
+    const int gshift = (tid & 63) & ~(LPQ - 1);               // bit position of my group inside the wave's ballot
     if (have && T.cell_start && best < INFINITY) {
-        const float r = sqrtf(best) * 1.00001f + 1e-30f;
-        int lo[3], hi[3];
-        const float q3[3] = {qx, qy, qz};
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const float top = (float)(T.gn[a] - 1);          // clamped as floats: a far query must not overflow the conversion
-            lo[a] = (int)fminf(fmaxf(floorf((q3[a] - r - T.gorg[a]) * T.ginv - GRID_EPS), 0.0f), top);
-            hi[a] = (int)fminf(fmaxf(floorf((q3[a] + r - T.gorg[a]) * T.ginv + GRID_EPS), 0.0f), top);
-        }
-        const int nyc = hi[1] - lo[1] + 1, ncol = (hi[0] - lo[0] + 1) * nyc, nzc = hi[2] - lo[2] + 1;
-        if (ncol >= 1 && nyc >= 1 && nzc >= 1 && ncol <= GRID_MAX_COLS && nzc <= GRID_MAX_ZRUN) {
-            int cs[3], ce[3];
-#pragma unroll
-            for (int u = 0; u < 3; u++) {                      // my columns: c, c + LPQ, c + 2 LPQ — all ranges requested together
-                const int col = c + u * LPQ;
-                cs[u] = ce[u] = 0;
-                if (col < ncol) {
-                    const int cx = lo[0] + col / nyc, cy = lo[1] + col % nyc;
-                    const int base = (cx * T.gn[1] + cy) * T.gn[2];
-                    cs[u] = T.cell_start[base + lo[2]];
-                    ce[u] = T.cell_start[base + hi[2] + 1];
-                }
+        const float ru = __builtin_amdgcn_sqrtf(best) * T.ginv * 1.0001f + 0.01f;          // (1 ulp: inside the slack)
+        const float uq[3] = {(qx - T.gorg[0]) * T.ginv, (qy - T.gorg[1]) * T.ginv, (qz - T.gorg[2]) * T.ginv};
+        const float topx = (float)(T.gn[0] - 1), topy = (float)(T.gn[1] - 1), topz = (float)(T.gn[2] - 1);
+        // clamped as floats: a far query must not overflow the conversion
+        const float flx = fminf(fmaxf(floorf(uq[0] - ru), 0.0f), topx), fhx = fminf(fmaxf(floorf(uq[0] + ru), 0.0f), topx);
+        const float fly = fminf(fmaxf(floorf(uq[1] - ru), 0.0f), topy), fhy = fminf(fmaxf(floorf(uq[1] + ru), 0.0f), topy);
+        const float fny = fhy - fly + 1.0f, fncand = (fhx - flx + 1.0f) * fny;
+        if (fncand <= (float)GRID_MAX_CAND) {
+            const int ncand = (int)fncand;
+            const float rny = __builtin_amdgcn_rcpf(fny), ru2 = ru * ru;
+            int nsurv = 0;
+            for (int c0 = 0; c0 < ncand; c0 += LPQ) {          // (uniform over the group)
+                const float fcol = (float)(c0 + c);
+                const float fcx = floorf((fcol + 0.5f) * rny);   // column index / ny: the quotient's fraction is >= 0.5 / ny, far from rounding
+                const float cxf = flx + fcx, cyf = fly + (fcol - fcx * fny);
+                // distance from uq to the column's rectangle, per axis; a side where the grid ends is open
+                const float ax = fmaxf(cxf > 0.0f ? cxf - uq[0] : 0.0f, cxf < topx ? uq[0] - cxf - 1.0f : 0.0f);
+                const float ay = fmaxf(cyf > 0.0f ? cyf - uq[1] : 0.0f, cyf < topy ? uq[1] - cyf - 1.0f : 0.0f);
+                const float dx = fmaxf(ax, 0.0f), dy = fmaxf(ay, 0.0f);
+                const float h2 = ru2 - dx * dx - dy * dy;
+                const bool ok = c0 + c < ncand && h2 >= 0.0f;
+                const float hz = __builtin_amdgcn_sqrtf(fmaxf(h2, 0.0f));
+                const int zlo = (int)fminf(fmaxf(floorf(uq[2] - hz), 0.0f), topz), zhi = (int)fminf(fmaxf(floorf(uq[2] + hz), 0.0f), topz);
+                const unsigned gm = (unsigned)(__ballot(ok) >> gshift) & ((1u << LPQ) - 1u);
+                const int pos = nsurv + __popc(gm & ((1u << c) - 1u));
+                if (ok && pos < GRID_COLS_PER_LANE * LPQ) stk_n[pos] = (((int)cxf * T.gn[1] + (int)cyf) << 14) | (zlo << 7) | zhi;
+                nsurv += __popc(gm);
             }
-            kd_key k = ~0ull;
+            if (nsurv <= GRID_COLS_PER_LANE * LPQ && nsurv > 0) {
+                // my z-runs, as ranges of PAIR records: first pair, rounds of two pairs
+                int ps[GRID_COLS_PER_LANE], nr[GRID_COLS_PER_LANE];
+                int cs[GRID_COLS_PER_LANE], ce[GRID_COLS_PER_LANE];
+                const char *csb = (const char *)T.cell_start;
 #pragma unroll
-            for (int u = 0; u < 3; u++) {
-                for (int i = cs[u]; i < ce[u]; i += 4) {        // four points per round trip (indices past the end repeat the last point)
-                    float4 pp[4];
+                for (int u = 0; u < GRID_COLS_PER_LANE; u++) {     // all ranges requested together; a slot past the list re-reads entry 0
+                    const int e = stk_n[c + u * LPQ < nsurv ? c + u * LPQ : 0];
+                    const unsigned base = (unsigned)(e >> 14) * (unsigned)T.gn[2];
+                    cs[u] = *(const int *)(csb + ((base + ((unsigned)e >> 7 & 127u)) << 2));
+                    ce[u] = *(const int *)(csb + ((base + ((unsigned)e & 127u) + 1u) << 2));
+                }
+                int rounds = 0;
+                PSI_KD_MARK(1);
 #pragma unroll
-                    for (int t = 0; t < 4; t++) pp[t] = T.gpts[min(i + t, ce[u] - 1)];
+                for (int u = 0; u < GRID_COLS_PER_LANE; u++) {
+                    ps[u] = cs[u] >> 1;
+                    nr[u] = (ce[u] > cs[u] && c + u * LPQ < nsurv) ? (((ce[u] + 1) >> 1) - ps[u] + GRID_PAIRS - 1) / GRID_PAIRS : 0;
+                    rounds += nr[u];
+                }
+                // one loop over the rounds of all my runs: round t reads pairs GRID_PAIRS t + off(t) .., off = the run's first pair minus
+                // GRID_PAIRS times the rounds before it
+                static_assert(GRID_COLS_PER_LANE == 3, "the round -> pair mapping below is written for three runs");
+                const int r01 = nr[0] + nr[1];
+                const int off1 = ps[1] - GRID_PAIRS * nr[0], off2 = ps[2] - GRID_PAIRS * r01;
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f qxx = {qx, qx}, qyy = {qy, qy}, qzz = {qz, qz};
+                float bd = INFINITY;
+                int bi = 0x7fffffff;
+                bool tie = false;
+                for (int t = 0; t < rounds; t++) {
+                    PSI_KD_STAT(ngp += 1;)
+                    const int pr = GRID_PAIRS * t + (t < nr[0] ? ps[0] : t < r01 ? off1 : off2);
+                    const float4 *rp = (const float4 *)((const char *)T.gpts + ((unsigned)pr << 5));
+                    float4 a[GRID_PAIRS], b[GRID_PAIRS];
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        float x2 = pp[t].x - qx, y2 = pp[t].y - qy, z2 = pp[t].z - qz;
-                        const kd_key ku = kd_pack(PSI_SQ3(x2, y2, z2), __float_as_int(pp[t].w));
-                        k = ku < k ? ku : k;
+                    for (int k = 0; k < GRID_PAIRS; k++) { a[k] = rp[2 * k]; b[k] = rp[2 * k + 1]; }
+#pragma unroll
+                    for (int k = 0; k < GRID_PAIRS; k++) {
+                        const v2f x2 = (v2f){a[k].x, a[k].y} - qxx, y2 = (v2f){a[k].z, a[k].w} - qyy, z2 = (v2f){b[k].x, b[k].y} - qzz;
+                        const v2f d = x2 * x2 + y2 * y2 + z2 * z2;     // PSI_SQ3 on two points (contraction is off in this function)
+                        const int i2[2] = {__float_as_int(b[k].z), __float_as_int(b[k].w)};
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            const bool lt = d[e] < bd;
+                            tie = tie || d[e] == bd;
+                            bi = lt ? i2[e] : bi;
+                            bd = lt ? d[e] : bd;
+                        }
                     }
                 }
+                kd_key k = group_min<LPQ>(kd_pack(bd, bi));
+                PSI_KD_MARK(2);
+                bestk = k < bestk ? k : bestk;
+                best = kd_key_d(bestk);
+                have = ((__ballot(tie) >> gshift) & ((1ull << LPQ) - 1ull)) != 0;     // done, unless a lane met two points at equal distance
             }
-            k = group_min<LPQ>(k);
-            bestk = k < bestk ? k : bestk;
-            best = kd_key_d(bestk);
-            have = false;                                      // done: the tree walk below is skipped for this query
         }
     }
-    const int gshift = (tid & 63) & ~(LPQ - 1);               // bit position of my group inside the wave's ballot
     while (true) {
         while (!have && sp > 0) {                             // pop until something survives the current bound (group-uniform)
             --sp;
@@ -230,6 +304,7 @@ __device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float 
             have = !(curd * 0.999999f > best);
         }
         if (!have) break;
+        PSI_KD_STAT(nvis += 1;)
         if (cur >= 0) {
             float dc[CPL];
             int ref[CPL];
@@ -284,14 +359,22 @@ __device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float 
             have = false;
         }
     }
+    PSI_KD_STAT(if (blockIdx.x < 8192 && psi_dbg_sstop == 10) {
+        int *st_ = psi_kd_stat + 4 * blockIdx.x;
+        if (c == 0 && nvis > 0) { atomicAdd(st_ + 0, 1); atomicAdd(st_ + 2, nvis); }
+        atomicMax(st_ + 1, nvis);
+        atomicMax(st_ + 3, ngp);
+    })
     float fval = 0.0f;
+    PSI_KD_MARK(3);
     if (active && c == 0) {
         const int besti = kd_key_i(bestk);
         if (dist) dist[o] = best;
         if (idx) idx[o] = besti;
         if (hint) hint[o] = besti;
         if (CONTACT) {
-            const float4 w = T.opts[besti];                   // the winner's coordinates (same values the scan used)
+            float4 w = hp;                                    // the winner's coordinates (same values the scan used): the warm candidate's
+            if (besti != h) w = T.opts[besti];                // are here already — a load only when the winner changed since the last call
             float sq = sqrtf(best + 1e-4f);
             float den = sq + cconst;
             fval = sq / den;
@@ -319,9 +402,16 @@ __device__ __forceinline__ void kd_query_body(KdDev T0, QSrc qsrc, int n, float 
     const size_t o = (size_t)b * n + (active ? j : 0);
     float qx = 0, qy = 0, qz = 0;
     float4 hp;
-    const int h = kd_warm_candidate(T, hint, active, o, hp);   // in flight while the query point is produced
+    // round 1: everything that depends on the slot only (the source's own loads, last iteration's winner); round 2: what those name (the
+    // winner's coordinates, the source's second-level loads) — then the workgroup phase and the arithmetic
+    qsrc.issue(b, active ? j : 0);
+    const int h0 = kd_warm_hint(hint, active, o);
+    qsrc.fetch(b);
+    const int h = kd_warm_candidate(T, h0, hp);
     qsrc.prepare(b);
     qsrc.point(b, active ? j : 0, c, qx, qy, qz);                // every lane of the group ends up with the same point
+    PSI_SSTOP(4);                                                // (dev: differential timing — the query source alone)
+    PSI_KD_MARK(0);
     const float fval = kd_query_round<CONTACT>(T, qx, qy, qz, active, o, dist, idx, cconst, gscale, gq, hint, rows, smem_i, h, hp);
     if (CONTACT) kd_block_fsum(fval, fpart + (size_t)b * nbx + bx);
 }

@@ -24,6 +24,18 @@ for step in "$@"; do
     ab) for r in 1 2; do for l in ${a1//,/ }; do uselib $l; timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 $a2 2>>$O/ab.err | tail -1 | tee -a "$O/ab_$l.json" | line "$l [$a2]"; done; done; uselib default ;;
     pmc512) args="--batch 512"; [ "$a1" = sparse ] && args="--batch 512 --weight-nnz 4"
       bash tools/pmc2.sh $TAG "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" ${a2:-psi_skin_fwd_kernel} python $GRAFT_REPO_ROOT/bench.py $args --steps 10 --warmup 3 --no-cpu-baseline --secondary 0 > $O/pmc_skin_fwd_sdf_b512_$a1.txt 2>&1; cat $O/pmc_skin_fwd_sdf_b512_$a1.txt ;;
+    pmc) # pmc:<kernel substring>:<bench args> — counters of one kernel of the default bench
+      bash tools/pmc2.sh $TAG "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE SQ_WAVES" ${a1:-fwd_scene_kernel} python $GRAFT_REPO_ROOT/bench.py $a2 --steps 10 --warmup 3 --no-cpu-baseline --secondary 0 > "$O/pmc_$a1.txt" 2>&1; cat "$O/pmc_$a1.txt" ;;
+    stops) # stops:<list of PSI_SKIN_STOP values>: rocprofv3 average of fwd_scene / skin_bwd_v / bwd_joint with the -DPSI_HEAD_STOPS library (tools/_variants/stops.so)
+      for k in ${a1//,/ }; do export PSI_HIP_LIB=$GRAFT_REPO_ROOT/tools/_variants/stops.so PSI_SKIN_STOP=$k; rm -rf /tmp/pst; ( cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pst -o p -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 $a2 > $O/stops_$k.log 2>&1 )
+        python - "$(find /tmp/pst -name '*kernel_stats.csv' | head -1)" $k <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if int(r['Calls']) > 1000]
+print('stop', sys.argv[2], ' '.join('%s=%.2f' % (r['Name'].split('(')[0].replace('void ', '').replace('(anonymous namespace)::', '')[:24], float(r['AverageNs']) / 1e3) for r in sorted(rows, key=lambda r: r['Name'])))
+PY
+      done; unset PSI_HIP_LIB PSI_SKIN_STOP ;;
+    timeline) PSI_HIP_LIB=$GRAFT_REPO_ROOT/tools/_variants/stops.so PSI_SKIN_STOP=9 python tools/timeline.py > $O/timeline.txt 2>&1; tail -18 $O/timeline.txt | cut -c1-400 ;;
+    timeline2) PSI_HIP_LIB=$GRAFT_REPO_ROOT/tools/_variants/stops2.so python tools/timeline2.py > $O/timeline2.txt 2>&1; tail -12 $O/timeline2.txt | cut -c1-300 ;;
     profab) for l in ${a1//,/ }; do uselib $l; rm -rf /tmp/pab; ( cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pab -o p -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 $a2 > "$O/profab_$l.log" 2>&1 )
         f=$(find /tmp/pab -name "*kernel_stats.csv" | head -1); cp $f "$O/kernel_stats_$l.csv"
         python - "$f" "$l" <<'PY'
