@@ -30,17 +30,20 @@
 #ifdef PSI_HEAD_STOPS
 __device__ int psi_dbg_sstop;            // dev: leave the skinning / scene kernels at this point (tools/head_stops.sh)
 #define PSI_SSTOP(k) do { if (psi_dbg_sstop == (k)) return; } while (0)
+#define PSI_TRACE(lo, hi) PsiBlockTrace trace_((lo), (hi))
 // dev (PSI_SKIN_STOP=9): the workgroup timeline of the LAST fwd_scene launch — {start, end} in 10 ns wall-clock ticks, the hardware id
 // words and the kind of workgroup, one record per workgroup (tools/timeline.py draws it)
 __device__ unsigned long long psi_dbg_tl[4 * 8192];
 struct PsiBlockTrace {
     unsigned long long t0;
     int kind;
-    __device__ PsiBlockTrace() : t0(wall_clock64()), kind(0) {}
+    int sel_lo, sel_hi;
+    __device__ PsiBlockTrace(int lo = 9, int hi = 10) : t0(wall_clock64()), kind(0), sel_lo(lo), sel_hi(hi) {}
     __device__ ~PsiBlockTrace()
     {
-        if (psi_dbg_sstop < 9 || threadIdx.x != 0 || blockIdx.x >= 8192) return;
-        unsigned long long *o = psi_dbg_tl + 4 * (size_t)blockIdx.x;
+        const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
+        if (psi_dbg_sstop < sel_lo || psi_dbg_sstop > sel_hi || threadIdx.x != 0 || bid >= 8192) return;
+        unsigned long long *o = psi_dbg_tl + 4 * (size_t)bid;
         o[0] = t0;
         o[1] = wall_clock64();
         o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
@@ -550,11 +553,7 @@ struct ContactSkinSrc {
     int v;
     float px, py, pz;
     float *sCT;
-#ifdef PSI_DBG_SHORT_BLEND
-    static constexpr int NWQ = 2, NWE = 2;                    // dev: timing bound only (wrong results)
-#else
-    static constexpr int NWQ = PSI_JP / 4 - 2, NWE = 10;
-#endif      // weight-row quads: 14 (56 joints); the first NWE are requested in fetch()
+    static constexpr int NWQ = PSI_JP / 4 - 2, NWE = 10;      // weight-row quads: 14 (56 joints); the first NWE are requested in fetch()
     f4 wq[NWE];
     int jslot;
     __device__ __forceinline__ void issue(int b, int j)
@@ -626,6 +625,7 @@ extern "C" int psi_dbg_kd_mark(unsigned long long *out, int nblocks)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psi_kd_mark), sizeof(unsigned long long) * 4 * (size_t)(nblocks < 8192 ? nblocks : 8192));
 }
+extern "C" int psi_dbg_kd_reason(int *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psi_kd_reason), sizeof(int) * 8); }
 extern "C" int psi_dbg_kd_stat(int *out, int nblocks)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psi_kd_stat), sizeof(int) * 4 * (size_t)(nblocks < 8192 ? nblocks : 8192));

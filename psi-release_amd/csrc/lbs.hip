@@ -352,13 +352,9 @@ __device__ __forceinline__ void skin_bwd_A_body(const LbsDev &m, const float *__
     // a load takes ~2 us: requested two quads ahead of their use, they made every quad wait, 1 us per quad)
     f4 wa[16];
     {
-#ifdef PSI_SKA_WT        // dev: the joint-major copy (nothing else reads it between two launches of this kernel)
-        const f4 *wr = (const f4 *)(m.WT + (size_t)(w * 16 + li) * m.Vpad + (size_t)vslice * 256 + lk * 64);
-#else
         // from the wave-tiled copy ([Vpad/64][64 joints][64 vertices]: the same 256 contiguous bytes per lane) — the copy skin_bwd_v streamed
         // just before this launch, so most of it is still in L2 / MALL
         const f4 *wr = (const f4 *)(m.WTt + (((size_t)vslice * 4 + lk) * PSI_JP + (w * 16 + li)) * 64);
-#endif
 #pragma unroll
         for (int q = 0; q < 16; q++) wa[q] = wr[q];
     }
@@ -400,6 +396,8 @@ __device__ __forceinline__ void skin_bwd_A_body(const LbsDev &m, const float *__
         poff[nt] = sx < 3 ? (bb * 3 + sx) * SKA_ROW + lk * 68 : -1;
         acc[nt] = (f4){0, 0, 0, 0};
     }
+    // (requesting quad q + 1's LDS operands before quad q's MFMAs — a denser MFMA stream of this wave — measured SLOWER, 23.1 against 21.8 us:
+    // the stream wave on the same SIMD then waits longer for the pipe, and the launch ends when the later of the two kinds does)
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         f4 bop[NT];
@@ -455,14 +453,14 @@ __device__ __forceinline__ void blend_bwd_body(const LbsDev &m, const float *__r
     for (int t = 0; t < MT; t++) grow[t] = g_vp + (size_t)min(b0 + t * 16 + li, B - 1) * m.Npad + 4 * lk;
     const float *drow[KT];
 #pragma unroll
-#ifdef PSI_BWD_DIRS_OLD
-    for (int kt = 0; kt < KT; kt++) drow[kt] = m.dirs + (size_t)(k0 + kt * 16 + li) * 64 + 4 * lk;
-#else
     for (int kt = 0; kt < KT; kt++) drow[kt] = m.dirs_b + (size_t)(k0 + kt * 16 + li) * 16 + 4 * lk;   // + step base: a wave-load is 1 KB contiguous
-#endif
-    // each wave owns steps s_begin+w, +4, ...; three steps' operands (3 x (MT + KT) 16-byte loads) are issued before the
-    // first MFMA group waits, and the scheduler is fenced so it cannot sink them back next to their uses
-    constexpr int PF = 3;
+    // each wave owns steps s_begin+w, +4, ...; PF steps' operands (PF x (MT + KT) 16-byte loads) are issued before the first MFMA group
+    // waits, and the scheduler is fenced so it cannot sink them back next to their uses.  PF = 1: with the skin_bwd_A waves sharing the SIMDs
+    // (one each) a short MFMA burst per round trip serves the LAUNCH best — rocprofv3, B = 32: PF = 1 22.0 us, 2 22.6, 3 23.9 (round 3's
+    // setting, tuned before the two kinds of wave were balanced), 4 25.1; double-buffered (the next step's loads in flight under the MFMAs)
+    // 22.0 at PF = 1 and 29-35 at PF = 2-3: whatever lets the stream wave hold the matrix pipe longer delays the other kind, and the
+    // launch ends with the later of the two
+    constexpr int PF = 1;
     for (int st0 = s_begin + w; st0 < s_end; st0 += 4 * PF) {
         f4 ga[PF][MT], db[PF][KT];
 #pragma unroll
@@ -472,11 +470,7 @@ __device__ __forceinline__ void blend_bwd_body(const LbsDev &m, const float *__r
 #pragma unroll
             for (int t = 0; t < MT; t++) ga[p][t] = *(const f4 *)(grow[t] + n0);
 #pragma unroll
-#ifdef PSI_BWD_DIRS_OLD
-            for (int kt = 0; kt < KT; kt++) db[p][kt] = *(const f4 *)(drow[kt] + (size_t)(n0 >> 6) * m.Kpad * 64 + (n0 & 63));
-#else
             for (int kt = 0; kt < KT; kt++) db[p][kt] = *(const f4 *)(drow[kt] + (size_t)st * m.Kpad * 16);
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -547,14 +541,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // blend_bwd: [4][KT][MT][64] f4; skin_bwd_A: SKA_NBODY bodies' staged operands (2 x 3 component rows each)
     constexpr int SMEM_A = SKA_NBODY * 2 * 3 * SKA_ROW / 4;
     __shared__ f4 smem[4 * 4 * MT * 64 > SMEM_A ? 4 * 4 * MT * 64 : SMEM_A];
-#ifdef PSI_SKA_LAST       // dev: the previous grid order (stream workgroups first)
-    const int bid = blockIdx.x;
-#else
     // the skin_bwd_A workgroups come FIRST in the grid: a CU serves its workgroups' loads in order, and behind the 72 KB each stream wave
     // requests at once the 100 KB of a skin_bwd_A workgroup arrived after 9.6 us (workgroup timeline) — in front of it they are short
     const int n_ska = (int)gridDim.x - n_blend;
     const int bid = (int)blockIdx.x >= n_ska ? (int)blockIdx.x - n_ska : (int)blockIdx.x + n_blend;
-#endif
 #ifdef PSI_HEAD_STOPS
     PsiBlockTrace2 trace;
     trace.kind = bid < n_blend;

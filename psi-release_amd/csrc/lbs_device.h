@@ -2,6 +2,9 @@
 // workspace view, and the per-body pose stages (executed by one workgroup per body), which the fused fitting engine
 // (fit.hip) inlines into its head / tail kernels.  Reference arithmetic: human_body_prior/body_model/lbs.py:165-262.
 #pragma once
+#ifndef PSI_TRACE
+#define PSI_TRACE(lo, hi)
+#endif
 #ifndef PSI_SSTOP
 #define PSI_SSTOP(k)
 #endif
@@ -743,6 +746,7 @@ __global__ __launch_bounds__(PSI_SKIN_BLK, 6) void psi_skin_bwd_v_kernel(LbsDev 
 {
     const int v = blockIdx.x * PSI_SKIN_BLK + threadIdx.x;
     const int b = blockIdx.y;
+    PSI_TRACE(30, 30);                                       // (dev: workgroup timeline, tools/timeline.py)
     // all first loads in one go: transforms to stage, weight row, the gradient source's operands and its statistics inputs
     PSI_SSTOP(11);
     typename Src::Pre pre = src.issue(b, v, v < m.V);

@@ -12,6 +12,7 @@
 #ifdef PSI_HEAD_STOPS
 // dev: per workgroup {queries that took the tree walk, most node + leaf visits of one query, visits summed, grid points evaluated (max)}
 __device__ int psi_kd_stat[4 * 8192];
+__device__ int psi_kd_reason[8];        // dev: why a warm query took the tree walk — 0 too many candidates, 1 too many surviving columns, 2 tie flag, 3 no warm candidate
 __device__ unsigned long long psi_kd_mark[4 * 8192];   // wall clock (10 ns) of thread 0 at four points of the search body
 #define PSI_KD_STAT(what) what
 #define PSI_KD_MARK(k) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 8192 && psi_dbg_sstop >= 9) psi_kd_mark[4 * blockIdx.x + (k)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -64,12 +65,19 @@ struct KdDev {
     int gn[3];
 };
 
-constexpr int GRID_COLS_PER_LANE = 3;       // (x,y) cell columns of the ball a lane scans (more columns than that: the tree walk) ...
+constexpr int GRID_COLS_PER_LANE = 3;       // (x,y) cell columns of the ball a lane scans per pass over the list of surviving columns ...
+#ifndef PSI_KD_GRID_LIST_MAX
+#define PSI_KD_GRID_LIST_MAX 48
+#endif
+constexpr int GRID_LIST_MAX = PSI_KD_GRID_LIST_MAX;   // ... which holds at most this many (more: the tree walk) ...
 #ifndef PSI_KD_GRID_PAIRS
 #define PSI_KD_GRID_PAIRS 4
 #endif
 constexpr int GRID_PAIRS = PSI_KD_GRID_PAIRS;   // pair records a lane requests per round of its scan (nnindex.hip pads the list for the overshoot)
-constexpr int GRID_MAX_CAND = 64;           // ... out of at most this many columns in the ball's bounding rectangle
+#ifndef PSI_KD_GRID_MAX_CAND
+#define PSI_KD_GRID_MAX_CAND 64
+#endif
+constexpr int GRID_MAX_CAND = PSI_KD_GRID_MAX_CAND;           // ... out of at most this many columns in the ball's bounding rectangle
 
 // lane permutations inside an 8-lane group as DPP modifiers (no LDS traffic)
 template <int CTRL>
@@ -197,8 +205,8 @@ __device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float 
     // evaluated: two dependent rounds of independent loads (cell ranges, then points).
     //   Which cells: in cell units u = (p - org) * ginv the cell of a point is clamp(floor(u)) per axis, the query sits at uq and the
     // ball has radius ru (inflated by 1e-4 relative + 0.01 cell: far above the rounding of u, of the distance expression and of the
-    // square root below).  Column (cx, cy) can hold a point of the ball only if its (x,y) rectangle — the unit square at (cx, cy),
-    // open-ended on the sides where the grid ends, since the cell formula clamps — is within ru of uq; if it is, the ball reaches
+    // square roots below).  Column (cx, cy) can hold a point of the ball only if its (x,y) rectangle — the unit square at (cx, cy)
+    // (no point has u outside [0, gn]: nnindex.hip puts the origin at the cloud's minimum) — is within ru of uq; if it is, the ball reaches
     // hz = sqrt(ru^2 - dxy^2) along z in that column, i.e. cells floor(uz - hz) .. floor(uz + hz).  The lanes of the group enumerate
     // the columns of the ball's bounding rectangle, the surviving ones are numbered with a ballot and handed out round-robin through
     // the group's (idle) stack rows, so every lane scans at most GRID_COLS_PER_LANE z-runs, each one contiguous point range.
@@ -212,39 +220,56 @@ __device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float 
         const float ru = __builtin_amdgcn_sqrtf(best) * T.ginv * 1.0001f + 0.01f;          // (1 ulp: inside the slack)
         const float uq[3] = {(qx - T.gorg[0]) * T.ginv, (qy - T.gorg[1]) * T.ginv, (qz - T.gorg[2]) * T.ginv};
         const float topx = (float)(T.gn[0] - 1), topy = (float)(T.gn[1] - 1), topz = (float)(T.gn[2] - 1);
+        // A query OUTSIDE the grid's box by (ox, oy, oz) cells: every point of the cloud is at least that far from it along those axes, so
+        // the ball reaches only rx = sqrt(ru^2 - oy^2 - oz^2) along x inside the box (ry alike) — the bounding rectangle of a body part
+        // that hangs out of the scene is the small cap where its ball touches the box, not the square around the whole ball (those queries
+        // used to fall to the tree walk and were the launch's tail: 12-25 dependent node visits each).
+        const float ru2 = ru * ru;
+        const float ox = fmaxf(fmaxf(-uq[0], uq[0] - topx - 1.0f), 0.0f), oy = fmaxf(fmaxf(-uq[1], uq[1] - topy - 1.0f), 0.0f),
+                    oz = fmaxf(fmaxf(-uq[2], uq[2] - topz - 1.0f), 0.0f);
+        const float oz2 = oz * oz;
+        const float rx = __builtin_amdgcn_sqrtf(fmaxf(ru2 - oy * oy - oz2, 0.0f)), ry = __builtin_amdgcn_sqrtf(fmaxf(ru2 - ox * ox - oz2, 0.0f));
         // clamped as floats: a far query must not overflow the conversion
-        const float flx = fminf(fmaxf(floorf(uq[0] - ru), 0.0f), topx), fhx = fminf(fmaxf(floorf(uq[0] + ru), 0.0f), topx);
-        const float fly = fminf(fmaxf(floorf(uq[1] - ru), 0.0f), topy), fhy = fminf(fmaxf(floorf(uq[1] + ru), 0.0f), topy);
+        const float flx = fminf(fmaxf(floorf(uq[0] - rx), 0.0f), topx), fhx = fminf(fmaxf(floorf(uq[0] + rx), 0.0f), topx);
+        const float fly = fminf(fmaxf(floorf(uq[1] - ry), 0.0f), topy), fhy = fminf(fmaxf(floorf(uq[1] + ry), 0.0f), topy);
         const float fny = fhy - fly + 1.0f, fncand = (fhx - flx + 1.0f) * fny;
         if (fncand <= (float)GRID_MAX_CAND) {
             const int ncand = (int)fncand;
-            const float rny = __builtin_amdgcn_rcpf(fny), ru2 = ru * ru;
+            const float rny = __builtin_amdgcn_rcpf(fny);
+            const int list_max = min(GRID_LIST_MAX, 2 * rows);  // the list lives in the group's stack rows
             int nsurv = 0;
             for (int c0 = 0; c0 < ncand; c0 += LPQ) {          // (uniform over the group)
                 const float fcol = (float)(c0 + c);
                 const float fcx = floorf((fcol + 0.5f) * rny);   // column index / ny: the quotient's fraction is >= 0.5 / ny, far from rounding
                 const float cxf = flx + fcx, cyf = fly + (fcol - fcx * fny);
-                // distance from uq to the column's rectangle, per axis; a side where the grid ends is open
-                const float ax = fmaxf(cxf > 0.0f ? cxf - uq[0] : 0.0f, cxf < topx ? uq[0] - cxf - 1.0f : 0.0f);
-                const float ay = fmaxf(cyf > 0.0f ? cyf - uq[1] : 0.0f, cyf < topy ? uq[1] - cyf - 1.0f : 0.0f);
-                const float dx = fmaxf(ax, 0.0f), dy = fmaxf(ay, 0.0f);
+                // distance from uq to the column's unit square, per axis (the grid's origin is the cloud's exact minimum and its last cell ends at
+                // or beyond the maximum, nnindex.hip: no point lies outside [0, gn], so the edge cells are ordinary unit cells)
+                const float dx = fmaxf(fmaxf(cxf - uq[0], uq[0] - cxf - 1.0f), 0.0f), dy = fmaxf(fmaxf(cyf - uq[1], uq[1] - cyf - 1.0f), 0.0f);
                 const float h2 = ru2 - dx * dx - dy * dy;
-                const bool ok = c0 + c < ncand && h2 >= 0.0f;
+                const bool ok = c0 + c < ncand && h2 >= oz2;         // (h2 = what is left for z; the box itself is oz away)
                 const float hz = __builtin_amdgcn_sqrtf(fmaxf(h2, 0.0f));
                 const int zlo = (int)fminf(fmaxf(floorf(uq[2] - hz), 0.0f), topz), zhi = (int)fminf(fmaxf(floorf(uq[2] + hz), 0.0f), topz);
                 const unsigned gm = (unsigned)(__ballot(ok) >> gshift) & ((1u << LPQ) - 1u);
                 const int pos = nsurv + __popc(gm & ((1u << c) - 1u));
-                if (ok && pos < GRID_COLS_PER_LANE * LPQ) stk_n[pos] = (((int)cxf * T.gn[1] + (int)cyf) << 14) | (zlo << 7) | zhi;
+                if (ok && pos < list_max) stk_n[pos] = (((int)cxf * T.gn[1] + (int)cyf) << 14) | (zlo << 7) | zhi;
                 nsurv += __popc(gm);
             }
-            if (nsurv <= GRID_COLS_PER_LANE * LPQ && nsurv > 0) {
-                // my z-runs, as ranges of PAIR records: first pair, rounds of two pairs
+            if (nsurv <= list_max && nsurv > 0) {
+              typedef float v2f __attribute__((ext_vector_type(2)));
+              const v2f qxx = {qx, qx}, qyy = {qy, qy}, qzz = {qz, qz};
+              float bd = INFINITY;
+              int bi = 0x7fffffff;
+              bool tie = false;
+              // GRID_COLS_PER_LANE z-runs per lane at a time; a ball with more columns than that (a body part outside the scene's box touches
+              // it in a wide, one-cell-deep cap) takes further passes over the list — each two dependent rounds, against the 12-25 of its tree walk
+              for (int s0 = 0; s0 < nsurv; s0 += GRID_COLS_PER_LANE * LPQ) {
+                // my z-runs, as ranges of PAIR records: first pair, rounds of GRID_PAIRS pairs
                 int ps[GRID_COLS_PER_LANE], nr[GRID_COLS_PER_LANE];
                 int cs[GRID_COLS_PER_LANE], ce[GRID_COLS_PER_LANE];
                 const char *csb = (const char *)T.cell_start;
 #pragma unroll
                 for (int u = 0; u < GRID_COLS_PER_LANE; u++) {     // all ranges requested together; a slot past the list re-reads entry 0
-                    const int e = stk_n[c + u * LPQ < nsurv ? c + u * LPQ : 0];
+                    const int e = stk_n[s0 + c + u * LPQ < nsurv ? s0 + c + u * LPQ : 0];
                     const unsigned base = (unsigned)(e >> 14) * (unsigned)T.gn[2];
                     cs[u] = *(const int *)(csb + ((base + ((unsigned)e >> 7 & 127u)) << 2));
                     ce[u] = *(const int *)(csb + ((base + ((unsigned)e & 127u) + 1u) << 2));
@@ -254,7 +279,7 @@ __device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float 
 #pragma unroll
                 for (int u = 0; u < GRID_COLS_PER_LANE; u++) {
                     ps[u] = cs[u] >> 1;
-                    nr[u] = (ce[u] > cs[u] && c + u * LPQ < nsurv) ? (((ce[u] + 1) >> 1) - ps[u] + GRID_PAIRS - 1) / GRID_PAIRS : 0;
+                    nr[u] = (ce[u] > cs[u] && s0 + c + u * LPQ < nsurv) ? (((ce[u] + 1) >> 1) - ps[u] + GRID_PAIRS - 1) / GRID_PAIRS : 0;
                     rounds += nr[u];
                 }
                 // one loop over the rounds of all my runs: round t reads pairs GRID_PAIRS t + off(t) .., off = the run's first pair minus
@@ -262,11 +287,6 @@ __device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float 
                 static_assert(GRID_COLS_PER_LANE == 3, "the round -> pair mapping below is written for three runs");
                 const int r01 = nr[0] + nr[1];
                 const int off1 = ps[1] - GRID_PAIRS * nr[0], off2 = ps[2] - GRID_PAIRS * r01;
-                typedef float v2f __attribute__((ext_vector_type(2)));
-                const v2f qxx = {qx, qx}, qyy = {qy, qy}, qzz = {qz, qz};
-                float bd = INFINITY;
-                int bi = 0x7fffffff;
-                bool tie = false;
                 for (int t = 0; t < rounds; t++) {
                     PSI_KD_STAT(ngp += 1;)
                     const int pr = GRID_PAIRS * t + (t < nr[0] ? ps[0] : t < r01 ? off1 : off2);
@@ -288,14 +308,16 @@ __device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float 
                         }
                     }
                 }
+              }
                 kd_key k = group_min<LPQ>(kd_pack(bd, bi));
                 PSI_KD_MARK(2);
                 bestk = k < bestk ? k : bestk;
                 best = kd_key_d(bestk);
                 have = ((__ballot(tie) >> gshift) & ((1ull << LPQ) - 1ull)) != 0;     // done, unless a lane met two points at equal distance
-            }
-        }
-    }
+                PSI_KD_STAT(if (have && c == 0 && psi_dbg_sstop == 10) atomicAdd(psi_kd_reason + 2, 1);)
+            } else { PSI_KD_STAT(if (c == 0 && psi_dbg_sstop == 10) { atomicAdd(psi_kd_reason + 1, 1); atomicMax(psi_kd_reason + 5, nsurv); }) }
+        } else { PSI_KD_STAT(if (c == 0 && psi_dbg_sstop == 10) { atomicAdd(psi_kd_reason + 0, 1); atomicMax(psi_kd_reason + 4, (int)fminf(fncand, 1e6f)); }) }
+    } else { PSI_KD_STAT(if (have && c == 0 && psi_dbg_sstop == 10) atomicAdd(psi_kd_reason + 3, 1);) }
     while (true) {
         while (!have && sp > 0) {                             // pop until something survives the current bound (group-uniform)
             --sp;

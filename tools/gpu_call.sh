@@ -34,7 +34,7 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if int(r['Calls']) > 1000]
 print('stop', sys.argv[2], ' '.join('%s=%.2f' % (r['Name'].split('(')[0].replace('void ', '').replace('(anonymous namespace)::', '')[:24], float(r['AverageNs']) / 1e3) for r in sorted(rows, key=lambda r: r['Name'])))
 PY
       done; unset PSI_HIP_LIB PSI_SKIN_STOP ;;
-    timeline) PSI_HIP_LIB=$GRAFT_REPO_ROOT/tools/_variants/stops.so PSI_SKIN_STOP=9 python tools/timeline.py > $O/timeline.txt 2>&1; tail -18 $O/timeline.txt | cut -c1-400 ;;
+    timeline) PSI_HIP_LIB=$GRAFT_REPO_ROOT/tools/_variants/stops.so PSI_SKIN_STOP=${a1:-9} python tools/timeline.py > $O/timeline_${a1:-9}.txt 2>&1; tail -18 $O/timeline_${a1:-9}.txt | cut -c1-400 ;;
     timeline2) PSI_HIP_LIB=$GRAFT_REPO_ROOT/tools/_variants/stops2.so python tools/timeline2.py > $O/timeline2.txt 2>&1; tail -12 $O/timeline2.txt | cut -c1-300 ;;
     profab) for l in ${a1//,/ }; do uselib $l; rm -rf /tmp/pab; ( cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pab -o p -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 $a2 > "$O/profab_$l.log" 2>&1 )
         f=$(find /tmp/pab -name "*kernel_stats.csv" | head -1); cp $f "$O/kernel_stats_$l.csv"

@@ -46,19 +46,25 @@ for k in (1, 0):
     m = a[:, 3] == k
     print('resident kind', k, ' '.join('%d' % int(((st[m] <= t) & (en[m] > t)).sum()) for t in T))
 
-m = a[:, 3] == 1
-d = en[m] - st[m]
-S = stat[m]
-print('search workgroups: tree-walk queries per workgroup (of 64) mean %.1f max %d; workgroups with none %d' % (S[:, 0].mean(), S[:, 0].max(), int((S[:, 0] == 0).sum())))
-print('most visits of one query: quantiles', np.quantile(S[:, 1], [0, .5, .9, .99, 1]), ' grid rounds (max per lane)', np.quantile(S[:, 3], [0, .5, .9, .99, 1]))
-order = np.argsort(d)
-for lo_, hi_ in ((0, 0.1), (0.45, 0.55), (0.9, 1.0), (0.99, 1.0)):
-    sel = order[int(lo_ * len(d)):max(int(hi_ * len(d)), int(lo_ * len(d)) + 1)]
-    print('duration quantile %.2f-%.2f: dur %.2f us, tree queries %.1f, max visits %.1f, visits summed %.1f, grid rounds %.1f' % (
-        lo_, hi_, d[sel].mean(), S[sel, 0].mean(), S[sel, 1].mean(), S[sel, 2].mean(), S[sel, 3].mean()))
-print('corr(dur, max visits) %.3f  corr(dur, tree queries) %.3f  corr(dur, grid rounds) %.3f' % (np.corrcoef(d, S[:, 1])[0, 1], np.corrcoef(d, S[:, 0])[0, 1], np.corrcoef(d, S[:, 3])[0, 1]))
+if (a[:, 3] == 1).any():
+    m = a[:, 3] == 1
+    d = en[m] - st[m]
+    S = stat[m]
+    print('search workgroups: tree-walk queries per workgroup (of 64) mean %.1f max %d; workgroups with none %d' % (S[:, 0].mean(), S[:, 0].max(), int((S[:, 0] == 0).sum())))
+    print('most visits of one query: quantiles', np.quantile(S[:, 1], [0, .5, .9, .99, 1]), ' grid rounds (max per lane)', np.quantile(S[:, 3], [0, .5, .9, .99, 1]))
+    order = np.argsort(d)
+    for lo_, hi_ in ((0, 0.1), (0.45, 0.55), (0.9, 1.0), (0.99, 1.0)):
+        sel = order[int(lo_ * len(d)):max(int(hi_ * len(d)), int(lo_ * len(d)) + 1)]
+        print('duration quantile %.2f-%.2f: dur %.2f us, tree queries %.1f, max visits %.1f, visits summed %.1f, grid rounds %.1f' % (
+            lo_, hi_, d[sel].mean(), S[sel, 0].mean(), S[sel, 1].mean(), S[sel, 2].mean(), S[sel, 3].mean()))
+    print('corr(dur, max visits) %.3f  corr(dur, tree queries) %.3f  corr(dur, grid rounds) %.3f' % (np.corrcoef(d, S[:, 1])[0, 1], np.corrcoef(d, S[:, 0])[0, 1], np.corrcoef(d, S[:, 3])[0, 1]))
 
-M = (marks[m] - a[m, 0:1]) * 0.01                      # us since the workgroup's start
-okm = (marks[m] > 0).all(axis=1)
-print('search phases (thread 0; us since workgroup start; median / p90): query point %.2f / %.2f, cell ranges in %.2f / %.2f, scan done %.2f / %.2f, '
-      'search done %.2f / %.2f, end %.2f / %.2f' % (tuple(x for k in range(4) for x in (np.median(M[okm, k]), np.quantile(M[okm, k], .9))) + (np.median(d), np.quantile(d, .9))))
+    M = (marks[m] - a[m, 0:1]) * 0.01                      # us since the workgroup's start
+    okm = (marks[m] > 0).all(axis=1)
+    print('search phases (thread 0; us since workgroup start; median / p90): query point %.2f / %.2f, cell ranges in %.2f / %.2f, scan done %.2f / %.2f, '
+          'search done %.2f / %.2f, end %.2f / %.2f' % (tuple(x for k in range(4) for x in (np.median(M[okm, k]), np.quantile(M[okm, k], .9))) + (np.median(d), np.quantile(d, .9))))
+
+if hasattr(lib, 'psi_dbg_kd_reason'):
+    rb = (ctypes.c_int * 8)()
+    lib.psi_dbg_kd_reason(rb)
+    print('tree-walk reasons summed over ALL launches of the run: too many candidate columns %d (largest %d), too many surviving columns %d (most %d), tie flag %d, no warm candidate %d' % (rb[0], rb[4], rb[1], rb[5], rb[2], rb[3]))
