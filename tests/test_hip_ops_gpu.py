@@ -209,6 +209,34 @@ def test_warm_queries_take_the_grid_and_stay_bit_exact(kind, m, spread):
             hint[1, :100] = -1
 
 
+@pytest.mark.parametrize('kind,m', [('uniform', 32768), ('surface', 20000), ('plane', 3000)])
+def test_warm_queries_outside_the_clouds_box_stay_bit_exact(kind, m):
+    """Body parts that hang out of the scene: warm queries OUTSIDE the cloud's bounding box — beyond a face, an edge, a corner, from a
+    fraction of a cell to several box sizes away.  Their ball touches the box in a cap: the grid path takes the cap's rectangle
+    (nnindex_device.h: the radius left after the outside distances), several passes over a long column list, or the tree walk — distances
+    and indices equal brute force bit for bit in every case, over several steps of a moving query."""
+    rs = np.random.RandomState(11 * m)
+    y = _clouds(kind, m, rs)
+    m = len(y)
+    lo, hi = y.min(0), y.max(0)
+    ext = np.maximum(hi - lo, 0.5)
+    B, n = 4, 2048
+    x = rs.uniform(lo - 0.05 * ext, hi + 0.05 * ext, (B, n, 3)).astype(np.float32)
+    out = 10.0 ** rs.uniform(-2.5, 0.6, (B, n, 3)) * ext                       # 0.003 .. 4 box sizes beyond the box
+    side = rs.randint(0, 3, (B, n, 3))                                         # per axis: inside / below / above
+    x = np.where(side == 1, lo - out, np.where(side == 2, hi + out, x)).astype(np.float32)
+    x[0, :256, 2] = hi[2] + np.float32(0.3) * ext[2]                           # a sheet of queries above the top face (one-cell-deep caps)
+    index = ops.SceneNNIndex(y, DEV)
+    yb = T(np.broadcast_to(y, (B, m, 3)).copy())
+    hint = torch.full((B, n), -1, dtype=torch.int32, device=DEV)
+    for step in range(4):
+        d, i = index.query(T(x), hint=hint)
+        rd, ri, _, _ = ops.chamfer_forward_raw(T(x), yb, both=False)
+        assert torch.equal(i, ri) and torch.equal(d, rd), (kind, step)
+        assert torch.equal(hint, ri)
+        x = (x + rs.standard_normal(x.shape) * 0.01 * ext).astype(np.float32)
+
+
 def test_kdtree_backward_matches_bruteforce():
     rs = np.random.RandomState(5)
     y = rs.uniform(-1, 1, (3000, 3)).astype(np.float32)
