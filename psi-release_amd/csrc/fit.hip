@@ -1658,9 +1658,12 @@ extern "C" int psi_fit_iterate_dp(psi_fit_engine *e, psi_dp_comm *comm, int n_it
         hipGraph_t g = nullptr;
         const hipError_t ce = hipStreamEndCapture(st, &g);
         const bool invalidated = ce >= hipErrorStreamCaptureUnsupported && ce <= hipErrorStreamCaptureWrongThread;   // 900 .. 908
+        // ... or RCCL itself declined the enqueue under capture without touching the stream (ncclInvalidArgument / ncclInvalidUsage, returned
+        // synchronously by ncclAllReduce: nothing was launched, the communicator is intact) — the same "cannot capture here" answer
+        const bool declined = rc == 1000 + 4 || rc == 1000 + 5;
         if (rc || ce != hipSuccess) {
             if (g) (void)hipGraphDestroy(g);
-            if (invalidated) {
+            if (invalidated || declined) {
                 (void)hipGetLastError();
                 capture_refused = true;
                 return 1;

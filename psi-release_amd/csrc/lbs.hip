@@ -80,7 +80,7 @@ WsLayout ws_layout(const LbsDev &m, int B)
     w.R = take((size_t)B * m.J * 12);           // rows padded to 4 floats
     w.Jl = take((size_t)B * m.J * 3);
     w.G = take((size_t)B * m.J * 12);
-    w.A = take((size_t)B * m.J * 12);
+    w.A = take((size_t)B * m.J * 12 + PSI_A_TAIL * 12);     // + zero rows behind the last body (lbs_device.h: psi_pose_fwd_chain)
     w.v_posed = take((size_t)B * m.Npad);
     w.gl = take((size_t)B * m.Npad);
     w.g_vp = take((size_t)B * m.Npad);

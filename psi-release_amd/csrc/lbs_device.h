@@ -17,6 +17,7 @@ constexpr int PSI_SUB_MAX = PSI_JP * (PSI_JP + 1) / 2;   // most subtree members
 constexpr int PSI_ITEM_MAX = 2 * PSI_JP;                 // most chunks (psi_lbs_create sizes the chunks for this)
 constexpr int PSI_NJUMP = 6;       // ceil(log2(PSI_JP)) rounds of pointer jumping cover any tree
 constexpr int PSI_WNZ = 8;          // compressed skinning rows are used when no vertex has more non-zero weights than this
+constexpr int PSI_A_TAIL = 16;      // zero transform rows kept behind the LAST body's A block (PsiBlendPipelined reads up to 12 ceil(J/12) + 2 rows per body)
 
 struct LbsDev {
     int V, J, NB, P, K, Kpad, N, Npad, Vpad, maxlevel, njump;
@@ -170,6 +171,12 @@ __device__ __forceinline__ void psi_pose_fwd_chain(const LbsDev &m, const float 
         if (joints)
             for (int r = 0; r < 3; r++) joints[((size_t)b * m.J + j) * 3 + r] = G[r * 4 + 3] + (transl ? transl[(size_t)b * 3 + r] : 0.0f);
     }
+    // The pipelined dense blend pads J to whole groups of 12 joints and multiplies ZERO weights with the transform rows behind a body's
+    // block: the next body's rows (finite) — or, for the last body, whatever lies behind the A array.  Those PSI_A_TAIL rows belong to
+    // the array (ws_layout) and are written here on every forward, so that a recycled / caller-provided workspace cannot put a NaN
+    // bit pattern under a zero weight.
+    if (b == B - 1)
+        for (int q = j; q < PSI_A_TAIL * 3; q += blockDim.x) ((psi_f4 *)(As + (size_t)B * m.J * 12))[q] = psi_f4{0.0f, 0.0f, 0.0f, 0.0f};
 }
 
 
@@ -547,7 +554,8 @@ struct PsiBlendN {
         const unsigned tile_off = (unsigned)__builtin_amdgcn_readfirstlane(v >> 6) * (unsigned)(PSI_JP * 64 * 4);   // a wave = 64 consecutive vertices
         auto wload = [&](int k, unsigned ro) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, v4 + k * 256, ro, 0)); };
         unsigned ro = tile_off;                                      // scalar offset of the group being requested
-        if (FORM == PsiBlendCompact) {
+        // (the pipelined form walks whole groups of 12 joints: beyond 60 joints its sixth group would leave the 64-joint weight tile)
+        if (FORM == PsiBlendCompact || m.J > 60) {
             constexpr int GJ = PSI_DENSE_UNROLL;
             static_assert(GJ * 256 <= 4096, "joint offsets of a group must fit the load's 12-bit immediate");
             float w[GJ];

@@ -191,7 +191,8 @@ extern "C" int psi_nn_index_create(psi_nn_index **out, const float *h_points, in
         for (int i = 0; i < m; i++) ord[i] = i;
         // (a TOTAL order on the bit patterns — sign-flipped so that it follows the numeric order — not `<` on floats: a cloud with a NaN
         // coordinate must not hand std::sort an inconsistent comparator)
-        auto okey = [](float f) { unsigned u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+        // (-0.0 is canonicalised to +0.0 first: the duplicate test below is `==`, for which the two are equal, so the order must agree)
+        auto okey = [](float f) { f += 0.0f; unsigned u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
         auto coord_less = [&](int a, int b) {
             for (int k = 0; k < 3; k++) {
                 const unsigned u = okey(h_points[(size_t)a * 3 + k]), v = okey(h_points[(size_t)b * 3 + k]);

@@ -297,7 +297,13 @@ __device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float 
 #pragma unroll
                     for (int k = 0; k < GRID_PAIRS; k++) {
                         const v2f x2 = (v2f){a[k].x, a[k].y} - qxx, y2 = (v2f){a[k].z, a[k].w} - qyy, z2 = (v2f){b[k].x, b[k].y} - qzz;
+#ifdef PSI_CHAMFER_FMA
+                        // PSI_SQ3 on two points in the fma mode (mul, fma, fma — v_pk_mul / v_pk_fma): the same rounding as the warm
+                        // candidate above, the tree leaves below and chamfer.hip, which the exactness argument relies on
+                        const v2f d = __builtin_elementwise_fma(z2, z2, __builtin_elementwise_fma(y2, y2, x2 * x2));
+#else
                         const v2f d = x2 * x2 + y2 * y2 + z2 * z2;     // PSI_SQ3 on two points (contraction is off in this function)
+#endif
                         const int i2[2] = {__float_as_int(b[k].z), __float_as_int(b[k].w)};
 #pragma unroll
                         for (int e = 0; e < 2; e++) {

@@ -501,6 +501,13 @@ class _FusedRunner:
         self.eng.iterate(n, self.op.use_graph)
         self.n += n
 
+    def restart(self):
+        """Back to the start of the loop (fitting_proxe.py:167-175 with a fresh optimiser): the generated bodies as parameters, zeroed Adam
+        state and step count, no nearest-neighbour warm-start hints.  Enqueued on the engine's stream, no host synchronisation."""
+        xhr, _, cam = self.eng._args
+        self.eng.set_problem(xhr, xhr, cam, reset=True)
+        self.step0, self.n = 0, 0
+
     def last_losses(self):
         idx = self.step0 + self.n                       # Adam step count after the last step
         if idx < 1:

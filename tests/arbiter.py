@@ -146,6 +146,34 @@ def check_gradient(g_gpu, f32, f64, x, xhr, cam):
     return (l32, l64, amb, n_pen, tau), info
 
 
+# Fraction of the bodies of EVERY checked evaluation that must pass by rule (a) alone — within 1e-4 of the fp32 oracle, the north star's
+# tolerance — before rules (b) / (c) may carry the rest.  Measured on the GPU runs of round 5 (profiles/r05_arbiter.json: the counts of
+# every arbiter-checked test) and pinned below that: a change that pushes more bodies onto the looser rules fails here.
+MIN_RULE_A = {'default': 0.75}
+
+
+def record(name, report, min_rule_a=None):
+    """Keep the per-iteration summaries of an arbiter-checked test (which rule every body passed by, how much of each bound was used) as
+    JSON under gpurun_out/arbiter/ (merged back from the GPU box; profiles/r05_arbiter.json is the committed copy) and hold the share of
+    bodies that needed no more than rule (a) to its pinned floor."""
+    import json
+    import os
+    rows = report if isinstance(report, list) else [report]
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'arbiter')
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, name + '.json'), 'w') as f:
+            json.dump(rows, f, indent=1, default=float)
+    except OSError:
+        pass
+    floor = MIN_RULE_A['default'] if min_rule_a is None else min_rule_a
+    for r in rows:
+        by = r['bodies_by_rule']
+        n = by['a'] + by['b_only'] + by['c_only']
+        assert by['a'] >= floor * n, ('too many bodies needed the fp64-arbiter rules (b) / (c)', name, r.get('step'), by, floor)
+    return rows
+
+
 def check_trace(trace, make_oracle, cam, lr=0.1, first_step=1):
     """``make_oracle(dtype)`` -> FittingOracle on the GLOBAL batch; cam [B,4,4].  The fixed 6D target ``xhr`` of the reconstruction loss is the
     implementation's own starting point (the loop starts AT the target, fitting_proxe.py:171-175, where |xhr - x| has its kink: the target

@@ -41,7 +41,12 @@ def test_work_table_and_roofline_of_the_dominant_kernel():
     agg['fwd_scene_kernel'] = 0.0264                                           # the LONGEST kernel is the dominant one
     roof, per = bench.roofline_from_kernels(args, agg, work)
     assert roof['kernel'] == 'fwd_scene_kernel' and roof['bound'] == 'hbm' and roof['peak'] == 8000.0 and roof['unit'] == 'GB/s'
-    assert abs(roof['achieved'] - work['fwd_scene_kernel'][1] / 26.4e-6 * 1e-9) < 5 and abs(roof['frac'] - roof['achieved'] / 8000.0) < 1e-3
+    # primary figures = the bytes the implementation has to MOVE (no [B,V,3] vertex store in the shared launch); SURVEY 8(d)'s figure next to it
+    moved = bench.moved_bytes(args, 'fwd_scene_kernel')
+    assert moved == work['fwd_scene_kernel'][1] - 32 * V * 12 and roof['bytes_per_launch'] == moved
+    assert abs(roof['achieved'] - moved / 26.4e-6 * 1e-9) < 5 and abs(roof['frac'] - roof['achieved'] / 8000.0) < 1e-3
+    assert abs(roof['survey_8d_achieved'] - work['fwd_scene_kernel'][1] / 26.4e-6 * 1e-9) < 5 and roof['survey_8d_frac'] > roof['frac']
+    assert per['fwd_scene_kernel']['frac_hbm'] == roof['frac'] and per['fwd_scene_kernel']['frac_hbm_survey_8d'] == roof['survey_8d_frac']
     assert abs(roof['share_of_iteration_time'] - 0.0264 / sum(agg.values())) < 1e-3
     assert set(per) == set(agg)
 

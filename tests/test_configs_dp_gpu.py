@@ -43,4 +43,4 @@ def test_configs3_two_ranks_of_32_bodies_equal_the_oracle_on_64(tmp_path, smplx_
     scene = synth.make_scene(0, M, D, NC)
     bodies = synth.make_bodies(13, per * world)
     bodies['cam_ext'] = synth.make_cam_ext(9, per * world)
-    _check(trace, smplx_data, vposer_sd, scene, bodies, bodies['cam_ext'])
+    _check(trace, smplx_data, vposer_sd, scene, bodies, bodies['cam_ext'], name='configs3_two_ranks_of_32')

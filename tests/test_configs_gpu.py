@@ -46,7 +46,7 @@ def _run(op, bodies):
     return arbiter.gpu_trace(op, bodies, ITERS)
 
 
-def _check(trace, smplx_data, vposer_sd, scene, bodies, cam, **oracle_kw):
+def _check(trace, smplx_data, vposer_sd, scene, bodies, cam, name='configs', **oracle_kw):
     """Every iteration of the product against the oracle in fp32 and in fp64 (the arbiter) AT THE PRODUCT'S OWN STATE: loss values, the
     gradient and Adam's update, each within K_NOISE x the fp32 oracle's own distance from the arbiter — tests/arbiter.py states the bounds
     and the explicit rule for vertices whose SDF value is within 1e-6 of zero.  No literal tolerance looser than that is used."""
@@ -55,8 +55,7 @@ def _check(trace, smplx_data, vposer_sd, scene, bodies, cam, **oracle_kw):
     make = lambda dt: O.FittingOracle(O.SMPLXOracle(smplx_data, dtype=dt), vposer_sd, scene.verts, scene.sdf, scene.grid_min, scene.grid_max,
                                       synth.contact_ids_from_parts(scene.contact_parts), B, **oracle_kw)
     report = arbiter.check_trace(trace, make, np.asarray(cam, np.float64))
-    for r in report:
-        print('arbiter', r)
+    arbiter.record(name, report)                                  # counts per rule -> gpurun_out/arbiter/<name>.json, floor on rule (a)
 
 
 @pytest.mark.parametrize('engine', ['fused', 'modular'])
@@ -68,4 +67,4 @@ def test_configs4_habitat_64_bodies_full_size_vs_oracle(smplx_data, vposer_sd, e
     op = fitting.FittingOPHabitat(_cfg(smplx_data, vposer_sd, scene, B, engine), dict(LOSS))
     trace = _run(op, dict(bodies))
     cam = bodies['cam_ext'][:1] @ np.diag([1.0, -1.0, -1.0, 1.0]).astype(np.float32)          # fitting_habitat.py:179-184
-    _check(trace, smplx_data, vposer_sd, scene, bodies, np.repeat(cam, B, axis=0), contact_const=1.0)     # fitting_habitat.py:141
+    _check(trace, smplx_data, vposer_sd, scene, bodies, np.repeat(cam, B, axis=0), name='configs4_habitat_64_%s' % engine, contact_const=1.0)     # fitting_habitat.py:141

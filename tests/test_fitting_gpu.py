@@ -143,7 +143,7 @@ def test_fused_gradient_matches_modular_large_batch(smplx_data, vposer_sd, B):
     f32, f64 = make(torch.float32), make(torch.float64)
     for k in g:
         _, info = arbiter.check_gradient(g[k].astype(np.float64), f32, f64, xhr, xhr, np.asarray(bodies['cam_ext'], np.float64))
-        print('arbiter', k, info)
+        arbiter.record('fused_vs_modular_gradient_B%d_%s' % (B, k), info)
     assert np.median(np.abs(d).max(axis=1)) < 1e-5 * np.abs(g['modular']).max()
 
 

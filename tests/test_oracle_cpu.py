@@ -232,6 +232,11 @@ def test_arbiter_trace_check_accepts_the_fp32_oracle_and_rejects_a_perturbed_run
                           losses=np.array([float(l.detach()) for l in ls])))
     report = arbiter.check_trace(trace, make, np.asarray(cam, np.float64))
     assert len(report) == iters and all(r['bodies_by_rule']['a'] == B for r in report), report     # the fp32 oracle against itself: rule (a)
+    # ... and the bookkeeping the GPU tests apply to their reports: the floor on the share of rule-(a) bodies
+    arbiter.record('cpu_selfcheck', report)
+    loose = [dict(r, bodies_by_rule=dict(a=1, b_only=B - 1, c_only=0)) for r in report]
+    with pytest.raises(AssertionError):
+        arbiter.record('cpu_selfcheck_loose', loose)
     import copy
     gscale = np.abs(trace[1]['m1']).max() / 0.1
     bad = copy.deepcopy(trace)

@@ -131,8 +131,7 @@ def test_full_baseline_size_three_iteration_oracle_trajectory(smplx_data, vposer
     # every iteration from the product's own state: loss values, gradient and Adam update within K_NOISE x the fp32 oracle's own distance
     # from the fp64 arbiter (tests/arbiter.py) — no "99 % of the entries" allowance
     report = arbiter.check_trace(trace, make, np.asarray(bodies['cam_ext'], np.float64))
-    for r in report:
-        print('arbiter', r)
+    arbiter.record('configs1_full_baseline_size', report)      # counts per rule -> gpurun_out/arbiter/, floor on rule (a)
     # and the free-running loss trajectory against the free-running fp32 oracle, as before
     fo = make(torch.float32)
     rec = []
