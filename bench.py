@@ -50,6 +50,7 @@ PEAK_FP32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vec
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 ROOMS = 7                     # fitting_habitat.py:238-241: seven MP3D-R rooms
+LOOP_ITERS = 100              # fitting_proxe.py / fitting_habitat.py: num_iter of the shipped configuration (BASELINE configs[1]: '100-iter loop')
 PMC_FILES = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
 
 
@@ -111,10 +112,12 @@ def spawn_ranks(args):
 # ----------------------------------------------------------------------------------------------------------------------
 # timing protocol
 # ----------------------------------------------------------------------------------------------------------------------
-def timed_blocks(run_steps, barrier, K, W, world, device, min_repeats=5, min_total_s=0.5, ramp_s=0.3, max_repeats=400, restart=None):
+def timed_blocks(run_steps, barrier, K, W, world, device, min_repeats=5, min_total_s=0.5, ramp_s=0.3, max_repeats=400, restart=None,
+                 restart_every=1):
     """run_steps(n) enqueues n steps.  Returns the per-block wall times (max over ranks) of R blocks of exactly K steps.
-    restart (optional) is called, untimed, in front of every timed block: it puts the problem back to its initial state (the metric is a
-    fitting LOOP from generated bodies, fitting_proxe.py:177-189, not the converged regime of one problem iterated for ever)."""
+    restart (optional) is called, untimed, in front of every `restart_every`-th timed block: it puts the problem back to its initial state
+    (the metric is a fitting LOOP from generated bodies, fitting_proxe.py:177-189, not the converged regime of one problem iterated for
+    ever); R is then a multiple of restart_every, so that the blocks form whole loops."""
     import torch
     run_steps(max(W, 0))
     barrier()
@@ -138,13 +141,15 @@ def timed_blocks(run_steps, barrier, K, W, world, device, min_repeats=5, min_tot
     est = (time.perf_counter() - t0) / max(n_ramp, 1)       # seconds per step, this rank
     R = max(min_repeats, int(math.ceil(min_total_s / max(est * K, 1e-9))))
     R = min(R, max_repeats)
+    if restart is not None and restart_every > 1:
+        R = int(math.ceil(R / restart_every)) * restart_every
     if world > 1:                                            # every rank must run the same number of blocks
         t = torch.tensor([R], device=device, dtype=torch.int64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         R = int(t.item())
     times = []
-    for _ in range(R):
-        if restart is not None:
+    for i in range(R):
+        if restart is not None and i % restart_every == 0:
             restart()
         barrier()
         t0 = time.perf_counter()
@@ -492,16 +497,29 @@ def bench_fitting(args):
     # one problem, i.e. times the converged regime (rounds 1-4 reported that as the headline).
     can_restart = args.engine_resolved == 'fused' and all(hasattr(r, 'restart') for r in runners)
     restart = (lambda: [r.restart() for r in runners]) if can_restart else None
-    times = timed_blocks(run_steps, barrier, args.steps, args.warmup, world, device, args.repeats, args.min_timed_s, restart=restart)
+    # blocks of exactly K steps; LOOP_ITERS / K consecutive blocks (rounded up) form one loop of the reference and share one restart
+    bpl = max(1, int(math.ceil(LOOP_ITERS / args.steps))) if restart else 1
+    times = timed_blocks(run_steps, barrier, args.steps, args.warmup, world, device, max(args.repeats, bpl), args.min_timed_s, restart=restart,
+                         restart_every=bpl)
     summ, med = summarize(times, args.steps)
+    if restart and bpl > 1:
+        # headline = the median LOOP: its blocks' times added up / its iterations (a median over single blocks would pick a warm block and
+        # hide the loop's cold first one)
+        loops = [sum(times[i:i + bpl]) for i in range(0, len(times), bpl)]
+        lmed = statistics.median(loops)
+        summ = dict(summ, ms_per_step=round(lmed / (bpl * args.steps) * 1e3, 4), ms_per_step_min=round(min(loops) / (bpl * args.steps) * 1e3, 4),
+                    ms_per_step_max=round(max(loops) / (bpl * args.steps) * 1e3, 4), loops=len(loops), blocks_per_loop=bpl,
+                    per_block_ms_per_step={'first_block_of_a_loop': round(statistics.median(times[0::bpl]) / args.steps * 1e3, 4),
+                                           'later_blocks': round(statistics.median([t for i, t in enumerate(times) if i % bpl]) / args.steps * 1e3, 4)})
+        med = lmed / bpl                                      # seconds per block of K steps, loop average
     steady = None
     if restart is not None:
         ts = timed_blocks(run_steps, barrier, args.steps, 0, world, device, 5, 0.2, ramp_s=0.05)
         steady, _ = summarize(ts, args.steps)
         steady['what'] = 'the same blocks WITHOUT the restart: one problem iterated on and on (converged regime, warm NN hints)'
     fresh = None
-    if world == 1 and not habitat and args.engine_resolved == 'fused' and args.steps != 100:
-        fresh = fresh_start_blocks(runner, 100)            # configs[1] in full: the 100-iteration loop, whatever --steps is
+    if world == 1 and not habitat and args.engine_resolved == 'fused':
+        fresh = fresh_start_blocks(runner, LOOP_ITERS)     # the same loop as ONE call of 100 iterations (no per-block synchronisation)
     losses = runners[-1].last_losses() if habitat else runner.last_losses()
     rccl_world = torch.distributed.get_world_size() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
     per_rank_ms = None
@@ -550,16 +568,17 @@ def bench_fitting(args):
                        'rccl_world_size': rccl_world, 'rccl_ranks_seen': rccl_seen, 'rccl_version': rccl_version, 'dp_launch_mode': dp_modes,
                        'backend': backend if world > 1 else 'none (single process)',
                        'launcher': 'bench.py self-spawn' if os.environ.get('PSI_BENCH_SPAWNED') == '1' else ('torchrun' if world > 1 else 'direct'),
-                       'protocol': 'median of %d blocks of %d steps (barrier + synchronize around each, max over ranks)%s' % (
-                           summ['repeats'], args.steps, '; every block starts from a FRESH problem (untimed psi_fit_set_problem with reset: generated '
-                           'bodies, zeroed Adam state, cold NN hints) = the first %d iterations of the reference loop' % args.steps if restart else ''),
+                       'protocol': '%d blocks of %d steps (barrier + synchronize around each, max over ranks)%s' % (
+                           summ['repeats'], args.steps, ('; %d consecutive blocks = ONE %d-iteration fitting loop from a FRESH problem (untimed '
+                           'psi_fit_set_problem with reset in front of its first block: generated bodies, zeroed Adam state, cold NN hints); '
+                           'ms_per_step = median loop / its iterations' % (bpl, bpl * args.steps)) if restart else '; median block'),
                        'final_losses': [round(float(x), 6) for x in losses]},
         }
         out.update(summ)
         if steady:
             out['steady_state'] = steady
         if fresh:
-            out['loop_100_iterations'] = fresh
+            out['loop_as_one_call'] = fresh
         if per_rank_ms:
             out['per_rank_ms_per_step'] = per_rank_ms
         # ---- per-kernel times of one iteration: HIP events recorded on the launch stream after every kernel launch

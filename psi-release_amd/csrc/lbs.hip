@@ -584,30 +584,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // One output per thread, ALL of its slices requested before the first add (the partials were just written by other XCDs'
 // workgroups: every dependent round of loads is a ~2 us trip to memory; measured 10 us with 4 loads in flight, and 15 us
 // when 32 workgroups did the whole 7.5 MB themselves).
-// RSPL threads share one output: thread s of the group adds slices s, s + RSPL, ... (all requested before the first add) and the group is
-// combined in lane order with shuffles — four times as many workgroups pulling the fresh partials (they were just written by other XCDs'
-// workgroups: a CU gets only ~15 GB/s of such data, so the kernel is bound by how many CUs pull at once, not by arithmetic).
-constexpr int RSPL = 4;
-template <int MAXS>
-__device__ __forceinline__ float sum_slices_split(const float *__restrict__ p, size_t stride, int n, int s0)
-{
-    float v[MAXS];
-#pragma unroll
-    for (int k = 0; k < MAXS; k++) {
-        const int sl = s0 + k * RSPL;
-        v[k] = sl < n ? p[(size_t)sl * stride] : 0.0f;
-    }
-    float a0 = 0, a1 = 0;
-#pragma unroll
-    for (int k = 0; k < MAXS; k += 2) { a0 += v[k]; a1 += v[k + 1]; }
-    float r = a0 + a1;
-    for (int sl = s0 + MAXS * RSPL; sl < n; sl += RSPL) r += p[(size_t)sl * stride];
-    // lanes s0 = 0..3 of the group -> ((r0 + r1) + (r2 + r3)), the same value in all four lanes
-    r += __shfl_xor(r, 1, 64);
-    r += __shfl_xor(r, 2, 64);
-    return r;
-}
-
+// (sum_slices_split / PSI_RSPL: lbs_device.h — the fused tail + head kernel of the fitting engine sums the same partials the same way)
+constexpr int RSPL = PSI_RSPL;
 __global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int Kpad, const float *__restrict__ gA_part, int nsv,
                                                               const float *__restrict__ gfeat_part, int nsn,
                                                               const float *__restrict__ gt_part, int nvb,
@@ -620,16 +598,16 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int Kpad, c
     const int s0 = (int)(t % RSPL);
     if (i < nA) {
         // (entries 12..15 of a joint's 16 do not exist: skin_bwd_A writes the 3 x 4 gradient only, and nothing reads them)
-        const float r = (i & 15) < 12 ? sum_slices_split<12>(gA_part + i, (size_t)nA, nsv, s0) : 0.0f;
+        const float r = (i & 15) < 12 ? psi_sum_slices_split<12>(gA_part + i, (size_t)nA, nsv, s0) : 0.0f;
         if (s0 == 0) gA[i] = r;
     } else if (i < nA + nF) {
         const long k = i - nA;
-        const float r = sum_slices_split<8>(gfeat_part + k, (size_t)nF, nsn, s0);
+        const float r = psi_sum_slices_split<8>(gfeat_part + k, (size_t)nF, nsn, s0);
         if (s0 == 0) gfeat[k] = r;
     } else if (i < nA + nF + nT) {
         const long k = i - nA - nF;
         const int b = (int)(k >> 2), c = (int)(k & 3);
-        const float r = sum_slices_split<12>(gt_part + (size_t)b * 4 + (c < 3 ? c : 0), (size_t)B * 4, nvb, s0);
+        const float r = psi_sum_slices_split<12>(gt_part + (size_t)b * 4 + (c < 3 ? c : 0), (size_t)B * 4, nvb, s0);
         if (s0 == 0 && c < 3 && g_transl) g_transl[(size_t)b * 3 + c] = r;
     }
 }
@@ -964,12 +942,12 @@ static int lbs_launch_reduce(const LbsDev &m, const WsLayout &L, int B, float *w
     return 0;
 }
 
-int psi_lbs_backward_joint_parts(const psi_lbs_model *mdl, int B, float *ws, float *g_transl, hipStream_t st)
+int psi_lbs_backward_joint_parts(const psi_lbs_model *mdl, int B, float *ws, float *g_transl, hipStream_t st, bool reduce)
 {
     const LbsDev &m = mdl->d;
     WsLayout L = ws_layout(m, B);
     int rc = lbs_launch_bwd_joint_parts(m, L, B, ws, st);
-    if (rc) return rc;
+    if (rc || !reduce) return rc;                 // !reduce: the caller's next kernel sums the partials itself (fit.hip: tail_head_kernel)
     return lbs_launch_reduce(m, L, B, ws, g_transl, st);
 }
 

@@ -205,59 +205,114 @@ __device__ __forceinline__ void psi_pose_fwd_body(const LbsDev &m, const float *
 // i.e. twelve numbers per joint summed over subtrees.  The subtree sets are constants of the model, stored as chunks of at most eight
 // members: all chunks are summed at once (one thread per chunk and component), then every joint adds up its chunks — two short
 // rounds over all threads of the workgroup instead of ten dependent rounds on one wave, in a fixed order.
-__device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *pose_b,
-                                                  const float *__restrict__ Rs, const float *__restrict__ Jls,
-                                                  const float *__restrict__ Gs, const float *gA_b, const float *gfeat_b, int b,
-                                                  float *g_betas_b, float *g_pose_b, float *g_rot_b)
+// The stage in two parts: psi_pose_bwd_issue() requests everything that does NOT depend on the reduced gradients (this body's pose row,
+// transforms, rest joints, the model's subtree / child tables), psi_pose_bwd_finish() does the arithmetic once gA_b / gfeat_b exist.  A
+// caller whose gradients arrive late (the fused tail + head kernel of the fitting engine: they come through a workgroup exchange) calls the
+// first part at the top of the kernel, so that those loads are in flight while it waits; psi_pose_bwd_body() = the two back to back.
+constexpr int PSI_POSE_JSP = 8;                          // J_s entries of the g_betas part held in registers
+struct PsiPoseBwdPre {
+    float aa[3], js[PSI_POSE_JSP], G[12], Jl[3], P[12];
+    int cp0, cp1, par;
+};
+struct PsiPoseBwdShared {
+    float sX[PSI_JP][12];     // U_d (3x3 row-major), w_d
+    float sS[PSI_JP][12];     // their sums over subtree(j)
+    float sP[PSI_ITEM_MAX][12];               // ... per chunk
+    unsigned int sItem[PSI_ITEM_MAX];
+    unsigned char sList[PSI_SUB_MAX], sFirst[PSI_JP + 1];
+    float sgJ[PSI_JP][3];     // gradient wrt the rest joint location J_j
+    float sgrel[PSI_JP][3];
+    int sChild[PSI_JP];       // child lists (CSR)
+    float sgb[32][32];
+};
+
+__device__ __forceinline__ PsiPoseBwdPre psi_pose_bwd_issue(const LbsDev &m, const float *pose_b, const float *__restrict__ Jls,
+                                                            const float *__restrict__ Gs, int b, bool want_betas, bool want_pose,
+                                                            PsiPoseBwdShared &sh)
 {
     const int j = threadIdx.x, nthr = blockDim.x;
     const bool act = j < m.J;
-    __shared__ float sX[PSI_JP][12];     // U_d (3x3 row-major), w_d
-    __shared__ float sS[PSI_JP][12];     // their sums over subtree(j)
-    __shared__ float sP[PSI_ITEM_MAX][12];               // ... per chunk
-    __shared__ unsigned int sItem[PSI_ITEM_MAX];
-    __shared__ unsigned char sList[PSI_SUB_MAX], sFirst[PSI_JP + 1];
-    __shared__ float sgJ[PSI_JP][3];     // gradient wrt the rest joint location J_j
-    __shared__ float sgrel[PSI_JP][3];
-    __shared__ int sChild[PSI_JP];       // child lists (CSR)
-    (void)Rs;
-    // operands of the LAST steps first: their loads are in flight while the chain part runs
-    float gf9[9], aa[3] = {0, 0, 0};
+    PsiPoseBwdPre p;
+    for (int e = 0; e < 3; e++) p.aa[e] = 0.0f;
+    if (act && want_pose)
+        for (int e = 0; e < 3; e++) p.aa[e] = pose_b[j * 3 + e];
+    constexpr int JSP = PSI_POSE_JSP;
+    const int nq = m.J * 3;
+    const int npart = m.NB > 0 ? min(32, max(1, nthr / m.NB)) : 1;
+    const int per = (nq + npart - 1) / npart;
+    const bool par_ok = m.NB <= 32, js_pre = want_betas && par_ok && per <= JSP && j < npart * m.NB;
+    const int bpart = m.NB > 0 ? j / m.NB : 0, bl = j - bpart * m.NB;
+    for (int i = 0; i < JSP; i++) p.js[i] = 0.0f;
+    if (js_pre)
+        for (int i = 0; i < JSP; i++) {
+            const int q = bpart * per + i;
+            if (i < per && q < nq) p.js[i] = m.J_s[(size_t)q * m.NB + bl];
+        }
+    p.cp0 = act ? m.child_ptr[j] : 0;
+    p.cp1 = act ? m.child_ptr[j + 1] : 0;
+    p.par = act ? m.parents[j] : -1;
+    if (j < m.J - 1) sh.sChild[j] = m.child_idx[j];
+    for (int i = j; i < m.n_sub; i += nthr) sh.sList[i] = m.sub_list[i];
+    for (int i = j; i < m.n_items; i += nthr) sh.sItem[i] = m.sub_item[i];
+    for (int i = j; i <= m.J; i += nthr) sh.sFirst[i] = m.sub_first[i];
+    for (int e = 0; e < 12; e++) { p.G[e] = 0.0f; p.P[e] = 0.0f; }
+    for (int c = 0; c < 3; c++) p.Jl[c] = 0.0f;
+    if (act) {
+        const psi_f4 *Gp = (const psi_f4 *)(Gs + ((size_t)b * m.J + j) * 12);
+        for (int r = 0; r < 3; r++) {
+            const psi_f4 gg = Gp[r];
+            for (int c = 0; c < 4; c++) p.G[r * 4 + c] = gg[c];
+        }
+        for (int c = 0; c < 3; c++) p.Jl[c] = Jls[((size_t)b * m.J + j) * 3 + c];
+    }
+    // the parent's transform for the local gradients
+    if (act && p.par >= 0) {
+        const psi_f4 *Pp = (const psi_f4 *)(Gs + ((size_t)b * m.J + p.par) * 12);
+        for (int r = 0; r < 3; r++) {
+            const psi_f4 pr = Pp[r];
+            for (int c = 0; c < 4; c++) p.P[r * 4 + c] = pr[c];
+        }
+    }
+    return p;
+}
+
+__device__ __forceinline__ void psi_pose_bwd_finish(const LbsDev &m, const PsiPoseBwdPre &pre, PsiPoseBwdShared &sh, const float *gA_b,
+                                                    const float *gfeat_b, float *g_betas_b, float *g_pose_b, float *g_rot_b)
+{
+    const int j = threadIdx.x, nthr = blockDim.x;
+    const bool act = j < m.J;
+    float (&sX)[PSI_JP][12] = sh.sX;
+    float (&sS)[PSI_JP][12] = sh.sS;
+    float (&sP)[PSI_ITEM_MAX][12] = sh.sP;
+    unsigned int (&sItem)[PSI_ITEM_MAX] = sh.sItem;
+    unsigned char (&sList)[PSI_SUB_MAX] = sh.sList;
+    unsigned char (&sFirst)[PSI_JP + 1] = sh.sFirst;
+    float (&sgJ)[PSI_JP][3] = sh.sgJ;
+    float (&sgrel)[PSI_JP][3] = sh.sgrel;
+    int (&sChild)[PSI_JP] = sh.sChild;
+    float gf9[9];
+    const float *aa = pre.aa;
     for (int e = 0; e < 9; e++) gf9[e] = 0.0f;
     if (act && (g_pose_b || g_rot_b) && j >= 1)
         for (int e = 0; e < 9; e++) gf9[e] = gfeat_b[m.NB + (j - 1) * 9 + e];
-    if (act && g_pose_b)
-        for (int e = 0; e < 3; e++) aa[e] = pose_b[j * 3 + e];
-    constexpr int JSP = 8;                               // J_s entries of the g_betas part held in registers
+    constexpr int JSP = PSI_POSE_JSP;
     const int nq = m.J * 3;
     const int npart = m.NB > 0 ? min(32, max(1, nthr / m.NB)) : 1;
     const int per = (nq + npart - 1) / npart;
     const bool par_ok = m.NB <= 32, js_pre = g_betas_b && par_ok && per <= JSP && j < npart * m.NB;
     const int bpart = m.NB > 0 ? j / m.NB : 0, bl = j - bpart * m.NB;
-    float js[JSP];
-    for (int i = 0; i < JSP; i++) js[i] = 0.0f;
-    if (js_pre)
-        for (int i = 0; i < JSP; i++) {
-            const int q = bpart * per + i;
-            if (i < per && q < nq) js[i] = m.J_s[(size_t)q * m.NB + bl];
-        }
-    const int cp0 = act ? m.child_ptr[j] : 0, cp1 = act ? m.child_ptr[j + 1] : 0;
-    const int par = act ? m.parents[j] : -1;
-    if (j < m.J - 1) sChild[j] = m.child_idx[j];
-    for (int i = j; i < m.n_sub; i += nthr) sList[i] = m.sub_list[i];
-    for (int i = j; i < m.n_items; i += nthr) sItem[i] = m.sub_item[i];
-    for (int i = j; i <= m.J; i += nthr) sFirst[i] = m.sub_first[i];
+    const float *js = pre.js;
+    const int cp0 = pre.cp0, cp1 = pre.cp1, par = pre.par;
     float G[12], gJ[3] = {0, 0, 0};
-    for (int e = 0; e < 12; e++) G[e] = 0.0f;
+    for (int e = 0; e < 12; e++) G[e] = pre.G[e];
     if (act) {
-        const psi_f4 *Gp = (const psi_f4 *)(Gs + ((size_t)b * m.J + j) * 12);
         const psi_f4 *Ap = (const psi_f4 *)(gA_b + j * 16);
         float gA[12], Jl[3];
         for (int r = 0; r < 3; r++) {
-            const psi_f4 gg = Gp[r], aa4 = Ap[r];
-            for (int c = 0; c < 4; c++) { G[r * 4 + c] = gg[c]; gA[r * 4 + c] = aa4[c]; }
+            const psi_f4 aa4 = Ap[r];
+            for (int c = 0; c < 4; c++) gA[r * 4 + c] = aa4[c];
         }
-        for (int c = 0; c < 3; c++) Jl[c] = Jls[((size_t)b * m.J + j) * 3 + c];
+        for (int c = 0; c < 3; c++) Jl[c] = pre.Jl[c];
         // A = [G_R | G_t - G_R J]: own gradient of G_j and the direct part of the rest-joint gradient
         float go[9], w[3];
         for (int r = 0; r < 3; r++) {
@@ -272,16 +327,7 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
             sX[j][9 + r] = w[r];
         }
     }
-    // the parent's transform for the local gradients below
-    float P[12];
-    for (int e = 0; e < 12; e++) P[e] = 0.0f;
-    if (act && par >= 0) {
-        const psi_f4 *Pp = (const psi_f4 *)(Gs + ((size_t)b * m.J + par) * 12);
-        for (int r = 0; r < 3; r++) {
-            const psi_f4 pr = Pp[r];
-            for (int c = 0; c < 4; c++) P[r * 4 + c] = pr[c];
-        }
-    }
+    const float *P = pre.P;
     __syncthreads();
     for (int i = j; i < m.n_items * 12; i += nthr) {
         const int it = i / 12, e = i - it * 12;
@@ -338,7 +384,7 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
     if (g_betas_b) {
         // g_betas[l] = g_feat[l] + sum_q gJ[q] J_s[q][l]: the (joint, axis) range is cut into nthr/NB parts summed through LDS,
         // so a thread has only a handful of independent loads (they were 165 dependent rounds for NB threads before)
-        __shared__ float sgb[32][32];
+        float (&sgb)[32][32] = sh.sgb;
         if (js_pre) {
             float a = 0.0f;
 #pragma unroll
@@ -398,6 +444,56 @@ __device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *
         float ga[3] = {gd[0] / th + gth * x / th, gd[1] / th + gth * y / th, gd[2] / th + gth * z / th};
         for (int q = 0; q < 3; q++) g_pose_b[j * 3 + q] = ga[q];
     }
+}
+
+__device__ __forceinline__ void psi_pose_bwd_body(const LbsDev &m, const float *pose_b,
+                                                  const float *__restrict__ Rs, const float *__restrict__ Jls,
+                                                  const float *__restrict__ Gs, const float *gA_b, const float *gfeat_b, int b,
+                                                  float *g_betas_b, float *g_pose_b, float *g_rot_b)
+{
+    (void)Rs;
+    __shared__ PsiPoseBwdShared sh;
+    const PsiPoseBwdPre pre = psi_pose_bwd_issue(m, pose_b, Jls, Gs, b, g_betas_b != nullptr, g_pose_b != nullptr, sh);
+    psi_pose_bwd_finish(m, pre, sh, gA_b, gfeat_b, g_betas_b, g_pose_b, g_rot_b);
+}
+
+
+// Sums of the split-contraction partials of the LBS backward (skin_bwd_A's vertex slices, blend_bwd's column slices, skin_bwd_v's
+// translation partials): used by reduce_partials_kernel (lbs.hip) and by the fitting engine's fused tail + head kernel (fit.hip), which
+// must add the slices in the same order.
+// PSI_RSPL threads share one output: thread s of the group adds slices s, s + PSI_RSPL, ... (all requested before the first add) and the group is
+// combined in lane order with shuffles — four times as many workgroups pulling the fresh partials (they were just written by other XCDs'
+// workgroups: a CU gets only ~15 GB/s of such data, so the kernel is bound by how many CUs pull at once, not by arithmetic).
+constexpr int PSI_RSPL = 4;
+// (two halves, so that a caller with several outputs per thread can request all of their slices before the first add)
+template <int MAXS>
+__device__ __forceinline__ void psi_slices_load(const float *__restrict__ p, size_t stride, int n, int s0, float (&v)[MAXS])
+{
+#pragma unroll
+    for (int k = 0; k < MAXS; k++) {
+        const int sl = s0 + k * PSI_RSPL;
+        v[k] = sl < n ? p[(size_t)sl * stride] : 0.0f;
+    }
+}
+template <int MAXS>
+__device__ __forceinline__ float psi_slices_sum(const float (&v)[MAXS], const float *__restrict__ p, size_t stride, int n, int s0)
+{
+    float a0 = 0, a1 = 0;
+#pragma unroll
+    for (int k = 0; k < MAXS; k += 2) { a0 += v[k]; a1 += v[k + 1]; }
+    float r = a0 + a1;
+    for (int sl = s0 + MAXS * PSI_RSPL; sl < n; sl += PSI_RSPL) r += p[(size_t)sl * stride];
+    // lanes s0 = 0..3 of the group -> ((r0 + r1) + (r2 + r3)), the same value in all four lanes
+    r += __shfl_xor(r, 1, 64);
+    r += __shfl_xor(r, 2, 64);
+    return r;
+}
+template <int MAXS>
+__device__ __forceinline__ float psi_sum_slices_split(const float *__restrict__ p, size_t stride, int n, int s0)
+{
+    float v[MAXS];
+    psi_slices_load<MAXS>(p, stride, n, s0, v);
+    return psi_slices_sum<MAXS>(v, p, stride, n, s0);
 }
 
 

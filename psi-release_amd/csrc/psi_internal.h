@@ -48,8 +48,8 @@ void psi_lbs_dims(const psi_lbs_model *mdl, int *V, int *J, int *NB);
 struct PsiLbsView;
 int psi_lbs_view(const psi_lbs_model *mdl, int B, float *ws, PsiLbsView *out);
 int psi_lbs_blend_forward(const psi_lbs_model *mdl, int B, float *ws, hipStream_t st);          // v_posed = v_t + feat @ dirs
-int psi_lbs_backward_joint_parts(const psi_lbs_model *mdl, int B, float *ws, float *g_transl,
-                                 hipStream_t st);   // skin_bwd_A + blend_bwd partials + their reduction (gA, gfeat in the workspace)
+int psi_lbs_backward_joint_parts(const psi_lbs_model *mdl, int B, float *ws, float *g_transl, hipStream_t st,
+                                 bool reduce = true);   // skin_bwd_A + blend_bwd partials (+ their reduction: gA, gfeat in the workspace)
 
 // dp.hip
 struct psi_dp_comm;
