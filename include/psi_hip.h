@@ -269,6 +269,11 @@ int psi_fit_copy_buffer(psi_fit_engine *engine, const char *name, float *d_out, 
 size_t psi_linear_workspace_floats(int M, int N, int K);
 int psi_linear_forward(const void *x, int x_is_bf16, const float *W, const float *bias, const float *residual, int M, int N, int K,
                        int act, float slope, float *y, float *act_out, float *ws, void *stream);
+/* psi_linear_forward3: the same layer at the fp32 model's precision (cvae.py:474-492 as shipped, no autocast) — three-term split products
+ * (see psi_conv2d_forward) — and for ANY K and N (the 3-, 72-, 75-wide layers included; rows that are not 16-byte aligned are gathered
+ * element by element).  Same arguments, same workspace. */
+int psi_linear_forward3(const void *x, int x_is_bf16, const float *W, const float *bias, const float *residual, int M, int N, int K,
+                        int act, float slope, float *y, float *act_out, float *ws, void *stream);
 size_t psi_linear_backward_workspace_floats(int M, int N, int K);
 int psi_linear_backward(const float *gy, const float *act_out, const void *x, int x_is_bf16, const float *W, int M, int N, int K,
                         float slope, void *gx, float *gW, float *gbias, float *ws, void *stream);
@@ -320,6 +325,32 @@ int psi_conv3x3_prepare_weight(const float *w32, int Cin, int Cout, void *wb, vo
  * maximum in scan order, like at::max_pool2d_with_indices).  Backward: dx [N,H,W,C] bf16 (OVERWRITTEN) gathers dy through idx. */
 int psi_maxpool3x3s2_forward(const void *x, int N, int H, int W, int C, void *y, void *idx, void *stream);
 int psi_maxpool3x3s2_backward(const void *dy, const void *idx, int N, int H, int W, int C, void *dx, void *stream);
+
+/* ---- the scene encoders at the REFERENCE'S PRECISION (fp32 model: cvae.py:427-455; torchvision resnet18 children[1:6]; the head
+ * convolutions cvae.py:436, net_layers.py:64,162) on hand-written kernels — replaces nn.Conv2d / nn.BatchNorm2d / nn.MaxPool2d of an fp32
+ * HumanCVAES1 / S2 (F.conv2d -> MIOpen, at::batch_norm, at::max_pool2d) on the GPU.
+ * psi_conv2d_forward: ANY 2-D convolution of that trunk (7x7 / stride 2 stem, stride-1 and stride-2 3x3, 1x1 / stride 2 downsample, 3x3 heads)
+ *   as ONE implicit-GEMM kernel (csrc/conv_gemm.hip).  x [N,H,W,Cin] NHWC, fp32 or bf16 (x_bf16); w [Cout,KH,KW,Cin] FP32 (the memory of a
+ *   channels_last Conv2d weight: the master weight is read directly, no prepared copy); bias [Cout] fp32 or NULL; y [N,OH,OW,Cout] NHWC fp32 or
+ *   bf16 (y_bf16), OH = (H + 2 pad - KH) / stride + 1.  nterm = 3: every product is a three-term bf16 split (hi*hi + hi*lo + lo*hi) with
+ *   fp32 accumulation — 0.6-3.2e-5 of the reference's recorded fp32 forward passes (tests/golden/cvae.npz; bound of the tests 2e-4);
+ *   nterm = 1: operands rounded to bf16 (the bf16 mode of the trunk: the convolutions psi_conv3x3_forward does not cover).
+ *   psi_conv2d_supported: Cout % 32 == 0 and (Cin % 64 == 0, or Cin * KH * KW <= 4096: the element-gather path of the stem).
+ * psi_bn_forward_t / psi_bn_backward_t / psi_maxpool3x3s2_forward_t / _backward_t: the operators above on maps of either element type
+ *   (map_f32 != 0: fp32 NHWC maps), psi_bn_forward_t also in the INFERENCE form (eval_mode != 0: y = gamma (x - running_mean) /
+ *   sqrt(running_var + eps) + beta, nothing updated, save_mean / save_invstd may be NULL) — the generation drivers run the encoders in
+ *   .eval() (test_habitat_s2.py:155-170).  idx == NULL in psi_maxpool3x3s2_forward_t: no window positions are kept (inference). */
+int psi_conv2d_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
+int psi_conv2d_forward(const void *x, int x_bf16, const float *w, const float *bias, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                       int stride, int pad, void *y, int y_bf16, int nterm, void *stream);
+int psi_bn_forward_t(const void *x, int map_f32, const void *residual, const float *gamma, const float *beta, float *running_mean,
+                     float *running_var, long long *num_batches_tracked, long M, int C, int relu, float momentum, float eps, void *y,
+                     float *save_mean, float *save_invstd, float *ws, int eval_mode, void *stream);
+int psi_bn_backward_t(const void *dy, int map_f32, const void *x, const void *y, const float *gamma, const float *save_mean,
+                      const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, float *ws,
+                      void *stream);
+int psi_maxpool3x3s2_forward_t(const void *x, int map_f32, int N, int H, int W, int C, void *y, void *idx, void *stream);
+int psi_maxpool3x3s2_backward_t(const void *dy, int map_f32, const void *idx, int N, int H, int W, int C, void *dx, void *stream);
 
 /* ---- body-vector glue of a CVAE training step (train_s1.py:95-133 / train_s2.py:102-139 cal_loss) ------------------------------
  * psi_cvae_target: out75[b] = convert_to_6D_rot(normalize_global_T(xh72[b], cam_int[b], max_d[b]))   (cvae.py:176-199 + 118-127, the

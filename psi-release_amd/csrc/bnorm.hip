@@ -49,6 +49,30 @@ __device__ __forceinline__ u4 pack8(const float (&f)[8])
     return v;
 }
 
+// Eight consecutive channels of a feature map of element type MT: bf16 (the bf16 mode of the trunk: one 16-byte access) or fp32 (the
+// fp32 model, whose convolutions run as three-term split products — conv_gemm.hip: two 16-byte accesses).  The arithmetic of every
+// kernel below is fp32 either way.
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <typename MT> struct Map8;
+template <> struct Map8<bf16raw> {
+    typedef u4 raw;
+    static __device__ __forceinline__ raw ld(const void *p, long i) { return ((const u4 *)p)[i]; }
+    static __device__ __forceinline__ void st(void *p, long i, const raw &v) { ((u4 *)p)[i] = v; }
+    static __device__ __forceinline__ void unpack(const raw &v, float (&f)[8]) { unpack8(v, f); }
+    static __device__ __forceinline__ raw pack(const float (&f)[8]) { return pack8(f); }
+};
+template <> struct Map8<float> {
+    struct raw { f4v a, b; };
+    static __device__ __forceinline__ raw ld(const void *p, long i) { const f4v *q = (const f4v *)p + 2 * i; return raw{q[0], q[1]}; }
+    static __device__ __forceinline__ void st(void *p, long i, const raw &v) { f4v *q = (f4v *)p + 2 * i; q[0] = v.a; q[1] = v.b; }
+    static __device__ __forceinline__ void unpack(const raw &v, float (&f)[8])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { f[k] = v.a[k]; f[4 + k] = v.b[k]; }
+    }
+    static __device__ __forceinline__ raw pack(const float (&f)[8]) { return raw{f4v{f[0], f[1], f[2], f[3]}, f4v{f[4], f[5], f[6], f[7]}}; }
+};
+
 constexpr int BN_BLK = 256;
 constexpr int BN_MAXC = 256;
 
@@ -74,8 +98,10 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[NQ][8], int C, i
     }
 }
 
-__global__ __launch_bounds__(BN_BLK) void bn_stats_kernel(const u4 *__restrict__ x, long M, int C, float *__restrict__ part)
+template <typename MT>
+__global__ __launch_bounds__(BN_BLK) void bn_stats_kernel(const void *__restrict__ x, long M, int C, float *__restrict__ part)
 {
+    typedef Map8<MT> V;
     const int ngrp = C / 8, rpb = BN_BLK / ngrp;
     const int g = threadIdx.x % ngrp, rr = threadIdx.x / ngrp;
     float acc[2][8];
@@ -85,13 +111,13 @@ __global__ __launch_bounds__(BN_BLK) void bn_stats_kernel(const u4 *__restrict__
     long r = (long)blockIdx.x * rpb + rr;
     // four rows in flight per thread
     for (; r + 3 * stride < M; r += 4 * stride) {
-        u4 v[4];
+        typename V::raw v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = x[(r + u * stride) * ngrp + g];
+        for (int u = 0; u < 4; u++) v[u] = V::ld(x, (r + u * stride) * ngrp + g);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             float f[8];
-            unpack8(v[u], f);
+            V::unpack(v[u], f);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 acc[0][i] += f[i];
@@ -101,7 +127,7 @@ __global__ __launch_bounds__(BN_BLK) void bn_stats_kernel(const u4 *__restrict__
     }
     for (; r < M; r += stride) {
         float fa[8];
-        unpack8(x[r * ngrp + g], fa);
+        V::unpack(V::ld(x, r * ngrp + g), fa);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             acc[0][i] += fa[i];
@@ -185,10 +211,11 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(const float *__re
     }
 }
 
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(BN_BLK) void bn_fwd_apply_kernel(const u4 *__restrict__ x, const u4 *__restrict__ res, long n16, int C,
-                                                              const float *__restrict__ scale_shift, u4 *__restrict__ y)
+template <typename MT, bool RELU, bool RES>
+__global__ __launch_bounds__(BN_BLK) void bn_fwd_apply_kernel(const void *__restrict__ x, const void *__restrict__ res, long n16, int C,
+                                                              const float *__restrict__ scale_shift, void *__restrict__ y)
 {
+    typedef Map8<MT> V;
     __shared__ float ss[2 * BN_MAXC];
     for (int i = threadIdx.x; i < 2 * C; i += BN_BLK) ss[i] = scale_shift[i];
     __syncthreads();
@@ -196,12 +223,12 @@ __global__ __launch_bounds__(BN_BLK) void bn_fwd_apply_kernel(const u4 *__restri
     const bool pow2 = (ngrp & (ngrp - 1)) == 0;
     for (long i = (long)blockIdx.x * BN_BLK + threadIdx.x; i < n16; i += (long)gridDim.x * BN_BLK) {
         const int c0 = (pow2 ? (int)(i & (ngrp - 1)) : (int)(i % ngrp)) * 8;
-        const u4 xv = x[i];
-        u4 rv;
-        if (RES) rv = res[i];
+        const typename V::raw xv = V::ld(x, i);
+        typename V::raw rv = xv;
+        if (RES) rv = V::ld(res, i);
         float f[8], r[8];
-        unpack8(xv, f);
-        if (RES) unpack8(rv, r);
+        V::unpack(xv, f);
+        if (RES) V::unpack(rv, r);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             float v = f[k] * ss[c0 + k] + ss[C + c0 + k];
@@ -209,16 +236,18 @@ __global__ __launch_bounds__(BN_BLK) void bn_fwd_apply_kernel(const u4 *__restri
             if (RELU) v = v > 0.0f ? v : 0.0f;
             f[k] = v;
         }
-        y[i] = pack8(f);
+        V::st(y, i, V::pack(f));
     }
 }
 
 // backward, pass 1: dz = dy * (y > 0) [ReLU] ; partial sums of dz and dz * xhat per channel, xhat = (x - mean) * invstd
-template <bool RELU>
-__global__ __launch_bounds__(BN_BLK) void bn_bwd_reduce_kernel(const u4 *__restrict__ dy, const u4 *__restrict__ x, const u4 *__restrict__ y,
+template <typename MT, bool RELU>
+__global__ __launch_bounds__(BN_BLK) void bn_bwd_reduce_kernel(const void *__restrict__ dy, const void *__restrict__ x, const void *__restrict__ y,
                                                                long M, int C, const float *__restrict__ mean, const float *__restrict__ invstd,
                                                                float *__restrict__ part)
 {
+    typedef Map8<MT> V;
+    typedef typename V::raw R8;
     const int ngrp = C / 8, rpb = BN_BLK / ngrp;
     const int g = threadIdx.x % ngrp, rr = threadIdx.x / ngrp;
     float mu[8], is[8];
@@ -228,11 +257,11 @@ __global__ __launch_bounds__(BN_BLK) void bn_bwd_reduce_kernel(const u4 *__restr
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[0][i] = acc[1][i] = 0.0f;
     const long stride = (long)gridDim.x * rpb;
-    auto row = [&](const u4 &dv, const u4 &xv, const u4 &yv) {
+    auto row = [&](const R8 &dv, const R8 &xv, const R8 &yv) {
         float d[8], xf[8], yf[8];
-        unpack8(dv, d);
-        unpack8(xv, xf);
-        if (RELU) unpack8(yv, yf);
+        V::unpack(dv, d);
+        V::unpack(xv, xf);
+        if (RELU) V::unpack(yv, yf);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const float dz = (RELU && !(yf[i] > 0.0f)) ? 0.0f : d[i];
@@ -243,17 +272,17 @@ __global__ __launch_bounds__(BN_BLK) void bn_bwd_reduce_kernel(const u4 *__restr
     long r = (long)blockIdx.x * rpb + rr;
     for (; r + stride < M; r += 2 * stride) {               // two rows (six 16-byte loads) in flight per thread
         const long i0 = r * ngrp + g, i1 = (r + stride) * ngrp + g;
-        const u4 d0 = dy[i0], x0 = x[i0], d1 = dy[i1], x1 = x[i1];
-        u4 y0 = d0, y1 = d1;
-        if (RELU) { y0 = y[i0]; y1 = y[i1]; }
+        const R8 d0 = V::ld(dy, i0), x0 = V::ld(x, i0), d1 = V::ld(dy, i1), x1 = V::ld(x, i1);
+        R8 y0 = d0, y1 = d1;
+        if (RELU) { y0 = V::ld(y, i0); y1 = V::ld(y, i1); }
         row(d0, x0, y0);
         row(d1, x1, y1);
     }
     if (r < M) {
         const long i0 = r * ngrp + g;
-        const u4 d0 = dy[i0], x0 = x[i0];
-        u4 y0 = d0;
-        if (RELU) y0 = y[i0];
+        const R8 d0 = V::ld(dy, i0), x0 = V::ld(x, i0);
+        R8 y0 = d0;
+        if (RELU) y0 = V::ld(y, i0);
         row(d0, x0, y0);
     }
     block_reduce_store<2>(acc, C, g, rr, rpb, part);
@@ -278,11 +307,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
     coef[2 * C + c] = (float)(-(double)a * s / (double)M);
 }
 
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(BN_BLK) void bn_bwd_apply_kernel(const u4 *__restrict__ dy, const u4 *__restrict__ x, const u4 *__restrict__ y, long n16,
+template <typename MT, bool RELU, bool RES>
+__global__ __launch_bounds__(BN_BLK) void bn_bwd_apply_kernel(const void *__restrict__ dy, const void *__restrict__ x, const void *__restrict__ y, long n16,
                                                               int C, const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                              const float *__restrict__ coef, u4 *__restrict__ dx, u4 *__restrict__ dres)
+                                                              const float *__restrict__ coef, void *__restrict__ dx, void *__restrict__ dres)
 {
+    typedef Map8<MT> V;
     __shared__ float sc[5 * BN_MAXC];
     for (int i = threadIdx.x; i < C; i += BN_BLK) {
         sc[i] = coef[i];
@@ -296,13 +326,13 @@ __global__ __launch_bounds__(BN_BLK) void bn_bwd_apply_kernel(const u4 *__restri
     const bool pow2 = (ngrp & (ngrp - 1)) == 0;
     for (long i = (long)blockIdx.x * BN_BLK + threadIdx.x; i < n16; i += (long)gridDim.x * BN_BLK) {
         const int c0 = (pow2 ? (int)(i & (ngrp - 1)) : (int)(i % ngrp)) * 8;
-        const u4 dv = dy[i], xv = x[i];
-        u4 yv;
-        if (RELU) yv = y[i];
+        const typename V::raw dv = V::ld(dy, i), xv = V::ld(x, i);
+        typename V::raw yv = dv;
+        if (RELU) yv = V::ld(y, i);
         float d[8], xf[8], yf[8], o[8];
-        unpack8(dv, d);
-        unpack8(xv, xf);
-        if (RELU) unpack8(yv, yf);
+        V::unpack(dv, d);
+        V::unpack(xv, xf);
+        if (RELU) V::unpack(yv, yf);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const float dz = (RELU && !(yf[k] > 0.0f)) ? 0.0f : d[k];
@@ -310,8 +340,8 @@ __global__ __launch_bounds__(BN_BLK) void bn_bwd_apply_kernel(const u4 *__restri
             const float xhat = (xf[k] - sc[3 * C + c0 + k]) * sc[4 * C + c0 + k];
             o[k] = sc[c0 + k] * dz + sc[C + c0 + k] * xhat + sc[2 * C + c0 + k];
         }
-        dx[i] = pack8(o);
-        if (RES) dres[i] = pack8(d);
+        V::st(dx, i, V::pack(o));
+        if (RES) V::st(dres, i, V::pack(d));
     }
 }
 
@@ -321,9 +351,11 @@ __global__ __launch_bounds__(BN_BLK) void bn_bwd_apply_kernel(const u4 *__restri
 // that contain it): no atomics, deterministic, one coalesced pass.  First maximum in (kh, kw) scan order wins (strict >), like
 // at::max_pool2d_with_indices.  The library's NHWC backward takes 107 us for the stem's 67 MB map; this pass is bandwidth-bound.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BN_BLK) void maxpool_fwd_kernel(const u4 *__restrict__ x, int N, int H, int W, int C, int OH, int OW,
-                                                             u4 *__restrict__ y, unsigned long long *__restrict__ idx)
+template <typename MT>
+__global__ __launch_bounds__(BN_BLK) void maxpool_fwd_kernel(const void *__restrict__ x, int N, int H, int W, int C, int OH, int OW,
+                                                             void *__restrict__ y, unsigned long long *__restrict__ idx)
 {
+    typedef Map8<MT> V;
     const int ngrp = C / 8;
     const long total = (long)N * OH * OW * ngrp;
     for (long i = (long)blockIdx.x * BN_BLK + threadIdx.x; i < total; i += (long)gridDim.x * BN_BLK) {
@@ -344,23 +376,26 @@ __global__ __launch_bounds__(BN_BLK) void maxpool_fwd_kernel(const u4 *__restric
                 const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
                 if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
                 float f[8];
-                unpack8(x[(((long)n * H + ih) * W + iw) * ngrp + g], f);
+                V::unpack(V::ld(x, (((long)n * H + ih) * W + iw) * ngrp + g), f);
 #pragma unroll
                 for (int k = 0; k < 8; k++)
                     if (first || f[k] > best[k] || f[k] != f[k]) { best[k] = f[k]; bi[k] = (unsigned char)(kh * 3 + kw); }
                 first = false;
             }
-        y[i] = pack8(best);
+        V::st(y, i, V::pack(best));
         unsigned long long pk = 0;
+        if (!idx) continue;                                  // (inference: nobody will ask for the backward)
 #pragma unroll
         for (int k = 0; k < 8; k++) pk |= (unsigned long long)bi[k] << (8 * k);
         idx[i] = pk;
     }
 }
 
-__global__ __launch_bounds__(BN_BLK) void maxpool_bwd_kernel(const u4 *__restrict__ dy, const unsigned long long *__restrict__ idx, int N, int H,
-                                                             int W, int C, int OH, int OW, u4 *__restrict__ dx)
+template <typename MT>
+__global__ __launch_bounds__(BN_BLK) void maxpool_bwd_kernel(const void *__restrict__ dy, const unsigned long long *__restrict__ idx, int N, int H,
+                                                             int W, int C, int OH, int OW, void *__restrict__ dx)
 {
+    typedef Map8<MT> V;
     const int ngrp = C / 8;
     const long total = (long)N * H * W * ngrp;
     for (long i = (long)blockIdx.x * BN_BLK + threadIdx.x; i < total; i += (long)gridDim.x * BN_BLK) {
@@ -384,13 +419,24 @@ __global__ __launch_bounds__(BN_BLK) void maxpool_bwd_kernel(const u4 *__restric
                 const long o = (((long)n * OH + oh) * OW + ow) * ngrp + g;
                 const unsigned long long pk = idx[o];
                 float d[8];
-                unpack8(dy[o], d);
+                V::unpack(V::ld(dy, o), d);
 #pragma unroll
                 for (int k = 0; k < 8; k++)
                     if ((int)((pk >> (8 * k)) & 0xff) == pos) acc[k] += d[k];
             }
-        dx[i] = pack8(acc);
+        V::st(dx, i, V::pack(acc));
     }
+}
+
+// eval mode (generation: cvae.py TestOP runs the encoders in .eval()): y = gamma (x - running_mean) / sqrt(running_var + eps) + beta
+__global__ void bn_eval_coef_kernel(const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ rmean,
+                                    const float *__restrict__ rvar, float eps, int C, float *__restrict__ scale_shift)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rvar[c] + eps);           // (the operator order of at::batch_norm's inference path)
+    scale_shift[c] = sc;
+    scale_shift[C + c] = beta[c] - rmean[c] * sc;
 }
 
 int bn_blocks(long M, int C)
@@ -405,24 +451,30 @@ int bn_blocks(long M, int C)
 
 extern "C" size_t psi_bn_workspace_floats(long M, int C) { return (size_t)bn_blocks(M, C) * 2 * C + 5 * (size_t)C + 64; }
 
-extern "C" int psi_bn_forward(const void *x, const void *residual, const float *gamma, const float *beta, float *running_mean,
-                              float *running_var, long long *num_batches_tracked, long M, int C, int relu, float momentum, float eps,
-                              void *y, float *save_mean, float *save_invstd, float *ws, void *stream)
+template <typename MT>
+static int bn_forward_t(const void *x, const void *residual, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                        long long *num_batches_tracked, long M, int C, int relu, float momentum, float eps, void *y, float *save_mean,
+                        float *save_invstd, float *ws, int eval_mode, hipStream_t st)
 {
-    PSI_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "null pointer");
+    PSI_REQUIRE(x && gamma && beta && y && ws, "null pointer");
+    PSI_REQUIRE(eval_mode ? (running_mean && running_var) : (save_mean && save_invstd), "null pointer (statistics)");
     PSI_REQUIRE(M > 0 && C >= 8 && C <= BN_MAXC && C % 8 == 0 && BN_BLK % (C / 8) == 0 && 1024 % (2 * C) == 0, "C must be 8, 16, 32, 64, 128 or 256");
-    hipStream_t st = (hipStream_t)stream;
     const int nb = bn_blocks(M, C);
     float *part = ws, *ss = ws + (size_t)nb * 2 * C;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(BN_BLK), 0, st, (const u4 *)x, M, C, part);
-    PSI_CHECK_LAUNCH("bn_stats_kernel");
-    psi_mark("bn_stats_kernel", st);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(bn_fin_blocks(C)), dim3(1024), 0, st, part, nb, M, C, gamma, beta, eps, momentum, running_mean, running_var,
-                       num_batches_tracked, save_mean, save_invstd, ss);
-    PSI_CHECK_LAUNCH("bn_fwd_finalize_kernel");
+    if (eval_mode) {
+        hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(psi_cdiv(C, 256)), dim3(256), 0, st, gamma, beta, running_mean, running_var, eps, C, ss);
+        PSI_CHECK_LAUNCH("bn_eval_coef_kernel");
+    } else {
+        hipLaunchKernelGGL(bn_stats_kernel<MT>, dim3(nb), dim3(BN_BLK), 0, st, x, M, C, part);
+        PSI_CHECK_LAUNCH("bn_stats_kernel");
+        psi_mark("bn_stats_kernel", st);
+        hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(bn_fin_blocks(C)), dim3(1024), 0, st, part, nb, M, C, gamma, beta, eps, momentum, running_mean,
+                           running_var, num_batches_tracked, save_mean, save_invstd, ss);
+        PSI_CHECK_LAUNCH("bn_fwd_finalize_kernel");
+    }
     const long n16 = M * (C / 8);
     const int ga = (int)((n16 + BN_BLK - 1) / BN_BLK < 2048 ? (n16 + BN_BLK - 1) / BN_BLK : 2048);
-#define PSI_BN_APPLY(R_, S_) hipLaunchKernelGGL((bn_fwd_apply_kernel<R_, S_>), dim3(ga), dim3(BN_BLK), 0, st, (const u4 *)x, (const u4 *)residual, n16, C, ss, (u4 *)y)
+#define PSI_BN_APPLY(R_, S_) hipLaunchKernelGGL((bn_fwd_apply_kernel<MT, R_, S_>), dim3(ga), dim3(BN_BLK), 0, st, x, residual, n16, C, ss, y)
     if (relu && residual) PSI_BN_APPLY(true, true);
     else if (relu) PSI_BN_APPLY(true, false);
     else if (residual) PSI_BN_APPLY(false, true);
@@ -433,29 +485,26 @@ extern "C" int psi_bn_forward(const void *x, const void *residual, const float *
     return 0;
 }
 
-extern "C" int psi_bn_backward(const void *dy, const void *x, const void *y, const float *gamma, const float *save_mean,
-                               const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
-                               float *ws, void *stream)
+template <typename MT>
+static int bn_backward_t(const void *dy, const void *x, const void *y, const float *gamma, const float *save_mean, const float *save_invstd, long M,
+                         int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, float *ws, hipStream_t st)
 {
     PSI_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && ws, "null pointer");
     PSI_REQUIRE(!relu || y, "the ReLU mask needs the forward output");
     PSI_REQUIRE(M > 0 && C >= 8 && C <= BN_MAXC && C % 8 == 0 && BN_BLK % (C / 8) == 0 && 1024 % (2 * C) == 0, "C must be 8, 16, 32, 64, 128 or 256");
-    hipStream_t st = (hipStream_t)stream;
     const int nb = bn_blocks(M, C);
     float *part = ws, *coef = ws + (size_t)nb * 2 * C;
     if (relu)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nb), dim3(BN_BLK), 0, st, (const u4 *)dy, (const u4 *)x, (const u4 *)y, M, C, save_mean,
-                           save_invstd, part);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<MT, true>), dim3(nb), dim3(BN_BLK), 0, st, dy, x, y, M, C, save_mean, save_invstd, part);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nb), dim3(BN_BLK), 0, st, (const u4 *)dy, (const u4 *)x, (const u4 *)y, M, C, save_mean,
-                           save_invstd, part);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<MT, false>), dim3(nb), dim3(BN_BLK), 0, st, dy, x, y, M, C, save_mean, save_invstd, part);
     PSI_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     psi_mark("bn_bwd_reduce_kernel", st);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(bn_fin_blocks(C)), dim3(1024), 0, st, part, nb, M, C, gamma, save_invstd, dgamma, dbeta, coef);
     PSI_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long n16 = M * (C / 8);
     const int ga = (int)((n16 + BN_BLK - 1) / BN_BLK < 2048 ? (n16 + BN_BLK - 1) / BN_BLK : 2048);
-#define PSI_BN_BAPPLY(R_, S_) hipLaunchKernelGGL((bn_bwd_apply_kernel<R_, S_>), dim3(ga), dim3(BN_BLK), 0, st, (const u4 *)dy, (const u4 *)x, (const u4 *)y, n16, C, save_mean, save_invstd, coef, (u4 *)dx, (u4 *)dresidual)
+#define PSI_BN_BAPPLY(R_, S_) hipLaunchKernelGGL((bn_bwd_apply_kernel<MT, R_, S_>), dim3(ga), dim3(BN_BLK), 0, st, dy, x, y, n16, C, save_mean, save_invstd, coef, dx, dresidual)
     if (relu && dresidual) PSI_BN_BAPPLY(true, true);
     else if (relu) PSI_BN_BAPPLY(true, false);
     else if (dresidual) PSI_BN_BAPPLY(false, true);
@@ -466,28 +515,89 @@ extern "C" int psi_bn_backward(const void *dy, const void *x, const void *y, con
     return 0;
 }
 
-extern "C" int psi_maxpool3x3s2_forward(const void *x, int N, int H, int W, int C, void *y, void *idx, void *stream)
+template <typename MT>
+static int maxpool_forward_t(const void *x, int N, int H, int W, int C, void *y, void *idx, hipStream_t st)
 {
-    PSI_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "bad arguments (C must be a multiple of 8)");
+    PSI_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "bad arguments (C must be a multiple of 8)");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const long total = (long)N * OH * OW * (C / 8);
     const int grid = (int)((total + BN_BLK - 1) / BN_BLK < 4096 ? (total + BN_BLK - 1) / BN_BLK : 4096);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid), dim3(BN_BLK), 0, (hipStream_t)stream, (const u4 *)x, N, H, W, C, OH, OW, (u4 *)y,
-                       (unsigned long long *)idx);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<MT>, dim3(grid), dim3(BN_BLK), 0, st, x, N, H, W, C, OH, OW, y, (unsigned long long *)idx);
     PSI_CHECK_LAUNCH("maxpool_fwd_kernel");
-    psi_mark("maxpool_fwd_kernel", (hipStream_t)stream);
+    psi_mark("maxpool_fwd_kernel", st);
     return 0;
 }
 
-extern "C" int psi_maxpool3x3s2_backward(const void *dy, const void *idx, int N, int H, int W, int C, void *dx, void *stream)
+template <typename MT>
+static int maxpool_backward_t(const void *dy, const void *idx, int N, int H, int W, int C, void *dx, hipStream_t st)
 {
     PSI_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "bad arguments (C must be a multiple of 8)");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const long total = (long)N * H * W * (C / 8);
     const int grid = (int)((total + BN_BLK - 1) / BN_BLK < 4096 ? (total + BN_BLK - 1) / BN_BLK : 4096);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid), dim3(BN_BLK), 0, (hipStream_t)stream, (const u4 *)dy, (const unsigned long long *)idx, N, H, W,
-                       C, OH, OW, (u4 *)dx);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<MT>, dim3(grid), dim3(BN_BLK), 0, st, dy, (const unsigned long long *)idx, N, H, W, C, OH, OW, dx);
     PSI_CHECK_LAUNCH("maxpool_bwd_kernel");
-    psi_mark("maxpool_bwd_kernel", (hipStream_t)stream);
+    psi_mark("maxpool_bwd_kernel", st);
     return 0;
+}
+
+// bf16 maps (the bf16 mode of the trunk)
+extern "C" int psi_bn_forward(const void *x, const void *residual, const float *gamma, const float *beta, float *running_mean,
+                              float *running_var, long long *num_batches_tracked, long M, int C, int relu, float momentum, float eps,
+                              void *y, float *save_mean, float *save_invstd, float *ws, void *stream)
+{
+    return bn_forward_t<bf16raw>(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, M, C, relu, momentum, eps, y, save_mean,
+                                 save_invstd, ws, 0, (hipStream_t)stream);
+}
+
+extern "C" int psi_bn_backward(const void *dy, const void *x, const void *y, const float *gamma, const float *save_mean,
+                               const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
+                               float *ws, void *stream)
+{
+    return bn_backward_t<bf16raw>(dy, x, y, gamma, save_mean, save_invstd, M, C, relu, dx, dresidual, dgamma, dbeta, ws, (hipStream_t)stream);
+}
+
+extern "C" int psi_maxpool3x3s2_forward(const void *x, int N, int H, int W, int C, void *y, void *idx, void *stream)
+{
+    PSI_REQUIRE(idx, "null pointer");
+    return maxpool_forward_t<bf16raw>(x, N, H, W, C, y, idx, (hipStream_t)stream);
+}
+
+extern "C" int psi_maxpool3x3s2_backward(const void *dy, const void *idx, int N, int H, int W, int C, void *dx, void *stream)
+{
+    return maxpool_backward_t<bf16raw>(dy, idx, N, H, W, C, dx, (hipStream_t)stream);
+}
+
+// The same operators on maps of either element type (map_f32 != 0: fp32 NHWC maps — the fp32 model), and with the inference form of the
+// normalisation (eval_mode != 0: running statistics, nothing is updated; save_mean / save_invstd may be NULL).  idx == NULL in
+// psi_maxpool3x3s2_forward_t: inference, no window positions are kept.
+extern "C" int psi_bn_forward_t(const void *x, int map_f32, const void *residual, const float *gamma, const float *beta, float *running_mean,
+                                float *running_var, long long *num_batches_tracked, long M, int C, int relu, float momentum, float eps, void *y,
+                                float *save_mean, float *save_invstd, float *ws, int eval_mode, void *stream)
+{
+    if (map_f32)
+        return bn_forward_t<float>(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, M, C, relu, momentum, eps, y, save_mean,
+                                   save_invstd, ws, eval_mode, (hipStream_t)stream);
+    return bn_forward_t<bf16raw>(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, M, C, relu, momentum, eps, y, save_mean,
+                                 save_invstd, ws, eval_mode, (hipStream_t)stream);
+}
+
+extern "C" int psi_bn_backward_t(const void *dy, int map_f32, const void *x, const void *y, const float *gamma, const float *save_mean,
+                                 const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, float *ws,
+                                 void *stream)
+{
+    if (map_f32) return bn_backward_t<float>(dy, x, y, gamma, save_mean, save_invstd, M, C, relu, dx, dresidual, dgamma, dbeta, ws, (hipStream_t)stream);
+    return bn_backward_t<bf16raw>(dy, x, y, gamma, save_mean, save_invstd, M, C, relu, dx, dresidual, dgamma, dbeta, ws, (hipStream_t)stream);
+}
+
+extern "C" int psi_maxpool3x3s2_forward_t(const void *x, int map_f32, int N, int H, int W, int C, void *y, void *idx, void *stream)
+{
+    if (map_f32) return maxpool_forward_t<float>(x, N, H, W, C, y, idx, (hipStream_t)stream);
+    return maxpool_forward_t<bf16raw>(x, N, H, W, C, y, idx, (hipStream_t)stream);
+}
+
+extern "C" int psi_maxpool3x3s2_backward_t(const void *dy, int map_f32, const void *idx, int N, int H, int W, int C, void *dx, void *stream)
+{
+    if (map_f32) return maxpool_backward_t<float>(dy, idx, N, H, W, C, dx, (hipStream_t)stream);
+    return maxpool_backward_t<bf16raw>(dy, idx, N, H, W, C, dx, (hipStream_t)stream);
 }

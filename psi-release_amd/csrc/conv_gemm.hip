@@ -1,0 +1,266 @@
+// General 2-D convolution forward of the scene encoders (cvae.py:427-438: Conv2d(2,64,7,2,3) stem, torchvision resnet18 layer1 / layer2 with
+// their stride-2 3x3 and 1x1 downsample convolutions, and the 3x3 head convolutions net_layers.py:64,162 / cvae.py:436) as ONE hand-written
+// implicit GEMM on the gfx950 matrix cores, in two arithmetic modes:
+//
+//   NTERM = 1   operands rounded to bf16 (RNE), fp32 accumulate — the bf16 mode of the trunk (models.py autocast_bf16=True): the
+//               convolutions the stride-1 kernel of conv.hip does not cover (7x7 stem, strided 3x3, 1x1 downsample, 128 -> 32 head);
+//   NTERM = 3   the REFERENCE'S PRECISION (fp32 model, cvae.py:427-455) on the bf16 matrix cores: every fp32 operand is split into
+//               hi = bf16(v), lo = bf16(v - hi) and a product is hi*hi + hi*lo + lo*hi with fp32 accumulation (the dropped lo*lo term and the
+//               split residue are < 2^-16 of the product).  Measured against the reference's recorded fp32 forward passes
+//               (tests/golden/cvae.npz): 0.6-3.2e-5 relative — the bound of the parity tests is 2e-4, a one-term bf16 product is at 3e-3..1e-2.
+//               v_mfma_f32_32x32x16_bf16 does 8x the multiply-adds of v_mfma_f32_32x32x2_f32 per issue slot, so three of them are 2.7x
+//               faster than the exact-fp32 matrix instruction.
+//
+// GEMM view: D[co][pixel] = sum_k Wt[co][k] * A[pixel][k], k = (kh, kw, ci) with channels fastest = the memory order of an NHWC activation
+// and of a channels_last Conv2d weight [Cout][KH][KW][Cin] (fp32 master weights are read and split / rounded on load: no prepared copy).
+// Workgroup = 4 waves = 128 output pixels x BN output channels (64, or 32 for the 32-channel head); the K range is walked in chunks of 64
+// staged through LDS (pixel rows / filter rows padded to 72 elements: the 16-byte operand reads of 16 adjacent lanes fall on different
+// bank groups); the next chunk's global loads are in flight while the current chunk is multiplied.  With Cin % 64 == 0 a chunk is 64
+// consecutive channels of ONE filter tap: 256 contiguous bytes per pixel.  The stem (Cin = 2, K = 98) takes the element-wise gather path.
+#include "psi_internal.h"
+#include <atomic>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, KC = 64, PITCH = KC + 8;
+
+__device__ __forceinline__ float bf_round(float v, __bf16 &hi)
+{
+    hi = (__bf16)v;
+    return v - (float)hi;
+}
+
+// 32 consecutive input elements of one pixel (or zeros) as floats
+__device__ __forceinline__ void load32(const float *p, bool ok, float (&v)[32])
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const f4 a = ok ? *(const f4 *)(p + 4 * i) : (f4){0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[4 * i + e] = a[e];
+    }
+}
+__device__ __forceinline__ void load32(const __bf16 *p, bool ok, float (&v)[32])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        bf16x8 a;
+        if (ok) a = *(const bf16x8 *)(p + 8 * i);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[8 * i + e] = ok ? (float)a[e] : 0.0f;
+    }
+}
+__device__ __forceinline__ float ldf(const float *p) { return *p; }
+__device__ __forceinline__ float ldf(const __bf16 *p) { return (float)*p; }
+
+__device__ __forceinline__ void store_out(float *y, const float (&v)[4]) { *(f4 *)y = (f4){v[0], v[1], v[2], v[3]}; }
+__device__ __forceinline__ void store_out(__bf16 *y, const float (&v)[4])
+{
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] = (__bf16)v[e];
+    *(bf16x4 *)y = o;
+}
+
+// floats -> LDS row pieces: hi (and lo) bf16, 8 elements per 16-byte store
+template <int NTERM, int NV>
+__device__ __forceinline__ void split_store(const float (&v)[NV], __bf16 *hi, __bf16 *lo)
+{
+#pragma unroll
+    for (int i = 0; i < NV / 8; i++) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            __bf16 hh;
+            const float r = bf_round(v[8 * i + e], hh);
+            h[e] = hh;
+            if (NTERM > 1) l[e] = (__bf16)r;
+        }
+        *(bf16x8 *)(hi + 8 * i) = h;
+        if (NTERM > 1) *(bf16x8 *)(lo + 8 * i) = l;
+    }
+}
+
+template <int NTERM, typename TIN, typename TOUT, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const TIN *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                           TOUT *__restrict__ y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH,
+                                                           int KW, int stride, int pad)
+{
+    static_assert(BN == 64 || BN == 32, "output-channel tile");
+    constexpr int NCT = BN / 32;                                   // 32-channel MFMA tiles per wave
+    constexpr int WPT = BN * KC / 256;                             // weight elements per thread and chunk (16 or 8)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 (*Ah)[PITCH] = (__bf16 (*)[PITCH])smem;                                           // [BM][PITCH]   pixels, hi
+    __bf16 (*Bh)[PITCH] = (__bf16 (*)[PITCH])(smem + (size_t)BM * PITCH * 2);                 // [BN][PITCH]   filters, hi
+    __bf16 (*Al)[PITCH] = (__bf16 (*)[PITCH])(smem + (size_t)(BM + BN) * PITCH * 2);          // lo parts (NTERM = 3)
+    __bf16 (*Bl)[PITCH] = (__bf16 (*)[PITCH])(smem + (size_t)(2 * BM + BN) * PITCH * 2);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int li = lane & 31, kb = (lane >> 5) * 8;
+    const long M = (long)N * OH * OW;
+    const long m0 = (long)blockIdx.x * BM;
+    const int co0 = blockIdx.y * BN;
+    const int K = KH * KW * Cin, nck = (K + KC - 1) / KC;
+    const bool fast = (Cin % KC) == 0;                             // a chunk = 64 consecutive channels of one tap
+    // ---- this thread's share of a chunk: pixel row ar (32 of its 64 elements), filter row br (WPT of its 64)
+    const int ar = t >> 1, ah = (t & 1) * 32;
+    const long am = m0 + ar;
+    const bool a_live = am < M;
+    int an = 0, aoy = 0, aox = 0;
+    if (a_live) {
+        an = (int)(am / ((long)OH * OW));
+        const int rem = (int)(am - (long)an * OH * OW);
+        aoy = rem / OW;
+        aox = rem - aoy * OW;
+    }
+    const int br = t / (KC / WPT), bq = (t % (KC / WPT)) * WPT;
+    const float *wrow = w + (size_t)(co0 + br) * K;
+    float av[32], bv[WPT];
+    auto load_chunk = [&](int ck) {
+        if (fast) {
+            const int cpt = Cin / KC, tap = ck / cpt, c0 = (ck - tap * cpt) * KC;
+            const int kh = tap / KW, kw = tap - kh * KW;
+            const int iy = aoy * stride - pad + kh, ix = aox * stride - pad + kw;
+            const bool ok = a_live && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            load32(x + (((size_t)an * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + c0 + ah, ok, av);
+#pragma unroll
+            for (int i = 0; i < WPT / 4; i++) {
+                const f4 a = *(const f4 *)(wrow + (size_t)ck * KC + bq + 4 * i);
+#pragma unroll
+                for (int e = 0; e < 4; e++) bv[4 * i + e] = a[e];
+            }
+        } else {
+            // any Cin (the stem: Cin = 2, K = 98): element k = (tap, ci), gathered one by one; rows beyond K are zeros
+#pragma unroll 8
+            for (int e = 0; e < 32; e++) {
+                const int k = ck * KC + ah + e;
+                float v = 0.0f;
+                if (a_live && k < K) {
+                    const int tap = k / Cin, ci = k - tap * Cin;
+                    const int kh = tap / KW, kw = tap - kh * KW;
+                    const int iy = aoy * stride - pad + kh, ix = aox * stride - pad + kw;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ldf(x + (((size_t)an * H + iy) * W + ix) * Cin + ci);
+                }
+                av[e] = v;
+            }
+#pragma unroll
+            for (int e = 0; e < WPT; e++) {
+                const int k = ck * KC + bq + e;
+                bv[e] = k < K ? wrow[k] : 0.0f;
+            }
+        }
+    };
+    f16v acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; c++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[c][i] = 0.0f;
+    load_chunk(0);
+    for (int ck = 0; ck < nck; ck++) {
+        __syncthreads();                                           // the previous chunk's MFMAs are done with LDS
+        split_store<NTERM, 32>(av, &Ah[ar][ah], &Al[ar][ah]);
+        split_store<NTERM, WPT>(bv, &Bh[br][bq], &Bl[br][bq]);
+        __syncthreads();
+        if (ck + 1 < nck) load_chunk(ck + 1);                      // in flight during this chunk's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ks++) {
+            const bf16x8 bh = *(const bf16x8 *)&Ah[wv * 32 + li][ks * 16 + kb];     // B operand: my pixel tile
+            bf16x8 bl;
+            if (NTERM > 1) bl = *(const bf16x8 *)&Al[wv * 32 + li][ks * 16 + kb];
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const bf16x8 ahh = *(const bf16x8 *)&Bh[c * 32 + li][ks * 16 + kb];  // A operand: filter rows
+                if (NTERM > 1) {
+                    const bf16x8 all = *(const bf16x8 *)&Bl[c * 32 + li][ks * 16 + kb];
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(all, bh, acc[c], 0, 0, 0);      // the small terms first
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahh, bl, acc[c], 0, 0, 0);
+                }
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahh, bh, acc[c], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: D[row = co][col = pixel]; lane (li, h) holds rows 8g + 4h + (0..3), g = 0..3, of column li
+    const long om = m0 + wv * 32 + li;
+    if (om >= M) return;
+    const int h = lane >> 5;
+    TOUT *yo = y + (size_t)om * Cout + co0;
+#pragma unroll
+    for (int c = 0; c < NCT; c++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int co = c * 32 + 8 * g + 4 * h;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = acc[c][4 * g + e] + (bias ? bias[co0 + co + e] : 0.0f);
+            store_out(yo + co, v);
+        }
+}
+
+static inline hipError_t set_max_lds(const void *kern, size_t lds, std::atomic<unsigned long long> &done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
+template <int NTERM, typename TIN, typename TOUT, int BN>
+int launch(const void *x, const float *w, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
+           int stride, int pad, hipStream_t st)
+{
+    const size_t lds = (size_t)(BM + BN) * PITCH * 2 * (NTERM > 1 ? 2 : 1);
+    auto kern = conv_gemm_kernel<NTERM, TIN, TOUT, BN>;
+    static std::atomic<unsigned long long> attr_set{0};
+    PSI_CHECK_HIP(set_max_lds((const void *)kern, lds, attr_set));
+    const long M = (long)N * OH * OW;
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(Cout / BN));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const TIN *)x, w, bias, (TOUT *)y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad);
+    PSI_CHECK_LAUNCH("conv_gemm_kernel");
+    psi_mark("conv_gemm_kernel", st);
+    return 0;
+}
+
+template <int NTERM, typename TIN, typename TOUT>
+int launch_bn(const void *x, const float *w, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
+              int stride, int pad, hipStream_t st)
+{
+    if (Cout % 64 == 0) return launch<NTERM, TIN, TOUT, 64>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, st);
+    return launch<NTERM, TIN, TOUT, 32>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, st);
+}
+
+}  // namespace
+
+extern "C" int psi_conv2d_supported(int Cin, int Cout, int KH, int KW, int stride, int pad)
+{
+    return Cin > 0 && Cout > 0 && Cout % 32 == 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && (Cin % 64 == 0 || Cin * KH * KW <= 4096);
+}
+
+// x [N,H,W,Cin] NHWC (x_bf16: bf16, else fp32); w [Cout,KH,KW,Cin] fp32 (a channels_last Conv2d weight); bias [Cout] fp32 or NULL;
+// y [N,OH,OW,Cout] NHWC (y_bf16: bf16, else fp32), OH = (H + 2 pad - KH) / stride + 1.  nterm = 1 | 3 (see the header of this file).
+extern "C" int psi_conv2d_forward(const void *x, int x_bf16, const float *w, const float *bias, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                  int stride, int pad, void *y, int y_bf16, int nterm, void *stream)
+{
+    PSI_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0, "bad arguments");
+    PSI_REQUIRE(psi_conv2d_supported(Cin, Cout, KH, KW, stride, pad), "shape not covered: Cout % 32 == 0 and (Cin % 64 == 0 or a small gather case)");
+    PSI_REQUIRE(nterm == 1 || nterm == 3, "nterm is 1 (bf16 products) or 3 (split products: the fp32 model's precision)");
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    PSI_REQUIRE(OH > 0 && OW > 0, "empty output");
+    hipStream_t st = (hipStream_t)stream;
+#define PSI_CONV_ARGS x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, st
+    if (nterm == 3) {
+        if (x_bf16) return y_bf16 ? launch_bn<3, __bf16, __bf16>(PSI_CONV_ARGS) : launch_bn<3, __bf16, float>(PSI_CONV_ARGS);
+        return y_bf16 ? launch_bn<3, float, __bf16>(PSI_CONV_ARGS) : launch_bn<3, float, float>(PSI_CONV_ARGS);
+    }
+    if (x_bf16) return y_bf16 ? launch_bn<1, __bf16, __bf16>(PSI_CONV_ARGS) : launch_bn<1, __bf16, float>(PSI_CONV_ARGS);
+    return y_bf16 ? launch_bn<1, float, __bf16>(PSI_CONV_ARGS) : launch_bn<1, float, float>(PSI_CONV_ARGS);
+#undef PSI_CONV_ARGS
+}

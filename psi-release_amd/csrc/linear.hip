@@ -16,6 +16,7 @@
 //   dW = G^T X           : A[n][m] = G[m][n], B[m][k] = X[m][k] (both eight 4-byte loads per lane, coalesced over n resp. k)
 #include "psi_internal.h"
 #include <math.h>
+#include <atomic>
 
 namespace {
 
@@ -65,33 +66,58 @@ __device__ __forceinline__ float ldf(const __bf16 *p) { return (float)*p; }
 // ------------------------------------------------------------------------------------------------
 constexpr int BK = 64, PITCH = BK + 8;
 
+// NTERM = 3 (psi_linear_forward3): the fp32 model's precision on the bf16 matrix cores — every operand is split into hi = bf16(v) and
+// lo = bf16(v - hi), a product is hi*hi + hi*lo + lo*hi with fp32 accumulation (conv_gemm.hip explains and quantifies it); the lo parts
+// live in a second set of LDS tiles.  `vec` = rows are 16-byte aligned (K % 4 == 0); otherwise (the 3-, 75-wide input layers) the tiles
+// are gathered element by element.
+template <int NTERM>
+__device__ __forceinline__ void split4(const f4 &v, __bf16 *hi, __bf16 *lo)
+{
+    bf4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        h[e] = (__bf16)v[e];
+        if (NTERM > 1) l[e] = (__bf16)(v[e] - (float)h[e]);
+    }
+    *(bf4 *)hi = h;
+    if (NTERM > 1) *(bf4 *)lo = l;
+}
+
+__device__ __forceinline__ f4 load4_checked(const float *row, int c, int k_end, bool row_ok, bool vec)
+{
+    if (!row_ok || c >= k_end) return (f4){0, 0, 0, 0};
+    if (vec) return *(const f4 *)(row + c);
+    f4 r = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+        if (c + e < k_end) r[e] = row[c + e];
+    return r;
+}
+
 template <typename XT> struct XTile;
 template <> struct XTile<float> {                           // 128 x 64 fp32: 8 float4 per thread
     f4 r[8];
-    __device__ __forceinline__ void load(const float *x, int M, int K, int mblk, int k0, int k_end)
+    __device__ __forceinline__ void load(const float *x, int M, int K, int mblk, int k0, int k_end, bool vec)
     {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
-            const bool ok = mblk + row < M && k0 + c < k_end;
-            r[i] = ok ? *(const f4 *)(x + (size_t)(mblk + row) * K + k0 + c) : (f4){0, 0, 0, 0};
+            r[i] = load4_checked(x + (size_t)(mblk + row) * K, k0 + c, k_end, mblk + row < M, vec);
         }
     }
-    __device__ __forceinline__ void store(__bf16 (*As)[PITCH]) const
+    template <int NTERM>
+    __device__ __forceinline__ void store(__bf16 (*As)[PITCH], __bf16 (*Al)[PITCH]) const
     {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
-            bf4 v;
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = (__bf16)r[i][e];
-            *(bf4 *)&As[row][c] = v;
+            split4<NTERM>(r[i], &As[row][c], &Al[row][c]);
         }
     }
 };
-template <> struct XTile<__bf16> {                          // 128 x 64 bf16: 4 x 16 bytes per thread
+template <> struct XTile<__bf16> {                          // 128 x 64 bf16: 4 x 16 bytes per thread (exact in bf16: no lo part)
     bf16x8 r[4];
-    __device__ __forceinline__ void load(const __bf16 *x, int M, int K, int mblk, int k0, int k_end)
+    __device__ __forceinline__ void load(const __bf16 *x, int M, int K, int mblk, int k0, int k_end, bool)
     {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -104,28 +130,43 @@ template <> struct XTile<__bf16> {                          // 128 x 64 bf16: 4 
             }
         }
     }
-    __device__ __forceinline__ void store(__bf16 (*As)[PITCH]) const
+    template <int NTERM>
+    __device__ __forceinline__ void store(__bf16 (*As)[PITCH], __bf16 (*Al)[PITCH]) const
     {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int idx = threadIdx.x + 256 * i, row = idx >> 3, c = (idx & 7) * 8;
             *(bf16x8 *)&As[row][c] = r[i];
+            if (NTERM > 1) {
+                bf16x8 z;
+#pragma unroll
+                for (int e = 0; e < 8; e++) z[e] = (__bf16)0.0f;
+                *(bf16x8 *)&Al[row][c] = z;
+            }
         }
     }
 };
 
-template <typename XT>
+constexpr size_t linear_fwd_lds(int nterm) { return (size_t)2 * (128 + TN) * PITCH * 2 * (nterm > 1 ? 2 : 1); }
+
+template <typename XT, int NTERM>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const XT *__restrict__ x, const float *__restrict__ W, const float *__restrict__ bias,
                                                          const float *__restrict__ residual, int M, int N, int K, int kchunk, int act,
                                                          float slope, float *__restrict__ y, float *__restrict__ act_out,
                                                          float *__restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][128][PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TN][PITCH];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __bf16 (*Tile)[PITCH];
+    // [2][128][PITCH] rows of x (hi), [2][TN][PITCH] rows of W (hi), then the same again for the lo parts (NTERM = 3)
+    auto As = [&](int buf) { return (Tile)(smem + (size_t)buf * 128 * PITCH * 2); };
+    auto Bs = [&](int buf) { return (Tile)(smem + (size_t)(2 * 128 + buf * TN) * PITCH * 2); };
+    auto Al = [&](int buf) { return (Tile)(smem + (size_t)(2 * (128 + TN) + buf * 128) * PITCH * 2); };
+    auto Bl = [&](int buf) { return (Tile)(smem + (size_t)(2 * (128 + TN) + 2 * 128 + buf * TN) * PITCH * 2); };
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n0 = blockIdx.x * TN, mblk = blockIdx.y * 128, m0 = mblk + w * TM, ks = blockIdx.z;
     const int k_begin = ks * kchunk, k_end = min(K, k_begin + kchunk);
     const int li = lane & 31, kb = (lane >> 5) * 8;
+    const bool vec = (K & 3) == 0;
     f16v acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
@@ -135,40 +176,42 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const XT *__restrict__ 
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
-            const bool ok = n0 + row < N && k0 + c < k_end;
-            wb[i] = ok ? *(const f4 *)(W + (size_t)(n0 + row) * K + k0 + c) : (f4){0, 0, 0, 0};
+            wb[i] = load4_checked(W + (size_t)(n0 + row) * K, k0 + c, k_end, n0 + row < N, vec);
         }
     };
     auto store_w = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
-            bf4 v;
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = (__bf16)wb[i][e];
-            *(bf4 *)&Bs[buf][row][c] = v;
+            split4<NTERM>(wb[i], &Bs(buf)[row][c], &Bl(buf)[row][c]);
         }
     };
-    xa.load(x, M, K, mblk, k_begin, k_end);
+    xa.load(x, M, K, mblk, k_begin, k_end, vec);
     load_w(k_begin);
-    xa.store(As[0]);
+    xa.template store<NTERM>(As(0), Al(0));
     store_w(0);
     __syncthreads();
     int buf = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK, buf ^= 1) {
         const bool more = k0 + BK < k_end;
         if (more) {                                         // next tile: global loads in flight during this tile's MFMAs
-            xa.load(x, M, K, mblk, k0 + BK, k_end);
+            xa.load(x, M, K, mblk, k0 + BK, k_end, vec);
             load_w(k0 + BK);
         }
 #pragma unroll
         for (int st = 0; st < BK / TK; st++) {
-            const bf16x8 a = *(const bf16x8 *)&As[buf][w * TM + li][st * TK + kb];
-            const bf16x8 b = *(const bf16x8 *)&Bs[buf][li][st * TK + kb];
+            const bf16x8 a = *(const bf16x8 *)&As(buf)[w * TM + li][st * TK + kb];
+            const bf16x8 b = *(const bf16x8 *)&Bs(buf)[li][st * TK + kb];
+            if (NTERM > 1) {                                // the small terms first
+                const bf16x8 al = *(const bf16x8 *)&Al(buf)[w * TM + li][st * TK + kb];
+                const bf16x8 bl = *(const bf16x8 *)&Bl(buf)[li][st * TK + kb];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc, 0, 0, 0);
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
         if (more) {
-            xa.store(As[buf ^ 1]);
+            xa.template store<NTERM>(As(buf ^ 1), Al(buf ^ 1));
             store_w(buf ^ 1);
         }
         __syncthreads();
@@ -476,13 +519,31 @@ extern "C" size_t psi_linear_workspace_floats(int M, int N, int K)
     return s > 1 ? (size_t)s * M * N : 0;
 }
 
-extern "C" int psi_linear_forward(const void *x, int x_is_bf16, const float *W, const float *bias, const float *residual, int M, int N, int K,
-                                  int act, float slope, float *y, float *act_out, float *ws, void *stream)
+template <typename XT, int NTERM>
+static int launch_linear_fwd(const void *x, const float *W, const float *bias, const float *residual, int M, int N, int K, int kchunk, int S, int act,
+                             float slope, float *y, float *act_out, float *part, hipStream_t st)
 {
-    PSI_REQUIRE(x && W && y, "null pointer");
-    PSI_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0, "K must be a positive multiple of 16");
-    PSI_REQUIRE(act == 0 || (act == 1 && slope > 0.0f), "act: 0 = none, 1 = LeakyReLU with slope > 0");
-    hipStream_t st = (hipStream_t)stream;
+    constexpr size_t lds = linear_fwd_lds(NTERM);
+    auto kern = linear_fwd_kernel<XT, NTERM>;
+    if (lds > 48 * 1024) {                                  // the attribute is per device: set once per device
+        static std::atomic<unsigned long long> done{0};
+        int dev = 0;
+        PSI_CHECK_HIP(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            PSI_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    dim3 grid(psi_cdiv(N, TN), psi_cdiv(M, 128), S);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const XT *)x, W, bias, residual, M, N, K, kchunk, act, slope, y, act_out, part);
+    PSI_CHECK_LAUNCH("linear_fwd_kernel");
+    return 0;
+}
+
+static int linear_forward_any(const void *x, int x_is_bf16, const float *W, const float *bias, const float *residual, int M, int N, int K, int act,
+                              float slope, float *y, float *act_out, float *ws, int nterm, hipStream_t st)
+{
     int S = pick_ksplit(M, N, K);
     int kchunk = K;
     if (S > 1) {
@@ -490,21 +551,41 @@ extern "C" int psi_linear_forward(const void *x, int x_is_bf16, const float *W, 
         kchunk = psi_cdiv(psi_cdiv(K, S), 16) * 16;
         S = psi_cdiv(K, kchunk);
     }
-    dim3 grid(psi_cdiv(N, TN), psi_cdiv(M, 128), S);
     float *part = S > 1 ? ws : nullptr;
-    if (x_is_bf16)
-        hipLaunchKernelGGL(linear_fwd_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16 *)x, W, bias, residual, M, N, K, kchunk, act, slope, y,
-                           act_out, part);
+    int rc;
+    if (nterm == 3)
+        rc = x_is_bf16 ? launch_linear_fwd<__bf16, 3>(x, W, bias, residual, M, N, K, kchunk, S, act, slope, y, act_out, part, st)
+                       : launch_linear_fwd<float, 3>(x, W, bias, residual, M, N, K, kchunk, S, act, slope, y, act_out, part, st);
     else
-        hipLaunchKernelGGL(linear_fwd_kernel<float>, grid, dim3(256), 0, st, (const float *)x, W, bias, residual, M, N, K, kchunk, act, slope, y,
-                           act_out, part);
-    PSI_CHECK_LAUNCH("linear_fwd_kernel");
+        rc = x_is_bf16 ? launch_linear_fwd<__bf16, 1>(x, W, bias, residual, M, N, K, kchunk, S, act, slope, y, act_out, part, st)
+                       : launch_linear_fwd<float, 1>(x, W, bias, residual, M, N, K, kchunk, S, act, slope, y, act_out, part, st);
+    if (rc) return rc;
     if (S > 1) {
         hipLaunchKernelGGL(linear_reduce_kernel, dim3(psi_cdiv((long)M * N, 256)), dim3(256), 0, st, part, S, bias, residual, M, N, act, slope, y,
                            act_out);
         PSI_CHECK_LAUNCH("linear_reduce_kernel");
     }
     return 0;
+}
+
+extern "C" int psi_linear_forward(const void *x, int x_is_bf16, const float *W, const float *bias, const float *residual, int M, int N, int K,
+                                  int act, float slope, float *y, float *act_out, float *ws, void *stream)
+{
+    PSI_REQUIRE(x && W && y, "null pointer");
+    PSI_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0, "K must be a positive multiple of 16");
+    PSI_REQUIRE(act == 0 || (act == 1 && slope > 0.0f), "act: 0 = none, 1 = LeakyReLU with slope > 0");
+    return linear_forward_any(x, x_is_bf16, W, bias, residual, M, N, K, act, slope, y, act_out, ws, 1, (hipStream_t)stream);
+}
+
+// The same layer at the fp32 model's precision (three-term split products, see the kernel) and for ANY K and N (the 3-, 72-, 75-wide layers of
+// cvae.py:474-492 / net_layers.py:66-93 included: rows that are not 16-byte aligned are gathered element by element).
+extern "C" int psi_linear_forward3(const void *x, int x_is_bf16, const float *W, const float *bias, const float *residual, int M, int N, int K,
+                                   int act, float slope, float *y, float *act_out, float *ws, void *stream)
+{
+    PSI_REQUIRE(x && W && y, "null pointer");
+    PSI_REQUIRE(M > 0 && N > 0 && K > 0 && !(x_is_bf16 && K % 8), "bad sizes (a bf16 input needs K % 8 == 0)");
+    PSI_REQUIRE(act == 0 || (act == 1 && slope > 0.0f), "act: 0 = none, 1 = LeakyReLU with slope > 0");
+    return linear_forward_any(x, x_is_bf16, W, bias, residual, M, N, K, act, slope, y, act_out, ws, 3, (hipStream_t)stream);
 }
 
 extern "C" size_t psi_linear_backward_workspace_floats(int M, int N, int K)

@@ -47,6 +47,8 @@ SIGNATURES = {
     'psi_linear_workspace_floats': (c_size_t, [c_int] * 3),
     'psi_linear_forward': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    'psi_linear_forward3': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
     'psi_linear_backward_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
     'psi_linear_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
@@ -59,6 +61,12 @@ SIGNATURES = {
     'psi_bn_workspace_floats': (c_size_t, [c_long, c_int]),
     'psi_bn_forward': (c_int, [c_void_p] * 7 + [c_long, c_int, c_int, c_float, c_float] + [c_void_p] * 5),
     'psi_bn_backward': (c_int, [c_void_p] * 6 + [c_long, c_int, c_int] + [c_void_p] * 6),
+    'psi_bn_forward_t': (c_int, [c_void_p, c_int] + [c_void_p] * 6 + [c_long, c_int, c_int, c_float, c_float] + [c_void_p] * 4 + [c_int, c_void_p]),
+    'psi_bn_backward_t': (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_long, c_int, c_int] + [c_void_p] * 6),
+    'psi_maxpool3x3s2_forward_t': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'psi_maxpool3x3s2_backward_t': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'psi_conv2d_supported': (c_int, [c_int] * 6),
+    'psi_conv2d_forward': (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_int, c_int, c_void_p]),
     'psi_conv3x3_supported': (c_int, [c_int] * 4),
     'psi_conv3x3_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'psi_conv3x3_wrw_workspace_floats': (c_size_t, [c_int] * 5),

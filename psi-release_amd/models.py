@@ -20,6 +20,26 @@ import torch
 from torch import nn
 
 
+def _precise(x):
+    """The fp32 models (``autocast_bf16=False``: the reference's precision, cvae.py:427-455) on a GPU run their convolutions, BatchNorms,
+    max-pool and dense layers on the hand-written kernels of libpsi_hip.so as well: fp32 NHWC maps, three-term split products on the
+    bf16 matrix cores with fp32 accumulation (ops.conv2d_split / bn_act_t / maxpool3x3s2_t / linear_act3; csrc/conv_gemm.hip quantifies the
+    arithmetic: 0.6-3.2e-5 of the reference's recorded forward passes).  PSI_HIP_PRECISE=0 keeps the library (MIOpen / hipBLASLt) path."""
+    import os
+    return (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and os.environ.get('PSI_HIP_PRECISE', '1') != '0')
+
+
+def _lin(owner, layer, x, act=None, slope=0.01, residual=None):
+    """``act(layer(x)) (+ residual)`` for an nn.Linear: the fp32 model on the GPU -> ops.linear_act3 (any width); the bf16 mode -> ``_linear``."""
+    if _precise(x) and not getattr(owner, 'hip_linear', False):
+        from .ops import linear_act3
+        return linear_act3(x, layer.weight, layer.bias, act, slope, residual)
+    y = _linear(owner, layer, x)
+    if act:
+        y = torch.nn.functional.leaky_relu(y, slope)
+    return y if residual is None else y + residual
+
+
 class ResBlock(nn.Module):
     def __init__(self, n_dim):
         super().__init__()
@@ -36,6 +56,11 @@ class ResBlock(nn.Module):
             slope = self.acfun.negative_slope
             x = linear_act(x0, self.fc1.weight, self.fc1.bias, 'leaky_relu', slope)
             return linear_act(x, self.fc2.weight, self.fc2.bias, 'leaky_relu', slope, residual=x0)      # fc2 + LeakyReLU + skip: one kernel
+        if _precise(x0) and not self.hip_linear:
+            from .ops import linear_act3
+            slope = self.acfun.negative_slope
+            x = linear_act3(x0, self.fc1.weight, self.fc1.bias, 'leaky_relu', slope)
+            return linear_act3(x, self.fc2.weight, self.fc2.bias, 'leaky_relu', slope, residual=x0)
         x = self.acfun(self.fc1(x0))
         x = self.acfun(self.fc2(x))
         return x + x0
@@ -56,11 +81,16 @@ class _BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
 
     def forward(self, x):
+        if _precise_trunk(self.bn1, x):
+            from .ops import bn_act_t
+            identity = x if self.downsample is None else bn_act_t(_conv(self.downsample[0], x), self.downsample[1], relu=False)
+            out = bn_act_t(_conv(self.conv1, x), self.bn1, relu=True)
+            return bn_act_t(_conv(self.conv2, out), self.bn2, relu=True, residual=identity)
         if _use_hip_bn(self.bn1, x):
             # training statistics on bf16 NHWC maps: BN + ReLU (+ the skip connection) as ONE fused HIP op per BN (ops.bn_act) instead
             # of the library's three launches per BN and separate ReLU / add launches — same arithmetic, same running-statistics update
             from .ops import bn_act
-            identity = x if self.downsample is None else bn_act(self.downsample[0](x), self.downsample[1], relu=False)
+            identity = x if self.downsample is None else bn_act(_conv(self.downsample[0], x), self.downsample[1], relu=False)
             out = bn_act(_conv(self.conv1, x), self.bn1, relu=True)
             return bn_act(_conv(self.conv2, out), self.bn2, relu=True, residual=identity)
         identity = x if self.downsample is None else self.downsample(x)
@@ -69,15 +99,28 @@ class _BasicBlock(nn.Module):
         return self.relu(out + identity)
 
 
+def _precise_trunk(bn, x):
+    from . import ops
+    return _precise(x) and x.dim() == 4 and ops.bn_t_supported(bn)
+
+
 def _conv(conv, x):
-    """A trunk convolution under bf16 autocast: the hand-written implicit-GEMM kernel where it applies (3x3, stride 1: ops.conv3x3;
-    PSI_HIP_CONV=0 keeps the library), the library otherwise (the 7x7 stem, the two strided convolutions)."""
+    """A trunk convolution.  fp32 model on the GPU: the general implicit-GEMM kernel with three-term split products (ops.conv2d_split).
+    Under bf16 autocast: the hand-written stride-1 3x3 kernel where it applies (ops.conv3x3; PSI_HIP_CONV=0 keeps the library), the general
+    kernel with one-term bf16 products for the rest (7x7 stem, strided 3x3, 1x1 downsample, 128 -> 32 head; PSI_HIP_CONV2=0: the library)."""
     import os
+    if _precise(x):
+        from . import ops
+        if ops.conv2d_supported(conv):
+            return ops.conv2d_split(x, conv, nterm=3)
+        return conv(x)
     if (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
             and os.environ.get('PSI_HIP_CONV', '1') != '0'):
         from . import ops
         if ops.conv3x3_supported(conv, x):
             return ops.conv3x3(x, conv)
+        if os.environ.get('PSI_HIP_CONV2', '1') != '0' and ops.conv2d_supported(conv):
+            return ops.conv2d_split(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv, nterm=1, out_bf16=True)
     return conv(x)
 
 
@@ -92,9 +135,17 @@ def _use_hip_bn(bn, x):
 def run_trunk(trunk, x):
     """forward of ``scene_trunk`` (an nn.Sequential, so that the state_dict keys stay ``resnet.0.weight``, ``resnet.1.*`` ...) with the
     stem's BN + ReLU fused when the fused kernels apply."""
+    if _precise_trunk(trunk[1], x):
+        from .ops import bn_act_t, maxpool3x3s2_t
+        x = bn_act_t(_conv(trunk[0], x), trunk[1], relu=True)
+        mp = trunk[3]
+        x = maxpool3x3s2_t(x) if (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False) else mp(x)
+        for i in range(4, len(trunk)):
+            x = trunk[i](x)
+        return x
     if _use_hip_bn(trunk[1], x):
         from .ops import bn_act, maxpool3x3s2
-        x = bn_act(trunk[0](x), trunk[1], relu=True)
+        x = bn_act(_conv(trunk[0], x), trunk[1], relu=True)
         mp = trunk[3]
         x = maxpool3x3s2(x) if (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False) else mp(x)
         for i in range(4, len(trunk)):
@@ -160,9 +211,9 @@ def _linear(owner, layer, x):
 def _decode(owner, seq, x):
     """``seq(x)`` for the decoders ``nn.Sequential(Linear, ResBlock, ResBlock, Linear)`` (net_layers.py:88-93, 181-186): the first layer through
     ``_linear`` (the state_dict keys stay ``decode.0.weight`` ...)."""
-    x = _linear(owner, seq[0], x)
+    x = _lin(owner, seq[0], x)
     for i in range(1, len(seq)):
-        x = seq[i](x)
+        x = _lin(owner, seq[i], x) if isinstance(seq[i], nn.Linear) else seq[i](x)
     return x
 
 
@@ -199,6 +250,13 @@ class _SceneCond(nn.Module):
                     from .ops import linear_act
                     return linear_act(f.reshape(b, -1), self.fc.weight, self.fc.bias)
                 return self.fc(f.reshape(b, -1)).float()
+        if _precise(scene):
+            if not getattr(self, '_nhwc', False):             # NHWC maps and [Cout,KH,KW,Cin] weights: what the kernels read
+                self.resnet.to(memory_format=torch.channels_last)
+                self.conv.to(memory_format=torch.channels_last)
+                self._nhwc = True
+            f = _conv(self.conv, run_trunk(self.resnet, scene.contiguous(memory_format=torch.channels_last)))
+            return _lin(self, self.fc, f.reshape(b, -1))
         f = self.conv(self.resnet(scene))
         return self.fc(f.reshape(b, -1))
 
@@ -226,8 +284,8 @@ class BodyGlobalPoseVAE(_SceneCond):
         if self.test:
             z = torch.randn(z_s.size(0), self.zdim, device=scene.device) if eps is None else eps
             return _decode(self, self.decode, torch.cat([z, z_s], dim=1))
-        feature = self.encode(torch.cat((z_s, self.torso_linear(torso)), dim=1))            # net_layers.py:118
-        mean, log_var = _linear(self, self.mean_linear, feature), _linear(self, self.log_var_linear, feature)
+        feature = self.encode(torch.cat((z_s, _lin(self, self.torso_linear, torso)), dim=1))            # net_layers.py:118
+        mean, log_var = _lin(self, self.mean_linear, feature), _lin(self, self.log_var_linear, feature)
         z = _reparam(mean, log_var, eps)
         return _decode(self, self.decode, torch.cat([z, z_s], dim=1)), mean, log_var        # net_layers.py:131
 
@@ -253,12 +311,12 @@ class BodyLocalPoseVAE(_SceneCond):
     def forward(self, scene, torso=None, pose=None, eps=None, rows=None, z_s=None):
         if z_s is None:
             z_s = self._scene_feature(scene, rows)
-        z_g = self.torso_linear(torso)
+        z_g = _lin(self, self.torso_linear, torso)
         if self.test:
             z = torch.randn(z_s.size(0), self.zdim, device=scene.device) if eps is None else eps
             return _decode(self, self.decode, torch.cat([z, z_g, z_s], dim=1))
-        feature = self.encode(torch.cat([self.pose_linear(pose), z_g, z_s], dim=1))         # net_layers.py:220
-        mean, log_var = _linear(self, self.mean_linear, feature), _linear(self, self.log_var_linear, feature)
+        feature = self.encode(torch.cat([_lin(self, self.pose_linear, pose), z_g, z_s], dim=1))         # net_layers.py:220
+        mean, log_var = _lin(self, self.mean_linear, feature), _lin(self, self.log_var_linear, feature)
         z = _reparam(mean, log_var, eps)
         return _decode(self, self.decode, torch.cat([z, z_g, z_s], dim=1)), mean, log_var   # net_layers.py:231
 
@@ -334,14 +392,14 @@ class HumanCVAES1(_SceneCond):
 
     def forward(self, x_body, x_s, eps=None):
         z_s = self._scene_feature(x_s)
-        z_hs = self.human_encoder(torch.cat([self.linear_in(x_body), z_s], dim=1))         # cvae.py:480
-        mu, logvar = _linear(self, self.mu_enc, z_hs), _linear(self, self.logvar_enc, z_hs)
-        z_h = _linear(self, self.linear_latent, _reparam(mu, logvar, eps))
-        return self.linear_out(self.human_decoder(torch.cat([z_h, z_s], dim=1))), mu, logvar   # cvae.py:488
+        z_hs = self.human_encoder(torch.cat([_lin(self, self.linear_in, x_body), z_s], dim=1))         # cvae.py:480
+        mu, logvar = _lin(self, self.mu_enc, z_hs), _lin(self, self.logvar_enc, z_hs)
+        z_h = _lin(self, self.linear_latent, _reparam(mu, logvar, eps))
+        return _lin(self, self.linear_out, self.human_decoder(torch.cat([z_h, z_s], dim=1))), mu, logvar   # cvae.py:488
 
     def _decode_latent(self, x_s, eps, rows=None):
         z_s = self._scene_feature(x_s, rows)
-        return self.linear_out(self.human_decoder(torch.cat([_linear(self, self.linear_latent, eps), z_s], dim=1)))
+        return _lin(self, self.linear_out, self.human_decoder(torch.cat([_lin(self, self.linear_latent, eps), z_s], dim=1)))
 
     def sample(self, x_s, eps=None, rows=None, **kwargs):
         if eps is None:

@@ -521,6 +521,198 @@ def conv3x3(x, conv):
     return _Conv3x3.apply(x, conv.weight, conv.bias)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# The scene encoders and dense layers at the REFERENCE'S PRECISION (fp32 models, cvae.py:427-455,474-492; net_layers.py:28-43,56-93) on
+# hand-written kernels: fp32 NHWC maps, every product a three-term bf16 split with fp32 accumulation (csrc/conv_gemm.hip explains and
+# quantifies it: 0.6-3.2e-5 of the reference's recorded forward passes, tests/golden/cvae.npz).  Forward: psi_conv2d_forward (ALL the
+# convolutions: 7x7 stem, stride-1 / stride-2 3x3, 1x1 downsample, heads), psi_bn_forward_t (batch or running statistics, + ReLU + skip),
+# psi_maxpool3x3s2_forward_t, psi_linear_forward3 (any width).  Backward: BatchNorm and max-pool on the same hand-written kernels; the
+# convolution and dense-layer gradients through the library in fp32 (aten.convolution_backward / matmul) on the saved fp32 operands.
+# ------------------------------------------------------------------------------------------------------------------
+def conv2d_supported(conv):
+    return (conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros' and conv.kernel_size[0] == conv.kernel_size[1]
+            and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
+            and bool(hip.lib().psi_conv2d_supported(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.kernel_size[1], conv.stride[0],
+                                                    conv.padding[0])))
+
+
+class _Conv2dSplit(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, nterm, out_bf16):
+        N, Cin, H, W = x.shape
+        Cout, _, KH, KW = weight.shape
+        xc = x.contiguous(memory_format=torch.channels_last)
+        w4 = weight.detach().permute(0, 2, 3, 1)                     # [Cout,KH,KW,Cin]: a view of a channels_last weight, else a copy
+        w4 = (w4 if w4.is_contiguous() else w4.contiguous()).float()
+        OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32, memory_format=torch.channels_last)
+        b = bias.detach().float().contiguous() if bias is not None else None
+        hip.check(hip.lib().psi_conv2d_forward(_ptr_cl(xc), int(xc.dtype == torch.bfloat16), hip.ptr(w4), hip.ptr(b), N, H, W, Cin, Cout, KH, KW,
+                                               stride, pad, _ptr_cl(y), int(out_bf16), nterm, hip.stream()), 'psi_conv2d_forward')
+        ctx.save_for_backward(xc, weight)
+        ctx.geom = (stride, pad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, weight = ctx.saved_tensors
+        stride, pad, has_bias = ctx.geom
+        dyc = dy.contiguous(memory_format=torch.channels_last).to(xc.dtype)
+        mask = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2])
+        gx, gw, gb = torch.ops.aten.convolution_backward(dyc, xc, weight.detach().to(xc.dtype), [weight.shape[0]] if has_bias else None,
+                                                         (stride, stride), (pad, pad), (1, 1), False, (0, 0), 1, mask)
+        return gx, gw.float() if gw is not None else None, gb.float() if gb is not None else None, None, None, None, None
+
+
+def conv2d_split(x, conv, nterm=3, out_bf16=False):
+    """``conv(x)`` for an ``nn.Conv2d`` on an fp32 (or bf16) channels_last map through the general implicit-GEMM kernel: nterm = 3 = the fp32
+    model's precision (three-term split products), nterm = 1 = bf16 products."""
+    return _Conv2dSplit.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], nterm, out_bf16)
+
+
+class _BNActT(Function):
+    """y = act(batch_norm(x) (+ residual)) on NHWC maps of either type, batch statistics (training) or running statistics (eval)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, bn, relu):
+        N, C, H, W = x.shape
+        M = N * H * W
+        f32 = x.dtype == torch.float32
+        xc = x.contiguous(memory_format=torch.channels_last)
+        rc = residual.contiguous(memory_format=torch.channels_last) if residual is not None else None
+        y = torch.empty_like(xc, memory_format=torch.channels_last)
+        evalm = not bn.training
+        mean = torch.empty(C, device=x.device, dtype=torch.float32) if not evalm else None
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32) if not evalm else None
+        L = hip.lib()
+        ws = torch.empty(L.psi_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
+        track = bn.track_running_stats and bn.running_mean is not None
+        hip.check(L.psi_bn_forward_t(_ptr_cl(xc), int(f32), _ptr_cl(rc), hip.ptr(weight), hip.ptr(bias),
+                                     hip.ptr(bn.running_mean) if track else None, hip.ptr(bn.running_var) if track else None,
+                                     hip.ptr(bn.num_batches_tracked) if (track and not evalm) else None, M, C, int(relu),
+                                     float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), _ptr_cl(y), hip.ptr(mean),
+                                     hip.ptr(invstd), hip.ptr(ws), int(evalm), hip.stream()), 'psi_bn_forward_t')
+        if evalm:
+            # inference form: the gradient is that of an affine map with the running statistics (only needed if someone differentiates an
+            # eval-mode model: kept correct through the saved statistics)
+            mean, invstd = bn.running_mean.detach().float(), torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+        ctx.save_for_backward(xc, y if relu else None, weight, mean, invstd)
+        ctx.relu, ctx.has_res, ctx.dims, ctx.evalm, ctx.f32 = bool(relu), residual is not None, (M, C), evalm, f32
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, y, weight, mean, invstd = ctx.saved_tensors
+        M, C = ctx.dims
+        dyc = dy.contiguous(memory_format=torch.channels_last).to(xc.dtype)
+        if ctx.evalm:
+            dz = dyc if not ctx.relu else dyc * (y > 0).to(dyc.dtype)
+            sc = (weight * invstd).view(1, C, 1, 1)
+            xhat = (xc.float() - mean.view(1, C, 1, 1)) * invstd.view(1, C, 1, 1)
+            return ((dz.float() * sc).to(xc.dtype), (dz.float() * xhat).sum((0, 2, 3)), dz.float().sum((0, 2, 3)),
+                    dz if (ctx.has_res and ctx.needs_input_grad[3]) else None, None, None)
+        dx = torch.empty_like(xc, memory_format=torch.channels_last)
+        dres = torch.empty_like(xc, memory_format=torch.channels_last) if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        dgamma = torch.empty(C, device=xc.device, dtype=torch.float32)
+        dbeta = torch.empty(C, device=xc.device, dtype=torch.float32)
+        L = hip.lib()
+        ws = torch.empty(L.psi_bn_workspace_floats(M, C), device=xc.device, dtype=torch.float32)
+        hip.check(L.psi_bn_backward_t(_ptr_cl(dyc), int(ctx.f32), _ptr_cl(xc), _ptr_cl(y), hip.ptr(weight), hip.ptr(mean), hip.ptr(invstd), M, C,
+                                      int(ctx.relu), _ptr_cl(dx), _ptr_cl(dres), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), hip.stream()),
+                  'psi_bn_backward_t')
+        return dx, dgamma, dbeta, dres, None, None
+
+
+def bn_act_t(x, bn, relu=True, residual=None):
+    """``relu(bn(x) + residual)`` (each part optional) of an ``nn.BatchNorm2d`` in training OR eval mode on an fp32 or bf16 channels_last map."""
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_cuda or x.dim() != 4:
+        raise ValueError('bn_act_t: expected a 4-D fp32 / bf16 CUDA tensor')
+    if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape):
+        raise ValueError('bn_act_t: residual must match x')
+    return _BNActT.apply(x, bn.weight, bn.bias, residual, bn, relu)
+
+
+def bn_t_supported(bn):
+    return (bn.affine and bn.track_running_stats and bn.running_mean is not None and (bn.momentum is not None or not bn.training)
+            and bn.num_features in (8, 16, 32, 64, 128, 256))
+
+
+class _MaxPoolT(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        xc = x.contiguous(memory_format=torch.channels_last)
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, C, OH, OW), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+        idx = torch.empty(N * OH * OW * C, device=x.device, dtype=torch.uint8) if ctx.needs_input_grad[0] else None
+        hip.check(hip.lib().psi_maxpool3x3s2_forward_t(_ptr_cl(xc), int(x.dtype == torch.float32), N, H, W, C, _ptr_cl(y), hip.ptr(idx), hip.stream()),
+                  'psi_maxpool3x3s2_forward_t')
+        ctx.save_for_backward(idx)
+        ctx.dims = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, = ctx.saved_tensors
+        N, C, H, W = ctx.dims
+        dyc = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=dy.dtype, memory_format=torch.channels_last)
+        hip.check(hip.lib().psi_maxpool3x3s2_backward_t(_ptr_cl(dyc), int(dy.dtype == torch.float32), hip.ptr(idx), N, H, W, C, _ptr_cl(dx), hip.stream()),
+                  'psi_maxpool3x3s2_backward_t')
+        return dx
+
+
+def maxpool3x3s2_t(x):
+    """``nn.MaxPool2d(3, 2, 1)`` on an fp32 or bf16 channels_last map."""
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_cuda or x.dim() != 4 or x.shape[1] % 8:
+        raise ValueError('maxpool3x3s2_t: expected a 4-D fp32 / bf16 CUDA tensor with a multiple of 8 channels')
+    return _MaxPoolT.apply(x)
+
+
+class _LinearAct3(Function):
+    """nn.Linear (+ LeakyReLU, + skip connection) at the fp32 model's precision: ONE hand-written kernel forward (psi_linear_forward3: three-term
+    split products, any width), the two gradient GEMMs through the library in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, act, slope):
+        M, K = x.shape
+        N = weight.shape[0]
+        xc = x.detach().contiguous().float()
+        w = weight.detach().contiguous().float()
+        b = bias.detach().contiguous().float() if bias is not None else None
+        r = residual.detach().contiguous().float() if residual is not None else None
+        y = torch.empty(M, N, device=x.device)
+        a_out = torch.empty(M, N, device=x.device) if (act and residual is not None) else None
+        L = hip.lib()
+        nws = L.psi_linear_workspace_floats(M, N, K)
+        ws = torch.empty(nws, device=x.device) if nws else None
+        hip.check(L.psi_linear_forward3(hip.ptr(xc), 0, hip.ptr(w), hip.ptr(b), hip.ptr(r), M, N, K, int(act), float(slope), hip.ptr(y), hip.ptr(a_out),
+                                        hip.ptr(ws), hip.stream()), 'psi_linear_forward3')
+        ctx.act, ctx.slope = int(act), float(slope)
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.save_for_backward(xc, w, (a_out if a_out is not None else y) if act else torch.empty(0, device=x.device))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, w, a_out = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        g = gy if not ctx.act else torch.where(a_out > 0, gy, gy * ctx.slope)
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = g.t() @ xc if ctx.needs_input_grad[1] else None
+        gb = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, gy if (ctx.has_res and ctx.needs_input_grad[3]) else None, None, None
+
+
+def linear_act3(x, weight, bias=None, act=None, slope=0.01, residual=None):
+    """act(x @ weight.T + bias) (+ residual) at fp32 precision on the HIP kernels (any K, N); ``act`` is None or 'leaky_relu'."""
+    if act not in (None, 'leaky_relu'):
+        raise ValueError('act must be None or "leaky_relu"')
+    if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1]:
+        raise ValueError('linear_act3: x [M,K] and weight [N,K] expected, got %s / %s' % (tuple(x.shape), tuple(weight.shape)))
+    return _LinearAct3.apply(x, weight, bias, residual, 1 if act else 0, slope)
+
+
 # ------------------------------------------------------------------------------------------
 # Body-vector glue of a CVAE training step (csrc/cvae_loss.hip): target representation, reconstruction / KL / VPoser losses
 # ------------------------------------------------------------------------------------------
