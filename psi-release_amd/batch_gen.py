@@ -128,6 +128,20 @@ class BatchGeneratorWithSceneMesh:
     def has_next_batch(self):
         return self.index_rec < self.n_samples
 
+    def epoch_batch_validity(self, batch_size):
+        """For every batch the current epoch will ask for (in order): will next_batch return data?  The two skip rules of next_batch
+        (batch_gen_hdf5.py:198-199 short last batch, :211-214 a body beyond the view's depth range) evaluated on the host index — what a
+        data-parallel trainer needs to agree on the steps of an epoch with ONE collective (training.py: _epoch_validity)."""
+        out = []
+        for lb in range(0, self.n_samples, batch_size):
+            ub = min(lb + batch_size, self.n_samples)
+            if ub - lb < batch_size:
+                out.append(False)
+                continue
+            idx_ = sorted(self.index[lb:ub])
+            out.append(not (np.abs(self.body_stream[idx_][:, 2]).max() > np.abs(self.max_d_stream[idx_]).max()))
+        return out
+
     def next_batch(self, batch_size):
         lb = self.index_rec
         ub = min(self.index_rec + batch_size, self.n_samples)

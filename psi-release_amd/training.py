@@ -169,20 +169,20 @@ class _TrainBase:
                     'optimizer_h_state_dict': self.optimizer_h.state_dict()},
                    self.save_dir + "/epoch-{:06d}".format(ep + 1) + ".ckp")
 
-    def _allreduce_grads(self):
-        """One flattened all-reduce of the model gradients per step (RCCL picks direct reduce-scatter/all-gather on xGMI)."""
+    # ---- data-parallel gradient exchange: buckets that the gradients alias, reduced from autograd hooks while the backward pass is still
+    # running (psi_release_amd/dist.py: GradBuckets; PSI_GRAD_BUCKET_MB sets the bucket size, default 16)
+    def _buckets_begin(self):
+        """Start of a step's gradient accumulation: zero the gradients.  Data parallel: through the buckets (created on first use)."""
         if not psi_dist.is_dist():
+            self.optimizer_h.zero_grad(set_to_none=self.use_graph)
             return
-        import torch.distributed as tdist
-        grads = [p.grad for p in self.model_h.parameters() if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        tdist.all_reduce(flat, op=tdist.ReduceOp.SUM)
-        flat /= psi_dist.world_size()
-        o = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[o:o + n].view_as(g))
-            o += n
+        if getattr(self, '_buckets', None) is None:
+            self._buckets = psi_dist.GradBuckets(self.model_h, float(os.environ.get('PSI_GRAD_BUCKET_MB', '16')))
+        self._buckets.begin()
+
+    def _buckets_finish(self):
+        if psi_dist.is_dist():
+            self._buckets.finish()
 
     # ---- whole-step HIP graph ------------------------------------------------------------------------------------
     # A train_s{1,2} step is ~2500 small launches (rotation glue, BN, Adam, ...) and is bound by the host issuing them.
@@ -225,8 +225,12 @@ class _TrainBase:
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for _ in range(3):
-                self.optimizer_h.zero_grad(set_to_none=True)
+                if psi_dist.is_dist():
+                    self._buckets_begin()
+                else:
+                    self.optimizer_h.zero_grad(set_to_none=True)
                 sum(self._losses_from_batch(st, ep)).backward()
+                self._buckets_finish()
                 self.optimizer_h.step()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
@@ -235,9 +239,13 @@ class _TrainBase:
         for g in self.optimizer_h.param_groups:
             g['capturable'] = True
         if not self.optimizer_h.state:                     # fresh optimiser: materialise its state outside the graph
-            self.optimizer_h.zero_grad(set_to_none=True)
+            if psi_dist.is_dist():
+                self._buckets_begin()                      # (zero gradients that keep aliasing their buckets)
+                self._buckets._armed = False
+            else:
+                self.optimizer_h.zero_grad(set_to_none=True)
             for p in self.model_h.parameters():
-                if p.requires_grad:
+                if p.requires_grad and p.grad is None:
                     p.grad = torch.zeros_like(p)
             lr = [g['lr'] for g in self.optimizer_h.param_groups]
             for g in self.optimizer_h.param_groups:
@@ -251,11 +259,14 @@ class _TrainBase:
                 stt['exp_avg_sq'].zero_()
         torch.cuda.set_rng_state(rng, self.device)
         graph = torch.cuda.CUDAGraph()
-        self.optimizer_h.zero_grad(set_to_none=True)
+        if not psi_dist.is_dist():
+            self.optimizer_h.zero_grad(set_to_none=True)
         with torch.cuda.graph(graph):
+            if psi_dist.is_dist():
+                self._buckets_begin()                      # (zeroing the buckets is part of the captured step; the collectives are its branches)
             losses = self._losses_from_batch(st, ep)
             sum(losses).backward()
-            self._allreduce_grads()
+            self._buckets_finish()
             self.optimizer_h.step()
         return {'graph': graph, 'batch': st, 'losses': losses}
 
@@ -277,15 +288,35 @@ class _TrainBase:
         try:
             if self.use_graph:
                 return self._train_step_graph(train_data, ep)
-            self.optimizer_h.zero_grad()
+            if psi_dist.is_dist():
+                self._buckets_begin()
+            else:
+                self.optimizer_h.zero_grad()
             losses = self._losses_from_batch(train_data, ep)
             loss_h = sum(losses)
             loss_h.backward()
-            self._allreduce_grads()
+            self._buckets_finish()
             self.optimizer_h.step()
             return losses
         finally:
             torch.backends.cudnn.benchmark = prev
+
+    def _epoch_validity(self, batch_gen):
+        """Data parallel: which of this epoch's batches EVERY rank has (batch_gen_hdf5.py:198-199,211-214 drop a short batch and a batch with a
+        wrong PROX fitting) — decided ONCE per epoch from the sharded index (BatchGeneratorWithSceneMesh.epoch_batch_validity: host arrays
+        only) with one all-reduce, instead of a host-synchronising collective in front of every step.  None: decide per step."""
+        if not psi_dist.is_dist() or not hasattr(batch_gen, 'epoch_batch_validity'):
+            return None
+        import torch.distributed as tdist
+        v = batch_gen.epoch_batch_validity(self.batch_size)
+        t = torch.tensor([1.0 if x else 0.0 for x in v], device=self.device if tdist.get_backend() == 'nccl' else 'cpu')
+        n = torch.tensor([float(len(v))], device=t.device)
+        tdist.all_reduce(n, op=tdist.ReduceOp.MIN)
+        if int(n.item()) != len(v):
+            raise RuntimeError('ranks disagree on the number of batches of an epoch (%d here, %d elsewhere): shard the index evenly' % (len(v), int(n.item())))
+        if len(v):
+            tdist.all_reduce(t, op=tdist.ReduceOp.MIN)
+        return [bool(x > 0.5) for x in t.tolist()]
 
     def _all_ranks_have(self, train_data):
         """Skip decision of the batch loop (batch_gen_hdf5.py:198-199,211-214 return None).  It must be COLLECTIVE: train_step
@@ -306,9 +337,15 @@ class _TrainBase:
         print('--[INFO] start training')
         start_time = time.time()
         for ep in range(starting_ep, self.epoch):
+            valid, bi = self._epoch_validity(batch_gen), 0
             while batch_gen.has_next_batch():
                 train_data = batch_gen.next_batch(self.batch_size)
-                if not self._all_ranks_have(train_data):
+                if valid is not None:
+                    ok, bi = (valid[bi] if bi < len(valid) else False), bi + 1
+                    assert not ok or train_data is not None, 'epoch_batch_validity and next_batch disagree'
+                    if not ok:
+                        continue
+                elif not self._all_ranks_have(train_data):
                     continue
                 losses = self.train_step(train_data, ep)
                 if self.verbose:

@@ -24,7 +24,7 @@ def pytest_configure(config):
 # Collection order of the -m gpu suite (the driver runs it with -x): the oracle / golden parity tests come first, the multi-process
 # tests (gloo rendezvous, torchrun subprocesses) last, so that a launcher or port problem can never hide a parity result.
 _ORDER = ['test_hip_ops_gpu', 'test_lbs_gpu', 'test_fitting_gpu', 'test_parity_gaps_gpu', 'test_configs_gpu', 'test_linear_gpu', 'test_bnorm_gpu', 'test_conv_gpu', 'test_cvae_glue_gpu',
-          'test_training_gpu', 'test_section8f_gpu']
+          'test_precise_gpu', 'test_training_gpu', 'test_configs2_gpu', 'test_section8f_gpu']
 _LAST = ['test_configs_dp_gpu', 'test_stress_gpu', 'test_dist_gpu', 'test_entrypoints_gpu', 'test_rccl_multigpu_gpu']
 
 

@@ -91,7 +91,7 @@ def _worker_training_pen(rank, world, port, tmp):
     loss.backward()
     g = w.grad.clone()
     dist.all_reduce(g)
-    g /= world                                                                     # what TrainOP._allreduce_grads does
+    g /= world                                                                     # the mean over the ranks (dist.GradBuckets)
     wf = Wt.clone().requires_grad_()
     sf = S * wf[0] + wf[1] * 0.1 + wf[2] * S ** 2 * 0.01
     neg = sf < 0
@@ -125,3 +125,69 @@ def test_training_penetration_global_and_helpers_world2(tmp_path):
         port = sk.getsockname()[1]
     mp.spawn(_worker_training_pen, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / 'pen0').read() == '1' and open(tmp_path / 'pen1').read() == '1'
+
+
+def _worker_buckets(rank, world, port, tmp):
+    """dist.GradBuckets: gradients that alias a few flat buckets, all-reduced from autograd hooks, equal the full-batch gradients; several
+    buckets, a channels_last convolution weight, a parameter that gets no gradient; two steps through an optimiser; the per-epoch skip
+    decision of the training loop."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from psi_release_amd import dist as pd
+
+    def make():
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Conv2d(2, 8, 3, 1, 1), torch.nn.ReLU(), torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 40), torch.nn.LeakyReLU(),
+                                torch.nn.Linear(40, 5))
+        m[0].to(memory_format=torch.channels_last)
+        m.unused = torch.nn.Parameter(torch.ones(7))                     # never reaches the loss
+        return m
+    rs = np.random.RandomState(2)
+    X = torch.tensor(rs.standard_normal((8, 2, 6, 6)), dtype=torch.float32)
+    Y = torch.tensor(rs.standard_normal((8, 5)), dtype=torch.float32)
+    lo, hi = pd.shard_rows(8, rank, world)
+    full, mine = make(), make()
+    opt_f, opt_m = torch.optim.Adam(full.parameters(), lr=1e-2), torch.optim.Adam(mine.parameters(), lr=1e-2)
+    b = pd.GradBuckets(mine, bucket_mb=0.004)                            # 1000 floats per bucket: several buckets
+    ok = b.n_buckets() >= 3
+    for step in range(2):
+        opt_f.zero_grad()
+        ((full(X) - Y) ** 2).mean().backward()
+        b.begin()
+        ((mine(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
+        b.finish()
+        for (k, pf), (_, pm) in zip(full.named_parameters(), mine.named_parameters()):
+            gf = pf.grad if pf.grad is not None else torch.zeros_like(pf)
+            ok = ok and pm.grad is not None and float((pm.grad - gf).abs().max()) < 1e-6 and pm.grad.stride() == pm.stride()
+        opt_f.step()
+        opt_m.step()
+        ok = ok and all(float((pf - pm).abs().max()) < 1e-6 for pf, pm in zip(full.parameters(), mine.parameters()))
+    # a step that drops the aliasing must be reported, not silently ignored
+    opt_m.zero_grad(set_to_none=True)
+    try:
+        b.begin()
+        ((mine(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
+        ok = False
+    except RuntimeError:
+        pass
+    dist.barrier()
+    # per-epoch skip decision: rank 1 lacks batch 1 -> both skip it; one collective per epoch
+    import types
+    from psi_release_amd import training
+    gen = types.SimpleNamespace(epoch_batch_validity=lambda bs: [True, rank == 0, True])
+    me = types.SimpleNamespace(device=torch.device('cpu'), batch_size=4)
+    ok = ok and training._TrainBase._epoch_validity(me, gen) == [True, False, True]
+    ok = ok and training._TrainBase._epoch_validity(me, types.SimpleNamespace()) is None
+    open(os.path.join(tmp, 'bk%d' % rank), 'w').write('1' if ok else '0')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_and_epoch_skip_decision_world2(tmp_path):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker_buckets, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / 'bk0').read() == '1' and open(tmp_path / 'bk1').read() == '1'
