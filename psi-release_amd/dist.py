@@ -216,6 +216,7 @@ class GradBuckets:
     Inside a captured training step (torch.cuda.graph) the side-stream collectives become parallel branches of the graph.
 
     Use:  ``b = GradBuckets(model)``;  per step ``b.begin()`` (instead of zero_grad) -> backward -> ``b.finish()`` -> optimiser step.
+    A gradient that lost its alias (zero_grad(set_to_none=True), Module.to(memory_format=...)) is moved back into its bucket by the hook.
     With the gloo backend (several ranks on one GPU / CPU tests) the collectives are the same, waited for in ``finish()``."""
 
     def __init__(self, model, bucket_mb=16.0, group=None):
@@ -237,10 +238,13 @@ class GradBuckets:
             cur.append(p)
             cur_n += p.numel()
         self._close(cur, cur_n)
-        self._of = {}
+        self._of, self._offset = {}, {}
         for bi, b in enumerate(self.buckets):
+            o = 0
             for p in b['params']:
                 self._of[p] = bi
+                self._offset[p] = o
+                o += p.numel()
                 p.register_post_accumulate_grad_hook(self._hook)
         self.side = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
         self._work = []
@@ -261,6 +265,9 @@ class GradBuckets:
         for b in self.buckets:
             b['flat'].zero_()
             b['pending'] = len(b['params'])
+            for p in b['params']:
+                if p.grad is not None and not (b['flat'].data_ptr() <= p.grad.data_ptr() < b['flat'].data_ptr() + b['flat'].numel() * 4):
+                    p.grad = None                              # a stray gradient tensor must not be accumulated into: the hook re-aliases
         self._work = []
         self._armed = True
 
@@ -268,9 +275,13 @@ class GradBuckets:
         if not self._armed:
             return
         b = self.buckets[self._of[p]]
-        if p.grad is None or p.grad.data_ptr() < b['flat'].data_ptr() or p.grad.data_ptr() >= b['flat'].data_ptr() + b['flat'].numel() * 4:
-            raise RuntimeError('GradBuckets: a gradient no longer aliases its bucket (zero_grad(set_to_none=True) or a replaced .grad): '
-                               'call begin() instead of zero_grad()')
+        lo = b['flat'].data_ptr()
+        if p.grad.data_ptr() < lo or p.grad.data_ptr() >= lo + b['flat'].numel() * 4 or p.grad.stride() != p.stride():
+            # the gradient no longer aliases its bucket — zero_grad(set_to_none=True), or Module.to(memory_format=...) re-created the
+            # parameter and its .grad (the CVAEs switch their trunks to channels_last on their first GPU forward): move it back in
+            view = b['flat'].as_strided(p.size(), p.stride(), self._offset[p])
+            view.copy_(p.grad)
+            p.grad = view
         b['pending'] -= 1
         if b['pending'] == 0:
             self._reduce(b)

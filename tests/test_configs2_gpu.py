@@ -109,8 +109,10 @@ def test_one_train_s2_step_at_the_bench_configuration(tmp_path, smplx_data, vpos
     # ---- behind the network: the oracle on the CPU at the product's own network outputs
     ref_losses, ref_g = _oracle_tail(smplx_data, vposer_sd, scenes, inp, prod['outs'], prod['op'])
     assert np.abs(prod['losses'] - ref_losses).max() <= 1e-4 * max(1.0, np.abs(ref_losses).max()), (prod['losses'], ref_losses)
-    for got, want, name in zip(prod['g_outs'], ref_g, ('x_rec', 'mu_g', 'logvar_g', 'mu_l', 'logvar_l')):
-        assert got is not None and rel_err(got, want) < 1e-3, (name, rel_err(got, want))
+    # the gradient of the seven losses' sum with respect to the reconstructed body vector (the network's first output: everything above
+    # reaches the network through it; the latent statistics' retained gradients also carry the path through the decoder and are not
+    # a property of the tail alone — their KL VALUES are among the seven)
+    assert prod['g_outs'][0] is not None and rel_err(prod['g_outs'][0], ref_g[0]) < 1e-3, rel_err(prod['g_outs'][0], ref_g[0])
     # ---- the network: plain PyTorch (library kernels, operator-sequence losses) on the same inputs and the same noise
     lib = _run(str(tmp_path / 'b'), smplx_data, vposer_sd, scenes, inp, monkeypatch, product=False)
     assert np.abs(prod['losses'] - lib['losses']).max() <= 1e-4 * max(1.0, np.abs(lib['losses']).max()), (prod['losses'], lib['losses'])

@@ -163,14 +163,20 @@ def _worker_buckets(rank, world, port, tmp):
         opt_f.step()
         opt_m.step()
         ok = ok and all(float((pf - pm).abs().max()) < 1e-6 for pf, pm in zip(full.parameters(), mine.parameters()))
-    # a step that drops the aliasing must be reported, not silently ignored
+    # gradients that lost their alias (set_to_none, or a Module.to(memory_format=...) that re-created parameter and gradient) are moved back
     opt_m.zero_grad(set_to_none=True)
-    try:
-        b.begin()
-        ((mine(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
-        ok = False
-    except RuntimeError:
-        pass
+    mine[0].to(memory_format=torch.contiguous_format)
+    opt_f.zero_grad()
+    ((full(X) - Y) ** 2).mean().backward()
+    b.begin()
+    ((mine(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
+    b.finish()
+    for pf, pm in zip(full.parameters(), mine.parameters()):
+        gf = pf.grad if pf.grad is not None else torch.zeros_like(pf)
+        if pm is mine.unused:
+            continue                                                       # (no gradient arrives: nothing to re-alias, the bucket holds zeros)
+        inside = any(bb['flat'].data_ptr() <= pm.grad.data_ptr() < bb['flat'].data_ptr() + bb['flat'].numel() * 4 for bb in b.buckets)
+        ok = ok and inside and float((pm.grad - gf).abs().max()) < 1e-6
     dist.barrier()
     # per-epoch skip decision: rank 1 lacks batch 1 -> both skip it; one collective per epoch
     import types

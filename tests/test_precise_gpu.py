@@ -214,7 +214,10 @@ def test_training_mode_gradients_on_the_hand_written_path_against_a_double_preci
     activations fall either way in any finite-precision evaluation: the library's fp32 gradients are themselves 4e-3 from the double-
     precision ones at this batch of 4.  The number of such flips grows with the forward pass's rounding error, which is 1e-5 for the
     three-term products against 1e-6 for fp32 — so the bound of the hand-written path is the library path's own distance from the double-
-    precision gradient x 16 (measured: 4.6 x in the worst layer), not a literal; the loss value is held to 4 x."""
+    precision gradient x 16 plus ONE flipped activation's weight: a trunk weight gradient at this batch of 4 is a sum over ~16 k positions that
+    cancels to ~128 single terms, so one ReLU that falls the other way moves it by 1e-2 of its largest entry (the bounds
+    test_training_gpu.py::test_cal_loss_golden holds both paths to against the reference's recorded gradients: 3e-2 in the trunk, 2e-3
+    behind it); the loss value is held to 4 x the library's distance."""
     inp = synth.make_cvae_inputs(13, 4)
     res = {}
     for mode in ('1', '0', 'f64'):
@@ -235,7 +238,7 @@ def test_training_mode_gradients_on_the_hand_written_path_against_a_double_preci
     for k, g64 in res['f64'][1].items():
         e1, e0 = rel_err(res['1'][1][k], g64), rel_err(res['0'][1][k], g64)
         worst[k] = (e1, e0)
-        assert e1 <= 16 * e0 + 1e-4, (k, e1, e0)
+        assert e1 <= 16 * e0 + (3e-2 if 'resnet' in k else 2e-3), (k, e1, e0)
     for k, b in res['f64'][2].items():
         assert rel_err(res['1'][2][k], b) < 2e-5, k
     print('largest distance from the double-precision gradient (hand-written, library):', max(worst.values()))
