@@ -343,6 +343,16 @@ int psi_maxpool3x3s2_backward(const void *dy, const void *idx, int N, int H, int
 int psi_conv2d_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
 int psi_conv2d_forward(const void *x, int x_bf16, const float *w, const float *bias, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                        int stride, int pad, void *y, int y_bf16, int nterm, void *stream);
+/* psi_conv2d_input_grad: dX of the same convolution — dy [N,OH,OW,Cout] -> dx [N,H,W,Cin] (OVERWRITTEN); wt = the weight re-laid out as
+ *   [Cin][KH][KW][Cout] fp32 (torch: weight.permute(1,2,3,0).contiguous()); the forward kernel in its transposed-gather form, any stride
+ *   (Cin % 32 == 0; Cout % 64 == 0 or Cout * KH * KW <= 4096).  psi_conv2d_weight_grad: gw [Cout,KH,KW,Cin] fp32 (OVERWRITTEN) = sum over pixels of dy x im2col(x); the
+ *   pixel range is split over workgroups, partial tiles summed in slice order (deterministic); ws: psi_conv2d_wgrad_workspace_floats floats.
+ *   Both replace aten::convolution_backward (MIOpen igemm_bwd / igemm_wrw) for the trunk's convolutions; nterm as in the forward. */
+int psi_conv2d_input_grad(const void *dy, int dy_bf16, const float *wt, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                          void *dx, int dx_bf16, int nterm, void *stream);
+size_t psi_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int psi_conv2d_weight_grad(const void *x, int x_bf16, const void *dy, int dy_bf16, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                           int pad, float *gw, float *ws, int nterm, void *stream);
 int psi_bn_forward_t(const void *x, int map_f32, const void *residual, const float *gamma, const float *beta, float *running_mean,
                      float *running_var, long long *num_batches_tracked, long M, int C, int relu, float momentum, float eps, void *y,
                      float *save_mean, float *save_invstd, float *ws, int eval_mode, void *stream);

@@ -56,6 +56,26 @@ __device__ __forceinline__ void load32(const __bf16 *p, bool ok, float (&v)[32])
         for (int e = 0; e < 8; e++) v[8 * i + e] = ok ? (float)a[e] : 0.0f;
     }
 }
+// 16 consecutive elements (or zeros) as floats
+__device__ __forceinline__ void load16(const float *p, bool ok, float (&v)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const f4 a = ok ? *(const f4 *)(p + 4 * i) : (f4){0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[4 * i + e] = a[e];
+    }
+}
+__device__ __forceinline__ void load16(const __bf16 *p, bool ok, float (&v)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        bf16x8 a;
+        if (ok) a = *(const bf16x8 *)(p + 8 * i);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[8 * i + e] = ok ? (float)a[e] : 0.0f;
+    }
+}
 __device__ __forceinline__ float ldf(const float *p) { return *p; }
 __device__ __forceinline__ float ldf(const __bf16 *p) { return (float)*p; }
 
@@ -90,8 +110,11 @@ __device__ __forceinline__ void split_store(const float (&v)[NV], __bf16 *hi, __
 template <int NTERM, typename TIN, typename TOUT, int BN>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const TIN *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                                                            TOUT *__restrict__ y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH,
-                                                           int KW, int stride, int pad)
+                                                           int KW, int stride, int pad, int transposed)
 {
+    // transposed != 0: the INPUT GRADIENT of a convolution — "x" is dY [N,H,W,Cin] (H x W = the forward's output size, Cin = its Cout), "y" is
+    // dX [N,OH,OW,Cout] (the forward's input), w = the forward weight re-laid out as [Cin_fwd][KH][KW][Cout_fwd]; output pixel (iy, ix) takes
+    // tap (kh, kw) from dY[(iy + pad - kh) / stride, (ix + pad - kw) / stride] where that division is exact (no weight flip in this form)
     static_assert(BN == 64 || BN == 32, "output-channel tile");
     constexpr int NCT = BN / 32;                                   // 32-channel MFMA tiles per wave
     constexpr int WPT = BN * KC / 256;                             // weight elements per thread and chunk (16 or 8)
@@ -125,8 +148,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const TIN *__restrict
         if (fast) {
             const int cpt = Cin / KC, tap = ck / cpt, c0 = (ck - tap * cpt) * KC;
             const int kh = tap / KW, kw = tap - kh * KW;
-            const int iy = aoy * stride - pad + kh, ix = aox * stride - pad + kw;
-            const bool ok = a_live && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            int iy, ix;
+            bool ok = a_live;
+            if (transposed) {
+                const int ty = aoy + pad - kh, tx = aox + pad - kw;
+                iy = ty / stride;
+                ix = tx / stride;
+                ok = ok && ty >= 0 && tx >= 0 && iy * stride == ty && ix * stride == tx && iy < H && ix < W;
+            } else {
+                iy = aoy * stride - pad + kh;
+                ix = aox * stride - pad + kw;
+                ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            }
             load32(x + (((size_t)an * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + c0 + ah, ok, av);
 #pragma unroll
             for (int i = 0; i < WPT / 4; i++) {
@@ -143,8 +176,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const TIN *__restrict
                 if (a_live && k < K) {
                     const int tap = k / Cin, ci = k - tap * Cin;
                     const int kh = tap / KW, kw = tap - kh * KW;
-                    const int iy = aoy * stride - pad + kh, ix = aox * stride - pad + kw;
-                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ldf(x + (((size_t)an * H + iy) * W + ix) * Cin + ci);
+                    int iy, ix;
+                    bool ok;
+                    if (transposed) {
+                        const int ty = aoy + pad - kh, tx = aox + pad - kw;
+                        iy = ty / stride;
+                        ix = tx / stride;
+                        ok = ty >= 0 && tx >= 0 && iy * stride == ty && ix * stride == tx && iy < H && ix < W;
+                    } else {
+                        iy = aoy * stride - pad + kh;
+                        ix = aox * stride - pad + kw;
+                        ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                    }
+                    if (ok) v = ldf(x + (((size_t)an * H + iy) * W + ix) * Cin + ci);
                 }
                 av[e] = v;
             }
@@ -201,6 +245,148 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const TIN *__restrict
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolutions:  dW[co][k] = sum_m dY[m][co] * A[m][k],  m = output pixel, k = (kh, kw, ci), A the im2col view
+// the forward gathers.  The contraction runs over PIXELS, along which neither operand is contiguous in memory (channels are fastest), so
+// both 64-pixel tiles are TRANSPOSED on their way into LDS ([channel][pixel] rows, 2-byte stores; the split into hi / lo parts happens in
+// the same pass) and the MFMA operands are 16-byte LDS reads again.  A workgroup owns the 64 x 64 tile (co-tile, one 64-wide K chunk = 64
+// channels of one tap) and a slice of the pixel range; the slices' partial tiles are summed in slice order by conv_wgrad_reduce_kernel
+// (deterministic: no atomics).  NTERM as in the forward: 3 = both operands split (the fp32 model's precision), 1 = bf16 products.
+// ------------------------------------------------------------------------------------------------
+constexpr int WG_PX = 64, WG_PITCH = WG_PX + 8;
+
+template <int NTERM, int NV>
+__device__ __forceinline__ void split_store_t(const float (&v)[NV], __bf16 (*hi)[WG_PITCH], __bf16 (*lo)[WG_PITCH], int row0, int col)
+{
+#pragma unroll
+    for (int e = 0; e < NV; e++) {                               // element e of this pixel -> row (channel) row0 + e, column (pixel) col
+        __bf16 hh;
+        const float r = bf_round(v[e], hh);
+        hi[row0 + e][col] = hh;
+        if (NTERM > 1) lo[row0 + e][col] = (__bf16)r;
+    }
+}
+
+template <int NTERM, typename TIN, typename TDY>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const TIN *__restrict__ x, const TDY *__restrict__ dy, float *__restrict__ part, int N,
+                                                            int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
+                                                            int nsplit, int stages_per_split)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 Dh[64][WG_PITCH], Xh[64][WG_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Dl[NTERM > 1 ? 64 : 1][WG_PITCH], Xl[NTERM > 1 ? 64 : 1][WG_PITCH];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int li = lane & 31, kb = (lane >> 5) * 8, h = lane >> 5;
+    const int ct = wv & 1, kt = wv >> 1;                          // this wave's 32 x 32 quadrant of the tile
+    const int K = KH * KW * Cin;
+    const int ck = blockIdx.x, co0 = blockIdx.y * 64, split = blockIdx.z;
+    const long M = (long)N * OH * OW;
+    const bool fast = (Cin % KC) == 0;
+    int tap = 0, c0 = ck * KC, kh = 0, kw = 0;
+    if (fast) {
+        const int cpt = Cin / KC;
+        tap = ck / cpt;
+        c0 = (ck - tap * cpt) * KC;
+        kh = tap / KW;
+        kw = tap - kh * KW;
+    }
+    // this thread's share of a stage: pixel row pr (of 64), 16 of its 64 elements, of dY and of the gathered input
+    const int pr = t >> 2, q16 = (t & 3) * 16;
+    f16v acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    float dv[16], xv[16];
+    auto load_stage = [&](long m0) {
+        const long m = m0 + pr;
+        const bool live = m < M;
+        int n = 0, oy = 0, ox = 0;
+        if (live) {
+            n = (int)(m / ((long)OH * OW));
+            const int rem = (int)(m - (long)n * OH * OW);
+            oy = rem / OW;
+            ox = rem - oy * OW;
+        }
+        const bool dok = live && co0 + q16 + 16 <= Cout;           // (Cout % 16 == 0: whole 16-channel pieces)
+        load16(dy + (size_t)(dok ? m : 0) * Cout + (dok ? co0 + q16 : 0), dok, dv);
+        if (fast) {
+            const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+            const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            load16(x + (((size_t)n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + c0 + q16, ok, xv);
+        } else {
+#pragma unroll 4
+            for (int e = 0; e < 16; e++) {
+                const int k = c0 + q16 + e;
+                float v = 0.0f;
+                if (live && k < K) {
+                    const int tp = k / Cin, ci = k - tp * Cin;
+                    const int kh2 = tp / KW, kw2 = tp - kh2 * KW;
+                    const int iy = oy * stride - pad + kh2, ix = ox * stride - pad + kw2;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ldf(x + (((size_t)n * H + iy) * W + ix) * Cin + ci);
+                }
+                xv[e] = v;
+            }
+        }
+    };
+    const long stage0 = (long)split * stages_per_split, nstage = (M + WG_PX - 1) / WG_PX;
+    const long stage1 = stage0 + stages_per_split < nstage ? stage0 + stages_per_split : nstage;
+    if (stage0 < stage1) load_stage(stage0 * WG_PX);
+    for (long sg = stage0; sg < stage1; sg++) {
+        __syncthreads();                                           // the previous stage's MFMAs are done with LDS
+        split_store_t<NTERM, 16>(dv, Dh, Dl, q16, pr);
+        split_store_t<NTERM, 16>(xv, Xh, Xl, q16, pr);
+        __syncthreads();
+        if (sg + 1 < stage1) load_stage((sg + 1) * WG_PX);         // in flight during this stage's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < WG_PX / 16; ks++) {
+            const bf16x8 a = *(const bf16x8 *)&Dh[ct * 32 + li][ks * 16 + kb];
+            const bf16x8 b = *(const bf16x8 *)&Xh[kt * 32 + li][ks * 16 + kb];
+            if (NTERM > 1) {
+                const bf16x8 al = *(const bf16x8 *)&Dl[ct * 32 + li][ks * 16 + kb];
+                const bf16x8 bl = *(const bf16x8 *)&Xl[kt * 32 + li][ks * 16 + kb];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+    }
+    // partial tile: D[row = co][col = k] -> part[split][co][k]
+    float *po = part + (size_t)split * Cout * K;
+    const int kcol = c0 + (fast ? tap * Cin : 0) + kt * 32 + li;
+    if (kcol < K) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = co0 + ct * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (co < Cout) po[(size_t)co * K + kcol] = acc[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, long n, float *__restrict__ gw)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int s = 0;
+    for (; s + 7 < nsplit; s += 8) {                          // eight loads in flight; fixed order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = part[(size_t)(s + u) * n + i];
+        a0 += v[0] + v[4];
+        a1 += v[1] + v[5];
+        a2 += v[2] + v[6];
+        a3 += v[3] + v[7];
+    }
+    for (; s < nsplit; s++) a0 += part[(size_t)s * n + i];
+    gw[i] = (a0 + a1) + (a2 + a3);
+}
+
+static int wgrad_splits(long M, int K, int Cout)
+{
+    const long tiles = (long)((K + KC - 1) / KC) * ((Cout + 63) / 64), nstage = (M + WG_PX - 1) / WG_PX;
+    long S = 512 / tiles;                                          // about two workgroups per compute unit
+    if (S > nstage) S = nstage;
+    return (int)(S < 1 ? 1 : S);
+}
+
 static inline hipError_t set_max_lds(const void *kern, size_t lds, std::atomic<unsigned long long> &done)
 {
     int dev = 0;
@@ -215,7 +401,7 @@ static inline hipError_t set_max_lds(const void *kern, size_t lds, std::atomic<u
 
 template <int NTERM, typename TIN, typename TOUT, int BN>
 int launch(const void *x, const float *w, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
-           int stride, int pad, hipStream_t st)
+           int stride, int pad, int transposed, hipStream_t st)
 {
     const size_t lds = (size_t)(BM + BN) * PITCH * 2 * (NTERM > 1 ? 2 : 1);
     auto kern = conv_gemm_kernel<NTERM, TIN, TOUT, BN>;
@@ -223,7 +409,7 @@ int launch(const void *x, const float *w, const float *bias, void *y, int N, int
     PSI_CHECK_HIP(set_max_lds((const void *)kern, lds, attr_set));
     const long M = (long)N * OH * OW;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(Cout / BN));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const TIN *)x, w, bias, (TOUT *)y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const TIN *)x, w, bias, (TOUT *)y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed);
     PSI_CHECK_LAUNCH("conv_gemm_kernel");
     psi_mark("conv_gemm_kernel", st);
     return 0;
@@ -231,10 +417,10 @@ int launch(const void *x, const float *w, const float *bias, void *y, int N, int
 
 template <int NTERM, typename TIN, typename TOUT>
 int launch_bn(const void *x, const float *w, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
-              int stride, int pad, hipStream_t st)
+              int stride, int pad, int transposed, hipStream_t st)
 {
-    if (Cout % 64 == 0) return launch<NTERM, TIN, TOUT, 64>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, st);
-    return launch<NTERM, TIN, TOUT, 32>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, st);
+    if (Cout % 64 == 0) return launch<NTERM, TIN, TOUT, 64>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
+    return launch<NTERM, TIN, TOUT, 32>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
 }
 
 }  // namespace
@@ -255,7 +441,7 @@ extern "C" int psi_conv2d_forward(const void *x, int x_bf16, const float *w, con
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     PSI_REQUIRE(OH > 0 && OW > 0, "empty output");
     hipStream_t st = (hipStream_t)stream;
-#define PSI_CONV_ARGS x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, st
+#define PSI_CONV_ARGS x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, st
     if (nterm == 3) {
         if (x_bf16) return y_bf16 ? launch_bn<3, __bf16, __bf16>(PSI_CONV_ARGS) : launch_bn<3, __bf16, float>(PSI_CONV_ARGS);
         return y_bf16 ? launch_bn<3, float, __bf16>(PSI_CONV_ARGS) : launch_bn<3, float, float>(PSI_CONV_ARGS);
@@ -263,4 +449,74 @@ extern "C" int psi_conv2d_forward(const void *x, int x_bf16, const float *w, con
     if (x_bf16) return y_bf16 ? launch_bn<1, __bf16, __bf16>(PSI_CONV_ARGS) : launch_bn<1, __bf16, float>(PSI_CONV_ARGS);
     return y_bf16 ? launch_bn<1, float, __bf16>(PSI_CONV_ARGS) : launch_bn<1, float, float>(PSI_CONV_ARGS);
 #undef PSI_CONV_ARGS
+}
+
+// Input gradient of the convolution above: dy [N,OH,OW,Cout] -> dx [N,H,W,Cin] (OVERWRITTEN), wt = the forward weight re-laid out as
+// [Cin][KH][KW][Cout] fp32 (torch: weight.permute(1, 2, 3, 0).contiguous()).  The same kernel in its transposed-gather form; Cin % 32 == 0,
+// Cout % 64 == 0 (or Cout * KH * KW <= 4096: the element-gather path, e.g. the 128 -> 32 head).
+extern "C" int psi_conv2d_input_grad(const void *dy, int dy_bf16, const float *wt, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                     int pad, void *dx, int dx_bf16, int nterm, void *stream)
+{
+    PSI_REQUIRE(dy && wt && dx && N > 0 && H > 0 && W > 0, "bad arguments");
+    PSI_REQUIRE(Cin % 32 == 0 && (Cout % 64 == 0 || Cout * KH * KW <= 4096) && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+                "shape not covered: Cin % 32 == 0 and (Cout % 64 == 0 or a small gather case)");
+    PSI_REQUIRE(nterm == 1 || nterm == 3, "nterm is 1 or 3");
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    hipStream_t st = (hipStream_t)stream;
+    // roles swapped: the kernel's "input" is dY (OH x OW x Cout), its "output" dX (H x W x Cin)
+#define PSI_DG_ARGS dy, wt, nullptr, dx, N, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 1, st
+    if (nterm == 3) {
+        if (dy_bf16) return dx_bf16 ? launch_bn<3, __bf16, __bf16>(PSI_DG_ARGS) : launch_bn<3, __bf16, float>(PSI_DG_ARGS);
+        return dx_bf16 ? launch_bn<3, float, __bf16>(PSI_DG_ARGS) : launch_bn<3, float, float>(PSI_DG_ARGS);
+    }
+    if (dy_bf16) return dx_bf16 ? launch_bn<1, __bf16, __bf16>(PSI_DG_ARGS) : launch_bn<1, __bf16, float>(PSI_DG_ARGS);
+    return dx_bf16 ? launch_bn<1, float, __bf16>(PSI_DG_ARGS) : launch_bn<1, float, float>(PSI_DG_ARGS);
+#undef PSI_DG_ARGS
+}
+
+extern "C" size_t psi_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad)
+{
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return 0;
+    const int K = KH * KW * Cin;
+    return (size_t)wgrad_splits((long)N * OH * OW, K, Cout) * Cout * K;
+}
+
+// Weight gradient: x [N,H,W,Cin], dy [N,OH,OW,Cout] (each fp32 or bf16) -> gw [Cout,KH,KW,Cin] fp32 (OVERWRITTEN; the memory of a
+// channels_last Conv2d weight gradient).  ws: psi_conv2d_wgrad_workspace_floats floats.  Any shape psi_conv2d_supported accepts (Cout % 16 == 0).
+extern "C" int psi_conv2d_weight_grad(const void *x, int x_bf16, const void *dy, int dy_bf16, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                      int stride, int pad, float *gw, float *ws, int nterm, void *stream)
+{
+    PSI_REQUIRE(x && dy && gw && ws && N > 0 && H > 0 && W > 0, "bad arguments");
+    PSI_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && Cout % 16 == 0 && (Cin % 64 == 0 || Cin * KH * KW <= 4096), "shape not covered");
+    PSI_REQUIRE(nterm == 1 || nterm == 3, "nterm is 1 or 3");
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    PSI_REQUIRE(OH > 0 && OW > 0, "empty output");
+    hipStream_t st = (hipStream_t)stream;
+    const int K = KH * KW * Cin;
+    const long M = (long)N * OH * OW, nstage = (M + WG_PX - 1) / WG_PX;
+    const int S = wgrad_splits(M, K, Cout);
+    const int sps = (int)((nstage + S - 1) / S);
+    dim3 grid((unsigned)((K + KC - 1) / KC), (unsigned)((Cout + 63) / 64), (unsigned)S);
+#define PSI_WG_LAUNCH(NT_, TX_, TD_)                                                                                                         \
+    hipLaunchKernelGGL((conv_wgrad_kernel<NT_, TX_, TD_>), grid, dim3(256), 0, st, (const TX_ *)x, (const TD_ *)dy, ws, N, H, W, Cin, OH, OW, Cout, \
+                       KH, KW, stride, pad, S, sps)
+    if (nterm == 3) {
+        if (x_bf16 && dy_bf16) PSI_WG_LAUNCH(3, __bf16, __bf16);
+        else if (x_bf16) PSI_WG_LAUNCH(3, __bf16, float);
+        else if (dy_bf16) PSI_WG_LAUNCH(3, float, __bf16);
+        else PSI_WG_LAUNCH(3, float, float);
+    } else {
+        if (x_bf16 && dy_bf16) PSI_WG_LAUNCH(1, __bf16, __bf16);
+        else if (x_bf16) PSI_WG_LAUNCH(1, __bf16, float);
+        else if (dy_bf16) PSI_WG_LAUNCH(1, float, __bf16);
+        else PSI_WG_LAUNCH(1, float, float);
+    }
+#undef PSI_WG_LAUNCH
+    PSI_CHECK_LAUNCH("conv_wgrad_kernel");
+    psi_mark("conv_wgrad_kernel", st);
+    const long n = (long)Cout * K;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, S, n, gw);
+    PSI_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
+    return 0;
 }

@@ -526,8 +526,9 @@ def conv3x3(x, conv):
 # hand-written kernels: fp32 NHWC maps, every product a three-term bf16 split with fp32 accumulation (csrc/conv_gemm.hip explains and
 # quantifies it: 0.6-3.2e-5 of the reference's recorded forward passes, tests/golden/cvae.npz).  Forward: psi_conv2d_forward (ALL the
 # convolutions: 7x7 stem, stride-1 / stride-2 3x3, 1x1 downsample, heads), psi_bn_forward_t (batch or running statistics, + ReLU + skip),
-# psi_maxpool3x3s2_forward_t, psi_linear_forward3 (any width).  Backward: BatchNorm and max-pool on the same hand-written kernels; the
-# convolution and dense-layer gradients through the library in fp32 (aten.convolution_backward / matmul) on the saved fp32 operands.
+# psi_maxpool3x3s2_forward_t, psi_linear_forward3 (any width).  Backward: BatchNorm and max-pool on the same hand-written kernels, the
+# convolutions' input and weight gradients on psi_conv2d_input_grad / psi_conv2d_weight_grad (same split products); the dense layers'
+# gradient GEMMs through the library in fp32 (matmul) on the saved fp32 operands.
 # ------------------------------------------------------------------------------------------------------------------
 def conv2d_supported(conv):
     return (conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros' and conv.kernel_size[0] == conv.kernel_size[1]
@@ -550,18 +551,44 @@ class _Conv2dSplit(Function):
         hip.check(hip.lib().psi_conv2d_forward(_ptr_cl(xc), int(xc.dtype == torch.bfloat16), hip.ptr(w4), hip.ptr(b), N, H, W, Cin, Cout, KH, KW,
                                                stride, pad, _ptr_cl(y), int(out_bf16), nterm, hip.stream()), 'psi_conv2d_forward')
         ctx.save_for_backward(xc, weight)
-        ctx.geom = (stride, pad, bias is not None)
+        ctx.geom = (stride, pad, bias is not None, nterm)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xc, weight = ctx.saved_tensors
-        stride, pad, has_bias = ctx.geom
-        dyc = dy.contiguous(memory_format=torch.channels_last).to(xc.dtype)
-        mask = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2])
-        gx, gw, gb = torch.ops.aten.convolution_backward(dyc, xc, weight.detach().to(xc.dtype), [weight.shape[0]] if has_bias else None,
-                                                         (stride, stride), (pad, pad), (1, 1), False, (0, 0), 1, mask)
-        return gx, gw.float() if gw is not None else None, gb.float() if gb is not None else None, None, None, None, None
+        stride, pad, has_bias, nterm = ctx.geom
+        N, Cin, H, W = xc.shape
+        Cout, _, KH, KW = weight.shape
+        dyc = dy.contiguous(memory_format=torch.channels_last)
+        if dyc.dtype not in (torch.float32, torch.bfloat16):
+            dyc = dyc.float()
+        L = hip.lib()
+        gx = gw = gb = None
+        if os.environ.get('PSI_HIP_CONV2_BWD', '1') == '0':
+            # PSI_HIP_CONV2_BWD=0: both gradients through the library (aten.convolution_backward -> MIOpen) on the saved operands
+            mask = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2])
+            gx, gw, gb = torch.ops.aten.convolution_backward(dyc.to(xc.dtype), xc, weight.detach().to(xc.dtype), [Cout] if has_bias else None,
+                                                             (stride, stride), (pad, pad), (1, 1), False, (0, 0), 1, mask)
+            return gx, gw.float() if gw is not None else None, gb.float() if gb is not None else None, None, None, None, None
+        if ctx.needs_input_grad[0]:
+            if Cin % 32 == 0 and (Cout % 64 == 0 or Cout * KH * KW <= 4096):
+                wt = weight.detach().float().permute(1, 2, 3, 0).contiguous()            # [Cin,KH,KW,Cout]
+                gx = torch.empty((N, Cin, H, W), device=dy.device, dtype=xc.dtype, memory_format=torch.channels_last)
+                hip.check(L.psi_conv2d_input_grad(_ptr_cl(dyc), int(dyc.dtype == torch.bfloat16), hip.ptr(wt), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                                  _ptr_cl(gx), int(gx.dtype == torch.bfloat16), nterm, hip.stream()), 'psi_conv2d_input_grad')
+            else:
+                gx = torch.ops.aten.convolution_backward(dyc.to(xc.dtype), xc, weight.detach().to(xc.dtype), None, (stride, stride), (pad, pad), (1, 1),
+                                                         False, (0, 0), 1, (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            gw4 = torch.empty(Cout, KH, KW, Cin, device=dy.device, dtype=torch.float32)
+            ws = torch.empty(L.psi_conv2d_wgrad_workspace_floats(N, H, W, Cin, Cout, KH, KW, stride, pad), device=dy.device, dtype=torch.float32)
+            hip.check(L.psi_conv2d_weight_grad(_ptr_cl(xc), int(xc.dtype == torch.bfloat16), _ptr_cl(dyc), int(dyc.dtype == torch.bfloat16), N, H, W, Cin,
+                                               Cout, KH, KW, stride, pad, hip.ptr(gw4), hip.ptr(ws), nterm, hip.stream()), 'psi_conv2d_weight_grad')
+            gw = gw4.permute(0, 3, 1, 2)                             # [Cout,Cin,KH,KW] view with channels_last strides, like the parameter
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = dyc.float().sum((0, 2, 3))
+        return gx, gw, gb, None, None, None, None
 
 
 def conv2d_split(x, conv, nterm=3, out_bf16=False):

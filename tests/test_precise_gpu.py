@@ -47,17 +47,42 @@ def test_conv2d_split_matches_double_precision(N, Cin, Cout, K, stride, pad, H, 
     assert y1.dtype == torch.bfloat16 and float((y1.float() - r1).abs().max()) <= 2 ** -7 * float(r1.abs().max())
 
 
-def test_conv2d_split_gradients_are_the_fp32_gradients():
-    torch.manual_seed(5)
-    conv = torch.nn.Conv2d(64, 128, 3, 2, 1, bias=True).to(DEV).to(memory_format=torch.channels_last)
-    x = torch.randn(3, 64, 32, 32, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
-    g = torch.randn(3, 128, 16, 16, device=DEV)
+@pytest.mark.parametrize('N,Cin,Cout,K,stride,pad,H,bias', CONVS)
+def test_conv2d_split_gradients_match_double_precision(N, Cin, Cout, K, stride, pad, H, bias):
+    """Input gradient (the forward kernel in its transposed-gather form) and weight gradient (conv_wgrad_kernel: pixel-contraction with
+    transposed LDS tiles, ordered split sums) of ops.conv2d_split against double precision, three-term and one-term products; the
+    library path (PSI_HIP_CONV2_BWD=0) gives the same numbers to fp32 rounding."""
+    torch.manual_seed(N + Cin + Cout + K + 1)
+    conv = torch.nn.Conv2d(Cin, Cout, K, stride, pad, bias=bias).to(DEV).to(memory_format=torch.channels_last)
+    x = torch.randn(N, Cin, H, H, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(Cin > 2)     # (the stem's input needs none)
+    OH = (H + 2 * pad - K) // stride + 1
+    g = torch.randn(N, Cout, OH, OH, device=DEV).contiguous(memory_format=torch.channels_last)
     ops.conv2d_split(x, conv, nterm=3).backward(g)
-    gx, gw, gb = x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()
-    x.grad = None
+    gx = x.grad.clone() if Cin > 2 else None
+    gw, gb = conv.weight.grad.clone(), (conv.bias.grad.clone() if bias else None)
+    xd = x.detach().double().cpu().requires_grad_(Cin > 2)
+    wd = conv.weight.detach().double().cpu().requires_grad_()
+    bd = conv.bias.detach().double().cpu().requires_grad_() if bias else None
+    F.conv2d(xd, wd, bd, stride, pad).backward(g.double().cpu())
+    if Cin > 2:
+        mag = torch.nn.grad.conv2d_input(xd.shape, wd.detach().abs(), g.double().cpu().abs(), stride, pad)
+        assert float(((gx.cpu().double() - xd.grad).abs() / (mag + 1e-30)).max()) <= SPLIT3 + 4e-7
+        assert rel_err(gx.cpu(), xd.grad) < 2e-5
+    magw = torch.nn.grad.conv2d_weight(xd.detach().abs(), wd.shape, g.double().cpu().abs(), stride, pad)
+    assert float(((gw.cpu().double() - wd.grad).abs() / (magw + 1e-30)).max()) <= SPLIT3 + 2e-6      # + fp32 sums over up to 131072 pixels
+    assert rel_err(gw.cpu(), wd.grad) < 2e-5
+    if bias:
+        assert rel_err(gb.cpu(), bd.grad) < 1e-5
+    # one-term products on bf16 maps: against fp32 arithmetic on the bf16-rounded operands
     conv.zero_grad()
-    conv(x).backward(g)
-    assert rel_err(gx.cpu(), x.grad.cpu()) < 1e-5 and rel_err(gw.cpu(), conv.weight.grad.cpu()) < 1e-5 and rel_err(gb.cpu(), conv.bias.grad.cpu()) < 1e-5
+    xb = x.detach().to(torch.bfloat16).requires_grad_(Cin > 2)
+    ops.conv2d_split(xb, conv, nterm=1, out_bf16=True).backward(g.to(torch.bfloat16))
+    xr = xb.detach().float().requires_grad_(Cin > 2)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_()
+    F.conv2d(xr, wr, None, stride, pad).backward(g.to(torch.bfloat16).float())
+    if Cin > 2:
+        assert float((xb.grad.float() - xr.grad).abs().max()) <= 2 ** -7 * float(xr.grad.abs().max())
+    assert float((conv.weight.grad - wr.grad).abs().max()) <= 2e-5 * float(wr.grad.abs().max()) + 1e-6
 
 
 @pytest.mark.parametrize('C,H,N,relu,res,train', [(64, 64, 3, True, False, True), (64, 32, 4, True, True, True), (128, 16, 5, False, False, True),
