@@ -275,6 +275,10 @@ int psi_linear_forward(const void *x, int x_is_bf16, const float *W, const float
 int psi_linear_forward3(const void *x, int x_is_bf16, const float *W, const float *bias, const float *residual, int M, int N, int K,
                         int act, float slope, float *y, float *act_out, float *ws, void *stream);
 size_t psi_linear_backward_workspace_floats(int M, int N, int K);
+/* psi_linear_backward3: the backward of psi_linear_forward3 — dX = G W and dW = G^T X (+ gbias) with three-term split operands, fp32 x, ANY N
+ * and K; arguments and workspace as psi_linear_backward. */
+int psi_linear_backward3(const float *gy, const float *act_out, const float *x, const float *W, int M, int N, int K, float slope, float *gx,
+                         float *gW, float *gbias, float *ws, void *stream);
 int psi_linear_backward(const float *gy, const float *act_out, const void *x, int x_is_bf16, const float *W, int M, int N, int K,
                         float slope, void *gx, float *gW, float *gbias, float *ws, void *stream);
 

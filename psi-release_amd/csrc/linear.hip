@@ -277,17 +277,25 @@ constexpr int DXP = DXN + 8;             // LDS pitch (elements): 16-byte aligne
 
 // dX[M,K] = G[M,N] W[N,K]: workgroup = 128 rows x 64 k-columns, wave w = rows [32w, 32w+32) x two 32-column tiles; contraction over n in
 // tiles of 64: G tile [128][64] row-major (A operand as in the forward), W tile [64 n][64 k] stored TRANSPOSED as Wt[k][n].
-template <typename XT>
+constexpr size_t linear_dx_lds(int nterm) { return (size_t)2 * (128 + DXK) * DXP * 2 * (nterm > 1 ? 2 : 1); }
+
+template <typename XT, int NTERM>
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restrict__ gy, const float *__restrict__ act_out,
                                                             const float *__restrict__ W, int M, int N, int K, float slope,
                                                             XT *__restrict__ gx, int nchunk, float *__restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 Gs[2][128][DXP];
-    __shared__ __attribute__((aligned(16))) __bf16 Wt[2][DXK][DXP];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __bf16 (*Tile)[DXP];
+    // [2][128][DXP] rows of G (hi), [2][DXK][DXP] W transposed (hi), then the lo parts (NTERM = 3: psi_linear_backward3)
+    auto Gs = [&](int buf) { return (Tile)(smem + (size_t)buf * 128 * DXP * 2); };
+    auto Wt = [&](int buf) { return (Tile)(smem + (size_t)(2 * 128 + buf * DXK) * DXP * 2); };
+    auto Gl = [&](int buf) { return (Tile)(smem + (size_t)(2 * (128 + DXK) + buf * 128) * DXP * 2); };
+    auto Wl = [&](int buf) { return (Tile)(smem + (size_t)(2 * (128 + DXK) + 2 * 128 + buf * DXK) * DXP * 2); };
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int k0 = blockIdx.x * DXK, mblk = blockIdx.y * 128, m0 = mblk + w * TM;
     const int n_begin = blockIdx.z * nchunk, n_end = min(N, n_begin + nchunk);      // this workgroup's slice of the contraction
     const int li = lane & 31, kb = (lane >> 5) * 8;
+    const bool vecN = (N & 3) == 0, vecK = (K & 3) == 0;    // rows of G / act_out and of W are 16-byte aligned
     f16v acc[2];
 #pragma unroll
     for (int t = 0; t < 2; t++)
@@ -298,32 +306,37 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restr
 #pragma unroll
         for (int i = 0; i < 8; i++) {                       // G: 128 rows x 64 n = 2048 float4, 8 per thread, a wave covers 4 whole rows
             const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
-            const bool ok = mblk + row < M && n0 + c < n_end;
-            const size_t o = (size_t)(mblk + row) * N + n0 + c;
-            gr[i] = ok ? *(const f4 *)(gy + o) : (f4){0, 0, 0, 0};
-            if (act_out) mr[i] = ok ? *(const f4 *)(act_out + o) : (f4){1, 1, 1, 1};
+            const bool rok = mblk + row < M;
+            gr[i] = load4_checked(gy + (size_t)(mblk + row) * N, n0 + c, n_end, rok, vecN);
+            if (act_out) {
+                mr[i] = load4_checked(act_out + (size_t)(mblk + row) * N, n0 + c, n_end, rok, vecN);
+                if (!rok || n0 + c >= n_end) mr[i] = (f4){1, 1, 1, 1};
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {                       // W: 64 n-rows x 64 k = 1024 float4, 4 per thread
             const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
-            const bool ok = n0 + row < n_end && k0 + c < K;
-            wr[i] = ok ? *(const f4 *)(W + (size_t)(n0 + row) * K + k0 + c) : (f4){0, 0, 0, 0};
+            wr[i] = load4_checked(W + (size_t)(n0 + row) * K, k0 + c, K, n0 + row < n_end, vecK);
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
-            bf4 v;
+            f4 g;
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = (__bf16)(act_out ? (mr[i][e] > 0.0f ? gr[i][e] : gr[i][e] * slope) : gr[i][e]);
-            *(bf4 *)&Gs[buf][row][c] = v;
+            for (int e = 0; e < 4; e++) g[e] = act_out ? (mr[i][e] > 0.0f ? gr[i][e] : gr[i][e] * slope) : gr[i][e];
+            split4<NTERM>(g, &Gs(buf)[row][c], &Gl(buf)[row][c]);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {                       // transposed: element (n = row, k = c + e) -> Wt[c + e][row]
             const int idx = threadIdx.x + 256 * i, row = idx >> 4, c = (idx & 15) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; e++) Wt[buf][c + e][row] = (__bf16)wr[i][e];
+            for (int e = 0; e < 4; e++) {
+                const __bf16 hh = (__bf16)wr[i][e];
+                Wt(buf)[c + e][row] = hh;
+                if (NTERM > 1) Wl(buf)[c + e][row] = (__bf16)(wr[i][e] - (float)hh);
+            }
         }
     };
     load_tiles(n_begin);
@@ -335,10 +348,17 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restr
         if (more) load_tiles(n0 + DXN);                     // next tile's global loads in flight during this tile's MFMAs
 #pragma unroll
         for (int st = 0; st < DXN / TK; st++) {
-            const bf16x8 a = *(const bf16x8 *)&Gs[buf][w * TM + li][st * TK + kb];
+            const bf16x8 a = *(const bf16x8 *)&Gs(buf)[w * TM + li][st * TK + kb];
+            bf16x8 al;
+            if (NTERM > 1) al = *(const bf16x8 *)&Gl(buf)[w * TM + li][st * TK + kb];
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                const bf16x8 b = *(const bf16x8 *)&Wt[buf][t * TN + li][st * TK + kb];
+                const bf16x8 b = *(const bf16x8 *)&Wt(buf)[t * TN + li][st * TK + kb];
+                if (NTERM > 1) {
+                    const bf16x8 bl = *(const bf16x8 *)&Wl(buf)[t * TN + li][st * TK + kb];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc[t], 0, 0, 0);
+                }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
             }
         }
@@ -366,10 +386,18 @@ __global__ __launch_bounds__(256) void linear_dx_reduce_kernel(const float *__re
 {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= MK) return;
-    f4 a = *(const f4 *)(part + i);
-    for (int s = 1; s < S; s++) a += *(const f4 *)(part + (size_t)s * MK + i);
+    if ((MK & 3) == 0) {
+        f4 a = *(const f4 *)(part + i);
+        for (int s = 1; s < S; s++) a += *(const f4 *)(part + (size_t)s * MK + i);
 #pragma unroll
-    for (int e = 0; e < 4; e++) gx[i + e] = (XT)a[e];
+        for (int e = 0; e < 4; e++) gx[i + e] = (XT)a[e];
+    } else {
+        for (int e = 0; e < 4 && i + e < MK; e++) {
+            float a = part[i + e];
+            for (int s = 1; s < S; s++) a += part[(size_t)s * MK + i + e];
+            gx[i + e] = (XT)a;
+        }
+    }
 }
 
 // dW[N,K] = G^T[N,M] X[M,K] (+ gbias[n] = sum_m G[m][n]): workgroup = 32 n-rows x 128 k-columns (wave w: k tile w), contraction over m in
@@ -381,21 +409,22 @@ constexpr int DWP = DWM + 8;             // pitch in elements (16-byte aligned r
 
 template <typename XT> struct XPair;     // the float4 / 4 x bf16 of rows 2p and 2p+1 at columns c..c+3 -> four packed bf16 pairs
 template <> struct XPair<float> {
-    __device__ static __forceinline__ void load(const float *x, size_t o0, size_t o1, bool ok0, bool ok1, float (&a)[4], float (&b)[4])
+    // c .. c + 3 of rows o0 / o1 (row starts), columns beyond `end` are zeros; vec: the rows are 16-byte aligned
+    __device__ static __forceinline__ void load(const float *r0, const float *r1, int c, int end, bool ok0, bool ok1, bool vec, float (&a)[4], float (&b)[4])
     {
-        const f4 v0 = ok0 ? *(const f4 *)(x + o0) : (f4){0, 0, 0, 0}, v1 = ok1 ? *(const f4 *)(x + o1) : (f4){0, 0, 0, 0};
+        const f4 v0 = load4_checked(r0, c, end, ok0, vec), v1 = load4_checked(r1, c, end, ok1, vec);
 #pragma unroll
         for (int e = 0; e < 4; e++) { a[e] = v0[e]; b[e] = v1[e]; }
     }
 };
 template <> struct XPair<__bf16> {
-    __device__ static __forceinline__ void load(const __bf16 *x, size_t o0, size_t o1, bool ok0, bool ok1, float (&a)[4], float (&b)[4])
+    __device__ static __forceinline__ void load(const __bf16 *r0, const __bf16 *r1, int c, int end, bool ok0, bool ok1, bool, float (&a)[4], float (&b)[4])
     {
         bf4 v0, v1;
 #pragma unroll
         for (int e = 0; e < 4; e++) v0[e] = v1[e] = (__bf16)0.0f;
-        if (ok0) v0 = *(const bf4 *)(x + o0);
-        if (ok1) v1 = *(const bf4 *)(x + o1);
+        if (ok0 && c < end) v0 = *(const bf4 *)(r0 + c);
+        if (ok1 && c < end) v1 = *(const bf4 *)(r1 + c);
 #pragma unroll
         for (int e = 0; e < 4; e++) { a[e] = (float)v0[e]; b[e] = (float)v1[e]; }
     }
@@ -406,44 +435,58 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
     return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
 }
 
-template <typename XT>
+constexpr size_t linear_dw_lds(int nterm) { return (size_t)(TM + DWK) * DWP * 2 * (nterm > 1 ? 2 : 1); }
+
+// two values -> one packed {lo, hi} bf16 pair per part (hi part, and the split residue for NTERM = 3)
+template <int NTERM>
+__device__ __forceinline__ void pack_split(float v0, float v1, unsigned *hi, unsigned *lo)
+{
+    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+    *hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    if (NTERM > 1) {
+        const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
+        *lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+}
+
+template <typename XT, int NTERM>
 __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float *__restrict__ gy, const float *__restrict__ act_out,
                                                             const XT *__restrict__ x, int M, int N, int K, float slope,
                                                             float *__restrict__ gW, float *__restrict__ gbias)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 Gt[TM][DWP];
-    __shared__ __attribute__((aligned(16))) __bf16 Xt[DWK][DWP];
-    __shared__ float bsum_s[8][TM];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __bf16 (*Tile)[DWP];
+    const Tile Gt = (Tile)smem, Xt = (Tile)(smem + (size_t)TM * DWP * 2);                                 // [TM][DWP], [DWK][DWP]
+    const Tile Gl = (Tile)(smem + (size_t)(TM + DWK) * DWP * 2), Xl = (Tile)(smem + (size_t)(2 * TM + DWK) * DWP * 2);   // lo parts (NTERM = 3)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n0 = blockIdx.y * TM, k0 = blockIdx.x * DWK;
     const int li = lane & 31, mb = (lane >> 5) * 8;
+    const bool vecN = (N & 3) == 0, vecK = (K & 3) == 0;
     f16v acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-    float bsum = 0.0f;                                      // thread (pair p, quad q) accumulates G over its rows for columns 4q..4q+3 -> gbias
-    float bs4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float bs4[4] = {0.0f, 0.0f, 0.0f, 0.0f};               // thread (pair p, quad q): sums of G over its rows for columns 4q..4q+3 -> gbias
     for (int mt = 0; mt < M; mt += DWM) {
         // G tile: 128 m x 32 n = 64 row pairs x 8 column quads = 512 items, 2 per thread
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int idx = threadIdx.x + 256 * i, q = idx & 7, p = idx >> 3;
             const int ma = mt + 2 * p, c = n0 + 4 * q;
-            const bool ok0 = ma < M && c < N, ok1 = ma + 1 < M && c < N;
-            const size_t o0 = (size_t)ma * N + c, o1 = o0 + N;
+            const bool ok0 = ma < M, ok1 = ma + 1 < M;
             float a[4], b[4], ma4[4], mb4[4];
-            XPair<float>::load(gy, o0, o1, ok0, ok1, a, b);
+            XPair<float>::load(gy + (size_t)ma * N, gy + (size_t)(ma + 1) * N, c, N, ok0, ok1, vecN, a, b);
             if (act_out) {
-                XPair<float>::load(act_out, o0, o1, ok0, ok1, ma4, mb4);
+                XPair<float>::load(act_out + (size_t)ma * N, act_out + (size_t)(ma + 1) * N, c, N, ok0, ok1, vecN, ma4, mb4);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    a[e] = (ok0 && !(ma4[e] > 0.0f)) ? a[e] * slope : a[e];
-                    b[e] = (ok1 && !(mb4[e] > 0.0f)) ? b[e] * slope : b[e];
+                    a[e] = (ok0 && c + e < N && !(ma4[e] > 0.0f)) ? a[e] * slope : a[e];
+                    b[e] = (ok1 && c + e < N && !(mb4[e] > 0.0f)) ? b[e] * slope : b[e];
                 }
             }
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 bs4[e] += a[e] + b[e];
-                *(unsigned *)&Gt[4 * q + e][2 * p] = pack_bf16x2(a[e], b[e]);
+                pack_split<NTERM>(a[e], b[e], (unsigned *)&Gt[4 * q + e][2 * p], (unsigned *)&Gl[4 * q + e][2 * p]);
             }
         }
         // X tile: 128 m x 128 k = 64 row pairs x 32 column quads = 2048 items, 8 per thread
@@ -451,26 +494,31 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float *__restr
         for (int i = 0; i < 8; i++) {
             const int idx = threadIdx.x + 256 * i, q = idx & 31, p = idx >> 5;
             const int ma = mt + 2 * p, c = k0 + 4 * q;
-            const bool ok0 = ma < M && c < K, ok1 = ma + 1 < M && c < K;
+            const bool ok0 = ma < M, ok1 = ma + 1 < M;
             float a[4], b[4];
-            XPair<XT>::load(x, (size_t)ma * K + c, (size_t)(ma + 1) * K + c, ok0, ok1, a, b);
+            XPair<XT>::load(x + (size_t)ma * K, x + (size_t)(ma + 1) * K, c, K, ok0, ok1, vecK, a, b);
 #pragma unroll
-            for (int e = 0; e < 4; e++) *(unsigned *)&Xt[4 * q + e][2 * p] = pack_bf16x2(a[e], b[e]);
+            for (int e = 0; e < 4; e++) pack_split<NTERM>(a[e], b[e], (unsigned *)&Xt[4 * q + e][2 * p], (unsigned *)&Xl[4 * q + e][2 * p]);
         }
         __syncthreads();
 #pragma unroll
         for (int st = 0; st < DWM / TK; st++) {
             const bf16x8 a = *(const bf16x8 *)&Gt[li][st * TK + mb];
             const bf16x8 b = *(const bf16x8 *)&Xt[w * TN + li][st * TK + mb];
+            if (NTERM > 1) {
+                const bf16x8 al = *(const bf16x8 *)&Gl[li][st * TK + mb];
+                const bf16x8 bl = *(const bf16x8 *)&Xl[w * TN + li][st * TK + mb];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc, 0, 0, 0);
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
         __syncthreads();
     }
-    (void)bsum;
     if (gbias && blockIdx.x == 0) {
         // column sums of G: thread (p, q) of item slots i = 0, 1 holds partial sums of columns 4q..4q+3 over its row pairs; the 64 threads
-        // sharing q (p = idx >> 3 over both slots) are combined in a fixed order through LDS
-        __shared__ float bred[256][4];
+        // sharing q (p = idx >> 3 over both slots) are combined in a fixed order through LDS (the operand tiles are no longer needed)
+        float (*bred)[4] = (float (*)[4])smem;
 #pragma unroll
         for (int e = 0; e < 4; e++) bred[threadIdx.x][e] = bs4[e];
         __syncthreads();
@@ -595,12 +643,23 @@ extern "C" size_t psi_linear_backward_workspace_floats(int M, int N, int K)
     return s > 1 ? (size_t)s * M * K : 0;
 }
 
-extern "C" int psi_linear_backward(const float *gy, const float *act_out, const void *x, int x_is_bf16, const float *W, int M, int N, int K,
-                                   float slope, void *gx, float *gW, float *gbias, float *ws, void *stream)
+static hipError_t set_lds_once(const void *kern, size_t lds, std::atomic<unsigned long long> &done)
 {
-    PSI_REQUIRE(gy && x && W, "null pointer");
-    PSI_REQUIRE(M > 0 && N > 0 && K > 0 && N % 16 == 0 && K % 4 == 0, "N must be a positive multiple of 16 and K of 4");
-    hipStream_t st = (hipStream_t)stream;
+    if (lds <= 48 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
+template <typename XT, int NTERM>
+static int linear_backward_t(const float *gy, const float *act_out, const void *x, const float *W, int M, int N, int K, float slope, void *gx,
+                             float *gW, float *gbias, float *ws, hipStream_t st)
+{
     if (gx) {
         int S = pick_nsplit(M, N, K), nchunk = N;
         if (S > 1) {
@@ -610,26 +669,42 @@ extern "C" int psi_linear_backward(const float *gy, const float *act_out, const 
         }
         float *part = S > 1 ? ws : nullptr;
         dim3 grid(psi_cdiv(K, DXK), psi_cdiv(M, 128), S);
-        if (x_is_bf16)
-            hipLaunchKernelGGL(linear_bwd_dx_kernel<__bf16>, grid, dim3(256), 0, st, gy, act_out, W, M, N, K, slope, (__bf16 *)gx, nchunk, part);
-        else
-            hipLaunchKernelGGL(linear_bwd_dx_kernel<float>, grid, dim3(256), 0, st, gy, act_out, W, M, N, K, slope, (float *)gx, nchunk, part);
+        static std::atomic<unsigned long long> a_dx{0};
+        PSI_CHECK_HIP(set_lds_once((const void *)linear_bwd_dx_kernel<XT, NTERM>, linear_dx_lds(NTERM), a_dx));
+        hipLaunchKernelGGL((linear_bwd_dx_kernel<XT, NTERM>), grid, dim3(256), linear_dx_lds(NTERM), st, gy, act_out, W, M, N, K, slope, (XT *)gx, nchunk, part);
         PSI_CHECK_LAUNCH("linear_bwd_dx_kernel");
         if (S > 1) {
             const size_t MK = (size_t)M * K;
-            const dim3 rg((unsigned)psi_cdiv((long)(MK / 4), 256));
-            if (x_is_bf16) hipLaunchKernelGGL(linear_dx_reduce_kernel<__bf16>, rg, dim3(256), 0, st, (const float *)part, S, MK, (__bf16 *)gx);
-            else hipLaunchKernelGGL(linear_dx_reduce_kernel<float>, rg, dim3(256), 0, st, (const float *)part, S, MK, (float *)gx);
+            const dim3 rg((unsigned)psi_cdiv((long)((MK + 3) / 4), 256));
+            hipLaunchKernelGGL(linear_dx_reduce_kernel<XT>, rg, dim3(256), 0, st, (const float *)part, S, MK, (XT *)gx);
             PSI_CHECK_LAUNCH("linear_dx_reduce_kernel");
         }
     }
     if (gW) {
         dim3 grid(psi_cdiv(K, DWK), psi_cdiv(N, TM));
-        if (x_is_bf16)
-            hipLaunchKernelGGL(linear_bwd_dw_kernel<__bf16>, grid, dim3(256), 0, st, gy, act_out, (const __bf16 *)x, M, N, K, slope, gW, gbias);
-        else
-            hipLaunchKernelGGL(linear_bwd_dw_kernel<float>, grid, dim3(256), 0, st, gy, act_out, (const float *)x, M, N, K, slope, gW, gbias);
+        static std::atomic<unsigned long long> a_dw{0};
+        PSI_CHECK_HIP(set_lds_once((const void *)linear_bwd_dw_kernel<XT, NTERM>, linear_dw_lds(NTERM), a_dw));
+        hipLaunchKernelGGL((linear_bwd_dw_kernel<XT, NTERM>), grid, dim3(256), linear_dw_lds(NTERM), st, gy, act_out, (const XT *)x, M, N, K, slope, gW, gbias);
         PSI_CHECK_LAUNCH("linear_bwd_dw_kernel");
     }
     return 0;
+}
+
+extern "C" int psi_linear_backward(const float *gy, const float *act_out, const void *x, int x_is_bf16, const float *W, int M, int N, int K,
+                                   float slope, void *gx, float *gW, float *gbias, float *ws, void *stream)
+{
+    PSI_REQUIRE(gy && x && W, "null pointer");
+    PSI_REQUIRE(M > 0 && N > 0 && K > 0 && N % 16 == 0 && K % 4 == 0, "N must be a positive multiple of 16 and K of 4");
+    if (x_is_bf16) return linear_backward_t<__bf16, 1>(gy, act_out, x, W, M, N, K, slope, gx, gW, gbias, ws, (hipStream_t)stream);
+    return linear_backward_t<float, 1>(gy, act_out, x, W, M, N, K, slope, gx, gW, gbias, ws, (hipStream_t)stream);
+}
+
+// The backward of psi_linear_forward3: the same two products with three-term split operands (the fp32 model's precision), fp32 x, ANY N and K
+// (rows that are not 16-byte aligned are gathered element by element).  Same arguments and workspace as psi_linear_backward.
+extern "C" int psi_linear_backward3(const float *gy, const float *act_out, const float *x, const float *W, int M, int N, int K, float slope,
+                                    float *gx, float *gW, float *gbias, float *ws, void *stream)
+{
+    PSI_REQUIRE(gy && x && W, "null pointer");
+    PSI_REQUIRE(M > 0 && N > 0 && K > 0, "bad sizes");
+    return linear_backward_t<float, 3>(gy, act_out, x, W, M, N, K, slope, gx, gW, gbias, ws, (hipStream_t)stream);
 }

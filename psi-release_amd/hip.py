@@ -52,6 +52,7 @@ SIGNATURES = {
     'psi_linear_backward_workspace_floats': (c_size_t, [c_int, c_int, c_int]),
     'psi_linear_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
+    'psi_linear_backward3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'psi_fit_create': (c_int, [c_void_p] * 17),
     'psi_fit_destroy': (None, [c_void_p]),
     'psi_fit_set_problem': (c_int, [c_void_p] * 4 + [c_int, c_void_p]),

@@ -527,8 +527,8 @@ def conv3x3(x, conv):
 # quantifies it: 0.6-3.2e-5 of the reference's recorded forward passes, tests/golden/cvae.npz).  Forward: psi_conv2d_forward (ALL the
 # convolutions: 7x7 stem, stride-1 / stride-2 3x3, 1x1 downsample, heads), psi_bn_forward_t (batch or running statistics, + ReLU + skip),
 # psi_maxpool3x3s2_forward_t, psi_linear_forward3 (any width).  Backward: BatchNorm and max-pool on the same hand-written kernels, the
-# convolutions' input and weight gradients on psi_conv2d_input_grad / psi_conv2d_weight_grad (same split products); the dense layers'
-# gradient GEMMs through the library in fp32 (matmul) on the saved fp32 operands.
+# convolutions' input and weight gradients on psi_conv2d_input_grad / psi_conv2d_weight_grad and the dense layers' on psi_linear_backward3
+# (the same split products).
 # ------------------------------------------------------------------------------------------------------------------
 def conv2d_supported(conv):
     return (conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros' and conv.kernel_size[0] == conv.kernel_size[1]
@@ -698,7 +698,7 @@ def maxpool3x3s2_t(x):
 
 class _LinearAct3(Function):
     """nn.Linear (+ LeakyReLU, + skip connection) at the fp32 model's precision: ONE hand-written kernel forward (psi_linear_forward3: three-term
-    split products, any width), the two gradient GEMMs through the library in fp32."""
+    split products, any width) and per gradient (psi_linear_backward3: dX, dW + dbias with the same products)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, act, slope):
@@ -724,11 +724,23 @@ class _LinearAct3(Function):
     def backward(ctx, gy):
         xc, w, a_out = ctx.saved_tensors
         gy = gy.contiguous().float()
-        g = gy if not ctx.act else torch.where(a_out > 0, gy, gy * ctx.slope)
-        gx = g @ w if ctx.needs_input_grad[0] else None
-        gw = g.t() @ xc if ctx.needs_input_grad[1] else None
-        gb = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return gx, gw, gb, gy if (ctx.has_res and ctx.needs_input_grad[3]) else None, None, None
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if os.environ.get('PSI_HIP_LINEAR3_BWD', '1') == '0':
+            # PSI_HIP_LINEAR3_BWD=0: the two gradient GEMMs through the library (hipBLASLt, fp32) on the saved operands
+            g = gy if not ctx.act else torch.where(a_out > 0, gy, gy * ctx.slope)
+            return (g @ w if need_x else None, g.t() @ xc if need_w else None, g.sum(0) if need_b else None,
+                    gy if (ctx.has_res and ctx.needs_input_grad[3]) else None, None, None)
+        M, K = xc.shape
+        N = w.shape[0]
+        gx = torch.empty(M, K, device=gy.device) if need_x else None
+        gw = torch.empty(N, K, device=gy.device) if (need_w or need_b) else None         # gbias is produced by the dW kernel
+        gb = torch.empty(N, device=gy.device) if need_b else None
+        L = hip.lib()
+        nws = L.psi_linear_backward_workspace_floats(M, N, K) if need_x else 0
+        ws = torch.empty(nws, device=gy.device) if nws else None
+        hip.check(L.psi_linear_backward3(hip.ptr(gy), hip.ptr(a_out) if ctx.act else None, hip.ptr(xc), hip.ptr(w), M, N, K, ctx.slope, hip.ptr(gx),
+                                         hip.ptr(gw), hip.ptr(gb), hip.ptr(ws), hip.stream()), 'psi_linear_backward3')
+        return gx, gw if need_w else None, gb, gy if (ctx.has_res and ctx.needs_input_grad[3]) else None, None, None
 
 
 def linear_act3(x, weight, bias=None, act=None, slope=0.01, residual=None):
