@@ -680,8 +680,8 @@ def bench_fitting(args):
             except Exception as e:
                 out['secondary']['train_s2'] = {'error': repr(e)}
             # the same step at the REFERENCE's precision (fp32 model, cvae.py:427-455): what `train_s1/s2.py` run out of the box (`--bf16 0` is
-            # their default: a drop-in must not change a checkpoint's arithmetic silently); the trunk then stays with MIOpen / hipBLASLt in
-            # fp32 — the hand-written convolution / BN / dense kernels are the bf16 mode's
+            # their default: a drop-in must not change a checkpoint's arithmetic silently) — since round 5 on hand-written kernels as well:
+            # fp32 maps, three-term split products on the bf16 matrix cores with fp32 accumulation (conv_gemm.hip, linear.hip, bnorm.hip)
             try:
                 import contextlib
                 import io
@@ -742,10 +742,10 @@ def bench_train_s2(args):
         # (counted with the hand-written convolution / dense / BN ops switched off: the flop counter only sees aten operators, and the
         # arithmetic of the model is the same on either path)
         flops = None
-        saved_env = {k: os.environ.get(k) for k in ('PSI_HIP_CONV', 'PSI_HIP_LINEAR', 'PSI_HIP_BN')}
+        saved_env = {k: os.environ.get(k) for k in ('PSI_HIP_CONV', 'PSI_HIP_LINEAR', 'PSI_HIP_BN', 'PSI_HIP_PRECISE', 'PSI_HIP_CONV2')}
         try:
             from torch.utils.flop_counter import FlopCounterMode
-            os.environ.update(PSI_HIP_CONV='0', PSI_HIP_LINEAR='0', PSI_HIP_BN='0')
+            os.environ.update(PSI_HIP_CONV='0', PSI_HIP_LINEAR='0', PSI_HIP_BN='0', PSI_HIP_PRECISE='0', PSI_HIP_CONV2='0')
             running = {k: v.clone() for k, v in op.model_h.state_dict().items() if 'running_' in k or 'num_batches' in k}
             with FlopCounterMode(display=False) as fc:
                 op.optimizer_h.zero_grad(set_to_none=True)
@@ -786,10 +786,16 @@ def bench_train_s2(args):
                            'note': 'matrix-core flops counted by torch.utils.flop_counter over one forward+backward (library path; the hand-written '
                                    'conv / dense kernels do the same arithmetic); a step is a chain of small (128-row) GEMMs/convs and elementwise '
                                    'passes, bound by launch count and activation traffic, not by the MFMA pipe',
-                           'hand_written': 'conv3x3 forward + input gradient + weight gradient (conv.hip), dense layers forward + backward (linear.hip), '
-                                           'BatchNorm + ReLU + skip (bnorm.hip), stem max-pool, the loss glue of cal_loss (cvae_loss.hip, scene_loss.hip), '
-                                           'body decode / NN / SDF operators; library (MIOpen, measured solver search): 7x7 stem, strided 3x3 and 1x1 '
-                                           'convolutions, the 128 -> 32 head convolution'}
+                           'hand_written': ('bf16 mode: stride-1 3x3 convolutions forward + input gradient + weight gradient (conv.hip), every other '
+                                            'convolution (7x7 stem, strided 3x3, 1x1 downsample, 128 -> 32 head) forward + both gradients on the general '
+                                            'implicit-GEMM kernel with bf16 products (conv_gemm.hip), dense layers forward + backward (linear.hip), BatchNorm + '
+                                            'ReLU + skip (bnorm.hip), stem max-pool' if args.bf16 else
+                                            'fp32 mode (the reference\'s precision): EVERY convolution forward + input gradient + weight gradient on the general '
+                                            'implicit-GEMM kernel with three-term split products (conv_gemm.hip), every dense layer forward + backward likewise '
+                                            '(linear.hip: psi_linear_forward3 / _backward3), BatchNorm + ReLU + skip and max-pool on fp32 maps (bnorm.hip) — no '
+                                            'MIOpen / hipBLASLt kernel is left in the step (profiles/r05_train_s2_fp32_kernel_stats.csv)') +
+                                           '; the loss glue of cal_loss (cvae_loss.hip, scene_loss.hip), body decode / NN / SDF operators; aten: fused Adam, '
+                                           'gradient accumulation adds, weight re-layout copies'}
     try:
         res['conv_kernel_roofline'] = conv_kernel_roofline(dev, B)
     except Exception as e:

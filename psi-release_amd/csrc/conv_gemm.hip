@@ -19,6 +19,10 @@
 // consecutive channels of ONE filter tap: 256 contiguous bytes per pixel.  The stem (Cin = 2, K = 98) takes the element-wise gather path.
 #include "psi_internal.h"
 #include <atomic>
+#include <stdlib.h>
+#ifndef PSI_CONV_BM_DEFAULT
+#define PSI_CONV_BM_DEFAULT 64
+#endif
 
 namespace {
 
@@ -28,7 +32,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, KC = 64, PITCH = KC + 8;
+constexpr int KC = 64, PITCH = KC + 8;
 
 __device__ __forceinline__ float bf_round(float v, __bf16 &hi)
 {
@@ -78,6 +82,8 @@ __device__ __forceinline__ void load16(const __bf16 *p, bool ok, float (&v)[16])
 }
 __device__ __forceinline__ float ldf(const float *p) { return *p; }
 __device__ __forceinline__ float ldf(const __bf16 *p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void loadN(const T *p, bool ok, float (&v)[32]) { load32(p, ok, v); }
+template <typename T> __device__ __forceinline__ void loadN(const T *p, bool ok, float (&v)[16]) { load16(p, ok, v); }
 
 __device__ __forceinline__ void store_out(float *y, const float (&v)[4]) { *(f4 *)y = (f4){v[0], v[1], v[2], v[3]}; }
 __device__ __forceinline__ void store_out(__bf16 *y, const float (&v)[4])
@@ -107,16 +113,21 @@ __device__ __forceinline__ void split_store(const float (&v)[NV], __bf16 *hi, __
     }
 }
 
-template <int NTERM, typename TIN, typename TOUT, int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const TIN *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+template <int NTERM, typename TIN, typename TOUT, int BN, int BM, bool RUNS>
+__global__ __launch_bounds__(256, BM == 64 ? 4 : 2) void conv_gemm_kernel(const TIN *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                                                            TOUT *__restrict__ y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH,
                                                            int KW, int stride, int pad, int transposed)
 {
     // transposed != 0: the INPUT GRADIENT of a convolution — "x" is dY [N,H,W,Cin] (H x W = the forward's output size, Cin = its Cout), "y" is
     // dX [N,OH,OW,Cout] (the forward's input), w = the forward weight re-laid out as [Cin_fwd][KH][KW][Cout_fwd]; output pixel (iy, ix) takes
     // tap (kh, kw) from dY[(iy + pad - kh) / stride, (ix + pad - kw) / stride] where that division is exact (no weight flip in this form)
-    static_assert(BN == 64 || BN == 32, "output-channel tile");
-    constexpr int NCT = BN / 32;                                   // 32-channel MFMA tiles per wave
+    // BM = 128 pixels per workgroup (wave w = pixel tile w, all channel tiles), or 64 (waves = 2 pixel tiles x 2 channel tiles): the small
+    // tile has half the LDS and registers, FOUR workgroups fit a compute unit instead of two — the kernel waits for its global loads once per
+    // 64-wide K chunk (one chunk's MFMAs are ~0.3 us, a load round trip ~1.5 us), and more resident workgroups are what covers that
+    static_assert((BN == 64 || BN == 32) && (BM == 128 || BM == 64) && !(BN == 32 && BM == 64), "tile shape");
+    constexpr int NCT = BN / 32;                                   // 32-channel MFMA tiles of the workgroup
+    constexpr int WPX = BM / 32, WCO = 4 / WPX, CPW = NCT / WCO;   // waves along pixels / channels; channel tiles per wave
+    constexpr int APT = BM * KC / 256;                             // input elements per thread and chunk (32 or 16)
     constexpr int WPT = BN * KC / 256;                             // weight elements per thread and chunk (16 or 8)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 (*Ah)[PITCH] = (__bf16 (*)[PITCH])smem;                                           // [BM][PITCH]   pixels, hi
@@ -128,67 +139,113 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const TIN *__restrict
     const long M = (long)N * OH * OW;
     const long m0 = (long)blockIdx.x * BM;
     const int co0 = blockIdx.y * BN;
-    const int K = KH * KW * Cin, nck = (K + KC - 1) / KC;
-    const bool fast = (Cin % KC) == 0;                             // a chunk = 64 consecutive channels of one tap
-    // ---- this thread's share of a chunk: pixel row ar (32 of its 64 elements), filter row br (WPT of its 64)
-    const int ar = t >> 1, ah = (t & 1) * 32;
+    const int K = KH * KW * Cin;
+    // how a thread's run of APT consecutive k of a chunk is fetched:
+    //   RUNS    Cin % APT == 0: the run lies inside ONE filter tap — APT consecutive channels of one pixel, vector loads;
+    //   ROWS    small Cin (Cin * KW <= 16: the 7x7 stem, Cin = 2): k is re-indexed as (kh, 16 slots) — the Cin * KW values of one filter ROW are
+    //           contiguous in an NHWC map (14 floats for the stem), a thread fetches one such row per 16 slots, two slots stay zero;
+    //   GATHER  anything else: element by element.
+    const int rowlen = Cin * KW;
+    const int mode = RUNS ? 0 : ((rowlen <= 16 && !transposed) ? 1 : 2);      // (RUNS <=> Cin % APT == 0: decided at launch, its own instantiation)
+    const int Keff = mode == 1 ? KH * 16 : K;
+    const int nck = (Keff + KC - 1) / KC;
+    // ---- this thread's share of a chunk: pixel row ar (APT of its 64 elements), filter row br (WPT of its 64)
+    const int ar = t / (KC / APT), ah = (t % (KC / APT)) * APT;
+    // pixel order.  The input gradient of a stride-2 convolution (transposed != 0) takes a tap only where (i + pad - k) is even: the pixels are
+    // numbered CLASS-major (class = parity of (iy, ix)) so that a workgroup's pixels share their class — a tap is then valid for all of them or
+    // for none, and the chunks of the other 5-8 of 9 taps are skipped outright (they would multiply zeros)
+    const bool classes = transposed && stride == 2 && (OH & 1) == 0 && (OW & 1) == 0 && ((M / 4) % BM) == 0;
+    const long Mq = M / 4;
+    auto pixel = [&](long m, int &n, int &oy, int &ox) {
+        if (classes) {
+            const int cls = (int)(m / Mq);
+            const long r = m - (long)cls * Mq;
+            const int OHq = OH >> 1, OWq = OW >> 1;
+            n = (int)(r / ((long)OHq * OWq));
+            const int rem = (int)(r - (long)n * OHq * OWq);
+            oy = 2 * (rem / OWq) + (cls >> 1);
+            ox = 2 * (rem % OWq) + (cls & 1);
+        } else {
+            n = (int)(m / ((long)OH * OW));
+            const int rem = (int)(m - (long)n * OH * OW);
+            oy = rem / OW;
+            ox = rem - oy * OW;
+        }
+    };
+    const int wg_cls = classes ? (int)(m0 / Mq) : 0;
     const long am = m0 + ar;
     const bool a_live = am < M;
     int an = 0, aoy = 0, aox = 0;
-    if (a_live) {
-        an = (int)(am / ((long)OH * OW));
-        const int rem = (int)(am - (long)an * OH * OW);
-        aoy = rem / OW;
-        aox = rem - aoy * OW;
-    }
+    if (a_live) pixel(am, an, aoy, aox);
     const int br = t / (KC / WPT), bq = (t % (KC / WPT)) * WPT;
     const float *wrow = w + (size_t)(co0 + br) * K;
-    float av[32], bv[WPT];
+    float av[APT], bv[WPT];
+    auto src = [&](int kh, int kw, int &iy, int &ix) {            // input pixel of tap (kh, kw) for my output pixel; false: outside / no such tap
+        if (transposed) {
+            const int ty = aoy + pad - kh, tx = aox + pad - kw;
+            iy = ty / stride;
+            ix = tx / stride;
+            return ty >= 0 && tx >= 0 && iy * stride == ty && ix * stride == tx && iy < H && ix < W;
+        }
+        iy = aoy * stride - pad + kh;
+        ix = aox * stride - pad + kw;
+        return iy >= 0 && iy < H && ix >= 0 && ix < W;
+    };
+    auto chunk_live = [&](int ck) {                                // (workgroup-uniform) does any tap of this chunk exist for this pixel class?
+        if (!classes) return true;
+        const int t0 = (ck * KC) / Cin, t1 = min((ck * KC + KC - 1) / Cin, KH * KW - 1);
+        for (int tp = t0; tp <= t1; tp++) {
+            const int kh = tp / KW, kw = tp - kh * KW;
+            if ((((wg_cls >> 1) + pad - kh) & 1) == 0 && (((wg_cls & 1) + pad - kw) & 1) == 0) return true;
+        }
+        return false;
+    };
     auto load_chunk = [&](int ck) {
-        if (fast) {
-            const int cpt = Cin / KC, tap = ck / cpt, c0 = (ck - tap * cpt) * KC;
+        if (mode == 0) {
+            const int k0r = ck * KC + ah;                          // my run: one tap, channels c0 .. c0 + APT
+            const int tap = k0r / Cin, c0 = k0r - tap * Cin;
             const int kh = tap / KW, kw = tap - kh * KW;
-            int iy, ix;
-            bool ok = a_live;
-            if (transposed) {
-                const int ty = aoy + pad - kh, tx = aox + pad - kw;
-                iy = ty / stride;
-                ix = tx / stride;
-                ok = ok && ty >= 0 && tx >= 0 && iy * stride == ty && ix * stride == tx && iy < H && ix < W;
-            } else {
-                iy = aoy * stride - pad + kh;
-                ix = aox * stride - pad + kw;
-                ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            }
-            load32(x + (((size_t)an * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + c0 + ah, ok, av);
+            int iy = 0, ix = 0;
+            const bool ok = a_live && k0r < K && src(kh, kw, iy, ix);
+            loadN(x + (((size_t)an * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + (ok ? c0 : 0), ok, av);
+            const bool wok = ck * KC + bq < K;
 #pragma unroll
             for (int i = 0; i < WPT / 4; i++) {
-                const f4 a = *(const f4 *)(wrow + (size_t)ck * KC + bq + 4 * i);
+                const f4 a = wok ? *(const f4 *)(wrow + (size_t)ck * KC + bq + 4 * i) : (f4){0, 0, 0, 0};
 #pragma unroll
                 for (int e = 0; e < 4; e++) bv[4 * i + e] = a[e];
             }
+        } else if (mode == 1) {
+#pragma unroll
+            for (int r0 = 0; r0 < APT; r0 += 16) {                 // one filter row per 16 slots
+                const int kh = (ck * KC + ah + r0) >> 4;
+                const int iy = aoy * stride - pad + kh, ixb = aox * stride - pad;
+                const bool rok = a_live && kh < KH && iy >= 0 && iy < H;
+                const TIN *row = x + ((size_t)an * H + (rok ? iy : 0)) * W * Cin;
+                int kw = 0, ci = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int ix = ixb + kw;
+                    av[r0 + j] = (rok && j < rowlen && ix >= 0 && ix < W) ? ldf(row + (size_t)ix * Cin + ci) : 0.0f;
+                    if (++ci == Cin) { ci = 0; kw++; }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < WPT; e++) {
+                const int kk = ck * KC + bq + e, kh = kk >> 4, j = kk & 15;
+                bv[e] = (kh < KH && j < rowlen) ? wrow[kh * rowlen + j] : 0.0f;
+            }
         } else {
-            // any Cin (the stem: Cin = 2, K = 98): element k = (tap, ci), gathered one by one; rows beyond K are zeros
+            // element k = (tap, ci), gathered one by one; rows beyond K are zeros
 #pragma unroll 8
-            for (int e = 0; e < 32; e++) {
+            for (int e = 0; e < APT; e++) {
                 const int k = ck * KC + ah + e;
                 float v = 0.0f;
                 if (a_live && k < K) {
                     const int tap = k / Cin, ci = k - tap * Cin;
                     const int kh = tap / KW, kw = tap - kh * KW;
                     int iy, ix;
-                    bool ok;
-                    if (transposed) {
-                        const int ty = aoy + pad - kh, tx = aox + pad - kw;
-                        iy = ty / stride;
-                        ix = tx / stride;
-                        ok = ty >= 0 && tx >= 0 && iy * stride == ty && ix * stride == tx && iy < H && ix < W;
-                    } else {
-                        iy = aoy * stride - pad + kh;
-                        ix = aox * stride - pad + kw;
-                        ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                    }
-                    if (ok) v = ldf(x + (((size_t)an * H + iy) * W + ix) * Cin + ci);
+                    if (src(kh, kw, iy, ix)) v = ldf(x + (((size_t)an * H + iy) * W + ix) * Cin + ci);
                 }
                 av[e] = v;
             }
@@ -199,28 +256,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const TIN *__restrict
             }
         }
     };
-    f16v acc[NCT];
+    const int wpt = wv % WPX, wc0 = (wv / WPX) * CPW;              // this wave's pixel tile and first channel tile
+    f16v acc[CPW];
 #pragma unroll
-    for (int c = 0; c < NCT; c++)
+    for (int c = 0; c < CPW; c++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[c][i] = 0.0f;
-    load_chunk(0);
-    for (int ck = 0; ck < nck; ck++) {
+    int ck = 0;
+    while (ck < nck && !chunk_live(ck)) ck++;
+    if (ck < nck) load_chunk(ck);
+    while (ck < nck) {
+        int nx = ck + 1;
+        while (nx < nck && !chunk_live(nx)) nx++;
         __syncthreads();                                           // the previous chunk's MFMAs are done with LDS
-        split_store<NTERM, 32>(av, &Ah[ar][ah], &Al[ar][ah]);
+        split_store<NTERM, APT>(av, &Ah[ar][ah], &Al[ar][ah]);
         split_store<NTERM, WPT>(bv, &Bh[br][bq], &Bl[br][bq]);
         __syncthreads();
-        if (ck + 1 < nck) load_chunk(ck + 1);                      // in flight during this chunk's MFMAs
+        if (nx < nck) load_chunk(nx);                              // in flight during this chunk's MFMAs
+        ck = nx;
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ks++) {
-            const bf16x8 bh = *(const bf16x8 *)&Ah[wv * 32 + li][ks * 16 + kb];     // B operand: my pixel tile
+            const bf16x8 bh = *(const bf16x8 *)&Ah[wpt * 32 + li][ks * 16 + kb];     // B operand: my pixel tile
             bf16x8 bl;
-            if (NTERM > 1) bl = *(const bf16x8 *)&Al[wv * 32 + li][ks * 16 + kb];
+            if (NTERM > 1) bl = *(const bf16x8 *)&Al[wpt * 32 + li][ks * 16 + kb];
 #pragma unroll
-            for (int c = 0; c < NCT; c++) {
-                const bf16x8 ahh = *(const bf16x8 *)&Bh[c * 32 + li][ks * 16 + kb];  // A operand: filter rows
+            for (int c = 0; c < CPW; c++) {
+                const bf16x8 ahh = *(const bf16x8 *)&Bh[(wc0 + c) * 32 + li][ks * 16 + kb];  // A operand: filter rows
                 if (NTERM > 1) {
-                    const bf16x8 all = *(const bf16x8 *)&Bl[c * 32 + li][ks * 16 + kb];
+                    const bf16x8 all = *(const bf16x8 *)&Bl[(wc0 + c) * 32 + li][ks * 16 + kb];
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(all, bh, acc[c], 0, 0, 0);      // the small terms first
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahh, bl, acc[c], 0, 0, 0);
                 }
@@ -229,15 +292,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const TIN *__restrict
         }
     }
     // ---- epilogue: D[row = co][col = pixel]; lane (li, h) holds rows 8g + 4h + (0..3), g = 0..3, of column li
-    const long om = m0 + wv * 32 + li;
+    const long om = m0 + wpt * 32 + li;
     if (om >= M) return;
     const int h = lane >> 5;
-    TOUT *yo = y + (size_t)om * Cout + co0;
+    long opix = om;
+    if (classes) {
+        int on, ooy, oox;
+        pixel(om, on, ooy, oox);
+        opix = ((long)on * OH + ooy) * OW + oox;
+    }
+    TOUT *yo = y + (size_t)opix * Cout + co0;
 #pragma unroll
-    for (int c = 0; c < NCT; c++)
+    for (int c = 0; c < CPW; c++)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const int co = c * 32 + 8 * g + 4 * h;
+            const int co = (wc0 + c) * 32 + 8 * g + 4 * h;
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] = acc[c][4 * g + e] + (bias ? bias[co0 + co + e] : 0.0f);
@@ -255,16 +324,36 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const TIN *__restrict
 // ------------------------------------------------------------------------------------------------
 constexpr int WG_PX = 64, WG_PITCH = WG_PX + 8;
 
-template <int NTERM, int NV>
-__device__ __forceinline__ void split_store_t(const float (&v)[NV], __bf16 (*hi)[WG_PITCH], __bf16 (*lo)[WG_PITCH], int row0, int col)
+// eight values of pixel 2p and of pixel 2p + 1 -> eight {pixel 2p, pixel 2p + 1} bf16 pairs (one 32-bit LDS store per channel row and part): a
+// thread that stored single 2-byte values did four times as many LDS writes, and those writes — not the MFMAs — set the pace of a stage
+template <int NTERM>
+__device__ __forceinline__ void split_store_pairs(const float (&v0)[8], const float (&v1)[8], __bf16 (*hi)[WG_PITCH], __bf16 (*lo)[WG_PITCH], int row0,
+                                                  int col)
 {
 #pragma unroll
-    for (int e = 0; e < NV; e++) {                               // element e of this pixel -> row (channel) row0 + e, column (pixel) col
-        __bf16 hh;
-        const float r = bf_round(v[e], hh);
-        hi[row0 + e][col] = hh;
-        if (NTERM > 1) lo[row0 + e][col] = (__bf16)r;
+    for (int e = 0; e < 8; e++) {
+        __bf16 h0, h1;
+        const float r0 = bf_round(v0[e], h0), r1 = bf_round(v1[e], h1);
+        *(unsigned *)&hi[row0 + e][col] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        if (NTERM > 1) {
+            const __bf16 l0 = (__bf16)r0, l1 = (__bf16)r1;
+            *(unsigned *)&lo[row0 + e][col] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
     }
+}
+
+__device__ __forceinline__ void load8(const float *p, bool ok, float (&v)[8])
+{
+    const f4 a = ok ? *(const f4 *)p : (f4){0, 0, 0, 0}, b = ok ? *(const f4 *)(p + 4) : (f4){0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; e++) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+__device__ __forceinline__ void load8(const __bf16 *p, bool ok, float (&v)[8])
+{
+    bf16x8 a;
+    if (ok) a = *(const bf16x8 *)p;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = ok ? (float)a[e] : 0.0f;
 }
 
 template <int NTERM, typename TIN, typename TDY>
@@ -277,52 +366,67 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const TIN *__restric
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int li = lane & 31, kb = (lane >> 5) * 8, h = lane >> 5;
     const int ct = wv & 1, kt = wv >> 1;                          // this wave's 32 x 32 quadrant of the tile
-    const int K = KH * KW * Cin;
+    const int K = KH * KW * Cin, rowlen = Cin * KW;
+    const int mode = (Cin % 8) == 0 ? 0 : (rowlen <= 16 ? 1 : 2);  // as in conv_gemm_kernel: tap runs / filter rows of a small Cin / element gather
     const int ck = blockIdx.x, co0 = blockIdx.y * 64, split = blockIdx.z;
     const long M = (long)N * OH * OW;
-    const bool fast = (Cin % KC) == 0;
-    int tap = 0, c0 = ck * KC, kh = 0, kw = 0;
-    if (fast) {
-        const int cpt = Cin / KC;
-        tap = ck / cpt;
-        c0 = (ck - tap * cpt) * KC;
+    // this thread's share of a stage: the pixel PAIR (2 pp, 2 pp + 1) of the 64, eight of the tile's 64 channels / k-columns
+    const int pp = t >> 3, q8 = (t & 7) * 8;
+    const int k0r = ck * KC + q8;                                  // my eight k-columns (mode 0: one tap; mode 1: eight slots of one filter row)
+    int kh = 0, kw = 0, c0 = 0, j0 = 0;
+    if (mode == 0) {
+        const int tap = k0r / Cin;
+        c0 = k0r - tap * Cin;
         kh = tap / KW;
         kw = tap - kh * KW;
+    } else if (mode == 1) {
+        kh = k0r >> 4;
+        j0 = k0r & 15;
     }
-    // this thread's share of a stage: pixel row pr (of 64), 16 of its 64 elements, of dY and of the gathered input
-    const int pr = t >> 2, q16 = (t & 3) * 16;
     f16v acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-    float dv[16], xv[16];
+    float dv[2][8], xv[2][8];
     auto load_stage = [&](long m0) {
-        const long m = m0 + pr;
-        const bool live = m < M;
-        int n = 0, oy = 0, ox = 0;
-        if (live) {
-            n = (int)(m / ((long)OH * OW));
-            const int rem = (int)(m - (long)n * OH * OW);
-            oy = rem / OW;
-            ox = rem - oy * OW;
-        }
-        const bool dok = live && co0 + q16 + 16 <= Cout;           // (Cout % 16 == 0: whole 16-channel pieces)
-        load16(dy + (size_t)(dok ? m : 0) * Cout + (dok ? co0 + q16 : 0), dok, dv);
-        if (fast) {
-            const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
-            const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            load16(x + (((size_t)n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + c0 + q16, ok, xv);
-        } else {
-#pragma unroll 4
-            for (int e = 0; e < 16; e++) {
-                const int k = c0 + q16 + e;
-                float v = 0.0f;
-                if (live && k < K) {
-                    const int tp = k / Cin, ci = k - tp * Cin;
-                    const int kh2 = tp / KW, kw2 = tp - kh2 * KW;
-                    const int iy = oy * stride - pad + kh2, ix = ox * stride - pad + kw2;
-                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ldf(x + (((size_t)n * H + iy) * W + ix) * Cin + ci);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const long m = m0 + 2 * pp + u;
+            const bool live = m < M;
+            int n = 0, oy = 0, ox = 0;
+            if (live) {
+                n = (int)(m / ((long)OH * OW));
+                const int rem = (int)(m - (long)n * OH * OW);
+                oy = rem / OW;
+                ox = rem - oy * OW;
+            }
+            const bool dok = live && co0 + q8 + 8 <= Cout;        // (Cout % 8 == 0: whole 8-channel pieces)
+            load8(dy + (size_t)(dok ? m : 0) * Cout + (dok ? co0 + q8 : 0), dok, dv[u]);
+            if (mode == 0) {
+                const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+                const bool ok = live && k0r < K && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                load8(x + (((size_t)n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + (ok ? c0 : 0), ok, xv[u]);
+            } else if (mode == 1) {
+                const int iy = oy * stride - pad + kh, ixb = ox * stride - pad;
+                const bool rok = live && kh < KH && iy >= 0 && iy < H;
+                const TIN *row = x + ((size_t)n * H + (rok ? iy : 0)) * W * Cin;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int j = j0 + e, kwj = j / Cin, ci = j - kwj * Cin, ix = ixb + kwj;
+                    xv[u][e] = (rok && j < rowlen && ix >= 0 && ix < W) ? ldf(row + (size_t)ix * Cin + ci) : 0.0f;
                 }
-                xv[e] = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int k = k0r + e;
+                    float v = 0.0f;
+                    if (live && k < K) {
+                        const int tp = k / Cin, ci = k - tp * Cin;
+                        const int kh2 = tp / KW, kw2 = tp - kh2 * KW;
+                        const int iy = oy * stride - pad + kh2, ix = ox * stride - pad + kw2;
+                        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ldf(x + (((size_t)n * H + iy) * W + ix) * Cin + ci);
+                    }
+                    xv[u][e] = v;
+                }
             }
         }
     };
@@ -331,8 +435,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const TIN *__restric
     if (stage0 < stage1) load_stage(stage0 * WG_PX);
     for (long sg = stage0; sg < stage1; sg++) {
         __syncthreads();                                           // the previous stage's MFMAs are done with LDS
-        split_store_t<NTERM, 16>(dv, Dh, Dl, q16, pr);
-        split_store_t<NTERM, 16>(xv, Xh, Xl, q16, pr);
+        split_store_pairs<NTERM>(dv[0], dv[1], Dh, Dl, q8, 2 * pp);
+        split_store_pairs<NTERM>(xv[0], xv[1], Xh, Xl, q8, 2 * pp);
         __syncthreads();
         if (sg + 1 < stage1) load_stage((sg + 1) * WG_PX);         // in flight during this stage's MFMAs
 #pragma unroll
@@ -348,9 +452,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const TIN *__restric
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
     }
-    // partial tile: D[row = co][col = k] -> part[split][co][k]
+    // partial tile: D[row = co][col = k-column] -> part[split][co][k]
     float *po = part + (size_t)split * Cout * K;
-    const int kcol = c0 + (fast ? tap * Cin : 0) + kt * 32 + li;
+    int kcol = ck * KC + kt * 32 + li;
+    if (mode == 1) {                                              // slot (kh, j) -> k = kh * rowlen + j (the two padding slots of a row: nothing to store)
+        const int khc = kcol >> 4, j = kcol & 15;
+        kcol = (khc < KH && j < rowlen) ? khc * rowlen + j : K;
+    }
     if (kcol < K) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -399,12 +507,12 @@ static inline hipError_t set_max_lds(const void *kern, size_t lds, std::atomic<u
     return e;
 }
 
-template <int NTERM, typename TIN, typename TOUT, int BN>
-int launch(const void *x, const float *w, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
-           int stride, int pad, int transposed, hipStream_t st)
+template <int NTERM, typename TIN, typename TOUT, int BN, int BM, bool RUNS>
+int launch_r(const void *x, const float *w, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
+             int stride, int pad, int transposed, hipStream_t st)
 {
     const size_t lds = (size_t)(BM + BN) * PITCH * 2 * (NTERM > 1 ? 2 : 1);
-    auto kern = conv_gemm_kernel<NTERM, TIN, TOUT, BN>;
+    auto kern = conv_gemm_kernel<NTERM, TIN, TOUT, BN, BM, RUNS>;
     static std::atomic<unsigned long long> attr_set{0};
     PSI_CHECK_HIP(set_max_lds((const void *)kern, lds, attr_set));
     const long M = (long)N * OH * OW;
@@ -415,19 +523,34 @@ int launch(const void *x, const float *w, const float *bias, void *y, int N, int
     return 0;
 }
 
+template <int NTERM, typename TIN, typename TOUT, int BN, int BM>
+int launch(const void *x, const float *w, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
+           int stride, int pad, int transposed, hipStream_t st)
+{
+    // a thread's run of BM * 64 / 256 consecutive k lies inside one filter tap: the vector-load instantiation; else filter rows / element gather
+    if (Cin % (BM * KC / 256) == 0)
+        return launch_r<NTERM, TIN, TOUT, BN, BM, true>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
+    return launch_r<NTERM, TIN, TOUT, BN, BM, false>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
+}
+
 template <int NTERM, typename TIN, typename TOUT>
 int launch_bn(const void *x, const float *w, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
               int stride, int pad, int transposed, hipStream_t st)
 {
-    if (Cout % 64 == 0) return launch<NTERM, TIN, TOUT, 64>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
-    return launch<NTERM, TIN, TOUT, 32>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
+    // pixel tile: 64 (four workgroups per compute unit) unless PSI_CONV_BM=128 says otherwise; the 32-channel tile keeps 128 pixels
+    static const int bm = getenv("PSI_CONV_BM") ? atoi(getenv("PSI_CONV_BM")) : PSI_CONV_BM_DEFAULT;
+    if (Cout % 64 == 0) {
+        if (bm == 64 || Cin % 32 != 0) return launch<NTERM, TIN, TOUT, 64, 64>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
+        return launch<NTERM, TIN, TOUT, 64, 128>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
+    }
+    return launch<NTERM, TIN, TOUT, 32, 128>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
 }
 
 }  // namespace
 
 extern "C" int psi_conv2d_supported(int Cin, int Cout, int KH, int KW, int stride, int pad)
 {
-    return Cin > 0 && Cout > 0 && Cout % 32 == 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && (Cin % 64 == 0 || Cin * KH * KW <= 4096);
+    return Cin > 0 && Cout > 0 && Cout % 32 == 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && (Cin % 16 == 0 || Cin * KH * KW <= 4096);
 }
 
 // x [N,H,W,Cin] NHWC (x_bf16: bf16, else fp32); w [Cout,KH,KW,Cin] fp32 (a channels_last Conv2d weight); bias [Cout] fp32 or NULL;
@@ -483,21 +606,22 @@ extern "C" size_t psi_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin
 }
 
 // Weight gradient: x [N,H,W,Cin], dy [N,OH,OW,Cout] (each fp32 or bf16) -> gw [Cout,KH,KW,Cin] fp32 (OVERWRITTEN; the memory of a
-// channels_last Conv2d weight gradient).  ws: psi_conv2d_wgrad_workspace_floats floats.  Any shape psi_conv2d_supported accepts (Cout % 16 == 0).
+// channels_last Conv2d weight gradient).  ws: psi_conv2d_wgrad_workspace_floats floats.  Any shape psi_conv2d_supported accepts (Cout % 8 == 0).
 extern "C" int psi_conv2d_weight_grad(const void *x, int x_bf16, const void *dy, int dy_bf16, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                       int stride, int pad, float *gw, float *ws, int nterm, void *stream)
 {
     PSI_REQUIRE(x && dy && gw && ws && N > 0 && H > 0 && W > 0, "bad arguments");
-    PSI_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && Cout % 16 == 0 && (Cin % 64 == 0 || Cin * KH * KW <= 4096), "shape not covered");
+    PSI_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && Cout % 8 == 0 && (Cin % 8 == 0 || Cin * KH * KW <= 4096), "shape not covered");
     PSI_REQUIRE(nterm == 1 || nterm == 3, "nterm is 1 or 3");
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     PSI_REQUIRE(OH > 0 && OW > 0, "empty output");
     hipStream_t st = (hipStream_t)stream;
     const int K = KH * KW * Cin;
+    const int Keff = (Cin % 8) != 0 && Cin * KW <= 16 ? KH * 16 : K;      // (filter-row indexing of a small Cin: conv_wgrad_kernel mode 1)
     const long M = (long)N * OH * OW, nstage = (M + WG_PX - 1) / WG_PX;
     const int S = wgrad_splits(M, K, Cout);
     const int sps = (int)((nstage + S - 1) / S);
-    dim3 grid((unsigned)((K + KC - 1) / KC), (unsigned)((Cout + 63) / 64), (unsigned)S);
+    dim3 grid((unsigned)((Keff + KC - 1) / KC), (unsigned)((Cout + 63) / 64), (unsigned)S);
 #define PSI_WG_LAUNCH(NT_, TX_, TD_)                                                                                                         \
     hipLaunchKernelGGL((conv_wgrad_kernel<NT_, TX_, TD_>), grid, dim3(256), 0, st, (const TX_ *)x, (const TD_ *)dy, ws, N, H, W, Cin, OH, OW, Cout, \
                        KH, KW, stride, pad, S, sps)
