@@ -18,6 +18,7 @@
 // bank groups); the next chunk's global loads are in flight while the current chunk is multiplied.  With Cin % 64 == 0 a chunk is 64
 // consecutive channels of ONE filter tap: 256 contiguous bytes per pixel.  The stem (Cin = 2, K = 98) takes the element-wise gather path.
 #include "psi_internal.h"
+#include <algorithm>
 #include <atomic>
 #include <stdlib.h>
 #ifndef PSI_CONV_BM_DEFAULT
@@ -546,6 +547,13 @@ int launch_bn(const void *x, const float *w, const float *bias, void *y, int N, 
     return launch<NTERM, TIN, TOUT, 32, 128>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
 }
 
+// the stem has kernels of its own (conv_stem.hip); PSI_CONV_STEM=0 sends it through the general kernels (dev A/B)
+static bool stem_route(int Cin, int Cout, int KH, int KW, int stride, int pad)
+{
+    static const bool on = !(getenv("PSI_CONV_STEM") && atoi(getenv("PSI_CONV_STEM")) == 0);
+    return on && psi_conv_stem_shape(Cin, Cout, KH, KW, stride, pad);
+}
+
 }  // namespace
 
 extern "C" int psi_conv2d_supported(int Cin, int Cout, int KH, int KW, int stride, int pad)
@@ -564,6 +572,7 @@ extern "C" int psi_conv2d_forward(const void *x, int x_bf16, const float *w, con
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     PSI_REQUIRE(OH > 0 && OW > 0, "empty output");
     hipStream_t st = (hipStream_t)stream;
+    if (stem_route(Cin, Cout, KH, KW, stride, pad)) return psi_conv_stem_forward(x, x_bf16, w, bias, N, H, W, y, y_bf16, nterm, st);
 #define PSI_CONV_ARGS x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, st
     if (nterm == 3) {
         if (x_bf16) return y_bf16 ? launch_bn<3, __bf16, __bf16>(PSI_CONV_ARGS) : launch_bn<3, __bf16, float>(PSI_CONV_ARGS);
@@ -602,7 +611,9 @@ extern "C" size_t psi_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return 0;
     const int K = KH * KW * Cin;
-    return (size_t)wgrad_splits((long)N * OH * OW, K, Cout) * Cout * K;
+    const size_t general = (size_t)wgrad_splits((long)N * OH * OW, K, Cout) * Cout * K;
+    if (psi_conv_stem_shape(Cin, Cout, KH, KW, stride, pad)) return std::max(general, psi_conv_stem_wgrad_floats(N, H, W));
+    return general;
 }
 
 // Weight gradient: x [N,H,W,Cin], dy [N,OH,OW,Cout] (each fp32 or bf16) -> gw [Cout,KH,KW,Cin] fp32 (OVERWRITTEN; the memory of a
@@ -616,6 +627,7 @@ extern "C" int psi_conv2d_weight_grad(const void *x, int x_bf16, const void *dy,
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     PSI_REQUIRE(OH > 0 && OW > 0, "empty output");
     hipStream_t st = (hipStream_t)stream;
+    if (stem_route(Cin, Cout, KH, KW, stride, pad)) return psi_conv_stem_weight_grad(x, x_bf16, dy, dy_bf16, N, H, W, gw, ws, nterm, st);
     const int K = KH * KW * Cin;
     const int Keff = (Cin % 8) != 0 && Cin * KW <= 16 ? KH * 16 : K;      // (filter-row indexing of a small Cin: conv_wgrad_kernel mode 1)
     const long M = (long)N * OH * OW, nstage = (M + WG_PX - 1) / WG_PX;

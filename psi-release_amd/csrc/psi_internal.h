@@ -54,3 +54,11 @@ int psi_lbs_backward_joint_parts(const psi_lbs_model *mdl, int B, float *ws, flo
 // dp.hip
 struct psi_dp_comm;
 int psi_dp_world(const psi_dp_comm *c);
+
+// conv_stem.hip: the 2 -> 64 channel 7x7 stride-2 stem convolution (forward, weight gradient); conv_gemm.hip's entry points route to it
+bool psi_conv_stem_shape(int Cin, int Cout, int kh, int kw, int stride, int pad);
+int psi_conv_stem_forward(const void *x, int x_bf16, const float *w, const float *bias, int N, int H, int W, void *y, int y_bf16, int nterm,
+                          hipStream_t st);
+size_t psi_conv_stem_wgrad_floats(int N, int H, int W);
+int psi_conv_stem_weight_grad(const void *x, int x_bf16, const void *dy, int dy_bf16, int N, int H, int W, float *gw, float *ws, int nterm,
+                              hipStream_t st);

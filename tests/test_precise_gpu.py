@@ -23,7 +23,8 @@ SPLIT3 = 2.0 ** -16               # |hi*hi + hi*lo + lo*hi - a*b| per product, r
 
 # (N, Cin, Cout, K, stride, pad, H, bias): the convolutions of the scene trunk and the heads, plus odd batch sizes (M not a multiple of 128)
 CONVS = [(2, 2, 64, 7, 2, 3, 128, False), (3, 64, 64, 3, 1, 1, 32, False), (2, 64, 128, 3, 2, 1, 32, False), (2, 64, 128, 1, 2, 0, 32, False),
-         (5, 128, 128, 3, 1, 1, 16, False), (3, 128, 32, 3, 1, 1, 16, True), (1, 128, 128, 3, 1, 1, 16, True), (128, 64, 64, 3, 1, 1, 32, False)]
+         (5, 128, 128, 3, 1, 1, 16, False), (3, 128, 32, 3, 1, 1, 16, True), (1, 128, 128, 3, 1, 1, 16, True), (128, 64, 64, 3, 1, 1, 32, False),
+         (3, 2, 64, 7, 2, 3, 50, True), (100, 2, 64, 7, 2, 3, 36, False)]      # the stem's own kernels (conv_stem.hip): partial 8 x 16 tiles, bias, more tiles than workgroups
 
 
 @pytest.mark.parametrize('N,Cin,Cout,K,stride,pad,H,bias', CONVS)
