@@ -357,6 +357,15 @@ int psi_conv2d_input_grad(const void *dy, int dy_bf16, const float *wt, int N, i
 size_t psi_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int psi_conv2d_weight_grad(const void *x, int x_bf16, const void *dy, int dy_bf16, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                            int pad, float *gw, float *ws, int nterm, void *stream);
+/* psi_adam_step: ONE Adam step over all `count` fp32 parameter tensors of a model (train_s1.py:229 / train_s2.py:295-296:
+ *   optim.Adam(model_h.parameters(), lr) stepped once per batch) — replaces torch.optim.Adam's multi-tensor launches (_foreach_add on the
+ *   step counters + 4 x multi_tensor_apply for HumanCVAES2's 122 tensors) by one or two hand-written launches (80 tensors each; addresses in
+ *   the kernel arguments, so a hipGraph captures them by value).  p / g / m / v: HOST arrays of `count` device pointers (parameter,
+ *   gradient, exp_avg, exp_avg_sq), n: element counts; step: device fp32 scalar = steps taken so far, shared by all tensors, incremented
+ *   by the last workgroup to finish; ticket: device uint32, zero before the first call.  Arithmetic: the operation order of PyTorch's fused
+ *   Adam (moments in double, rounded to fp32 once); weight_decay is the L2 form (grad += wd * p), no amsgrad / maximize. */
+int psi_adam_step(void *const *p, const void *const *g, void *const *m, void *const *v, const long *n, int count, float *step, unsigned *ticket,
+                  double lr, double beta1, double beta2, double eps, double weight_decay, void *stream);
 int psi_bn_forward_t(const void *x, int map_f32, const void *residual, const float *gamma, const float *beta, float *running_mean,
                      float *running_var, long long *num_batches_tracked, long M, int C, int relu, float momentum, float eps, void *y,
                      float *save_mean, float *save_invstd, float *ws, int eval_mode, void *stream);

@@ -280,11 +280,10 @@ constexpr int DXP = DXN + 8;             // LDS pitch (elements): 16-byte aligne
 constexpr size_t linear_dx_lds(int nterm) { return (size_t)2 * (128 + DXK) * DXP * 2 * (nterm > 1 ? 2 : 1); }
 
 template <typename XT, int NTERM>
-__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restrict__ gy, const float *__restrict__ act_out,
-                                                            const float *__restrict__ W, int M, int N, int K, float slope,
-                                                            XT *__restrict__ gx, int nchunk, float *__restrict__ part)
+__device__ __forceinline__ void linear_bwd_dx_body(unsigned char *smem, int bx, int by, int bz, const float *__restrict__ gy,
+                                                   const float *__restrict__ act_out, const float *__restrict__ W, int M, int N, int K, float slope,
+                                                   XT *__restrict__ gx, int nchunk, float *__restrict__ part)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __bf16 (*Tile)[DXP];
     // [2][128][DXP] rows of G (hi), [2][DXK][DXP] W transposed (hi), then the lo parts (NTERM = 3: psi_linear_backward3)
     auto Gs = [&](int buf) { return (Tile)(smem + (size_t)buf * 128 * DXP * 2); };
@@ -292,8 +291,8 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restr
     auto Gl = [&](int buf) { return (Tile)(smem + (size_t)(2 * (128 + DXK) + buf * 128) * DXP * 2); };
     auto Wl = [&](int buf) { return (Tile)(smem + (size_t)(2 * (128 + DXK) + 2 * 128 + buf * DXK) * DXP * 2); };
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int k0 = blockIdx.x * DXK, mblk = blockIdx.y * 128, m0 = mblk + w * TM;
-    const int n_begin = blockIdx.z * nchunk, n_end = min(N, n_begin + nchunk);      // this workgroup's slice of the contraction
+    const int k0 = bx * DXK, mblk = by * 128, m0 = mblk + w * TM;
+    const int n_begin = bz * nchunk, n_end = min(N, n_begin + nchunk);      // this workgroup's slice of the contraction
     const int li = lane & 31, kb = (lane >> 5) * 8;
     const bool vecN = (N & 3) == 0, vecK = (K & 3) == 0;    // rows of G / act_out and of W are 16-byte aligned
     f16v acc[2];
@@ -374,10 +373,19 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restr
         for (int r = 0; r < 16; r++) {
             const int i = m0 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
             if (i >= M) continue;
-            if (part) part[((size_t)blockIdx.z * M + i) * K + col] = acc[t][r];
+            if (part) part[((size_t)bz * M + i) * K + col] = acc[t][r];
             else gx[(size_t)i * K + col] = (XT)acc[t][r];
         }
     }
+}
+
+template <typename XT, int NTERM>
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restrict__ gy, const float *__restrict__ act_out,
+                                                            const float *__restrict__ W, int M, int N, int K, float slope,
+                                                            XT *__restrict__ gx, int nchunk, float *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    linear_bwd_dx_body<XT, NTERM>(smem, blockIdx.x, blockIdx.y, blockIdx.z, gy, act_out, W, M, N, K, slope, gx, nchunk, part);
 }
 
 // sum of the n-slices of dX in slice order (deterministic), converted to the gradient's type
@@ -450,16 +458,15 @@ __device__ __forceinline__ void pack_split(float v0, float v1, unsigned *hi, uns
 }
 
 template <typename XT, int NTERM>
-__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float *__restrict__ gy, const float *__restrict__ act_out,
-                                                            const XT *__restrict__ x, int M, int N, int K, float slope,
-                                                            float *__restrict__ gW, float *__restrict__ gbias)
+__device__ __forceinline__ void linear_bwd_dw_body(unsigned char *smem, int bx, int by, const float *__restrict__ gy, const float *__restrict__ act_out,
+                                                   const XT *__restrict__ x, int M, int N, int K, float slope, float *__restrict__ gW,
+                                                   float *__restrict__ gbias)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __bf16 (*Tile)[DWP];
     const Tile Gt = (Tile)smem, Xt = (Tile)(smem + (size_t)TM * DWP * 2);                                 // [TM][DWP], [DWK][DWP]
     const Tile Gl = (Tile)(smem + (size_t)(TM + DWK) * DWP * 2), Xl = (Tile)(smem + (size_t)(2 * TM + DWK) * DWP * 2);   // lo parts (NTERM = 3)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int n0 = blockIdx.y * TM, k0 = blockIdx.x * DWK;
+    const int n0 = by * TM, k0 = bx * DWK;
     const int li = lane & 31, mb = (lane >> 5) * 8;
     const bool vecN = (N & 3) == 0, vecK = (K & 3) == 0;
     f16v acc;
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float *__restr
         }
         __syncthreads();
     }
-    if (gbias && blockIdx.x == 0) {
+    if (gbias && bx == 0) {
         // column sums of G: thread (p, q) of item slots i = 0, 1 holds partial sums of columns 4q..4q+3 over its row pairs; the 64 threads
         // sharing q (p = idx >> 3 over both slots) are combined in a fixed order through LDS (the operand tiles are no longer needed)
         float (*bred)[4] = (float (*)[4])smem;
@@ -535,6 +542,35 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float *__restr
     for (int r = 0; r < 16; r++) {
         const int i = n0 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
         if (i < N) gW[(size_t)i * K + kcol] = acc[r];
+    }
+}
+
+template <typename XT, int NTERM>
+__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float *__restrict__ gy, const float *__restrict__ act_out,
+                                                            const XT *__restrict__ x, int M, int N, int K, float slope,
+                                                            float *__restrict__ gW, float *__restrict__ gbias)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    linear_bwd_dw_body<XT, NTERM>(smem, blockIdx.x, blockIdx.y, gy, act_out, x, M, N, K, slope, gW, gbias);
+}
+
+// Both products of a layer's backward in ONE launch: the first ndx workgroups are the input-gradient tiles (gdx x gdy x slices), the rest the
+// weight-gradient tiles.  Each product alone leaves most of the chip idle (64 .. 256 workgroups, a latency chain each) and the two only share
+// their input G: side by side they take the time of the longer one, and a layer's backward is one launch (plus the slice sum) instead of two.
+template <typename XT, int NTERM>
+__global__ __launch_bounds__(256) void linear_bwd_both_kernel(const float *__restrict__ gy, const float *__restrict__ act_out, const float *__restrict__ W,
+                                                              const XT *__restrict__ x, int M, int N, int K, float slope, XT *__restrict__ gx,
+                                                              int nchunk, float *__restrict__ part, float *__restrict__ gW,
+                                                              float *__restrict__ gbias, int gdx, int gdy, int ndx, int gwx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int b = blockIdx.x;
+    if (b < ndx) {
+        const int bx = b % gdx, r = b / gdx;
+        linear_bwd_dx_body<XT, NTERM>(smem, bx, r % gdy, r / gdy, gy, act_out, W, M, N, K, slope, gx, nchunk, part);
+    } else {
+        b -= ndx;
+        linear_bwd_dw_body<XT, NTERM>(smem, b % gwx, b / gwx, gy, act_out, x, M, N, K, slope, gW, gbias);
     }
 }
 
@@ -660,6 +696,29 @@ template <typename XT, int NTERM>
 static int linear_backward_t(const float *gy, const float *act_out, const void *x, const float *W, int M, int N, int K, float slope, void *gx,
                              float *gW, float *gbias, float *ws, hipStream_t st)
 {
+    if (gx && gW) {                                            // the usual case: both products, one launch
+        int S = pick_nsplit(M, N, K), nchunk = N;
+        if (S > 1) {
+            PSI_REQUIRE(ws, "this shape is split over n: pass psi_linear_backward_workspace_floats() floats of workspace");
+            nchunk = psi_cdiv(psi_cdiv(N, S), DXN) * DXN;
+            S = psi_cdiv(N, nchunk);
+        }
+        float *part = S > 1 ? ws : nullptr;
+        const int gdx = psi_cdiv(K, DXK), gdy = psi_cdiv(M, 128), ndx = gdx * gdy * S, gwx = psi_cdiv(K, DWK), ndw = gwx * psi_cdiv(N, TM);
+        constexpr size_t lds = linear_dx_lds(NTERM) > linear_dw_lds(NTERM) ? linear_dx_lds(NTERM) : linear_dw_lds(NTERM);
+        static std::atomic<unsigned long long> a_both{0};
+        PSI_CHECK_HIP(set_lds_once((const void *)linear_bwd_both_kernel<XT, NTERM>, lds, a_both));
+        hipLaunchKernelGGL((linear_bwd_both_kernel<XT, NTERM>), dim3((unsigned)(ndx + ndw)), dim3(256), lds, st, gy, act_out, W, (const XT *)x, M, N, K,
+                           slope, (XT *)gx, nchunk, part, gW, gbias, gdx, gdy, ndx, gwx);
+        PSI_CHECK_LAUNCH("linear_bwd_both_kernel");
+        if (S > 1) {
+            const size_t MK = (size_t)M * K;
+            const dim3 rg((unsigned)psi_cdiv((long)((MK + 3) / 4), 256));
+            hipLaunchKernelGGL(linear_dx_reduce_kernel<XT>, rg, dim3(256), 0, st, (const float *)part, S, MK, (XT *)gx);
+            PSI_CHECK_LAUNCH("linear_dx_reduce_kernel");
+        }
+        return 0;
+    }
     if (gx) {
         int S = pick_nsplit(M, N, K), nchunk = N;
         if (S > 1) {

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get('PSI_HIP_LIB') or os.path.join(
     _PKG, 'lib', 'libpsi_hip_fma.so' if os.environ.get('PSI_CHAMFER_FMA') == '1' else 'libpsi_hip.so')
 _lib = None
 
-c_void_p, c_int, c_long, c_size_t, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_float
+c_void_p, c_int, c_long, c_size_t, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_float, ctypes.c_double
 
 # name -> (restype, argtypes); every symbol declared in include/psi_hip.h must appear here
 SIGNATURES = {
@@ -53,6 +53,7 @@ SIGNATURES = {
     'psi_linear_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     'psi_linear_backward3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'psi_adam_step': (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p] + [c_double] * 5 + [c_void_p]),
     'psi_fit_create': (c_int, [c_void_p] * 17),
     'psi_fit_destroy': (None, [c_void_p]),
     'psi_fit_set_problem': (c_int, [c_void_p] * 4 + [c_int, c_void_p]),

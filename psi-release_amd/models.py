@@ -16,6 +16,8 @@ generator and copies it, net_layers.py:88-92) and can be injected (``eps=``) for
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -34,6 +36,15 @@ def _lin(owner, layer, x, act=None, slope=0.01, residual=None):
     if _precise(x) and not getattr(owner, 'hip_linear', False):
         from .ops import linear_act3
         return linear_act3(x, layer.weight, layer.bias, act, slope, residual)
+    if _use_hip_linear(owner, x):
+        # the bf16 mode: bias, LeakyReLU and the skip connection are part of the same launch; the 3-, 72-, 75-wide layers (no 16-wide operand
+        # tiles) take the any-width kernel, whose three-term products are at least the library's fp32 precision (PSI_HIP_LINEAR_ODD=0: library)
+        if layer.in_features % 16 == 0 and layer.out_features % 16 == 0:
+            from .ops import linear_act
+            return linear_act(x, layer.weight, layer.bias, 'leaky_relu' if act else None, slope, residual=residual)
+        if os.environ.get('PSI_HIP_LINEAR_ODD', '1') != '0' and x.dim() == 2:
+            from .ops import linear_act3
+            return linear_act3(x.float(), layer.weight, layer.bias, act, slope, residual)
     y = _linear(owner, layer, x)
     if act:
         y = torch.nn.functional.leaky_relu(y, slope)

@@ -23,7 +23,7 @@ import torch
 import torch.nn.functional as F
 import torch.optim as optim
 
-from . import body_model, dist as psi_dist, ops
+from . import body_model, dist as psi_dist, ops, optim as psi_optim
 from .geometry import BodyParamParser, GeometryTransformer
 from .models import HumanCVAES1, HumanCVAES2
 from .vposer import load_vposer
@@ -61,7 +61,8 @@ class _TrainBase:
         self.model_h_latentD = 256
         self.model_h = self._make_model(n_dim_body)
         # train_s1.py:229 optim.Adam defaults; fused=True is the same update as ONE multi-tensor kernel instead of ~10 per step
-        self.optimizer_h = optim.Adam(self.model_h.parameters(), lr=self.init_lr_h, fused=bool(getattr(self, 'fused_adam', True)))
+        # the same optimiser as ONE hand-written multi-tensor launch on the GPU (optim.py / csrc/adam.hip; state layout of torch.optim.Adam)
+        self.optimizer_h = psi_optim.Adam(self.model_h.parameters(), lr=self.init_lr_h, fused=bool(getattr(self, 'fused_adam', True)))
         vposer_src = getattr(self, 'vposer_state', None) or self.vposer_ckpt_path
         self.vposer, _ = load_vposer(vposer_src, vp_model='snapshot')
         self.vposer.to(self.device)
