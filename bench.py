@@ -13,10 +13,13 @@ VPoser(512,32,[1,21,3]), n_c=2048 contact vertices, m=32768 scene points, 256^3 
 timed region).  Weak scaling: every rank fits its own 32 bodies; the only data-path collective is the one 6-float
 all-reduce per iteration of the loss normalisers (psi-release_amd/dist.py).
 
-Protocol: W untimed warm-up steps plus an untimed clock-ramp warm-up (>= 0.3 s of iterations), then
-R >= 5 timed blocks of EXACTLY K steps each, every block bracketed by a barrier + torch.cuda.synchronize() on both sides
-and timed as the MAX over ranks; R is raised so that the timed GPU time is >= 0.5 s whatever K is.  `ms_per_step` is the
-MEDIAN block (min / max are reported next to it) and value = N / median seconds per step  [batch-32 iterations / s].
+Protocol (the metric's own: BASELINE configs[1] is quoted on the reference's 100-iteration loop): W untimed warm-up
+steps plus an untimed clock-ramp warm-up (>= 0.3 s of iterations), then timed blocks of EXACTLY K steps each, every block bracketed by a
+barrier + torch.cuda.synchronize() on both sides and timed as the MAX over ranks.  Consecutive blocks form 100-ITERATION FRESH-START LOOPS
+(fitting_proxe.py:177-189: a new batch starts from the initial body vector with a fresh Adam — an untimed psi_fit_set_problem(reset)
+before the first block of every loop); at least 5 loops and 0.5 s of timed GPU time.  `ms_per_step` / `value` = the MEDIAN LOOP's time
+per iteration (loop total / 100; min / max next to it); `steady_state` carries the median block of iterations 20 .. 100 of the loops
+(the number earlier rounds reported), `loop_as_one_call` the same loop issued as ONE psi_fit_iterate call.
 
 Workloads:  --workload fitting (default, configs[1]; configs[3] at --gpus 8) | fitting_habitat (configs[4]: contact
 constant 1.0, Habitat camera flip, 64 bodies per GPU, a sweep over 7 synthetic rooms) | train_s2 (configs[2]).
@@ -25,8 +28,9 @@ by the same run, and `secondary.fitting_smplx_sparse_weights`: the headline work
 released SMPL-X model's 4 non-zeros (the headline keeps the dense random [V, 55] weight matrix of the earlier rounds).
 
 The JSON line also carries
-  roofline     — the dominant kernel of the iteration: algorithmic bytes per launch / its average
-                 launch duration measured with HIP events on the launch stream; peak = 8 TB/s HBM3E (MI355X guide);
+  roofline     — the dominant (longest) kernel of the iteration: the bytes the implementation has to MOVE per launch (DESIGN.md section 3;
+                 SURVEY 8(d)'s per-unit figure next to it as survey_8d_*) / its average launch duration measured with HIP events on the
+                 launch stream; peak = 8 TB/s HBM3E (MI355X guide); traffic = the PMC bytes of profiles/r05_pmc_traffic.json;
   cpu_baseline — the oracle (oracle/psi_oracle.py + oracle/chamfer_oracle.c, a CPU port of the reference path,
                  validated against the reference's golden vectors) timed on this box's host cores on a bounded
                  sample of the same workload (rank 0, N=1 only).
@@ -51,7 +55,7 @@ PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 ROOMS = 7                     # fitting_habitat.py:238-241: seven MP3D-R rooms
 LOOP_ITERS = 100              # fitting_proxe.py / fitting_habitat.py: num_iter of the shipped configuration (BASELINE configs[1]: '100-iter loop')
-PMC_FILES = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
+PMC_FILES = ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json')
 
 
 def parse(argv=None):
@@ -306,7 +310,7 @@ def load_rocprof_stats(kernel):
     HIP-event deltas of single launches (the live measurement below) contain the launch gap — about 3 us on this stack — that the
     profiler's begin/end timestamps exclude; the committed summary is quoted next to the live figure so the two can be compared."""
     import csv
-    for f in ('r04_kernel_stats.csv', 'r03_kernel_stats.csv'):
+    for f in ('r05_kernel_stats.csv', 'r04_kernel_stats.csv', 'r03_kernel_stats.csv'):
         p = os.path.join(ROOT, 'profiles', f)
         if not os.path.exists(p):
             continue

@@ -93,6 +93,7 @@ class Adam(torch.optim.Adam):
                                                   (ctypes.c_long * n)(*[p.numel() for p in params]), n, shared.data_ptr(), tk.data_ptr(),
                                                   float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']),
                                                   hip.stream()), 'psi_adam_step')
+            torch.autograd.graph.increment_version(params)      # the kernel wrote the parameters behind autograd's back: saved-tensor checks stay valid
             self.hip_steps += 1
         return loss
 

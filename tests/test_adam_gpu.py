@@ -57,6 +57,7 @@ def test_step_equals_torch_adam(wd, many):
     assert om.hip_steps == 7
     for a, b, c in zip(mine, fused, plain):
         scale = float(b.detach().abs().max()) + 1e-3
+        a, b, c = a.detach(), b.detach(), c.detach()
         assert float((a - b).abs().max()) <= 2.0 ** -22 * scale, (tuple(a.shape), float((a - b).abs().max()))      # <= 2 ulp of the largest element
         assert float((a - c).abs().max()) <= 1e-6 * scale + 3e-3 * 1e-5, tuple(a.shape)                             # the plain fp32 operator sequence
         sa, sb = om.state[a], of.state[b]
@@ -89,7 +90,7 @@ def test_step_in_a_hip_graph_and_state_dict_round_trip():
     torch.cuda.synchronize()
     assert float(om.state[mine[0]]['step']) == 3.0
     for a, b in zip(mine, ref):
-        assert float((a - b).abs().max()) <= 2.0 ** -22 * (float(b.detach().abs().max()) + 1e-3), tuple(a.shape)
+        assert float((a.detach() - b.detach()).abs().max()) <= 2.0 ** -22 * (float(b.detach().abs().max()) + 1e-3), tuple(a.shape)
     # ---- checkpoints travel both ways
     sd = copy.deepcopy(om.state_dict())
     other = torch.optim.Adam(_make(2), lr=1e-3, fused=True)
@@ -104,4 +105,4 @@ def test_step_in_a_hip_graph_and_state_dict_round_trip():
     orf.step()
     assert back.hip_steps == 1 and float(back.state[cont[0]]['step']) == 4.0
     for a, b in zip(cont, ref):
-        assert float((a - b).abs().max()) <= 2.0 ** -22 * (float(b.detach().abs().max()) + 1e-3), tuple(a.shape)
+        assert float((a.detach() - b.detach()).abs().max()) <= 2.0 ** -22 * (float(b.detach().abs().max()) + 1e-3), tuple(a.shape)
