@@ -55,12 +55,12 @@ def test_step_equals_torch_adam(wd, many):
             _grads(ps, 100 + it)
             o.step()
     assert om.hip_steps == 7
-    for a, b, c in zip(mine, fused, plain):
-        scale = float(b.detach().abs().max()) + 1e-3
-        a, b, c = a.detach(), b.detach(), c.detach()
+    for pa, pb, pc in zip(mine, fused, plain):
+        a, b, c = pa.detach(), pb.detach(), pc.detach()
+        scale = float(b.abs().max()) + 1e-3
         assert float((a - b).abs().max()) <= 2.0 ** -22 * scale, (tuple(a.shape), float((a - b).abs().max()))      # <= 2 ulp of the largest element
         assert float((a - c).abs().max()) <= 1e-6 * scale + 3e-3 * 1e-5, tuple(a.shape)                             # the plain fp32 operator sequence
-        sa, sb = om.state[a], of.state[b]
+        sa, sb = om.state[pa], of.state[pb]
         assert float(sa['step']) == 7.0 == float(sb['step'])
         for k in ('exp_avg', 'exp_avg_sq'):
             assert sa[k].stride() == a.stride()
