@@ -167,3 +167,59 @@ def test_vposer_experiment_dir_loaded_by_path(tmp_path, vposer_sd):
     assert np.abs(a.view(z.shape[0], -1).numpy() - golden('vposer_decode')['aa']).max() < 1e-4
     with pytest.raises(ValueError):
         load_vposer(str(tmp_path / 'nope'))
+
+
+def test_hdf5_branch_of_the_reader(tmp_path, monkeypatch):
+    """`.hdf5` files (batch_gen_hdf5.py:48-67: `h5py.File(path, 'r')`, datasets read whole, row 0 a placeholder) go through h5py.  The image
+    has no h5py, so the branch is driven by a stand-in with h5py's File / dataset protocol (context manager, `f[name][...]`) over the same
+    arrays: the generator built from the `.hdf5` names equals the one built from the `.npz` twins; without h5py the error says what to do."""
+    import sys
+    import types
+    files, vdir, sdir = _write_dataset(str(tmp_path))
+    h5_files = [f[:-4] + '.hdf5' for f in files]
+    store = {h: dict(np.load(f)) for h, f in zip(h5_files, files)}
+
+    class _Dataset:
+        def __init__(self, a):
+            self._a = a
+
+        def __getitem__(self, idx):
+            assert idx is Ellipsis                                    # the reader takes whole datasets
+            return self._a.copy()
+
+    class _File:
+        opened = []
+
+        def __init__(self, path, mode='r'):
+            assert mode == 'r'
+            self._d = store[path]
+            _File.opened.append(path)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+        def __getitem__(self, k):
+            return _Dataset(self._d[k])
+
+    monkeypatch.delitem(sys.modules, 'h5py', raising=False)
+    monkeypatch.setattr(sys, 'meta_path', [type('NoH5', (), {'find_spec': staticmethod(lambda name, path=None, target=None: (_ for _ in ()).throw(ImportError('no h5py')) if name == 'h5py' else None)})()] + list(sys.meta_path))
+    with pytest.raises(ImportError, match='convert the file to .npz'):
+        batch_gen._read_table(h5_files[0])
+    monkeypatch.undo()
+    h5 = types.ModuleType('h5py')
+    h5.File = _File
+    monkeypatch.setitem(sys.modules, 'h5py', h5)
+    kw = dict(device='cpu', scene_verts_path=vdir, scene_sdf_path=sdir, mode='train', read_all_to_ram=True)
+    random.seed(5)
+    a = batch_gen.BatchGeneratorWithSceneMesh(dataset_path=h5_files, **kw)
+    random.seed(5)
+    b = batch_gen.BatchGeneratorWithSceneMesh(dataset_path=files, **kw)
+    assert _File.opened == h5_files and a.n_samples == b.n_samples > 0
+    for k in ('depth_stream', 'seg_stream', 'body_stream', 'cam_ext_stream', 'cam_int_stream', 'max_d_stream', 'sceneid_stream'):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    ba, bb = a.next_batch(2), b.next_batch(2)
+    for x, y in zip(ba[:6], bb[:6]):
+        assert torch.equal(x, y)
