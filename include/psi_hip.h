@@ -354,6 +354,17 @@ int psi_conv2d_forward(const void *x, int x_bf16, const float *w, const float *b
  *   Both replace aten::convolution_backward (MIOpen igemm_bwd / igemm_wrw) for the trunk's convolutions; nterm as in the forward. */
 int psi_conv2d_input_grad(const void *dy, int dy_bf16, const float *wt, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                           void *dx, int dx_bf16, int nterm, void *stream);
+/* Prepared weights: psi_conv2d_prepare_weight rounds / splits the fp32 master weight ONCE per layer and step into bf16 parts (hi parts, for
+ *   nterm = 3 followed by the lo parts; Cout*KH*KW*Cin elements each) in the forward layout `wf` [Cout][KH][KW][Cin] and / or the input
+ *   gradient's layout `wt` [Cin][KH][KW][Cout] (either may be NULL) — instead of a re-layout copy for the backward and a re-split of every
+ *   64 x 64 weight tile in every workgroup of both kernels.  psi_conv2d_forward_p / psi_conv2d_input_grad_p take those buffers in place of
+ *   the fp32 weight (same results, bit for bit); psi_conv2d_prepared_ok: the layers they cover (Cin % 16 == 0: all but the stem). */
+int psi_conv2d_prepared_ok(int Cin, int Cout, int KH, int KW, int stride, int pad);
+int psi_conv2d_prepare_weight(const float *w, int Cout, int KH, int KW, int Cin, int nterm, void *wf, void *wt, void *stream);
+int psi_conv2d_forward_p(const void *x, int x_bf16, const void *wf, const float *bias, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                         int stride, int pad, void *y, int y_bf16, int nterm, void *stream);
+int psi_conv2d_input_grad_p(const void *dy, int dy_bf16, const void *wt, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                            void *dx, int dx_bf16, int nterm, void *stream);
 size_t psi_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int psi_conv2d_weight_grad(const void *x, int x_bf16, const void *dy, int dy_bf16, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                            int pad, float *gw, float *ws, int nterm, void *stream);

@@ -114,10 +114,13 @@ __device__ __forceinline__ void split_store(const float (&v)[NV], __bf16 *hi, __
     }
 }
 
-template <int NTERM, typename TIN, typename TOUT, int BN, int BM, bool RUNS>
-__global__ __launch_bounds__(256, BM == 64 ? 4 : 2) void conv_gemm_kernel(const TIN *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                                                           TOUT *__restrict__ y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH,
-                                                           int KW, int stride, int pad, int transposed)
+// PREP: the weights arrive already split (psi_conv2d_prepare_weight: [Cout][K] bf16 hi parts, the lo parts Cout * K elements behind them) and
+// go from memory to LDS as they are — the forward and the input gradient of a layer share one preparation per step, and a workgroup no longer
+// spends a quarter of its vector instructions re-splitting a 64 x 64 weight tile that 2000 other workgroups split as well.
+template <int NTERM, typename TIN, typename TOUT, int BN, int BM, bool RUNS, bool PREP>
+__global__ __launch_bounds__(256, BM == 64 ? 4 : 2) void conv_gemm_kernel(const TIN *__restrict__ x, const float *__restrict__ w, const __bf16 *__restrict__ wp,
+                                                           const float *__restrict__ bias, TOUT *__restrict__ y, int N, int H, int W, int Cin, int OH,
+                                                           int OW, int Cout, int KH, int KW, int stride, int pad, int transposed)
 {
     // transposed != 0: the INPUT GRADIENT of a convolution — "x" is dY [N,H,W,Cin] (H x W = the forward's output size, Cin = its Cout), "y" is
     // dX [N,OH,OW,Cout] (the forward's input), w = the forward weight re-laid out as [Cin_fwd][KH][KW][Cout_fwd]; output pixel (iy, ix) takes
@@ -181,6 +184,20 @@ __global__ __launch_bounds__(256, BM == 64 ? 4 : 2) void conv_gemm_kernel(const 
     const int br = t / (KC / WPT), bq = (t % (KC / WPT)) * WPT;
     const float *wrow = w + (size_t)(co0 + br) * K;
     float av[APT], bv[WPT];
+    bf16x8 pwh[WPT / 8], pwl[WPT / 8];                            // PREP: my piece of the chunk's weight tile, as stored
+    auto load_prepared = [&](int ck) {
+        const size_t at = (size_t)(co0 + br) * K + (size_t)ck * KC + bq;
+#pragma unroll
+        for (int i = 0; i < WPT / 8; i++) {
+            const bool ok = ck * KC + bq + 8 * i < K;              // (K % 8 == 0)
+#pragma unroll
+            for (int e = 0; e < 8; e++) pwh[i][e] = pwl[i][e] = (__bf16)0.0f;
+            if (ok) {
+                pwh[i] = *(const bf16x8 *)(wp + at + 8 * i);
+                if (NTERM > 1) pwl[i] = *(const bf16x8 *)(wp + (size_t)Cout * K + at + 8 * i);
+            }
+        }
+    };
     auto src = [&](int kh, int kw, int &iy, int &ix) {            // input pixel of tap (kh, kw) for my output pixel; false: outside / no such tap
         if (transposed) {
             const int ty = aoy + pad - kh, tx = aox + pad - kw;
@@ -209,12 +226,16 @@ __global__ __launch_bounds__(256, BM == 64 ? 4 : 2) void conv_gemm_kernel(const 
             int iy = 0, ix = 0;
             const bool ok = a_live && k0r < K && src(kh, kw, iy, ix);
             loadN(x + (((size_t)an * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + (ok ? c0 : 0), ok, av);
-            const bool wok = ck * KC + bq < K;
+            if (PREP) {
+                load_prepared(ck);
+            } else {
+                const bool wok = ck * KC + bq < K;
 #pragma unroll
-            for (int i = 0; i < WPT / 4; i++) {
-                const f4 a = wok ? *(const f4 *)(wrow + (size_t)ck * KC + bq + 4 * i) : (f4){0, 0, 0, 0};
+                for (int i = 0; i < WPT / 4; i++) {
+                    const f4 a = wok ? *(const f4 *)(wrow + (size_t)ck * KC + bq + 4 * i) : (f4){0, 0, 0, 0};
 #pragma unroll
-                for (int e = 0; e < 4; e++) bv[4 * i + e] = a[e];
+                    for (int e = 0; e < 4; e++) bv[4 * i + e] = a[e];
+                }
             }
         } else if (mode == 1) {
 #pragma unroll
@@ -250,10 +271,14 @@ __global__ __launch_bounds__(256, BM == 64 ? 4 : 2) void conv_gemm_kernel(const 
                 }
                 av[e] = v;
             }
+            if (PREP) {
+                load_prepared(ck);
+            } else {
 #pragma unroll
-            for (int e = 0; e < WPT; e++) {
-                const int k = ck * KC + bq + e;
-                bv[e] = k < K ? wrow[k] : 0.0f;
+                for (int e = 0; e < WPT; e++) {
+                    const int k = ck * KC + bq + e;
+                    bv[e] = k < K ? wrow[k] : 0.0f;
+                }
             }
         }
     };
@@ -271,7 +296,15 @@ __global__ __launch_bounds__(256, BM == 64 ? 4 : 2) void conv_gemm_kernel(const 
         while (nx < nck && !chunk_live(nx)) nx++;
         __syncthreads();                                           // the previous chunk's MFMAs are done with LDS
         split_store<NTERM, APT>(av, &Ah[ar][ah], &Al[ar][ah]);
-        split_store<NTERM, WPT>(bv, &Bh[br][bq], &Bl[br][bq]);
+        if (PREP) {
+#pragma unroll
+            for (int i = 0; i < WPT / 8; i++) {
+                *(bf16x8 *)&Bh[br][bq + 8 * i] = pwh[i];
+                if (NTERM > 1) *(bf16x8 *)&Bl[br][bq + 8 * i] = pwl[i];
+            }
+        } else {
+            split_store<NTERM, WPT>(bv, &Bh[br][bq], &Bl[br][bq]);
+        }
         __syncthreads();
         if (nx < nck) load_chunk(nx);                              // in flight during this chunk's MFMAs
         ck = nx;
@@ -313,6 +346,30 @@ __global__ __launch_bounds__(256, BM == 64 ? 4 : 2) void conv_gemm_kernel(const 
             for (int e = 0; e < 4; e++) v[e] = acc[c][4 * g + e] + (bias ? bias[co0 + co + e] : 0.0f);
             store_out(yo + co, v);
         }
+}
+
+// fp32 master weight [Cout][taps][Cin] -> bf16 parts, in the forward layout ([Cout][K]: hi parts, then lo parts for NTERM = 3) and, when the
+// layer's input needs a gradient, in the input gradient's layout ([Cin][taps][Cout], the same way): one small launch per layer and step
+// instead of a re-layout copy for the backward plus a re-split of the tile in every workgroup of both kernels
+template <int NTERM>
+__global__ __launch_bounds__(256) void conv_weight_split_kernel(const float *__restrict__ w, int Cout, int taps, int Cin, __bf16 *__restrict__ wf,
+                                                                __bf16 *__restrict__ wt)
+{
+    const int total = Cout * taps * Cin, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    __bf16 hi;
+    const float r = bf_round(w[i], hi);
+    const __bf16 lo = (__bf16)r;
+    if (wf) {
+        wf[i] = hi;
+        if (NTERM > 1) wf[(size_t)total + i] = lo;
+    }
+    if (wt) {
+        const int ci = i % Cin, tap = (i / Cin) % taps, co = i / (Cin * taps);
+        const size_t j = ((size_t)ci * taps + tap) * Cout + co;
+        wt[j] = hi;
+        if (NTERM > 1) wt[(size_t)total + j] = lo;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -508,43 +565,57 @@ static inline hipError_t set_max_lds(const void *kern, size_t lds, std::atomic<u
     return e;
 }
 
-template <int NTERM, typename TIN, typename TOUT, int BN, int BM, bool RUNS>
-int launch_r(const void *x, const float *w, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
-             int stride, int pad, int transposed, hipStream_t st)
+template <int NTERM, typename TIN, typename TOUT, int BN, int BM, bool RUNS, bool PREP>
+int launch_p(const void *x, const float *w, const __bf16 *wp, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH,
+             int KW, int stride, int pad, int transposed, hipStream_t st)
 {
     const size_t lds = (size_t)(BM + BN) * PITCH * 2 * (NTERM > 1 ? 2 : 1);
-    auto kern = conv_gemm_kernel<NTERM, TIN, TOUT, BN, BM, RUNS>;
+    auto kern = conv_gemm_kernel<NTERM, TIN, TOUT, BN, BM, RUNS, PREP>;
     static std::atomic<unsigned long long> attr_set{0};
     PSI_CHECK_HIP(set_max_lds((const void *)kern, lds, attr_set));
     const long M = (long)N * OH * OW;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(Cout / BN));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const TIN *)x, w, bias, (TOUT *)y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const TIN *)x, w, wp, bias, (TOUT *)y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed);
     PSI_CHECK_LAUNCH("conv_gemm_kernel");
     psi_mark("conv_gemm_kernel", st);
     return 0;
 }
 
+// w: fp32 [Cout][K] as the layer holds it, or (prepared != 0) the bf16 parts psi_conv2d_prepare_weight wrote
+template <int NTERM, typename TIN, typename TOUT, int BN, int BM, bool RUNS>
+int launch_r(const void *x, const float *w, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
+             int stride, int pad, int transposed, hipStream_t st, int prepared)
+{
+    if (prepared) {
+        PSI_REQUIRE((KH * KW * Cin) % 8 == 0 && (RUNS || transposed || Cin * KW > 16), "prepared weights: K % 8 == 0, not the filter-row path");
+        return launch_p<NTERM, TIN, TOUT, BN, BM, RUNS, true>(x, nullptr, (const __bf16 *)w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad,
+                                                              transposed, st);
+    }
+    return launch_p<NTERM, TIN, TOUT, BN, BM, RUNS, false>(x, w, nullptr, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
+}
+
 template <int NTERM, typename TIN, typename TOUT, int BN, int BM>
 int launch(const void *x, const float *w, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
-           int stride, int pad, int transposed, hipStream_t st)
+           int stride, int pad, int transposed, hipStream_t st, int prepared)
 {
     // a thread's run of BM * 64 / 256 consecutive k lies inside one filter tap: the vector-load instantiation; else filter rows / element gather
     if (Cin % (BM * KC / 256) == 0)
-        return launch_r<NTERM, TIN, TOUT, BN, BM, true>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
-    return launch_r<NTERM, TIN, TOUT, BN, BM, false>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
+        return launch_r<NTERM, TIN, TOUT, BN, BM, true>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st, prepared);
+    return launch_r<NTERM, TIN, TOUT, BN, BM, false>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st, prepared);
 }
 
 template <int NTERM, typename TIN, typename TOUT>
 int launch_bn(const void *x, const float *w, const float *bias, void *y, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
-              int stride, int pad, int transposed, hipStream_t st)
+              int stride, int pad, int transposed, hipStream_t st, int prepared = 0)
 {
     // pixel tile: 64 (four workgroups per compute unit) unless PSI_CONV_BM=128 says otherwise; the 32-channel tile keeps 128 pixels
     static const int bm = getenv("PSI_CONV_BM") ? atoi(getenv("PSI_CONV_BM")) : PSI_CONV_BM_DEFAULT;
     if (Cout % 64 == 0) {
-        if (bm == 64 || Cin % 32 != 0) return launch<NTERM, TIN, TOUT, 64, 64>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
-        return launch<NTERM, TIN, TOUT, 64, 128>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
+        if (bm == 64 || Cin % 32 != 0)
+            return launch<NTERM, TIN, TOUT, 64, 64>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st, prepared);
+        return launch<NTERM, TIN, TOUT, 64, 128>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st, prepared);
     }
-    return launch<NTERM, TIN, TOUT, 32, 128>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st);
+    return launch<NTERM, TIN, TOUT, 32, 128>(x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, transposed, st, prepared);
 }
 
 // the stem has kernels of its own (conv_stem.hip); PSI_CONV_STEM=0 sends it through the general kernels (dev A/B)
@@ -563,8 +634,8 @@ extern "C" int psi_conv2d_supported(int Cin, int Cout, int KH, int KW, int strid
 
 // x [N,H,W,Cin] NHWC (x_bf16: bf16, else fp32); w [Cout,KH,KW,Cin] fp32 (a channels_last Conv2d weight); bias [Cout] fp32 or NULL;
 // y [N,OH,OW,Cout] NHWC (y_bf16: bf16, else fp32), OH = (H + 2 pad - KH) / stride + 1.  nterm = 1 | 3 (see the header of this file).
-extern "C" int psi_conv2d_forward(const void *x, int x_bf16, const float *w, const float *bias, int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                                  int stride, int pad, void *y, int y_bf16, int nterm, void *stream)
+static int conv2d_forward_any(const void *x, int x_bf16, const float *w, int prepared, const float *bias, int N, int H, int W, int Cin, int Cout, int KH,
+                              int KW, int stride, int pad, void *y, int y_bf16, int nterm, void *stream)
 {
     PSI_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0, "bad arguments");
     PSI_REQUIRE(psi_conv2d_supported(Cin, Cout, KH, KW, stride, pad), "shape not covered: Cout % 32 == 0 and (Cin % 64 == 0 or a small gather case)");
@@ -572,8 +643,11 @@ extern "C" int psi_conv2d_forward(const void *x, int x_bf16, const float *w, con
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     PSI_REQUIRE(OH > 0 && OW > 0, "empty output");
     hipStream_t st = (hipStream_t)stream;
-    if (stem_route(Cin, Cout, KH, KW, stride, pad)) return psi_conv_stem_forward(x, x_bf16, w, bias, N, H, W, y, y_bf16, nterm, st);
-#define PSI_CONV_ARGS x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, st
+    if (stem_route(Cin, Cout, KH, KW, stride, pad)) {
+        PSI_REQUIRE(!prepared, "the stem's kernels read the fp32 weight");
+        return psi_conv_stem_forward(x, x_bf16, w, bias, N, H, W, y, y_bf16, nterm, st);
+    }
+#define PSI_CONV_ARGS x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, st, prepared
     if (nterm == 3) {
         if (x_bf16) return y_bf16 ? launch_bn<3, __bf16, __bf16>(PSI_CONV_ARGS) : launch_bn<3, __bf16, float>(PSI_CONV_ARGS);
         return y_bf16 ? launch_bn<3, float, __bf16>(PSI_CONV_ARGS) : launch_bn<3, float, float>(PSI_CONV_ARGS);
@@ -583,11 +657,45 @@ extern "C" int psi_conv2d_forward(const void *x, int x_bf16, const float *w, con
 #undef PSI_CONV_ARGS
 }
 
+extern "C" int psi_conv2d_forward(const void *x, int x_bf16, const float *w, const float *bias, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                  int stride, int pad, void *y, int y_bf16, int nterm, void *stream)
+{
+    return conv2d_forward_any(x, x_bf16, w, 0, bias, N, H, W, Cin, Cout, KH, KW, stride, pad, y, y_bf16, nterm, stream);
+}
+
+// The same with a PREPARED weight (psi_conv2d_prepare_weight's `wf`): no per-workgroup rounding / splitting of the weight tile.
+extern "C" int psi_conv2d_forward_p(const void *x, int x_bf16, const void *wf, const float *bias, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                    int stride, int pad, void *y, int y_bf16, int nterm, void *stream)
+{
+    return conv2d_forward_any(x, x_bf16, (const float *)wf, 1, bias, N, H, W, Cin, Cout, KH, KW, stride, pad, y, y_bf16, nterm, stream);
+}
+
+extern "C" int psi_conv2d_prepared_ok(int Cin, int Cout, int KH, int KW, int stride, int pad)
+{
+    return psi_conv2d_supported(Cin, Cout, KH, KW, stride, pad) && Cin % 16 == 0 && !psi_conv_stem_shape(Cin, Cout, KH, KW, stride, pad);
+}
+
+// w [Cout][KH][KW][Cin] fp32 -> wf (forward layout) and / or wt (input-gradient layout [Cin][KH][KW][Cout]); each Cout*KH*KW*Cin bf16 (nterm = 1)
+// or twice that (nterm = 3: hi parts, then lo parts).  Either output may be NULL.
+extern "C" int psi_conv2d_prepare_weight(const float *w, int Cout, int KH, int KW, int Cin, int nterm, void *wf, void *wt, void *stream)
+{
+    PSI_REQUIRE(w && (wf || wt) && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "bad arguments");
+    PSI_REQUIRE(nterm == 1 || nterm == 3, "nterm is 1 or 3");
+    const int total = Cout * KH * KW * Cin;
+    hipStream_t st = (hipStream_t)stream;
+    if (nterm == 3)
+        hipLaunchKernelGGL(conv_weight_split_kernel<3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, Cout, KH * KW, Cin, (__bf16 *)wf, (__bf16 *)wt);
+    else
+        hipLaunchKernelGGL(conv_weight_split_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, Cout, KH * KW, Cin, (__bf16 *)wf, (__bf16 *)wt);
+    PSI_CHECK_LAUNCH("conv_weight_split_kernel");
+    return 0;
+}
+
 // Input gradient of the convolution above: dy [N,OH,OW,Cout] -> dx [N,H,W,Cin] (OVERWRITTEN), wt = the forward weight re-laid out as
 // [Cin][KH][KW][Cout] fp32 (torch: weight.permute(1, 2, 3, 0).contiguous()).  The same kernel in its transposed-gather form; Cin % 32 == 0,
 // Cout % 64 == 0 (or Cout * KH * KW <= 4096: the element-gather path, e.g. the 128 -> 32 head).
-extern "C" int psi_conv2d_input_grad(const void *dy, int dy_bf16, const float *wt, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                                     int pad, void *dx, int dx_bf16, int nterm, void *stream)
+static int conv2d_input_grad_any(const void *dy, int dy_bf16, const float *wt, int prepared, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                 int stride, int pad, void *dx, int dx_bf16, int nterm, void *stream)
 {
     PSI_REQUIRE(dy && wt && dx && N > 0 && H > 0 && W > 0, "bad arguments");
     PSI_REQUIRE(Cin % 32 == 0 && (Cout % 64 == 0 || Cout * KH * KW <= 4096) && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
@@ -596,7 +704,7 @@ extern "C" int psi_conv2d_input_grad(const void *dy, int dy_bf16, const float *w
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     hipStream_t st = (hipStream_t)stream;
     // roles swapped: the kernel's "input" is dY (OH x OW x Cout), its "output" dX (H x W x Cin)
-#define PSI_DG_ARGS dy, wt, nullptr, dx, N, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 1, st
+#define PSI_DG_ARGS dy, wt, nullptr, dx, N, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 1, st, prepared
     if (nterm == 3) {
         if (dy_bf16) return dx_bf16 ? launch_bn<3, __bf16, __bf16>(PSI_DG_ARGS) : launch_bn<3, __bf16, float>(PSI_DG_ARGS);
         return dx_bf16 ? launch_bn<3, float, __bf16>(PSI_DG_ARGS) : launch_bn<3, float, float>(PSI_DG_ARGS);
@@ -604,6 +712,19 @@ extern "C" int psi_conv2d_input_grad(const void *dy, int dy_bf16, const float *w
     if (dy_bf16) return dx_bf16 ? launch_bn<1, __bf16, __bf16>(PSI_DG_ARGS) : launch_bn<1, __bf16, float>(PSI_DG_ARGS);
     return dx_bf16 ? launch_bn<1, float, __bf16>(PSI_DG_ARGS) : launch_bn<1, float, float>(PSI_DG_ARGS);
 #undef PSI_DG_ARGS
+}
+
+extern "C" int psi_conv2d_input_grad(const void *dy, int dy_bf16, const float *wt, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                     int pad, void *dx, int dx_bf16, int nterm, void *stream)
+{
+    return conv2d_input_grad_any(dy, dy_bf16, wt, 0, N, H, W, Cin, Cout, KH, KW, stride, pad, dx, dx_bf16, nterm, stream);
+}
+
+// The same with psi_conv2d_prepare_weight's `wt`.
+extern "C" int psi_conv2d_input_grad_p(const void *dy, int dy_bf16, const void *wt, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                       int pad, void *dx, int dx_bf16, int nterm, void *stream)
+{
+    return conv2d_input_grad_any(dy, dy_bf16, (const float *)wt, 1, N, H, W, Cin, Cout, KH, KW, stride, pad, dx, dx_bf16, nterm, stream);
 }
 
 extern "C" size_t psi_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad)

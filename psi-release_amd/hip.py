@@ -70,6 +70,10 @@ SIGNATURES = {
     'psi_conv2d_supported': (c_int, [c_int] * 6),
     'psi_conv2d_forward': (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_int, c_int, c_void_p]),
     'psi_conv2d_input_grad': (c_int, [c_void_p, c_int, c_void_p] + [c_int] * 9 + [c_void_p, c_int, c_int, c_void_p]),
+    'psi_conv2d_prepared_ok': (c_int, [c_int] * 6),
+    'psi_conv2d_prepare_weight': (c_int, [c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
+    'psi_conv2d_forward_p': (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_int, c_int, c_void_p]),
+    'psi_conv2d_input_grad_p': (c_int, [c_void_p, c_int, c_void_p] + [c_int] * 9 + [c_void_p, c_int, c_int, c_void_p]),
     'psi_conv2d_wgrad_workspace_floats': (c_size_t, [c_int] * 9),
     'psi_conv2d_weight_grad': (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_void_p]),
     'psi_conv3x3_supported': (c_int, [c_int] * 4),

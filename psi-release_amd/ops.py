@@ -537,6 +537,11 @@ def conv2d_supported(conv):
                                                     conv.padding[0])))
 
 
+def _conv2d_dgrad_covered(Cin, Cout, KH, KW):
+    """shapes whose input gradient the general kernel takes in its transposed-gather form (psi_hip.h: psi_conv2d_input_grad)"""
+    return Cin % 32 == 0 and (Cout % 64 == 0 or Cout * KH * KW <= 4096)
+
+
 class _Conv2dSplit(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, nterm, out_bf16):
@@ -548,15 +553,27 @@ class _Conv2dSplit(Function):
         OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
         y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32, memory_format=torch.channels_last)
         b = bias.detach().float().contiguous() if bias is not None else None
-        hip.check(hip.lib().psi_conv2d_forward(_ptr_cl(xc), int(xc.dtype == torch.bfloat16), hip.ptr(w4), hip.ptr(b), N, H, W, Cin, Cout, KH, KW,
-                                               stride, pad, _ptr_cl(y), int(out_bf16), nterm, hip.stream()), 'psi_conv2d_forward')
-        ctx.save_for_backward(xc, weight)
+        L = hip.lib()
+        wt = None
+        if L.psi_conv2d_prepared_ok(Cin, Cout, KH, KW, stride, pad) and os.environ.get('PSI_HIP_CONV_PREP', '1') != '0':
+            # the weight's bf16 parts once per layer and step, in the forward's layout and (when x needs a gradient) the input gradient's
+            nel = Cout * KH * KW * Cin * (2 if nterm == 3 else 1)
+            wf = torch.empty(nel, device=x.device, dtype=torch.bfloat16)
+            if ctx.needs_input_grad[0] and _conv2d_dgrad_covered(Cin, Cout, KH, KW):
+                wt = torch.empty(nel, device=x.device, dtype=torch.bfloat16)
+            hip.check(L.psi_conv2d_prepare_weight(hip.ptr(w4), Cout, KH, KW, Cin, nterm, hip.ptr(wf), hip.ptr(wt), hip.stream()), 'psi_conv2d_prepare_weight')
+            hip.check(L.psi_conv2d_forward_p(_ptr_cl(xc), int(xc.dtype == torch.bfloat16), hip.ptr(wf), hip.ptr(b), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                             _ptr_cl(y), int(out_bf16), nterm, hip.stream()), 'psi_conv2d_forward_p')
+        else:
+            hip.check(L.psi_conv2d_forward(_ptr_cl(xc), int(xc.dtype == torch.bfloat16), hip.ptr(w4), hip.ptr(b), N, H, W, Cin, Cout, KH, KW,
+                                           stride, pad, _ptr_cl(y), int(out_bf16), nterm, hip.stream()), 'psi_conv2d_forward')
+        ctx.save_for_backward(xc, weight, wt)
         ctx.geom = (stride, pad, bias is not None, nterm)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xc, weight = ctx.saved_tensors
+        xc, weight, wt_prepared = ctx.saved_tensors
         stride, pad, has_bias, nterm = ctx.geom
         N, Cin, H, W = xc.shape
         Cout, _, KH, KW = weight.shape
@@ -572,11 +589,16 @@ class _Conv2dSplit(Function):
                                                              (stride, stride), (pad, pad), (1, 1), False, (0, 0), 1, mask)
             return gx, gw.float() if gw is not None else None, gb.float() if gb is not None else None, None, None, None, None
         if ctx.needs_input_grad[0]:
-            if Cin % 32 == 0 and (Cout % 64 == 0 or Cout * KH * KW <= 4096):
-                wt = weight.detach().float().permute(1, 2, 3, 0).contiguous()            # [Cin,KH,KW,Cout]
+            if _conv2d_dgrad_covered(Cin, Cout, KH, KW):
                 gx = torch.empty((N, Cin, H, W), device=dy.device, dtype=xc.dtype, memory_format=torch.channels_last)
-                hip.check(L.psi_conv2d_input_grad(_ptr_cl(dyc), int(dyc.dtype == torch.bfloat16), hip.ptr(wt), N, H, W, Cin, Cout, KH, KW, stride, pad,
-                                                  _ptr_cl(gx), int(gx.dtype == torch.bfloat16), nterm, hip.stream()), 'psi_conv2d_input_grad')
+                if wt_prepared is not None:
+                    hip.check(L.psi_conv2d_input_grad_p(_ptr_cl(dyc), int(dyc.dtype == torch.bfloat16), hip.ptr(wt_prepared), N, H, W, Cin, Cout, KH, KW,
+                                                        stride, pad, _ptr_cl(gx), int(gx.dtype == torch.bfloat16), nterm, hip.stream()),
+                              'psi_conv2d_input_grad_p')
+                else:
+                    wt = weight.detach().float().permute(1, 2, 3, 0).contiguous()        # [Cin,KH,KW,Cout]
+                    hip.check(L.psi_conv2d_input_grad(_ptr_cl(dyc), int(dyc.dtype == torch.bfloat16), hip.ptr(wt), N, H, W, Cin, Cout, KH, KW, stride,
+                                                      pad, _ptr_cl(gx), int(gx.dtype == torch.bfloat16), nterm, hip.stream()), 'psi_conv2d_input_grad')
             else:
                 gx = torch.ops.aten.convolution_backward(dyc.to(xc.dtype), xc, weight.detach().to(xc.dtype), None, (stride, stride), (pad, pad), (1, 1),
                                                          False, (0, 0), 1, (True, False, False))[0]

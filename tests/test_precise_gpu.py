@@ -86,6 +86,28 @@ def test_conv2d_split_gradients_match_double_precision(N, Cin, Cout, K, stride, 
     assert float((conv.weight.grad - wr.grad).abs().max()) <= 2e-5 * float(wr.grad.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize('N,Cin,Cout,K,stride,pad,H,nterm', [(4, 64, 64, 3, 1, 1, 32, 3), (3, 64, 128, 3, 2, 1, 32, 3), (2, 64, 128, 1, 2, 0, 32, 1),
+                                                            (5, 128, 32, 3, 1, 1, 16, 3), (2, 128, 128, 3, 1, 1, 16, 1)])
+def test_prepared_weights_give_the_same_bits(N, Cin, Cout, K, stride, pad, H, nterm, monkeypatch):
+    """psi_conv2d_prepare_weight + psi_conv2d_forward_p / _input_grad_p (the weight's bf16 parts written once per layer and step, in both
+    layouts) against the kernels that round / split the fp32 weight tile in every workgroup (PSI_HIP_CONV_PREP=0): the same parts, the same
+    products in the same order — outputs and input gradients bit for bit."""
+    torch.manual_seed(Cin + Cout + K)
+    dt = torch.float32 if nterm == 3 else torch.bfloat16
+    conv = torch.nn.Conv2d(Cin, Cout, K, stride, pad, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    x0 = torch.randn(N, Cin, H, H, device=DEV).to(dt).contiguous(memory_format=torch.channels_last)
+    got = {}
+    for prep in ('1', '0'):
+        monkeypatch.setenv('PSI_HIP_CONV_PREP', prep)
+        x = x0.clone().requires_grad_()
+        y = ops.conv2d_split(x, conv, nterm=nterm, out_bf16=nterm == 1)
+        conv.zero_grad()
+        y.backward(torch.ones_like(y) * 0.37)
+        got[prep] = (y.detach().clone(), x.grad.clone(), conv.weight.grad.clone())
+    for a, b in zip(got['1'], got['0']):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('C,H,N,relu,res,train', [(64, 64, 3, True, False, True), (64, 32, 4, True, True, True), (128, 16, 5, False, False, True),
                                                  (64, 32, 2, True, True, False), (128, 16, 1, False, False, False), (32, 16, 2, True, False, True)])
 def test_bn_act_on_fp32_maps(C, H, N, relu, res, train):
