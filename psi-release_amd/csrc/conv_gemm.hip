@@ -201,8 +201,13 @@ __global__ __launch_bounds__(256, BM == 64 ? 4 : 2) void conv_gemm_kernel(const 
     auto src = [&](int kh, int kw, int &iy, int &ix) {            // input pixel of tap (kh, kw) for my output pixel; false: outside / no such tap
         if (transposed) {
             const int ty = aoy + pad - kh, tx = aox + pad - kw;
-            iy = ty / stride;
-            ix = tx / stride;
+            if (stride <= 2) {                                     // (no run-time division in the chunk loop; negative ty / tx are rejected below)
+                iy = ty >> (stride - 1);
+                ix = tx >> (stride - 1);
+            } else {
+                iy = ty / stride;
+                ix = tx / stride;
+            }
             return ty >= 0 && tx >= 0 && iy * stride == ty && ix * stride == tx && iy < H && ix < W;
         }
         iy = aoy * stride - pad + kh;
@@ -218,14 +223,26 @@ __global__ __launch_bounds__(256, BM == 64 ? 4 : 2) void conv_gemm_kernel(const 
         }
         return false;
     };
+    // mode 0: my run of a chunk = one tap, channels rc0 .. rc0 + APT.  (kh, kw, channel) of the run are carried from chunk to chunk: the
+    // chunk loop had two integer divisions by run-time values per thread and chunk
+    int rck = 0, rkh, rkw, rc0;
+    {
+        const int tap = ah / Cin;
+        rc0 = ah - tap * Cin;
+        rkh = tap / KW;
+        rkw = tap - rkh * KW;
+    }
     auto load_chunk = [&](int ck) {
         if (mode == 0) {
-            const int k0r = ck * KC + ah;                          // my run: one tap, channels c0 .. c0 + APT
-            const int tap = k0r / Cin, c0 = k0r - tap * Cin;
-            const int kh = tap / KW, kw = tap - kh * KW;
+            rc0 += (ck - rck) * KC;                                // (ck only grows)
+            rck = ck;
+            while (rc0 >= Cin) {
+                rc0 -= Cin;
+                if (++rkw == KW) { rkw = 0; rkh++; }
+            }
             int iy = 0, ix = 0;
-            const bool ok = a_live && k0r < K && src(kh, kw, iy, ix);
-            loadN(x + (((size_t)an * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + (ok ? c0 : 0), ok, av);
+            const bool ok = a_live && rkh < KH && src(rkh, rkw, iy, ix);
+            loadN(x + (((size_t)an * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + (ok ? rc0 : 0), ok, av);
             if (PREP) {
                 load_prepared(ck);
             } else {
@@ -445,17 +462,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const TIN *__restric
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
     float dv[2][8], xv[2][8];
+    // (n, oy, ox) of my first pixel are carried from stage to stage (consecutive stages are 64 pixels apart): the stage loop had four integer
+    // divisions by run-time values per thread
+    long pm = -1;
+    int pn = 0, poy = 0, pox = 0;
     auto load_stage = [&](long m0) {
+        const long ma = m0 + 2 * pp;
+        if (pm < 0) {
+            pn = (int)(ma / ((long)OH * OW));
+            const int rem = (int)(ma - (long)pn * OH * OW);
+            poy = rem / OW;
+            pox = rem - poy * OW;
+        } else {
+            pox += (int)(ma - pm);
+            while (pox >= OW) {
+                pox -= OW;
+                if (++poy == OH) { poy = 0; pn++; }
+            }
+        }
+        pm = ma;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const long m = m0 + 2 * pp + u;
+            const long m = ma + u;
             const bool live = m < M;
-            int n = 0, oy = 0, ox = 0;
-            if (live) {
-                n = (int)(m / ((long)OH * OW));
-                const int rem = (int)(m - (long)n * OH * OW);
-                oy = rem / OW;
-                ox = rem - oy * OW;
+            int n = pn, oy = poy, ox = pox + u;
+            if (ox >= OW) {
+                ox -= OW;
+                if (++oy == OH) { oy = 0; n++; }
             }
             const bool dok = live && co0 + q8 + 8 <= Cout;        // (Cout % 8 == 0: whole 8-channel pieces)
             load8(dy + (size_t)(dok ? m : 0) * Cout + (dok ? co0 + q8 : 0), dok, dv[u]);
