@@ -380,7 +380,9 @@ int psi_adam_step(void *const *p, const void *const *g, void *const *m, void *co
 int psi_bn_forward_t(const void *x, int map_f32, const void *residual, const float *gamma, const float *beta, float *running_mean,
                      float *running_var, long long *num_batches_tracked, long M, int C, int relu, float momentum, float eps, void *y,
                      float *save_mean, float *save_invstd, float *ws, int eval_mode, void *stream);
-int psi_bn_backward_t(const void *dy, int map_f32, const void *x, const void *y, const float *gamma, const float *save_mean,
+/* psi_bn_backward_t: y may be NULL for a ReLU layer WITHOUT a skip connection when beta is given — the mask "y > 0" is then recomputed from x
+ *   (y = relu(fma(x, gamma * invstd, beta - mean * gamma * invstd)), rounded as the forward stored it): both backward passes read one map less. */
+int psi_bn_backward_t(const void *dy, int map_f32, const void *x, const void *y, const float *gamma, const float *beta, const float *save_mean,
                       const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, float *ws,
                       void *stream);
 int psi_maxpool3x3s2_forward_t(const void *x, int map_f32, int N, int H, int W, int C, void *y, void *idx, void *stream);

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(const float *__re
     save_invstd[c] = invstd;
     const float sc = gamma[c] * invstd;
     scale_shift[c] = sc;
-    scale_shift[C + c] = beta[c] - (float)mean * sc;
+    scale_shift[C + c] = __builtin_fmaf(-(float)mean, sc, beta[c]);          // (explicit: the backward re-forms scale and shift, relu_open)
     if (running_mean) {
         const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
         running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(BN_BLK) void bn_fwd_apply_kernel(const void *__rest
         if (RES) V::unpack(rv, r);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            float v = f[k] * ss[c0 + k] + ss[C + c0 + k];
+            float v = __builtin_fmaf(f[k], ss[c0 + k], ss[C + c0 + k]);      // (explicit: the backward recomputes this value for its ReLU mask)
             if (RES) v += r[k];
             if (RELU) v = v > 0.0f ? v : 0.0f;
             f[k] = v;
@@ -240,19 +240,40 @@ __global__ __launch_bounds__(BN_BLK) void bn_fwd_apply_kernel(const void *__rest
     }
 }
 
-// backward, pass 1: dz = dy * (y > 0) [ReLU] ; partial sums of dz and dz * xhat per channel, xhat = (x - mean) * invstd
+// ReLU mask of a BatchNorm WITHOUT a skip connection, recomputed from x: the forward stored y = relu(fma(x, scale, shift)) (rounded to bf16 on
+// bf16 maps), so "y > 0" is a function of x and two per-channel numbers — the backward passes then read two maps (dy, x) instead of three
+// and three (dy, x -> dx) instead of four: y never crosses HBM again.  scale = gamma * invstd, shift = beta - mean * scale exactly as
+// fwd_finalize_channel forms them.
+template <typename MT> __device__ __forceinline__ bool relu_open(float x, float scale, float shift)
+{
+    const float v = __builtin_fmaf(x, scale, shift);
+    if (sizeof(MT) == 2) return bf2f(f2bf(v > 0.0f ? v : 0.0f)) > 0.0f;      // what the forward's bf16 store kept of it
+    return v > 0.0f;
+}
+
+// backward, pass 1: dz = dy * (y > 0) [ReLU] ; partial sums of dz and dz * xhat per channel, xhat = (x - mean) * invstd.
+// y == NULL (RELU, no skip connection, beta given): the mask is recomputed from x.
 template <typename MT, bool RELU>
 __global__ __launch_bounds__(BN_BLK) void bn_bwd_reduce_kernel(const void *__restrict__ dy, const void *__restrict__ x, const void *__restrict__ y,
                                                                long M, int C, const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                               float *__restrict__ part)
+                                                               const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ part)
 {
     typedef Map8<MT> V;
     typedef typename V::raw R8;
     const int ngrp = C / 8, rpb = BN_BLK / ngrp;
     const int g = threadIdx.x % ngrp, rr = threadIdx.x / ngrp;
-    float mu[8], is[8];
+    const bool xmask = RELU && y == nullptr;
+    float mu[8], is[8], fs[8], fh[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) { mu[i] = mean[g * 8 + i]; is[i] = invstd[g * 8 + i]; }
+    for (int i = 0; i < 8; i++) {
+        mu[i] = mean[g * 8 + i];
+        is[i] = invstd[g * 8 + i];
+        fs[i] = fh[i] = 0.0f;
+        if (xmask) {
+            fs[i] = gamma[g * 8 + i] * is[i];
+            fh[i] = __builtin_fmaf(-mu[i], fs[i], beta[g * 8 + i]);
+        }
+    }
     float acc[2][8];
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[0][i] = acc[1][i] = 0.0f;
@@ -261,10 +282,11 @@ __global__ __launch_bounds__(BN_BLK) void bn_bwd_reduce_kernel(const void *__res
         float d[8], xf[8], yf[8];
         V::unpack(dv, d);
         V::unpack(xv, xf);
-        if (RELU) V::unpack(yv, yf);
+        if (RELU && !xmask) V::unpack(yv, yf);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float dz = (RELU && !(yf[i] > 0.0f)) ? 0.0f : d[i];
+            const bool open = !RELU || (xmask ? relu_open<MT>(xf[i], fs[i], fh[i]) : yf[i] > 0.0f);
+            const float dz = open ? d[i] : 0.0f;
             acc[0][i] += dz;
             acc[1][i] += dz * ((xf[i] - mu[i]) * is[i]);
         }
@@ -274,7 +296,7 @@ __global__ __launch_bounds__(BN_BLK) void bn_bwd_reduce_kernel(const void *__res
         const long i0 = r * ngrp + g, i1 = (r + stride) * ngrp + g;
         const R8 d0 = V::ld(dy, i0), x0 = V::ld(x, i0), d1 = V::ld(dy, i1), x1 = V::ld(x, i1);
         R8 y0 = d0, y1 = d1;
-        if (RELU) { y0 = V::ld(y, i0); y1 = V::ld(y, i1); }
+        if (RELU && !xmask) { y0 = V::ld(y, i0); y1 = V::ld(y, i1); }
         row(d0, x0, y0);
         row(d1, x1, y1);
     }
@@ -282,7 +304,7 @@ __global__ __launch_bounds__(BN_BLK) void bn_bwd_reduce_kernel(const void *__res
         const long i0 = r * ngrp + g;
         const R8 d0 = V::ld(dy, i0), x0 = V::ld(x, i0);
         R8 y0 = d0;
-        if (RELU) y0 = V::ld(y, i0);
+        if (RELU && !xmask) y0 = V::ld(y, i0);
         row(d0, x0, y0);
     }
     block_reduce_store<2>(acc, C, g, rr, rpb, part);
@@ -310,16 +332,23 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
 template <typename MT, bool RELU, bool RES>
 __global__ __launch_bounds__(BN_BLK) void bn_bwd_apply_kernel(const void *__restrict__ dy, const void *__restrict__ x, const void *__restrict__ y, long n16,
                                                               int C, const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                              const float *__restrict__ coef, void *__restrict__ dx, void *__restrict__ dres)
+                                                              const float *__restrict__ coef, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, void *__restrict__ dx, void *__restrict__ dres)
 {
     typedef Map8<MT> V;
-    __shared__ float sc[5 * BN_MAXC];
+    __shared__ float sc[7 * BN_MAXC];
+    const bool xmask = RELU && y == nullptr;                      // (see bn_bwd_reduce_kernel)
     for (int i = threadIdx.x; i < C; i += BN_BLK) {
         sc[i] = coef[i];
         sc[C + i] = coef[C + i];
         sc[2 * C + i] = coef[2 * C + i];
         sc[3 * C + i] = mean[i];
         sc[4 * C + i] = invstd[i];
+        if (xmask) {
+            const float fs = gamma[i] * invstd[i];
+            sc[5 * C + i] = fs;
+            sc[6 * C + i] = __builtin_fmaf(-mean[i], fs, beta[i]);
+        }
     }
     __syncthreads();
     const int ngrp = C / 8;
@@ -328,14 +357,15 @@ __global__ __launch_bounds__(BN_BLK) void bn_bwd_apply_kernel(const void *__rest
         const int c0 = (pow2 ? (int)(i & (ngrp - 1)) : (int)(i % ngrp)) * 8;
         const typename V::raw dv = V::ld(dy, i), xv = V::ld(x, i);
         typename V::raw yv = dv;
-        if (RELU) yv = V::ld(y, i);
+        if (RELU && !xmask) yv = V::ld(y, i);
         float d[8], xf[8], yf[8], o[8];
         V::unpack(dv, d);
         V::unpack(xv, xf);
-        if (RELU) V::unpack(yv, yf);
+        if (RELU && !xmask) V::unpack(yv, yf);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const float dz = (RELU && !(yf[k] > 0.0f)) ? 0.0f : d[k];
+            const bool open = !RELU || (xmask ? relu_open<MT>(xf[k], sc[5 * C + c0 + k], sc[6 * C + c0 + k]) : yf[k] > 0.0f);
+            const float dz = open ? d[k] : 0.0f;
             d[k] = dz;
             const float xhat = (xf[k] - sc[3 * C + c0 + k]) * sc[4 * C + c0 + k];
             o[k] = sc[c0 + k] * dz + sc[C + c0 + k] * xhat + sc[2 * C + c0 + k];
@@ -486,25 +516,26 @@ static int bn_forward_t(const void *x, const void *residual, const float *gamma,
 }
 
 template <typename MT>
-static int bn_backward_t(const void *dy, const void *x, const void *y, const float *gamma, const float *save_mean, const float *save_invstd, long M,
-                         int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, float *ws, hipStream_t st)
+static int bn_backward_t(const void *dy, const void *x, const void *y, const float *gamma, const float *beta, const float *save_mean,
+                         const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, float *ws,
+                         hipStream_t st)
 {
     PSI_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && ws, "null pointer");
-    PSI_REQUIRE(!relu || y, "the ReLU mask needs the forward output");
+    PSI_REQUIRE(!relu || y || (beta && !dresidual), "the ReLU mask needs the forward output (or beta, when the layer had no skip connection)");
     PSI_REQUIRE(M > 0 && C >= 8 && C <= BN_MAXC && C % 8 == 0 && BN_BLK % (C / 8) == 0 && 1024 % (2 * C) == 0, "C must be 8, 16, 32, 64, 128 or 256");
     const int nb = bn_blocks(M, C);
     float *part = ws, *coef = ws + (size_t)nb * 2 * C;
     if (relu)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<MT, true>), dim3(nb), dim3(BN_BLK), 0, st, dy, x, y, M, C, save_mean, save_invstd, part);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<MT, true>), dim3(nb), dim3(BN_BLK), 0, st, dy, x, y, M, C, save_mean, save_invstd, gamma, beta, part);
     else
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<MT, false>), dim3(nb), dim3(BN_BLK), 0, st, dy, x, y, M, C, save_mean, save_invstd, part);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<MT, false>), dim3(nb), dim3(BN_BLK), 0, st, dy, x, y, M, C, save_mean, save_invstd, gamma, beta, part);
     PSI_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     psi_mark("bn_bwd_reduce_kernel", st);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(bn_fin_blocks(C)), dim3(1024), 0, st, part, nb, M, C, gamma, save_invstd, dgamma, dbeta, coef);
     PSI_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long n16 = M * (C / 8);
     const int ga = (int)((n16 + BN_BLK - 1) / BN_BLK < 2048 ? (n16 + BN_BLK - 1) / BN_BLK : 2048);
-#define PSI_BN_BAPPLY(R_, S_) hipLaunchKernelGGL((bn_bwd_apply_kernel<MT, R_, S_>), dim3(ga), dim3(BN_BLK), 0, st, dy, x, y, n16, C, save_mean, save_invstd, coef, dx, dresidual)
+#define PSI_BN_BAPPLY(R_, S_) hipLaunchKernelGGL((bn_bwd_apply_kernel<MT, R_, S_>), dim3(ga), dim3(BN_BLK), 0, st, dy, x, y, n16, C, save_mean, save_invstd, coef, gamma, beta, dx, dresidual)
     if (relu && dresidual) PSI_BN_BAPPLY(true, true);
     else if (relu) PSI_BN_BAPPLY(true, false);
     else if (dresidual) PSI_BN_BAPPLY(false, true);
@@ -554,7 +585,7 @@ extern "C" int psi_bn_backward(const void *dy, const void *x, const void *y, con
                                const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta,
                                float *ws, void *stream)
 {
-    return bn_backward_t<bf16raw>(dy, x, y, gamma, save_mean, save_invstd, M, C, relu, dx, dresidual, dgamma, dbeta, ws, (hipStream_t)stream);
+    return bn_backward_t<bf16raw>(dy, x, y, gamma, nullptr, save_mean, save_invstd, M, C, relu, dx, dresidual, dgamma, dbeta, ws, (hipStream_t)stream);
 }
 
 extern "C" int psi_maxpool3x3s2_forward(const void *x, int N, int H, int W, int C, void *y, void *idx, void *stream)
@@ -582,12 +613,13 @@ extern "C" int psi_bn_forward_t(const void *x, int map_f32, const void *residual
                                  save_invstd, ws, eval_mode, (hipStream_t)stream);
 }
 
-extern "C" int psi_bn_backward_t(const void *dy, int map_f32, const void *x, const void *y, const float *gamma, const float *save_mean,
-                                 const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma, float *dbeta, float *ws,
-                                 void *stream)
+extern "C" int psi_bn_backward_t(const void *dy, int map_f32, const void *x, const void *y, const float *gamma, const float *beta,
+                                 const float *save_mean, const float *save_invstd, long M, int C, int relu, void *dx, void *dresidual, float *dgamma,
+                                 float *dbeta, float *ws, void *stream)
 {
-    if (map_f32) return bn_backward_t<float>(dy, x, y, gamma, save_mean, save_invstd, M, C, relu, dx, dresidual, dgamma, dbeta, ws, (hipStream_t)stream);
-    return bn_backward_t<bf16raw>(dy, x, y, gamma, save_mean, save_invstd, M, C, relu, dx, dresidual, dgamma, dbeta, ws, (hipStream_t)stream);
+    if (map_f32)
+        return bn_backward_t<float>(dy, x, y, gamma, beta, save_mean, save_invstd, M, C, relu, dx, dresidual, dgamma, dbeta, ws, (hipStream_t)stream);
+    return bn_backward_t<bf16raw>(dy, x, y, gamma, beta, save_mean, save_invstd, M, C, relu, dx, dresidual, dgamma, dbeta, ws, (hipStream_t)stream);
 }
 
 extern "C" int psi_maxpool3x3s2_forward_t(const void *x, int map_f32, int N, int H, int W, int C, void *y, void *idx, void *stream)

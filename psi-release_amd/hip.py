@@ -64,7 +64,7 @@ SIGNATURES = {
     'psi_bn_forward': (c_int, [c_void_p] * 7 + [c_long, c_int, c_int, c_float, c_float] + [c_void_p] * 5),
     'psi_bn_backward': (c_int, [c_void_p] * 6 + [c_long, c_int, c_int] + [c_void_p] * 6),
     'psi_bn_forward_t': (c_int, [c_void_p, c_int] + [c_void_p] * 6 + [c_long, c_int, c_int, c_float, c_float] + [c_void_p] * 4 + [c_int, c_void_p]),
-    'psi_bn_backward_t': (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_long, c_int, c_int] + [c_void_p] * 6),
+    'psi_bn_backward_t': (c_int, [c_void_p, c_int] + [c_void_p] * 6 + [c_long, c_int, c_int] + [c_void_p] * 6),
     'psi_maxpool3x3s2_forward_t': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'psi_maxpool3x3s2_backward_t': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'psi_conv2d_supported': (c_int, [c_int] * 6),

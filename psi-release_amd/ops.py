@@ -361,6 +361,11 @@ def _ptr_cl(t):
     return t.data_ptr()
 
 
+def _bn_mask_from_x():
+    """PSI_HIP_BN_XMASK=0: every ReLU mask of the BatchNorm backward from the stored output y (dev A/B)"""
+    return os.environ.get('PSI_HIP_BN_XMASK', '1') != '0'
+
+
 class _BNAct(Function):
     """y = act(batch_norm(x) (+ residual)) on NHWC bf16 maps, batch statistics (include/psi_hip.h: psi_bn_forward)."""
 
@@ -381,13 +386,15 @@ class _BNAct(Function):
                                    hip.ptr(bn.num_batches_tracked) if track else None, M, C, int(relu),
                                    float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), _ptr_cl(y), hip.ptr(mean),
                                    hip.ptr(invstd), hip.ptr(ws), hip.stream()), 'psi_bn_forward')
-        ctx.save_for_backward(xc, y if relu else None, weight, mean, invstd)
+        # a ReLU layer without a skip connection: the backward recomputes the mask from x (one map less per pass) and y is not kept for it
+        keep_y = relu and (residual is not None or not _bn_mask_from_x())
+        ctx.save_for_backward(xc, y if keep_y else None, weight, bias, mean, invstd)
         ctx.relu, ctx.has_res, ctx.dims = bool(relu), residual is not None, (M, C)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xc, y, weight, mean, invstd = ctx.saved_tensors
+        xc, y, weight, bias, mean, invstd = ctx.saved_tensors
         M, C = ctx.dims
         dyc = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(xc, memory_format=torch.channels_last)
@@ -396,9 +403,9 @@ class _BNAct(Function):
         dbeta = torch.empty(C, device=xc.device, dtype=torch.float32)
         L = hip.lib()
         ws = torch.empty(L.psi_bn_workspace_floats(M, C), device=xc.device, dtype=torch.float32)
-        hip.check(L.psi_bn_backward(_ptr_cl(dyc), _ptr_cl(xc), _ptr_cl(y), hip.ptr(weight), hip.ptr(mean), hip.ptr(invstd), M, C,
-                                    int(ctx.relu), _ptr_cl(dx), _ptr_cl(dres), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), hip.stream()),
-                  'psi_bn_backward')
+        hip.check(L.psi_bn_backward_t(_ptr_cl(dyc), 0, _ptr_cl(xc), _ptr_cl(y), hip.ptr(weight), hip.ptr(bias.detach().float()), hip.ptr(mean),
+                                      hip.ptr(invstd), M, C, int(ctx.relu), _ptr_cl(dx), _ptr_cl(dres), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws),
+                                      hip.stream()), 'psi_bn_backward_t')
         return dx, dgamma, dbeta, dres, None, None
 
 
@@ -645,13 +652,14 @@ class _BNActT(Function):
             # inference form: the gradient is that of an affine map with the running statistics (only needed if someone differentiates an
             # eval-mode model: kept correct through the saved statistics)
             mean, invstd = bn.running_mean.detach().float(), torch.rsqrt(bn.running_var.detach().float() + bn.eps)
-        ctx.save_for_backward(xc, y if relu else None, weight, mean, invstd)
+        keep_y = relu and (evalm or residual is not None or not _bn_mask_from_x())
+        ctx.save_for_backward(xc, y if keep_y else None, weight, bias, mean, invstd)
         ctx.relu, ctx.has_res, ctx.dims, ctx.evalm, ctx.f32 = bool(relu), residual is not None, (M, C), evalm, f32
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xc, y, weight, mean, invstd = ctx.saved_tensors
+        xc, y, weight, bias, mean, invstd = ctx.saved_tensors
         M, C = ctx.dims
         dyc = dy.contiguous(memory_format=torch.channels_last).to(xc.dtype)
         if ctx.evalm:
@@ -666,7 +674,8 @@ class _BNActT(Function):
         dbeta = torch.empty(C, device=xc.device, dtype=torch.float32)
         L = hip.lib()
         ws = torch.empty(L.psi_bn_workspace_floats(M, C), device=xc.device, dtype=torch.float32)
-        hip.check(L.psi_bn_backward_t(_ptr_cl(dyc), int(ctx.f32), _ptr_cl(xc), _ptr_cl(y), hip.ptr(weight), hip.ptr(mean), hip.ptr(invstd), M, C,
+        hip.check(L.psi_bn_backward_t(_ptr_cl(dyc), int(ctx.f32), _ptr_cl(xc), _ptr_cl(y), hip.ptr(weight), hip.ptr(bias.detach().float()), hip.ptr(mean),
+                                      hip.ptr(invstd), M, C,
                                       int(ctx.relu), _ptr_cl(dx), _ptr_cl(dres), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), hip.stream()),
                   'psi_bn_backward_t')
         return dx, dgamma, dbeta, dres, None, None

@@ -113,3 +113,32 @@ def test_trunk_with_fused_bn_is_as_close_to_fp32_as_the_library_path():
     e_hip = np.array([dist(outs['hip'][1][k], g32[k]) for k in sorted(g32)])
     assert e_hip.mean() <= 1.25 * e_lib.mean() + 0.01, (e_hip.mean(), e_lib.mean())
     assert e_hip.max() <= 1.5 * e_lib.max() + 0.02, (e_hip.max(), e_lib.max())
+
+
+@pytest.mark.parametrize('shape,f32', [((64, 64, 32, 32), False), ((8, 128, 16, 16), True), ((3, 64, 9, 5), False), ((2, 128, 7, 3), True)])
+def test_relu_mask_recomputed_from_x_equals_the_stored_mask(shape, f32, monkeypatch):
+    """BatchNorm + ReLU without a skip connection: the backward recomputes "y > 0" from x (y = relu(fma(x, scale, shift)), rounded as the forward
+    stored it) and reads one map less per pass; against the same backward with the mask taken from the stored y (PSI_HIP_BN_XMASK=0): every
+    gradient bit for bit — also with inputs placed ON the threshold (outputs that are exactly zero, and the smallest positive ones)."""
+    N, C, H, W = shape
+    torch.manual_seed(C + H + W)
+    dt = torch.float32 if f32 else torch.bfloat16
+    x0 = (torch.randn(shape, device=DEV) * 1.1 - 0.1).to(dt).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(shape, device=DEV).to(dt).contiguous(memory_format=torch.channels_last)
+    got = {}
+    for xmask in ('1', '0'):
+        monkeypatch.setenv('PSI_HIP_BN_XMASK', xmask)
+        torch.manual_seed(2)
+        bn = torch.nn.BatchNorm2d(C).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.uniform_(-1.5, 1.5)                           # negative scales too
+            bn.bias.uniform_(-0.5, 0.5)
+            bn.bias[::3] = 0.0                                      # shift = -mean * scale: outputs around zero
+        x = x0.clone().requires_grad_()
+        y = (ops.bn_act_t if f32 else ops.bn_act)(x, bn, relu=True)
+        y.backward(g)
+        got[xmask] = (y.detach().clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+        frac_open = float((y > 0).float().mean())
+        assert 0.2 < frac_open < 0.8
+    for a, b in zip(got['1'], got['0']):
+        assert torch.equal(a, b)
