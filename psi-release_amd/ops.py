@@ -867,6 +867,21 @@ def cvae_losses(rec, target, xh, cam_int, max_d, mu0, logvar0, mu1=None, logvar1
 _CHAIN_CACHE = {}
 
 
+_VID32_CACHE = {}
+
+
+def _vid32_of(vid):
+    """int32 copy of a contact-id tensor, cached per tensor (storage, length, version): a caller that passes no ``vid32`` gets the SAME int32
+    tensor on every call, so the chain below is built once for it as well (it was rebuilt on every call: every cast was a new cache key)."""
+    key = (vid.data_ptr(), vid.numel(), vid._version, vid.device)
+    hit = _VID32_CACHE.get(key)
+    if hit is None:
+        if len(_VID32_CACHE) > 64:
+            _VID32_CACHE.clear()
+        hit = _VID32_CACHE[key] = (vid, vid.to(torch.int32))     # keeps the int64 tensor alive: its address cannot be reused while cached
+    return hit[1]
+
+
 def _contact_chain(vid32):
     """psi_contact_slot_chain of a contact-id tensor, cached per tensor (the ids are a constant of the model; the cache is keyed by storage
     and version, so an id list that is modified in place gets a new chain)."""
@@ -903,7 +918,7 @@ class _SceneLosses(Function):
         hip.check(L.psi_scene_losses_forward(hip.ptr(dist), B * n_c, hip.ptr(vals), B * V, *ctx.w, hip.ptr(ws), hip.ptr(losses), hip.ptr(stats),
                                              hip.stream()), 'psi_scene_losses_forward')
         ctx.scenes = scenes
-        ctx.save_for_backward(dist, xyz1, idx, slot, vid32 if vid32 is not None else vid.to(torch.int32), vals, og, stats)
+        ctx.save_for_backward(dist, xyz1, idx, slot, vid32 if vid32 is not None else _vid32_of(vid), vals, og, stats)
         return losses
 
     @staticmethod
