@@ -106,6 +106,7 @@ struct FitDev {
     int *step;
     // per-iteration buffers
     float *h1, *h2, *o6, *betas20, *pose, *transl, *verts, *og, *gq, *fpart, *penpart, *recpart, *vppart;
+    float *cverts;                        // [B][n_c][3] the contact rows of `verts` in SLOT order (large batches: what the separate NN search reads)
     float *g_betas, *g_pose, *g_transl, *g_rot;
     unsigned long long *hx_o6, *hx_gh1;   // head / tail cluster exchange words {value, tag}: partial fc3 outputs [B][C][128], partial W2^T products [B][C][512]
     unsigned *hx_epoch;      // [2][B] launch counts of the head / tail kernel per body (the exchange tag)
@@ -473,10 +474,29 @@ struct SdfPenEpilogue {
     const float *sdf, *gmin, *gmax;
     float *og, *penpart;
     int D, align_corners, Vpad;
-    const int *contact_of;        // != nullptr: only the vertices that are contact queries (cs_first[v] != 0) are stored to `verts`
+    const int *contact_of;        // != nullptr: only the vertices that are contact queries (cs_first[v] != 0) are stored, to `cverts`
     float s[2];
     bool neg[2];                  // per body of the workgroup (the skinning kernel handles one or two)
-    __device__ __forceinline__ bool keeps_vertex(int v) const { return !contact_of || psi_ld<int>(contact_of, (unsigned)v * 4u) != 0; }
+    float *cverts;                // [B][n_c][3]: contact rows in SLOT order (+ the CSR for a vertex that several contact parts list)
+    const int *cs_ptr, *cs_idx;
+    int n_c;
+    // the vertex store of the skinning kernel.  All vertices: [B][V][3] as always.  Contact vertices only (large batches, where the NN search is
+    // a launch of its own and reads them): the rows go to their contact SLOT, not to their vertex — the slot list follows the vertex order
+    // within a contact part, so the 12-byte pieces of neighbouring lanes are neighbours in memory again (scattered through [B][V][3] they
+    // cost as much as storing every row), and the search reads row j instead of chasing vid[j]
+    __device__ __forceinline__ void store(float *verts, size_t body_off, int b, int v, unsigned v12, float x, float y, float z) const
+    {
+        if (!contact_of) {
+            if (verts) psi_st(verts + body_off, v12, psi_p3{x, y, z});
+            return;
+        }
+        const int cw = psi_ld<int>(contact_of, (unsigned)v * 4u);
+        if (!(cw >> 24)) return;
+        float *row = cverts + (size_t)b * n_c * 3;
+        psi_st(row, (unsigned)(cw & 0xffffff) * 12u, psi_p3{x, y, z});
+        if ((cw >> 24) > 1)
+            for (int ci = cs_ptr[v] + 1; ci < cs_ptr[v + 1]; ci++) psi_st(row, (unsigned)cs_idx[ci] * 12u, psi_p3{x, y, z});
+    }
     __device__ __forceinline__ void vertex(int n, int b, int v, float x, float y, float z, bool live)
     {
         s[n] = 0.0f;
@@ -525,7 +545,7 @@ struct SdfPenEpilogue {
 static inline SdfPenEpilogue make_sdf_epilogue(const FitDev &f, const PsiSdfGrid &G, bool contact_vertices_only = false)
 {
     return SdfPenEpilogue{G, f.sdf, f.gmin, f.gmax, f.og, f.penpart, f.D, f.align_corners, f.Vpad, contact_vertices_only ? f.cs_first : nullptr,
-                          {0.0f, 0.0f}, {false, false}};
+                          {0.0f, 0.0f}, {false, false}, f.cverts, f.cs_ptr, f.cs_idx, f.n_c};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1242,7 +1262,9 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
                            e->lv.v_posed, f.transl, f.cam, f.B, f.verts, make_sdf_epilogue(f, e->grid, !all_verts));
     PSI_CHECK_LAUNCH("skin_fwd_sdf_kernel");
     psi_mark("skin_fwd_sdf_kernel", st);
-    if (e->nn_index)
+    if (e->nn_index && !all_verts)                               // the contact rows in slot order: query j is row j
+        rc = psi_nn_index_contact(e->nn_index, f.cverts, (long)f.n_c * 3, nullptr, f.B, f.n_c, f.cconst, gscale, f.gq, f.fpart, f.nn_hint, st);
+    else if (e->nn_index)
         rc = psi_nn_index_contact(e->nn_index, f.verts, (long)f.V * 3, f.vid, f.B, f.n_c, f.cconst, gscale, f.gq, f.fpart, f.nn_hint, st);
     else
         rc = psi_nn_contact(f.verts, (long)f.V * 3, f.vid, f.scene, f.B, f.n_c, f.m, e->nn_ws, f.cconst, gscale, f.gq, f.fpart, nullptr, st);
@@ -1383,7 +1405,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     size_t o_x = take((size_t)B * XD * 4), o_xhr = take((size_t)B * XD * 4), o_cam = take((size_t)B * 16 * 4), o_am = take((size_t)B * XD * 4),
            o_av = take((size_t)B * XD * 4), o_step = take(256), o_h1 = take((size_t)B * NH * 4), o_h2 = take((size_t)B * NH * 4),
            o_o6 = take((size_t)B * 128 * 4), o_b20 = take((size_t)B * NB * 4), o_pose = take((size_t)B * J * 3 * 4), o_tr = take((size_t)B * 3 * 4),
-           o_verts = take((size_t)B * V * 3 * 4), o_og = take((size_t)B * psi_cdiv(V, 256) * 256 * 4 * 4),
+           o_verts = take((size_t)B * V * 3 * 4), o_cv = take((size_t)B * f.n_c * 3 * 4), o_og = take((size_t)B * psi_cdiv(V, 256) * 256 * 4 * 4),
            o_gq = take((size_t)B * f.n_c * 3 * 4), o_fp = take((size_t)B * f.nfp * 4), o_pp = take((size_t)B * f.nsdfblk * 2 * 4),
            o_rp = take((size_t)B * 4), o_vp = take((size_t)B * 4), o_gb = take((size_t)B * NB * 4), o_gp = take((size_t)B * J * 3 * 4),
            o_gt = take((size_t)B * 3 * 4), o_gr = take((size_t)B * J * 9 * 4), o_hist = take((size_t)f.max_hist * 4 * 4), o_stats = take(256), o_hint = take((size_t)B * f.n_c * 4);
@@ -1422,7 +1444,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.gmin = F(o_gmin); f.gmax = F(o_gmax);
     f.x = F(o_x); f.xhr = F(o_xhr); f.cam = F(o_cam); f.adam_m = F(o_am); f.adam_v = F(o_av); f.step = (int *)(bl + o_step); f.hx_err = f.step + 1;
     f.h1 = F(o_h1); f.h2 = F(o_h2); f.o6 = F(o_o6); f.betas20 = F(o_b20); f.pose = F(o_pose); f.transl = F(o_tr);
-    f.verts = F(o_verts); f.og = F(o_og); f.gq = F(o_gq); f.fpart = F(o_fp); f.penpart = F(o_pp);
+    f.verts = F(o_verts); f.cverts = F(o_cv); f.og = F(o_og); f.gq = F(o_gq); f.fpart = F(o_fp); f.penpart = F(o_pp);
     f.recpart = F(o_rp); f.vppart = F(o_vp); f.g_betas = F(o_gb); f.g_pose = F(o_gp); f.g_transl = F(o_gt); f.g_rot = F(o_gr);
     f.history = F(o_hist);
     f.nn_hint = (int *)(bl + o_hint);

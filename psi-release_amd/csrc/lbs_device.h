@@ -747,10 +747,13 @@ __device__ __forceinline__ float psi_dot3(float a, float b, float c, float x, fl
     return __builtin_fmaf(c, z, __builtin_fmaf(b, y, a * x));               // (a x + b y) + c z
 }
 
-// Epilogue hook of skin_fwd: keeps_vertex(v) says whether vertex v's result is stored to `verts` at all; vertex(n, b, v, ...) sees every lane's final world-space vertex of the workgroup's n-th body b (live = false
+// Epilogue hook of skin_fwd: store(...) writes vertex v's result (to `verts`, or wherever the epilogue keeps the rows it needs); vertex(n, b, v, ...) sees every lane's final world-space vertex of the workgroup's n-th body b (live = false
 // for padding lanes), finish(n, b, vblock, nvb) runs once per workgroup and body (vertex block vblock of nvb) with all threads present.
 struct PsiSkinNoEpilogue {
-    __device__ __forceinline__ bool keeps_vertex(int) const { return true; }
+    __device__ __forceinline__ void store(float *verts, size_t body_off, int, int, unsigned v12, float x, float y, float z) const
+    {
+        if (verts) psi_st(verts + body_off, v12, psi_p3{x, y, z});
+    }
     __device__ __forceinline__ void vertex(int, int, int, float, float, float, bool) {}
     __device__ __forceinline__ void finish(int, int, int, int) {}
 };
@@ -802,7 +805,7 @@ __device__ __forceinline__ void psi_skin_fwd_body(const LbsDev &m, const float *
         // stored AFTER the epilogue's lookups: a wait for a load also waits for the wave's earlier stores (one counter on gfx950).
         // verts == nullptr: the caller has no use for the vertices themselves (the fused fitting iteration: its search lanes skin their own
         // contact vertices and the backward reads the epilogue's outputs — 64 MB of stores per launch at B = 512 for nobody)
-        if (verts && live && on && epi.keeps_vertex(v)) psi_st(verts + (size_t)b * m.V * 3, v12, psi_p3{x, y, z});
+        if (live && on) epi.store(verts, (size_t)b * m.V * 3, b, v, v12, x, y, z);
     }
 #pragma unroll
     for (int n = 0; n < NB; n++) {
