@@ -36,4 +36,4 @@ for Cin, Cout, K, s, p, H in SHAPES:
             return timeit(f)
         t_b, t_bl = bwd(True), bwd(False)
         print('%3d->%3d k%d s%d @%3d %s: fwd %6.1f us (%5.0f TF eff; library %6.1f) | dgrad+wgrad %6.1f us (library %6.1f)' % (
-            Cin, Cout, K, s, H, 'fp32x3' if nterm == 3 else 'bf16  ', t_f, gflop / t_f * 1e-3, t_fl, t_b, t_bl))
+            Cin, Cout, K, s, H, 'fp32x3' if nterm == 3 else 'bf16  ', t_f, gflop / t_f * 1e3, t_fl, t_b, t_bl))
