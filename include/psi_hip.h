@@ -339,7 +339,8 @@ int psi_maxpool3x3s2_backward(const void *dy, const void *idx, int N, int H, int
  *   bf16 (y_bf16), OH = (H + 2 pad - KH) / stride + 1.  nterm = 3: every product is a three-term bf16 split (hi*hi + hi*lo + lo*hi) with
  *   fp32 accumulation — 0.6-3.2e-5 of the reference's recorded fp32 forward passes (tests/golden/cvae.npz; bound of the tests 2e-4);
  *   nterm = 1: operands rounded to bf16 (the bf16 mode of the trunk: the convolutions psi_conv3x3_forward does not cover).
- *   psi_conv2d_supported: Cout % 32 == 0 and (Cin % 64 == 0, or Cin * KH * KW <= 4096: the element-gather path of the stem).
+ *   psi_conv2d_supported: Cout % 32 == 0 and (Cin % 16 == 0, or Cin * KH * KW <= 4096: element-gather paths; the 2 -> 64 channel 7x7 stride-2
+ *   stem is routed to its own kernels, csrc/conv_stem.hip).
  * psi_bn_forward_t / psi_bn_backward_t / psi_maxpool3x3s2_forward_t / _backward_t: the operators above on maps of either element type
  *   (map_f32 != 0: fp32 NHWC maps), psi_bn_forward_t also in the INFERENCE form (eval_mode != 0: y = gamma (x - running_mean) /
  *   sqrt(running_var + eps) + beta, nothing updated, save_mean / save_invstd may be NULL) — the generation drivers run the encoders in

@@ -12,11 +12,14 @@
 //               faster than the exact-fp32 matrix instruction.
 //
 // GEMM view: D[co][pixel] = sum_k Wt[co][k] * A[pixel][k], k = (kh, kw, ci) with channels fastest = the memory order of an NHWC activation
-// and of a channels_last Conv2d weight [Cout][KH][KW][Cin] (fp32 master weights are read and split / rounded on load: no prepared copy).
-// Workgroup = 4 waves = 128 output pixels x BN output channels (64, or 32 for the 32-channel head); the K range is walked in chunks of 64
-// staged through LDS (pixel rows / filter rows padded to 72 elements: the 16-byte operand reads of 16 adjacent lanes fall on different
-// bank groups); the next chunk's global loads are in flight while the current chunk is multiplied.  With Cin % 64 == 0 a chunk is 64
-// consecutive channels of ONE filter tap: 256 contiguous bytes per pixel.  The stem (Cin = 2, K = 98) takes the element-wise gather path.
+// and of a channels_last Conv2d weight [Cout][KH][KW][Cin].  The weight arrives either as the fp32 master (split / rounded per tile on load)
+// or PREPARED (psi_conv2d_prepare_weight: its bf16 parts written once per layer and step, in this layout and in the input gradient's).
+// Workgroup = 4 waves = 64 output pixels x 64 output channels (four workgroups per CU; 128 pixels x 32 channels for the 32-channel head); the
+// K range is walked in chunks of 64 staged through LDS (pixel rows / filter rows padded to 72 elements: the 16-byte operand reads of 16
+// adjacent lanes fall on different bank groups); the next chunk's global loads are in flight while the current chunk is multiplied.  With
+// Cin % 16 == 0 a thread's run of a chunk is 16 consecutive channels of ONE filter tap (64 contiguous bytes per pixel).  The same kernel in its
+// transposed-gather form is the input gradient; the weight gradient (pixel contraction) follows below.  The 2-channel 7x7 stem has kernels
+// of its own (conv_stem.hip); what bounds this one (vector issue: 2033 vector instructions per wave against 108 MFMAs) is in DESIGN.md section 5.
 #include "psi_internal.h"
 #include <algorithm>
 #include <atomic>
