@@ -1149,7 +1149,10 @@ __global__ void adam_reset_kernel(float *m, float *v, int *step, int n)
 
 }  // namespace
 
-constexpr int GRAPH_UNROLL = 10;
+#ifndef PSI_GRAPH_UNROLL
+#define PSI_GRAPH_UNROLL 10
+#endif
+constexpr int GRAPH_UNROLL = PSI_GRAPH_UNROLL;
 
 struct psi_fit_engine {
     FitDev d;
