@@ -1169,9 +1169,9 @@ struct psi_fit_engine {
     bool keep_verts;              // the forward skinning kernel stores the camera-frame vertices (only needed when !self_skin)
     bool scene_skin_first;        // block order inside that launch: skinning + SDF workgroups before the NN-search workgroups
     int skin_nb;                  // bodies per workgroup of the forward skinning + SDF kernel (1 or 2: lbs_device.h)
-    hipGraph_t graph, graphN;     // one iteration / GRAPH_UNROLL iterations
-    hipGraphExec_t graph_exec, graphN_exec;
-    bool graph_ready, graphN_ready;
+    hipGraph_t graph, graphN, graph2N;     // one iteration / GRAPH_UNROLL iterations / twice that
+    hipGraphExec_t graph_exec, graphN_exec, graph2N_exec;
+    bool graph_ready, graphN_ready, graph2N_ready;
     // data-parallel path: forward and backward halves captured separately (the all-reduce sits between them)
     hipGraph_t g_half[2];
     hipGraphExec_t ge_half[2];
@@ -1514,6 +1514,10 @@ extern "C" void psi_fit_destroy(psi_fit_engine *e)
         (void)hipGraphExecDestroy(e->graphN_exec);
         (void)hipGraphDestroy(e->graphN);
     }
+    if (e->graph2N_ready) {
+        (void)hipGraphExecDestroy(e->graph2N_exec);
+        (void)hipGraphDestroy(e->graph2N);
+    }
     for (int i = 0; i < 2; i++) {
         if (e->half_ready[i]) {
             (void)hipGraphExecDestroy(e->ge_half[i]);
@@ -1615,7 +1619,17 @@ extern "C" int psi_fit_iterate(psi_fit_engine *e, int n_iter, int use_graph, voi
         return 0;
     };
     int done = 0;
-    if (n_iter >= GRAPH_UNROLL) {
+    // (a call of 2 GRAPH_UNROLL iterations or more — the reference's 100-iteration loop, the bench's 20-step blocks — takes the long graph
+    // first: one launch per 20 iterations instead of two, 0.1115 -> 0.1111 ms per iteration, A/B on one box)
+    if (n_iter >= 2 * GRAPH_UNROLL) {
+        if (!e->graph2N_ready) {
+            int rc = capture(2 * GRAPH_UNROLL, &e->graph2N, &e->graph2N_exec);
+            if (rc) return rc;
+            e->graph2N_ready = true;
+        }
+        for (; done + 2 * GRAPH_UNROLL <= n_iter; done += 2 * GRAPH_UNROLL) PSI_CHECK_HIP(hipGraphLaunch(e->graph2N_exec, st));
+    }
+    if (n_iter - done >= GRAPH_UNROLL) {
         if (!e->graphN_ready) {
             int rc = capture(GRAPH_UNROLL, &e->graphN, &e->graphN_exec);
             if (rc) return rc;
