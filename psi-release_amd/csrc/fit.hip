@@ -56,6 +56,7 @@ extern "C" int psi_dbg_timeline(unsigned long long *out, int nblocks)
 }
 #endif
 #include "lbs_device.h"
+#include "lbs_joint_device.h"
 #include "sdf_device.h"
 #ifndef PSI_SDF_CELLS
 #define PSI_SDF_CELLS 1      // the engine's copy of the SDF volume: 1 = cell-major records (two 16-byte gathers per sample), 0 = apron bricks (four 8-byte)
@@ -123,6 +124,16 @@ struct FitDev {
     int *nn_hint;        // [B,n_c] previous nearest-neighbour indices (warm start of the kd-tree search), -1 = none
     float *history;      // [max_hist][4] loss values per iteration
     int max_hist;
+    // ---- the skinning backward inside fwd_scene (fused_bwd; see the comment in front of fit_bwd_joint_kernel).  The contact slots are a second
+    // class of "vertices" of the joint-side contractions: ncp = n_c padded to whole 256-slot slices, rows [B][3 ncp] in slot order
+    int fused_bwd, ncp, ncp3;
+    float *glc, *gvpc, *vpc;              // [B][ncp3] contact part of g_local / g_vposed, and the posed contact vertices (padding slots stay zero)
+    float *gtc_part;                      // [B][nfp][4] translation-gradient partials of the search workgroups (contact part)
+    const float *WTt_c;                   // [ncp/64][PSI_JP][64] skinning weights of the contact slots, tiled per wave like LbsDev::WTt
+    const float *dirs_c;                  // [ncp3/16][Kpad][16] the blend-shape columns of the contact vertices, one copy per slot, in dirs_b's tiles
+    float *gA_part, *gfeat_part;          // [nsv + nsv_c][B][JP][16], [nsn_m + nsn_c][B][Kpad] split-contraction partials of both classes
+    float *spb;                           // [B] independent-bodies mode: -w_col / N_b (0 when N_b == 0) written by the statistics workgroup
+    int nsv, nsv_c, nsn_m, nsn_c, spm, spc;   // slices of the model's vertices / the contact slots (skin_bwd_A), of their columns (blend_bwd) and steps per slice
 };
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.0f ? v : v * slope; }
@@ -480,6 +491,12 @@ struct SdfPenEpilogue {
     float *cverts;                // [B][n_c][3]: contact rows in SLOT order (+ the CSR for a vertex that several contact parts list)
     const int *cs_ptr, *cs_idx;
     int n_c;
+    // != nullptr: the skinning backward of the vertex happens HERE (backward()), on the UNSCALED masked SDF gradient — d loss / d sdf = -w / N
+    // needs the batch-global count N (fitting_proxe.py:155-158), but everything behind dL/dverts is linear in it, so the 1 / N is applied where
+    // the split contractions are summed (fit_reduce_kernel): g_local, g_vposed [B][Npad] and the translation partials [nvb][B][4] instead of `og`
+    float *gl, *gvp, *gtp;
+    int Npad, B;
+    float gm[2][3], gs[2][3];
     // the vertex store of the skinning kernel.  All vertices: [B][V][3] as always.  Contact vertices only (large batches, where the NN search is
     // a launch of its own and reads them): the rows go to their contact SLOT, not to their vertex — the slot list follows the vertex order
     // within a contact part, so the 12-byte pieces of neighbouring lanes are neighbours in memory again (scattered through [B][V][3] they
@@ -501,6 +518,8 @@ struct SdfPenEpilogue {
     {
         s[n] = 0.0f;
         neg[n] = false;
+#pragma unroll
+        for (int a = 0; a < 3; a++) gm[n][a] = 0.0f;
         if (!live) return;
         float g[3];
         if (G.brick) {
@@ -521,17 +540,49 @@ struct SdfPenEpilogue {
             for (int a = 0; a < 3; a++) g[a] = neg[n] ? g[a] : 0.0f;
             s[n] = neg[n] ? -val : 0.0f;
         }
+        if (gl) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) gm[n][a] = g[a];
+            return;
+        }
         // [B][Vpad][4]: one ALIGNED 16-byte store per lane, a wave = 1 KB = eight whole cache lines (a [B][V][3] row starts 4 bytes past a
         // line boundary for every body but the first, and every wave's 768 bytes then end in two partially written lines)
         psi_st(og + (size_t)b * Vpad * 4, (unsigned)v * 16u, f4{g[0], g[1], g[2], 0.0f});
+    }
+    // the vertex's skinning backward (what psi_skin_bwd_v_kernel does in a launch of its own, with the same expressions): g_local = R_c^T g,
+    // g_vposed = T_R^T g_local — the lane still holds the blended transform.  Padding lanes store zeros (the contractions read whole slices).
+    __device__ __forceinline__ void backward(int n, int b, unsigned v12, const psi_f2 (&T2)[6], const float *C)
+    {
+        if (!gl) return;
+        const float gx = gm[n][0], gy = gm[n][1], gz = gm[n][2];
+        float lx = gx, ly = gy, lz = gz;
+        if (C) {
+            lx = psi_dot3(C[0], C[4], C[8], gx, gy, gz);
+            ly = psi_dot3(C[1], C[5], C[9], gx, gy, gz);
+            lz = psi_dot3(C[2], C[6], C[10], gx, gy, gz);
+        }
+        psi_st(gl + (size_t)b * Npad, v12, psi_p3{lx, ly, lz});
+        psi_st(gvp + (size_t)b * Npad, v12,
+               psi_p3{psi_dot3(T2[0].x, T2[2].x, T2[4].x, lx, ly, lz), psi_dot3(T2[0].y, T2[2].y, T2[4].y, lx, ly, lz),
+                      psi_dot3(T2[1].x, T2[3].x, T2[5].x, lx, ly, lz)});
+        gs[n][0] = lx; gs[n][1] = ly; gs[n][2] = lz;
     }
     __device__ __forceinline__ void finish(int n, int b, int vblock, int nvb)
     {
         // per workgroup: sum(-sdf) over the penetrating vertices by DPP adds, their count from the lane mask (scalar popcount)
         __shared__ psi_f2 red[PSI_SKIN_BLK / 64];
+        __shared__ float red3[PSI_SKIN_BLK / 64][3];
         const float ws = psi_wave_sum(s[n]);
         const float wc = (float)(int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(neg[n]));
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (psi_f2){ws, wc};
+        if (gl) {
+            const float sx = psi_wave_sum(gs[n][0]), sy = psi_wave_sum(gs[n][1]), sz = psi_wave_sum(gs[n][2]);
+            if ((threadIdx.x & 63) == 0) {
+                red3[threadIdx.x >> 6][0] = sx;
+                red3[threadIdx.x >> 6][1] = sy;
+                red3[threadIdx.x >> 6][2] = sz;
+            }
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             psi_f2 a = red[0];
@@ -539,13 +590,26 @@ struct SdfPenEpilogue {
             for (int w = 1; w < PSI_SKIN_BLK / 64; w++) a += red[w];
             *(psi_f2 *)(penpart + ((size_t)b * nvb + vblock) * 2) = a;
         }
+        if (gl && threadIdx.x < 3) {
+            float a = 0.0f;
+#pragma unroll
+            for (int w = 0; w < PSI_SKIN_BLK / 64; w++) a += red3[w][threadIdx.x];
+            gtp[((size_t)vblock * B + b) * 4 + threadIdx.x] = a;
+        }
     }
 };
 
-static inline SdfPenEpilogue make_sdf_epilogue(const FitDev &f, const PsiSdfGrid &G, bool contact_vertices_only = false)
+static inline SdfPenEpilogue make_sdf_epilogue(const FitDev &f, const PsiSdfGrid &G, bool contact_vertices_only = false, const PsiLbsView *bwd = nullptr)
 {
-    return SdfPenEpilogue{G, f.sdf, f.gmin, f.gmax, f.og, f.penpart, f.D, f.align_corners, f.Vpad, contact_vertices_only ? f.cs_first : nullptr,
-                          {0.0f, 0.0f}, {false, false}, f.cverts, f.cs_ptr, f.cs_idx, f.n_c};
+    SdfPenEpilogue e = {G, f.sdf, f.gmin, f.gmax, f.og, f.penpart, f.D, f.align_corners, f.Vpad, contact_vertices_only ? f.cs_first : nullptr,
+                        {0.0f, 0.0f}, {false, false}, f.cverts, f.cs_ptr, f.cs_idx, f.n_c, nullptr, nullptr, nullptr, 0, f.B, {}, {}};
+    if (bwd) {
+        e.gl = bwd->gl;
+        e.gvp = bwd->g_vp;
+        e.gtp = bwd->gt_part_w;
+        e.Npad = bwd->m.Npad;
+    }
+    return e;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -576,9 +640,16 @@ struct ContactSkinSrc {
     static constexpr int NWQ = PSI_JP / 4 - 2, NWE = 10;      // weight-row quads: 14 (56 joints); the first NWE are requested in fetch()
     f4 wq[NWE];
     int jslot;
+    // fused_bwd: the query's lane group also carries the gradient of its contact term back through its own skinning (contact_post): the
+    // rotation part of the blended transform waits in LDS (each of lanes 0..2 holds one row; held in registers across the search they would
+    // cost the launch an occupancy step), the camera is there already
+    float (*sTR)[9] = nullptr;    // [QPB][9] row-major rotation part of each query's blended transform
+    float gs[3] = {0.0f, 0.0f, 0.0f};     // this lane's g_local (lane 0 of a group with a query; 0 elsewhere): summed per workgroup for the translation gradient
+    int bq = 0;
     __device__ __forceinline__ void issue(int b, int j)
     {
         jslot = j;
+        bq = b;
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int idx = threadIdx.x + q * 256;
@@ -604,6 +675,7 @@ struct ContactSkinSrc {
     {
         __shared__ psi_f2 sA_[PSI_JP][6];
         __shared__ float sCT_[16];
+        __shared__ float sTR_[psikd::QPB][9];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int idx = threadIdx.x + q * 256;
@@ -614,6 +686,7 @@ struct ContactSkinSrc {
         __syncthreads();
         sA = sA_;
         sCT = sCT_;
+        sTR = sTR_;
     }
     __device__ __forceinline__ void point(int b, int j, int c, float &qx, float &qy, float &qz) const
     {
@@ -630,6 +703,10 @@ struct ContactSkinSrc {
                 T1 = __builtin_elementwise_fma(w2, sA[q * 4 + t][2 * r + 1], T1);
             }
         }
+        if (f.fused_bwd && c < 3) {
+            float *tr = &sTR[threadIdx.x / psikd::LPQ][3 * c];
+            tr[0] = T0.x; tr[1] = T0.y; tr[2] = T1.x;
+        }
         float xr = psi_dot3p(T0.x, T0.y, T1.x, T1.y, px, py, pz) + sCT[12 + r];
         const int base = (threadIdx.x & 63) & ~3;
         const float x = __shfl(xr, base, 64), y = __shfl(xr, base + 1, 64), z = __shfl(xr, base + 2, 64);
@@ -637,6 +714,41 @@ struct ContactSkinSrc {
         qx = psi_dot3p(C[0], C[1], C[2], C[3], x, y, z);
         qy = psi_dot3p(C[4], C[5], C[6], C[7], x, y, z);
         qz = psi_dot3p(C[8], C[9], C[10], C[11], x, y, z);
+    }
+    // lane 0 of a group with a query, after the search: (gx, gy, gz) = d(contact term) / d(query point), already scaled (gscale).  The same
+    // two maps as the skinning workgroups' backward, through the group's own blend: g_local = R_c^T g, g_vposed = T_R^T g_local, stored in
+    // SLOT order next to the posed vertex itself (skin_bwd_A's second operand) — the contact slots are a class of "vertices" of their own
+    // in the joint-side contractions (fit_bwd_joint_kernel), never merged with the penetration rows, which still lack their 1 / N
+    __device__ __forceinline__ void contact_post(size_t, float gx, float gy, float gz)
+    {
+        if (!f.fused_bwd) return;
+        const float *C = sCT;
+        const float lx = psi_dot3(C[0], C[4], C[8], gx, gy, gz), ly = psi_dot3(C[1], C[5], C[9], gx, gy, gz), lz = psi_dot3(C[2], C[6], C[10], gx, gy, gz);
+        const float *R = sTR[threadIdx.x / psikd::LPQ];
+        const size_t row = (size_t)bq * f.ncp3;
+        const unsigned off = (unsigned)jslot * 12u;
+        psi_st(f.glc + row, off, psi_p3{lx, ly, lz});
+        psi_st(f.gvpc + row, off, psi_p3{psi_dot3(R[0], R[3], R[6], lx, ly, lz), psi_dot3(R[1], R[4], R[7], lx, ly, lz), psi_dot3(R[2], R[5], R[8], lx, ly, lz)});
+        psi_st(f.vpc + row, off, psi_p3{px, py, pz});
+        gs[0] = lx; gs[1] = ly; gs[2] = lz;
+    }
+    __device__ __forceinline__ void contact_finish(int b, int bx, int nbx)
+    {
+        if (!f.fused_bwd) return;
+        __shared__ float wsum3[psikd::QBLK / 64][3];
+        const float sx = psi_wave_sum(gs[0]), sy = psi_wave_sum(gs[1]), sz = psi_wave_sum(gs[2]);
+        if ((threadIdx.x & 63) == 0) {
+            wsum3[threadIdx.x >> 6][0] = sx;
+            wsum3[threadIdx.x >> 6][1] = sy;
+            wsum3[threadIdx.x >> 6][2] = sz;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float a = 0.0f;
+#pragma unroll
+            for (int w = 0; w < psikd::QBLK / 64; w++) a += wsum3[w][threadIdx.x];
+            f.gtc_part[((size_t)b * nbx + bx) * 4 + threadIdx.x] = a;
+        }
     }
 };
 
@@ -683,7 +795,7 @@ __global__ __launch_bounds__(256, 6) void fwd_scene_kernel(FitDev f, LbsDev m, c
     if (is_kd) {
         const int b = bid / nqb, bx = bid % nqb;
         psikd::kd_query_body<true, false>(T, ContactSkinSrc{f, m, As, v_posed, nullptr, {}, 0.0f, 0, 0.0f, 0.0f, 0.0f, nullptr, {}, 0}, f.n_c, (float *)nullptr, (int *)nullptr, f.cconst, gscale,
-                                          f.gq, f.fpart, f.nn_hint, rows, (const psikd::KdDev *)nullptr, (const int *)nullptr, bx, b, nqb, smem_i);
+                                          f.fused_bwd ? (float *)nullptr : f.gq, f.fpart, f.nn_hint, rows, (const psikd::KdDev *)nullptr, (const int *)nullptr, bx, b, nqb, smem_i);
     } else {
         const int i = bid;
         psi_skin_fwd_body<NB, PsiBlendCompact>(m, As, v_posed, f.transl, f.cam, f.B, f.verts, epi, i % f.nsdfblk, (i / f.nsdfblk) * NB, f.nsdfblk);
@@ -726,6 +838,198 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(FitDev f, float *st
         stats[0] = s_rec; stats[1] = s_vp; stats[2] = s_f; stats[3] = s_pen; stats[4] = n_pen; stats[5] = 0.0f;
         *f.step += 1;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The backward of a batch of <= 128 bodies WITHOUT a per-vertex launch (fused_bwd).  d loss / d verts = -w_col / N * (masked SDF gradient)
+// + (contact gradient) needs the batch-global penetration count N (fitting_proxe.py:155-158), which exists only when the last skinning
+// workgroup of the forward has finished — the reason psi_skin_bwd_v_kernel used to be a launch of its own between fwd_scene and the joint-side
+// contractions, re-reading the weight rows and the posed vertices the forward had just held in registers.  But everything between dL/dverts
+// and the Adam update of the body vector is LINEAR in the gradient (lbs.py:108-116 and :94-99 backward, the pose backward, the VPoser / 6D
+// chain rule), so the two parts travel separately up to the point where they are sums of a few slices:
+//   * the skinning workgroups of fwd_scene do the vertex's backward on the spot for the UNSCALED penetration part (SdfPenEpilogue::backward);
+//   * the search lanes, which skin their own contact vertex, do the same for the contact part (ContactSkinSrc::contact_post), into rows in
+//     SLOT order — a vertex listed by several contact parts simply has several slots;
+//   * fit_bwd_joint_kernel runs the two contractions over BOTH classes of rows in one grid: skin_bwd_A over the model's 41 vertex slices and
+//     the n_c / 256 slot slices (weights: the wave-tiled copies WTt / WTt_c), blend_bwd over the model's columns and the 3 n_c contact
+//     columns (dirs_b / dirs_c: the contact vertices' blend-shape columns gathered once per engine, 12.6 MB at n_c = 2048), the column
+//     slices sized so that the 256 stream workgroups carry equal shares; one more workgroup produces the iteration's statistics;
+//   * fit_reduce_kernel sums the slices of each class in slice order and combines  sp * (penetration class) + (contact class),
+//     sp = -w_col / N  (per body in the independent-bodies mode).
+// Data-parallel runs need the all-reduced N only in that last step: the collective overlaps the joint kernel instead of stalling the iteration.
+// ------------------------------------------------------------------------------------------------
+// the iteration's statistics [sum|dx|, sum z^2, sum f, sum|sdf-|, N, 0] from the per-workgroup partials; one workgroup, every thread four
+// independent partial sums per quantity (all loads in flight together); also advances the Adam step
+__device__ __forceinline__ void fit_stats_body(const FitDev &f, float *__restrict__ stats)
+{
+    __shared__ float red[16];
+    const int t = threadIdx.x, nt = blockDim.x;
+    if (f.indep) {
+        // every body is its own problem (its own file in the reference's loop): the penetration mean runs over THIS body's penetrating
+        // vertices; the recorded loss values are means over the bodies of each body's loss
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int b = t; b < f.B; b += nt) {
+            a0 += f.recpart[b];
+            a1 += f.vppart[b];
+            float sf = 0, sp = 0, cn = 0;
+            for (int k = 0; k < f.nfp; k++) sf += f.fpart[(size_t)b * f.nfp + k];
+            for (int k = 0; k < f.nsdfblk; k++) {
+                sp += f.penpart[2 * ((size_t)b * f.nsdfblk + k)];
+                cn += f.penpart[2 * ((size_t)b * f.nsdfblk + k) + 1];
+            }
+            a2 += sf;
+            a3 += cn > 0.0f ? sp / cn : 0.0f;
+            f.spb[b] = cn > 0.0f ? -f.w_col / cn : 0.0f;
+        }
+        const float s0 = block_sum(a0, red), s1 = block_sum(a1, red), s2 = block_sum(a2, red), s3 = block_sum(a3, red);
+        if (t == 0) {
+            stats[0] = s0; stats[1] = s1; stats[2] = s2; stats[3] = s3; stats[4] = 0.0f; stats[5] = 0.0f;
+            *f.step += 1;
+        }
+        return;
+    }
+    auto total = [&](const float *p, int n, int stride) {
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int i = t;
+        for (; i + 3 * nt < n; i += 4 * nt) {
+            a0 += p[(size_t)i * stride];
+            a1 += p[(size_t)(i + nt) * stride];
+            a2 += p[(size_t)(i + 2 * nt) * stride];
+            a3 += p[(size_t)(i + 3 * nt) * stride];
+        }
+        for (; i < n; i += nt) a0 += p[(size_t)i * stride];
+        return block_sum((a0 + a1) + (a2 + a3), red);
+    };
+    const float s_rec = total(f.recpart, f.B, 1);
+    const float s_vp = total(f.vppart, f.B, 1);
+    const float s_f = total(f.fpart, f.B * f.nfp, 1);
+    const float s_pen = total(f.penpart, f.B * f.nsdfblk, 2);
+    const float n_pen = total(f.penpart + 1, f.B * f.nsdfblk, 2);
+    if (t == 0) {
+        stats[0] = s_rec; stats[1] = s_vp; stats[2] = s_f; stats[3] = s_pen; stats[4] = n_pen; stats[5] = 0.0f;
+        *f.step += 1;
+    }
+}
+
+// grid: [n_ska skin_bwd_A workgroups: (nsv + nsv_c) slices x body groups] [n_blend stream workgroups: k-groups x (nsn_m + nsn_c) column slices x
+// body groups] [one statistics workgroup when with_stats] — the short kinds first, as in bwd_joint_kernel (lbs.hip), whose bodies these are
+template <int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fit_bwd_joint_kernel(
+    FitDev f, LbsDev m, const float *__restrict__ g_vp, const float *__restrict__ gl, const float *__restrict__ v_posed, int n_ska, int n_blend,
+    int kgroups, int nbody, float *__restrict__ stats)
+{
+    constexpr int SMEM_B = psi_blend_bwd_smem_f4<MT>();
+    __shared__ f4 smem[SMEM_B > SKA_SMEM_F4 ? SMEM_B : SKA_SMEM_F4];
+    const int bid = blockIdx.x;
+    if (bid < n_ska) {
+        const int nsl = f.nsv + f.nsv_c, sl = bid % nsl, b0 = (bid / nsl) * nbody;
+        float *part = f.gA_part + (size_t)sl * f.B * PSI_JP * 16;
+        if (sl < f.nsv) {
+            const PsiSkaSlice o = {m.WTt + (size_t)sl * 4 * PSI_JP * 64, gl + (size_t)sl * 768, v_posed + (size_t)sl * 768, (size_t)m.Npad, part};
+            skin_bwd_A_dispatch(o, f.B, b0, nbody, smem);
+        } else {
+            const int c = sl - f.nsv;
+            const PsiSkaSlice o = {f.WTt_c + (size_t)c * 4 * PSI_JP * 64, f.glc + (size_t)c * 768, f.vpc + (size_t)c * 768, (size_t)f.ncp3, part};
+            skin_bwd_A_dispatch(o, f.B, b0, nbody, smem);
+        }
+    } else if (bid < n_ska + n_blend) {
+        int kg, slice, bg;
+        psi_blend_bwd_place(bid - n_ska, kgroups, f.nsn_m + f.nsn_c, kg, slice, bg);
+        float *part = f.gfeat_part + (size_t)slice * f.B * m.Kpad;
+        if (slice < f.nsn_m) {
+            const PsiBlendBwdCols o = {m.dirs_b, g_vp, (size_t)m.Npad, m.Kpad, m.Npad / 16};
+            blend_bwd_body<MT>(o, f.B, slice * f.spm, (slice + 1) * f.spm, part, kg, bg, smem);
+        } else {
+            const int c = slice - f.nsn_m;
+            const PsiBlendBwdCols o = {f.dirs_c, f.gvpc, (size_t)f.ncp3, m.Kpad, f.ncp3 / 16};
+            blend_bwd_body<MT>(o, f.B, c * f.spc, (c + 1) * f.spc, part, kg, bg, smem);
+        }
+    } else {
+        fit_stats_body(f, stats);
+    }
+}
+
+// Sums of the split-contraction partials of both classes, in slice order, and their combination  sp * (penetration) + (contact):
+// gA [B][JP][16], g_feat [B][Kpad], g_transl [B][3] — what the tail kernel reads.  One output per PSI_RSPL threads (lbs_device.h).
+// `stats` is final here (single process: written by the joint kernel's statistics workgroup; data parallel: all-reduced): thread 0 records
+// the iteration's loss values.
+__global__ __launch_bounds__(256) void fit_reduce_kernel(FitDev f, PsiLbsView lv, const float *__restrict__ stats)
+{
+    const int B = f.B, Kpad = lv.m.Kpad;
+    const long nA = (long)B * PSI_JP * 16, nF = (long)B * Kpad, nT = (long)B * 4;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = t / PSI_RSPL;
+    const int s0 = (int)(t % PSI_RSPL);
+    float spg = 0.0f;
+    if (!f.indep) {
+        const float N = stats[4];
+        spg = N > 0.0f ? -f.w_col / N : 0.0f;          // d/d sdf_k of w * sum(-sdf) / N on the penetrating entries
+    }
+    if (i < nA) {
+        const int b = (int)(i / (PSI_JP * 16));
+        const float sp = f.indep ? f.spb[b] : spg;
+        float r = 0.0f;
+        if ((i & 15) < 12) {        // (entries 12..15 of a joint's 16 do not exist: skin_bwd_A writes the 3 x 4 gradient only)
+            const float pen = psi_sum_slices_split<12>(f.gA_part + i, (size_t)nA, f.nsv, s0);
+            const float con = psi_sum_slices_split<2>(f.gA_part + (size_t)f.nsv * nA + i, (size_t)nA, f.nsv_c, s0);
+            r = __builtin_fmaf(sp, pen, con);
+        }
+        if (s0 == 0) ((float *)lv.gA)[i] = r;
+    } else if (i < nA + nF) {
+        const long k = i - nA;
+        const int b = (int)(k / Kpad);
+        const float sp = f.indep ? f.spb[b] : spg;
+        const float pen = psi_sum_slices_split<8>(f.gfeat_part + k, (size_t)nF, f.nsn_m, s0);
+        const float con = psi_sum_slices_split<2>(f.gfeat_part + (size_t)f.nsn_m * nF + k, (size_t)nF, f.nsn_c, s0);
+        if (s0 == 0) ((float *)lv.gfeat)[k] = __builtin_fmaf(sp, pen, con);
+    } else if (i < nA + nF + nT) {
+        const long k = i - nA - nF;
+        const int b = (int)(k >> 2), c = (int)(k & 3), cc = c < 3 ? c : 0;
+        const float sp = f.indep ? f.spb[b] : spg;
+        const float pen = psi_sum_slices_split<12>(lv.gt_part + (size_t)b * 4 + cc, (size_t)B * 4, lv.nvb, s0);
+        const float con = psi_sum_slices_split<8>(f.gtc_part + (size_t)b * f.nfp * 4 + cc, (size_t)4, f.nfp, s0);
+        if (s0 == 0 && c < 3) f.g_transl[(size_t)b * 3 + c] = __builtin_fmaf(sp, pen, con);
+    }
+    if (t == 0) {
+        const int it = *f.step - 1;
+        if (it >= 0) {
+            float *h = f.history + (size_t)(it % f.max_hist) * 4;     // ring buffer
+            if (f.indep) {          // mean over the bodies of each body's loss
+                h[0] = f.w_rec * stats[0] / ((float)B * XD);
+                h[1] = f.w_vp * stats[1] / ((float)B * NZ);
+                h[2] = f.w_contact * stats[2] / ((float)B * f.n_c);
+                h[3] = f.w_col * stats[3] / (float)B;
+            } else {
+                const float Bg = (float)B * (float)f.world, N = stats[4];
+                h[0] = f.w_rec * stats[0] / (Bg * XD);
+                h[1] = f.w_vp * stats[1] / (Bg * NZ);
+                h[2] = f.w_contact * stats[2] / (Bg * f.n_c);
+                h[3] = N > 0.0f ? f.w_col * stats[3] / N : 0.0f;
+            }
+        }
+    }
+}
+
+// one-off (psi_fit_create): the contact slots' skinning weights in LbsDev::WTt's wave tiles, and their blend-shape columns in dirs_b's tiles
+__global__ void contact_weight_tiles_kernel(const float *__restrict__ Wct, int n_c, int ncp, float *__restrict__ WTt_c)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ncp * PSI_JP) return;
+    const int tile = i / (PSI_JP * 64), j = (i / 64) % PSI_JP, s = tile * 64 + (i & 63);
+    WTt_c[i] = s < n_c ? Wct[(size_t)s * PSI_JP + j] : 0.0f;
+}
+__global__ void contact_dirs_kernel(const float *__restrict__ dirs_b, int Kpad, const int *__restrict__ vid, int n_c, int ncp3, float *__restrict__ dirs_c)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n_all = (size_t)ncp3 * Kpad;
+    if (i >= n_all) return;
+    const int n = (int)(i / ((size_t)Kpad * 16)) * 16 + (int)(i & 15), k = (int)((i >> 4) % Kpad);
+    const int slot = n / 3, comp = n - 3 * slot;
+    float v = 0.0f;
+    if (slot < n_c) {
+        const int col = 3 * vid[slot] + comp;
+        v = dirs_b[((size_t)(col >> 4) * Kpad + k) * 16 + (col & 15)];
+    }
+    dirs_c[i] = v;
 }
 
 // Gradient source of the skinning backward (lbs_device.h): dL/dverts[b][v] = penetration part (global count) + contact
@@ -1168,6 +1472,9 @@ struct psi_fit_engine {
     bool self_skin;               // the NN search can skin its own contact vertices (ContactSkinSrc): it does not read `verts`
     bool keep_verts;              // the forward skinning kernel stores the camera-frame vertices (only needed when !self_skin)
     bool scene_skin_first;        // block order inside that launch: skinning + SDF workgroups before the NN-search workgroups
+    bool fused_bwd;               // the skinning backward rides on fwd_scene (see fit_bwd_joint_kernel): six launches per iteration, no per-vertex backward launch
+    hipStream_t side;             // data-parallel loop with fused_bwd: statistics + all-reduce run here, beside the joint kernel
+    hipEvent_t ev_fork, ev_join;
     int skin_nb;                  // bodies per workgroup of the forward skinning + SDF kernel (1 or 2: lbs_device.h)
     hipGraph_t graph, graphN, graph2N;     // one iteration / GRAPH_UNROLL iterations / twice that
     hipGraphExec_t graph_exec, graphN_exec, graph2N_exec;
@@ -1218,10 +1525,12 @@ static void launch_head_bwd(const FitDev &f, const PsiLbsView &lv, float *g_out,
 // workgroup — O(B^2) in total — so from B = 128 on the separate one-workgroup statistics kernel is used instead.
 static inline bool fit_use_local_stats(const FitDev &f, bool local) { return local && f.B < PSI_SKIN_MB_MIN_B; }
 
-static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool local = false)
+// finalize = false (fused_bwd only): the caller produces the statistics itself (the data-parallel loop does it on a side stream)
+static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool local = false, bool finalize = true)
 {
     FitDev &f = e->d;
-    local = fit_use_local_stats(f, local);
+    // fused_bwd: a single-process iteration takes its statistics from the joint kernel's statistics workgroup at every batch size
+    local = e->fused_bwd ? (local || !finalize) : fit_use_local_stats(f, local);
     launch_head_fwd(f, e->lv, st);
     PSI_CHECK_LAUNCH("head_fwd_kernel");
     psi_mark("head_fwd_kernel", st);
@@ -1236,10 +1545,10 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
         if (!e->keep_verts) fk.verts = nullptr;
         if (e->skin_nb == 2)
             hipLaunchKernelGGL(fwd_scene_kernel<2>, dim3(n_kd + f.nsdfblk * psi_cdiv(f.B, 2)), dim3(256), psikd::kd_lds_bytes(T.rows), st, fk, e->lv.m,
-                               e->lv.A, e->lv.v_posed, T, n_kd, nqb, T.rows, gscale, e->scene_skin_first ? 1 : 0, make_sdf_epilogue(f, e->grid));
+                               e->lv.A, e->lv.v_posed, T, n_kd, nqb, T.rows, gscale, e->scene_skin_first ? 1 : 0, make_sdf_epilogue(f, e->grid, false, e->fused_bwd ? &e->lv : nullptr));
         else
             hipLaunchKernelGGL(fwd_scene_kernel<1>, dim3(n_kd + f.nsdfblk * f.B), dim3(256), psikd::kd_lds_bytes(T.rows), st, fk, e->lv.m, e->lv.A,
-                               e->lv.v_posed, T, n_kd, nqb, T.rows, gscale, e->scene_skin_first ? 1 : 0, make_sdf_epilogue(f, e->grid));
+                               e->lv.v_posed, T, n_kd, nqb, T.rows, gscale, e->scene_skin_first ? 1 : 0, make_sdf_epilogue(f, e->grid, false, e->fused_bwd ? &e->lv : nullptr));
         PSI_CHECK_LAUNCH("fwd_scene_kernel");
         psi_mark("fwd_scene_kernel", st);
         if (local) return 0;
@@ -1279,9 +1588,63 @@ static int fit_forward(psi_fit_engine *e, float *stats, hipStream_t st, bool loc
     return 0;
 }
 
+static int fit_launch_stats(psi_fit_engine *e, float *stats, hipStream_t st)
+{
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, e->d, stats);
+    PSI_CHECK_LAUNCH("loss_finalize_kernel");
+    psi_mark("loss_finalize_kernel", st);
+    return 0;
+}
+
+// fused_bwd: the joint-side contractions over both classes of rows (+ the statistics workgroup when `local`); the rest of the backward
+// (fit_backward_tail) needs the FINAL statistics
+static int fit_backward_joint(psi_fit_engine *e, float *stats, hipStream_t st, bool local)
+{
+    FitDev &f = e->d;
+    const LbsDev &m = e->lv.m;
+    const int kgroups = m.Kpad / 64;
+    const int mt = f.B > 32 ? 4 : (f.B > 16 ? 2 : 1);
+    const int bgroups = psi_cdiv(f.B, 16 * mt);
+    const int n_blend = kgroups * (f.nsn_m + f.nsn_c) * bgroups;
+    // bodies per skin_bwd_A workgroup: about one such workgroup per CU beside its stream workgroup
+    const int nsl = f.nsv + f.nsv_c;
+    int nbody = psi_cdiv((long)f.B * nsl, 256);
+    if (nbody < 1) nbody = 1;
+    if (nbody > SKA_NBODY) nbody = SKA_NBODY;
+    if (const char *ev = getenv("PSI_SKA_NBODY")) { int v = atoi(ev); if (v >= 1 && v <= SKA_NBODY) nbody = v; }
+    const int n_ska = nsl * psi_cdiv(f.B, nbody);
+    const dim3 grid(n_ska + n_blend + (local ? 1 : 0));
+#define PSI_LAUNCH_FIT_JOINT(MT_)                                                                                                  \
+    hipLaunchKernelGGL(fit_bwd_joint_kernel<MT_>, grid, dim3(256), 0, st, f, m, e->lv.g_vp, e->lv.gl, e->lv.v_posed, n_ska, n_blend, kgroups, nbody, stats)
+    if (mt == 4) PSI_LAUNCH_FIT_JOINT(4);
+    else if (mt == 2) PSI_LAUNCH_FIT_JOINT(2);
+    else PSI_LAUNCH_FIT_JOINT(1);
+#undef PSI_LAUNCH_FIT_JOINT
+    PSI_CHECK_LAUNCH("fit_bwd_joint_kernel");
+    psi_mark("bwd_joint_kernel", st);
+    return 0;
+}
+
+static int fit_backward_tail(psi_fit_engine *e, float *stats, hipStream_t st)
+{
+    FitDev &f = e->d;
+    const long nred = (long)f.B * PSI_JP * 16 + (long)f.B * e->lv.m.Kpad + (long)f.B * 4;
+    hipLaunchKernelGGL(fit_reduce_kernel, dim3(psi_cdiv(nred * PSI_RSPL, 256)), dim3(256), 0, st, f, e->lv, stats);
+    PSI_CHECK_LAUNCH("fit_reduce_kernel");
+    psi_mark("reduce_partials_kernel", st);
+    launch_head_bwd<true>(f, e->lv, nullptr, st);
+    PSI_CHECK_LAUNCH("head_bwd_adam_kernel");
+    psi_mark("head_bwd_adam_kernel", st);
+    return 0;
+}
+
 static int fit_backward(psi_fit_engine *e, float *stats, hipStream_t st, bool local = false)
 {
     FitDev &f = e->d;
+    if (e->fused_bwd) {
+        int rc = fit_backward_joint(e, stats, st, local);
+        return rc ? rc : fit_backward_tail(e, stats, st);
+    }
     local = fit_use_local_stats(f, local);
     // large batches: compressed rows keep the multi-body kernel (a lane's weights in registers, eight bodies per workgroup); DENSE rows
     // take one body per workgroup with the pipelined scalar-cache blend — the multi-body kernel reads the transforms as LDS broadcasts
@@ -1414,6 +1777,32 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
            o_gt = take((size_t)B * 3 * 4), o_gr = take((size_t)B * J * 9 * 4), o_hist = take((size_t)f.max_hist * 4 * 4), o_stats = take(256), o_hint = take((size_t)B * f.n_c * 4);
     size_t o_hxo = take((size_t)B * f.hc * 128 * 8), o_hxg = take((size_t)B * f.hc * NH * 8), o_hxc = take((size_t)2 * B * 4);
     size_t o_wct = take((size_t)f.n_c * PSI_JP * 4);
+    // the contact slots as a second class of rows of the joint-side contractions (fused_bwd)
+    e->fused_bwd = e->merged_scene && !(getenv("PSI_FIT_FUSED_BWD") && getenv("PSI_FIT_FUSED_BWD")[0] == '0');
+    f.fused_bwd = e->fused_bwd ? 1 : 0;
+    f.ncp = psi_cdiv(f.n_c, 256) * 256;
+    f.ncp3 = 3 * f.ncp;
+    size_t o_glc = 0, o_gvpc = 0, o_vpc = 0, o_gtc = 0, o_wttc = 0, o_dirsc = 0, o_gap = 0, o_gfp = 0, o_spb = 0;
+    {
+        // slice counts of the model's own rows: from the LBS workspace layout (offsets only: no memory is touched through this view)
+        PsiLbsView lv0;
+        if (int rcv = psi_lbs_view(lbs, B, reinterpret_cast<float *>((uintptr_t)4096), &lv0)) { delete e; return rcv; }
+        const int Kpad = lv0.m.Kpad, Npad = lv0.m.Npad, nsn = lv0.nsn;
+        const int SM = Npad / 16, SC = f.ncp3 / 16;
+        f.nsv = lv0.nsv;
+        f.nsv_c = f.ncp / 256;
+        f.nsn_c = nsn >= 2 ? std::min(nsn - 1, std::max(1, (int)lround((double)nsn * SC / (double)(SM + SC)))) : 0;
+        f.nsn_m = nsn - f.nsn_c;
+        f.spm = psi_cdiv(SM, f.nsn_m);
+        f.spc = f.nsn_c ? psi_cdiv(SC, f.nsn_c) : 0;
+        if (e->fused_bwd && !f.nsn_c) { e->fused_bwd = false; f.fused_bwd = 0; }
+        if (e->fused_bwd) {
+            o_glc = take((size_t)B * f.ncp3 * 4); o_gvpc = take((size_t)B * f.ncp3 * 4); o_vpc = take((size_t)B * f.ncp3 * 4);
+            o_gtc = take((size_t)B * f.nfp * 4 * 4); o_wttc = take((size_t)f.ncp * PSI_JP * 4); o_dirsc = take((size_t)f.ncp3 * Kpad * 4);
+            o_gap = take((size_t)(f.nsv + f.nsv_c) * B * PSI_JP * 16 * 4); o_gfp = take((size_t)(f.nsn_m + f.nsn_c) * B * Kpad * 4);
+            o_spb = take((size_t)B * 4);
+        }
+    }
     // (the bricked copy is addressed with 32-bit byte offsets: 512 bytes x (D / 4)^3 must stay below 4 GB, D <= 800)
     const bool bricks = (cfg->D % 4 == 0) && cfg->D <= (PSI_SDF_CELLS ? 480 : 800) && !(getenv("PSI_SDF_LINEAR") && getenv("PSI_SDF_LINEAR")[0] == '1');
 #if PSI_SDF_CELLS
@@ -1459,6 +1848,10 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
         if (rcv) { (void)hipFree(e->blob); delete e; return rcv; }
     }
     f.Wct = F(o_wct);
+    if (e->fused_bwd) {
+        f.glc = F(o_glc); f.gvpc = F(o_gvpc); f.vpc = F(o_vpc); f.gtc_part = F(o_gtc); f.WTt_c = F(o_wttc); f.dirs_c = F(o_dirsc);
+        f.gA_part = F(o_gap); f.gfeat_part = F(o_gfp); f.spb = F(o_spb);
+    }
     e->scene_skin_first = getenv("PSI_SCENE_ORDER") && getenv("PSI_SCENE_ORDER")[0] == '1';
     // two bodies per skinning workgroup share one pass over the vertex's weight row: from the batch size at which the kernel is
     // throughput-bound (its own launch, B > 128); PSI_SKIN_NB=1|2 overrides
@@ -1467,6 +1860,11 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     if (const char *nbv = getenv("PSI_SKIN_NB")) e->skin_nb = atoi(nbv) == 2 ? 2 : 1;
     hipLaunchKernelGGL(contact_weight_table_kernel, dim3(psi_cdiv((long)f.n_c * PSI_JP, 256)), dim3(256), 0, 0, e->lv.m.WT, e->lv.m.Vpad, f.vid,
                        f.n_c, J, (float *)f.Wct);
+    if (e->fused_bwd) {
+        hipLaunchKernelGGL(contact_weight_tiles_kernel, dim3(psi_cdiv((long)f.ncp * PSI_JP, 256)), dim3(256), 0, 0, f.Wct, f.n_c, f.ncp, (float *)f.WTt_c);
+        hipLaunchKernelGGL(contact_dirs_kernel, dim3(psi_cdiv((long)f.ncp3 * e->lv.m.Kpad, 256)), dim3(256), 0, 0, e->lv.m.dirs_b, e->lv.m.Kpad, f.vid,
+                           f.n_c, f.ncp3, (float *)f.dirs_c);
+    }
     f.sdf_brick = nullptr;
     if (bricks) {
 #if PSI_SDF_CELLS
@@ -1527,6 +1925,11 @@ extern "C" void psi_fit_destroy(psi_fit_engine *e)
             (void)hipGraphExecDestroy(e->ge_dp[i]);
             (void)hipGraphDestroy(e->g_dp[i]);
         }
+    }
+    if (e->side) {
+        (void)hipStreamDestroy(e->side);
+        (void)hipEventDestroy(e->ev_fork);
+        (void)hipEventDestroy(e->ev_join);
     }
     (void)hipFree(e->blob);
     delete e;
@@ -1657,7 +2060,28 @@ extern "C" int psi_fit_iterate_dp(psi_fit_engine *e, psi_dp_comm *comm, int n_it
     PSI_REQUIRE(psi_dp_world(comm) == e->d.world, "the communicator's size differs from psi_fit_config.world_size");
     hipStream_t st = (hipStream_t)stream;
     float *stats = d_stats ? d_stats : e->stats_local;
+    if (e->fused_bwd && !e->side) {
+        PSI_CHECK_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        PSI_CHECK_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        PSI_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
     auto one = [&]() -> int {
+        if (e->fused_bwd) {
+            // the global penetration count is needed only where the slices are summed (fit_reduce_kernel): the statistics kernel and the
+            // collective run on a side stream BESIDE the joint kernel (under capture: a fork / join of the graph) instead of between the halves
+            int rc = fit_forward(e, stats, st, false, false);
+            if (rc) return rc;
+            PSI_CHECK_HIP(hipEventRecord(e->ev_fork, st));
+            PSI_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+            rc = fit_launch_stats(e, stats, e->side);
+            if (!rc) rc = psi_dp_allreduce_sum(comm, stats, 6, e->side);
+            if (rc) return rc;
+            PSI_CHECK_HIP(hipEventRecord(e->ev_join, e->side));
+            rc = fit_backward_joint(e, stats, st, false);
+            if (rc) return rc;
+            PSI_CHECK_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
+            return fit_backward_tail(e, stats, st);
+        }
         int rc = fit_forward(e, stats, st);
         if (!rc) rc = psi_dp_allreduce_sum(comm, stats, 6, st);
         if (!rc) rc = fit_backward(e, stats, st);
@@ -1890,6 +2314,17 @@ extern "C" int psi_fit_copy_buffer(psi_fit_engine *e, const char *name, float *d
     else if (!strcmp(name, "stats")) { src = e->stats_local; cap = 8; }
     else if (!strcmp(name, "adam_m")) { src = f.adam_m; cap = (long)f.B * XD; }
     else if (!strcmp(name, "adam_v")) { src = f.adam_v; cap = (long)f.B * XD; }
+    // the reduced gradients the tail kernel reads, and the per-vertex rows of the skinning backward (fused_bwd: the UNSCALED penetration part in
+    // gl / g_vp, the contact part in slot order in glc / gvpc)
+    else if (!strcmp(name, "gA")) { src = e->lv.gA; cap = (long)f.B * PSI_JP * 16; }
+    else if (!strcmp(name, "gfeat")) { src = e->lv.gfeat; cap = (long)f.B * e->lv.m.Kpad; }
+    else if (!strcmp(name, "g_transl")) { src = f.g_transl; cap = (long)f.B * 3; }
+    else if (!strcmp(name, "gl")) { src = e->lv.gl; cap = (long)f.B * e->lv.m.Npad; }
+    else if (!strcmp(name, "g_vp")) { src = e->lv.g_vp; cap = (long)f.B * e->lv.m.Npad; }
+    else if (!strcmp(name, "v_posed")) { src = e->lv.v_posed; cap = (long)f.B * e->lv.m.Npad; }
+    else if (!strcmp(name, "glc") && e->fused_bwd) { src = f.glc; cap = (long)f.B * f.ncp3; }
+    else if (!strcmp(name, "gvpc") && e->fused_bwd) { src = f.gvpc; cap = (long)f.B * f.ncp3; }
+    else if (!strcmp(name, "vpc") && e->fused_bwd) { src = f.vpc; cap = (long)f.B * f.ncp3; }
     PSI_REQUIRE(src != nullptr, "unknown buffer name");
     PSI_REQUIRE(n_floats <= cap, "buffer is smaller than requested");
     PSI_CHECK_HIP(hipMemcpyAsync(d_out, src, (size_t)n_floats * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -314,195 +314,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // ------------------------------------------------------------------------------------------------
-// skinning backward, joint part (MFMA): gA[b][j][r*4+s] = sum_v W[v][j] * g_local[b][v][r] * [v_posed;1][s]
+// skinning backward, joint part + blend backward (both MFMA): the bodies live in lbs_joint_device.h (the fused fitting engine runs them
+// in a grid of its own, over the model's vertices AND its contact slots)
 // ------------------------------------------------------------------------------------------------
-// One workgroup = one 256-vertex slice x NBODY bodies; it is ONE product  D[64 joints][12 NBODY] = W^T[64][256] P[256][12 NBODY]  with
-// P[v][12 bb + 4 r + s] = g_local[bb][v][r] [v_posed[bb][v]; 1][s]: the 12 (r, s) entries of consecutive bodies are packed side by side, so
-// the 16-wide MFMA tiles carry no padding (a tile per body carried four zero columns: a quarter of the instructions).  Wave w owns joint
-// tile w (joints 16 w .. 16 w + 15) for the WHOLE slice and all column tiles: nothing to reduce across waves — the previous form split
-// the slice's vertices over the waves and met in LDS behind two barriers per body, which behind the blend_bwd stream's MFMA bursts (the
-// two share the launch and each SIMD) cost 2.5 us per body (workgroup timeline: operands staged at 5.6 us, end at 22 — later than the
-// stream itself, profiles/r04_timeline_bwd_joint.txt).
-//   A operand: lane (li, lk) supplies joint 16 w + li, vertex 64 lk + st in step st: 64 consecutive floats of its weight row, a quad
-// (16 B) per four steps, each used for every column tile.  B operand: the same vertex, column 16 nt + li: a product of two LDS values; the
-// staged operands are kept component-major ([body][component][vertex], 64-vertex runs padded by 4) so that the four steps of a quad
-// are ONE 16-byte LDS read each for g_local and v_posed.
-constexpr int SKA_NBODY = 8;
-constexpr int SKA_ROW = 256 + 16;          // floats per staged (body, component) row: vertex v sits at v + 4 (v / 64)
-constexpr int SKA_MAXT = (12 * SKA_NBODY + 15) / 16;
 #ifdef PSI_HEAD_STOPS
 __device__ unsigned long long psi_dbg_ska_mark[2 * 2048];     // dev: skin_bwd_A workgroup — operands staged, first quad done
 #define PSI_SKA_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) psi_dbg_ska_mark[2 * blockIdx.x + (k)] = wall_clock64(); } while (0)
 extern "C" int psi_dbg_ska_marks(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psi_dbg_ska_mark), sizeof(unsigned long long) * 2 * (size_t)(n < 2048 ? n : 2048)); }
-#else
-#define PSI_SKA_MARK(k)
 #endif
-
-// NT: column tiles of a full workgroup, (12 nbody + 15) / 16 — a compile-time count keeps the 16 quads straight-line code with all weight
-// quads in registers (a workgroup with fewer bodies than nbody repeats its last column in the spare tiles)
-template <int NT>
-__device__ __forceinline__ void skin_bwd_A_body(const LbsDev &m, const float *__restrict__ gl, const float *__restrict__ v_posed,
-                                                int B, float *__restrict__ part, int vslice, int b0, int nbody, f4 *smem)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int nb = min(nbody, B - b0);
-    const int ncol = 12 * nb;
-    // my weight row: joint 16 w + li, vertices 64 lk .. 64 lk + 63 of the slice — all 16 quads requested now (behind the stream's traffic
-    // a load takes ~2 us: requested two quads ahead of their use, they made every quad wait, 1 us per quad)
-    f4 wa[16];
-    {
-        // from the wave-tiled copy ([Vpad/64][64 joints][64 vertices]: the same 256 contiguous bytes per lane) — the copy skin_bwd_v streamed
-        // just before this launch, so most of it is still in L2 / MALL
-        const f4 *wr = (const f4 *)(m.WTt + (((size_t)vslice * 4 + lk) * PSI_JP + (w * 16 + li)) * 64);
-#pragma unroll
-        for (int q = 0; q < 16; q++) wa[q] = wr[q];
-    }
-    // ALL bodies' operands of this slice are requested up front, coalesced (768 consecutive floats of g_local and of v_posed per body: one
-    // 16-byte load each for threads 0..191), and parked in LDS component-major
-    float *sG = (float *)smem;                                  // [SKA_NBODY][3][SKA_ROW]
-    float *sP = sG + SKA_NBODY * 3 * SKA_ROW;                   // [SKA_NBODY][3][SKA_ROW]
-    {
-        f4 og[SKA_NBODY], op[SKA_NBODY];
-        const int t4 = threadIdx.x;
-#pragma unroll
-        for (int bb = 0; bb < SKA_NBODY; bb++)
-            if (bb < nb && t4 < 192) {
-                og[bb] = *(const f4 *)(gl + (size_t)(b0 + bb) * m.Npad + (size_t)vslice * 768 + t4 * 4);
-                op[bb] = *(const f4 *)(v_posed + (size_t)(b0 + bb) * m.Npad + (size_t)vslice * 768 + t4 * 4);
-            }
-#pragma unroll
-        for (int bb = 0; bb < SKA_NBODY; bb++)
-            if (bb < nb && t4 < 192) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int i = t4 * 4 + e, v = i / 3, comp = i - 3 * v;
-                    const int pos = (bb * 3 + comp) * SKA_ROW + v + 4 * (v >> 6);
-                    sG[pos] = og[bb][e];
-                    sP[pos] = op[bb][e];
-                }
-            }
-    }
-    __syncthreads();
-    PSI_SKA_MARK(0);
-    // my columns: tile nt -> column 16 nt + li = 12 bb + 4 r + s
-    int goff[NT], poff[NT];                                     // float offsets of my (body, r) / (body, s) rows + my 64-vertex run; poff < 0: s == 3
-    f4 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        const int c = min(16 * nt + li, ncol - 1);             // (columns past the last body repeat the last one; they are not stored)
-        const int bb = c / 12, rs = c - 12 * bb, r = rs >> 2, sx = rs & 3;
-        goff[nt] = (bb * 3 + r) * SKA_ROW + lk * 68;
-        poff[nt] = sx < 3 ? (bb * 3 + sx) * SKA_ROW + lk * 68 : -1;
-        acc[nt] = (f4){0, 0, 0, 0};
-    }
-    // (requesting quad q + 1's LDS operands before quad q's MFMAs — a denser MFMA stream of this wave — measured SLOWER, 23.1 against 21.8 us:
-    // the stream wave on the same SIMD then waits longer for the pipe, and the launch ends when the later of the two kinds does)
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        f4 bop[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-            const f4 g4 = *(const f4 *)(sG + goff[nt] + 4 * q);
-            const f4 p4 = *(const f4 *)(sP + max(poff[nt], 0) + 4 * q);
-            bop[nt] = poff[nt] >= 0 ? g4 * p4 : g4;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[q][e], bop[nt][e], acc[nt], 0, 0, 0);
-        if (q == 0) PSI_SKA_MARK(1);
-        __builtin_amdgcn_sched_barrier(0);                      // (the scheduler otherwise hoists every quad's LDS reads to the top and spills)
-    }
-    // D[row = 4 lk + e -> joint 16 w + 4 lk + e][col = li -> column 16 nt + li]
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        const int c = 16 * nt + li;
-        if (c < ncol) {
-            const int bb = c / 12, rs = c - 12 * bb;
-            float *o = part + (((size_t)vslice * B + b0 + bb) * JP + w * 16 + lk * 4) * 16 + rs;
-#pragma unroll
-            for (int e = 0; e < 4; e++) o[e * 16] = acc[nt][e];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// blend backward (MFMA): g_feat[b][k] = sum_n g_vp[b][n] dirs[k][n]
-// workgroup = 4 waves sharing a 64-row k group and an n-slice; wave w takes n-steps w, w+4, ...; LDS reduce.
-// ------------------------------------------------------------------------------------------------
-template <int MT>
-__device__ __forceinline__ void blend_bwd_body(const LbsDev &m, const float *__restrict__ g_vp, int B, int steps_per_slice,
-                                               float *__restrict__ part, int kgroup, int slice, int bgroup, f4 *smem)
-{
-    constexpr int KT = 4;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int k0 = kgroup * 16 * KT;
-    const int b0 = bgroup * 16 * MT;
-    const int total_steps = m.Npad / 16;
-    const int s_begin = slice * steps_per_slice;
-    const int s_end = min(s_begin + steps_per_slice, total_steps);
-    f4 acc[KT][MT];
-#pragma unroll
-    for (int kt = 0; kt < KT; kt++)
-#pragma unroll
-        for (int t = 0; t < MT; t++) acc[kt][t] = (f4){0, 0, 0, 0};
-    const float *grow[MT];
-#pragma unroll
-    for (int t = 0; t < MT; t++) grow[t] = g_vp + (size_t)min(b0 + t * 16 + li, B - 1) * m.Npad + 4 * lk;
-    const float *drow[KT];
-#pragma unroll
-    for (int kt = 0; kt < KT; kt++) drow[kt] = m.dirs_b + (size_t)(k0 + kt * 16 + li) * 16 + 4 * lk;   // + step base: a wave-load is 1 KB contiguous
-    // each wave owns steps s_begin+w, +4, ...; PF steps' operands (PF x (MT + KT) 16-byte loads) are issued before the first MFMA group
-    // waits, and the scheduler is fenced so it cannot sink them back next to their uses.  PF = 1: with the skin_bwd_A waves sharing the SIMDs
-    // (one each) a short MFMA burst per round trip serves the LAUNCH best — rocprofv3, B = 32: PF = 1 22.0 us, 2 22.6, 3 23.9 (round 3's
-    // setting, tuned before the two kinds of wave were balanced), 4 25.1; double-buffered (the next step's loads in flight under the MFMAs)
-    // 22.0 at PF = 1 and 29-35 at PF = 2-3: whatever lets the stream wave hold the matrix pipe longer delays the other kind, and the
-    // launch ends with the later of the two
-    constexpr int PF = 1;
-    for (int st0 = s_begin + w; st0 < s_end; st0 += 4 * PF) {
-        f4 ga[PF][MT], db[PF][KT];
-#pragma unroll
-        for (int p = 0; p < PF; p++) {
-            const int st = min(st0 + 4 * p, total_steps - 1);
-            const int n0 = st * 16;
-#pragma unroll
-            for (int t = 0; t < MT; t++) ga[p][t] = *(const f4 *)(grow[t] + n0);
-#pragma unroll
-            for (int kt = 0; kt < KT; kt++) db[p][kt] = *(const f4 *)(drow[kt] + (size_t)st * m.Kpad * 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int p = 0; p < PF; p++) {
-            if (st0 + 4 * p < s_end) {
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-#pragma unroll
-                    for (int kt = 0; kt < KT; kt++)
-#pragma unroll
-                        for (int t = 0; t < MT; t++)
-                            acc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[p][t][e], db[p][kt][e], acc[kt][t], 0, 0, 0);
-            }
-        }
-    }
-    f4 (*red)[KT][MT][64] = (f4 (*)[KT][MT][64])smem;      // [4][KT][MT][64]
-#pragma unroll
-    for (int kt = 0; kt < KT; kt++)
-#pragma unroll
-        for (int t = 0; t < MT; t++) red[w][kt][t][lane] = acc[kt][t];
-    __syncthreads();
-    // wave w finishes k-tile w: D[row = lk*4+e -> body][col = li -> k]
-#pragma unroll
-    for (int t = 0; t < MT; t++) {
-        f4 o = red[0][w][t][lane] + red[1][w][t][lane] + red[2][w][t][lane] + red[3][w][t][lane];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            int b = b0 + t * 16 + lk * 4 + e;
-            if (b < B) part[((size_t)slice * B + b) * m.Kpad + k0 + w * 16 + li] = o[e];
-        }
-    }
-}
+}  // namespace
+#include "lbs_joint_device.h"
+namespace {
 
 // The two joint-side halves of the LBS backward in ONE launch.  Both depend only on skin_bwd_v; blend_bwd is a 64.5 MB
 // stream with 256 long-lived workgroups (one per CU, one wave per SIMD), skin_bwd_A is a short L2-latency-bound contraction.
@@ -539,8 +361,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float *__restrict__ gfeat_part, float *__restrict__ gA_part, int n_blend, int kgroups, int nslices, int nsv, int nbody)
 {
     // blend_bwd: [4][KT][MT][64] f4; skin_bwd_A: SKA_NBODY bodies' staged operands (2 x 3 component rows each)
-    constexpr int SMEM_A = SKA_NBODY * 2 * 3 * SKA_ROW / 4;
-    __shared__ f4 smem[4 * 4 * MT * 64 > SMEM_A ? 4 * 4 * MT * 64 : SMEM_A];
+    constexpr int SMEM_B = psi_blend_bwd_smem_f4<MT>();
+    __shared__ f4 smem[SMEM_B > SKA_SMEM_F4 ? SMEM_B : SKA_SMEM_F4];
     // the skin_bwd_A workgroups come FIRST in the grid: a CU serves its workgroups' loads in order, and behind the 72 KB each stream wave
     // requests at once the 100 KB of a skin_bwd_A workgroup arrived after 9.6 us (workgroup timeline) — in front of it they are short
     const int n_ska = (int)gridDim.x - n_blend;
@@ -551,29 +373,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
     if (bid < n_blend) {
         int kg, slice, bg;
-        if ((nslices & 7) == 0) {
-            const int xcd = bid & 7, idx = bid >> 3, spx = nslices >> 3;
-            kg = idx % kgroups;
-            const int t = idx / kgroups;
-            slice = xcd + 8 * (t % spx);
-            bg = t / spx;
-        } else {
-            kg = bid % kgroups;
-            const int rest = bid / kgroups;
-            slice = rest % nslices;
-            bg = rest / nslices;
-        }
-        blend_bwd_body<MT>(m, g_vp, B, steps_per_slice, gfeat_part, kg, slice, bg, smem);
+        psi_blend_bwd_place(bid, kgroups, nslices, kg, slice, bg);
+        const PsiBlendBwdCols cols = {m.dirs_b, g_vp, (size_t)m.Npad, m.Kpad, m.Npad / 16};
+        blend_bwd_body<MT>(cols, B, slice * steps_per_slice, (slice + 1) * steps_per_slice, gfeat_part + (size_t)slice * B * m.Kpad, kg, bg, smem);
     } else {
-        const int i = bid - n_blend;
-        switch ((12 * nbody + 15) >> 4) {
-        case 1: skin_bwd_A_body<1>(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem); break;
-        case 2: skin_bwd_A_body<2>(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem); break;
-        case 3: skin_bwd_A_body<3>(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem); break;
-        case 4: skin_bwd_A_body<4>(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem); break;
-        case 5: skin_bwd_A_body<5>(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem); break;
-        default: skin_bwd_A_body<SKA_MAXT>(m, gl, v_posed, B, gA_part, i % nsv, (i / nsv) * nbody, nbody, smem); break;
-        }
+        const int i = bid - n_blend, vslice = i % nsv;
+        // (weights from the wave-tiled copy — the copy skin_bwd_v streamed just before this launch, so most of it is still in L2 / MALL)
+        const PsiSkaSlice sl = {m.WTt + (size_t)vslice * 4 * PSI_JP * 64, gl + (size_t)vslice * 768, v_posed + (size_t)vslice * 768, (size_t)m.Npad,
+                                gA_part + (size_t)vslice * B * JP * 16};
+        skin_bwd_A_dispatch(sl, B, (i / nsv) * nbody, nbody, smem);
     }
 }
 

@@ -748,8 +748,11 @@ __device__ __forceinline__ float psi_dot3(float a, float b, float c, float x, fl
 }
 
 // Epilogue hook of skin_fwd: store(...) writes vertex v's result (to `verts`, or wherever the epilogue keeps the rows it needs); vertex(n, b, v, ...) sees every lane's final world-space vertex of the workgroup's n-th body b (live = false
-// for padding lanes), finish(n, b, vblock, nvb) runs once per workgroup and body (vertex block vblock of nvb) with all threads present.
+// for padding lanes), backward(n, b, v12, T2, C) follows it with the lane's blended transform and the body's camera still in registers (an
+// epilogue that knows dL/dvertex at this point does the vertex's skinning backward on the spot: the fused fitting engine, fit.hip),
+// finish(n, b, vblock, nvb) runs once per workgroup and body (vertex block vblock of nvb) with all threads present.
 struct PsiSkinNoEpilogue {
+    __device__ __forceinline__ void backward(int, int, unsigned, const psi_f2 (&)[6], const float *) {}
     __device__ __forceinline__ void store(float *verts, size_t body_off, int, int, unsigned v12, float x, float y, float z) const
     {
         if (verts) psi_st(verts + body_off, v12, psi_p3{x, y, z});
@@ -802,6 +805,7 @@ __device__ __forceinline__ void psi_skin_fwd_body(const LbsDev &m, const float *
             x = X; y = Y; z = Z;
         }
         epi.vertex(n, b, v, x, y, z, live && on);
+        if (on) epi.backward(n, b, v12, T2[n], cam_ext ? cam_ext + (size_t)b * 16 : nullptr);
         // stored AFTER the epilogue's lookups: a wait for a load also waits for the wave's earlier stores (one counter on gfx950).
         // verts == nullptr: the caller has no use for the vertices themselves (the fused fitting iteration: its search lanes skin their own
         // contact vertices and the backward reads the epilogue's outputs — 64 MB of stores per launch at B = 512 for nobody)

@@ -1,0 +1,249 @@
+// Device bodies of the joint-side half of the LBS backward — skin_bwd_A (gA = W^T (g_local (x) [v_posed; 1]), a contraction over
+// vertices) and blend_bwd (g_feat = g_vposed dirs^T, a contraction over columns with the blend-shape matrix streamed again) — as
+// functions of their OPERANDS, so that two kernels can share them: bwd_joint_kernel (lbs.hip: the operator's own backward, the model's
+// vertices) and the fused fitting engine's fit_bwd_joint_kernel (fit.hip), which runs the same bodies over two classes of "vertices"
+// in one grid: the model's 10475 (carrying the UNSCALED penetration gradient) and the engine's n_c contact slots (carrying the contact
+// gradient) — everything behind dL/dverts is linear in it (lbs.py:108-116 backward), so the two parts travel side by side as extra
+// slices of the same split contractions and meet, with the 1 / N of the penetration term (fitting_proxe.py:155-158), in the reduction.
+#pragma once
+#include "lbs_device.h"
+
+#ifndef PSI_SKA_MARK
+#define PSI_SKA_MARK(k)
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// skinning backward, joint part (MFMA): gA[b][j][r*4+s] = sum_v W[v][j] * g_local[b][v][r] * [v_posed;1][s]
+// ------------------------------------------------------------------------------------------------
+// One workgroup = one 256-vertex slice x NBODY bodies; it is ONE product  D[64 joints][12 NBODY] = W^T[64][256] P[256][12 NBODY]  with
+// P[v][12 bb + 4 r + s] = g_local[bb][v][r] [v_posed[bb][v]; 1][s]: the 12 (r, s) entries of consecutive bodies are packed side by side, so
+// the 16-wide MFMA tiles carry no padding (a tile per body carried four zero columns: a quarter of the instructions).  Wave w owns joint
+// tile w (joints 16 w .. 16 w + 15) for the WHOLE slice and all column tiles: nothing to reduce across waves — the previous form split
+// the slice's vertices over the waves and met in LDS behind two barriers per body, which behind the blend_bwd stream's MFMA bursts (the
+// two share the launch and each SIMD) cost 2.5 us per body (workgroup timeline: operands staged at 5.6 us, end at 22 — later than the
+// stream itself, profiles/r04_timeline_bwd_joint.txt).
+//   A operand: lane (li, lk) supplies joint 16 w + li, vertex 64 lk + st in step st: 64 consecutive floats of its weight row, a quad
+// (16 B) per four steps, each used for every column tile.  B operand: the same vertex, column 16 nt + li: a product of two LDS values; the
+// staged operands are kept component-major ([body][component][vertex], 64-vertex runs padded by 4) so that the four steps of a quad
+// are ONE 16-byte LDS read each for g_local and v_posed.
+constexpr int SKA_NBODY = 8;
+constexpr int SKA_ROW = 256 + 16;          // floats per staged (body, component) row: vertex v sits at v + 4 (v / 64)
+constexpr int SKA_MAXT = (12 * SKA_NBODY + 15) / 16;
+constexpr int SKA_SMEM_F4 = SKA_NBODY * 2 * 3 * SKA_ROW / 4;      // LDS of one skin_bwd_A workgroup, in 16-byte units
+
+// operands of ONE 256-vertex slice
+struct PsiSkaSlice {
+    const float *wtt;          // the slice's four wave tiles of the tiled weights: [4][PSI_JP][64]
+    const float *gl, *vp;      // g_local / posed vertices of the slice's 256 vertices (768 floats), body b at + b * row_stride
+    size_t row_stride;
+    float *part;               // [B][PSI_JP][16]: this slice's partial joint-transform gradients
+};
+
+// NT: column tiles of a full workgroup, (12 nbody + 15) / 16 — a compile-time count keeps the 16 quads straight-line code with all weight
+// quads in registers (a workgroup with fewer bodies than nbody repeats its last column in the spare tiles)
+template <int NT>
+__device__ __forceinline__ void skin_bwd_A_body(const PsiSkaSlice &o, int B, int b0, int nbody, psi_f4 *smem)
+{
+    typedef psi_f4 f4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nb = min(nbody, B - b0);
+    const int ncol = 12 * nb;
+    // my weight row: joint 16 w + li, vertices 64 lk .. 64 lk + 63 of the slice — all 16 quads requested now (behind the stream's traffic
+    // a load takes ~2 us: requested two quads ahead of their use, they made every quad wait, 1 us per quad)
+    f4 wa[16];
+    {
+        // from the wave-tiled copy ([Vpad/64][64 joints][64 vertices]: the same 256 contiguous bytes per lane)
+        const f4 *wr = (const f4 *)(o.wtt + ((size_t)lk * PSI_JP + (w * 16 + li)) * 64);
+#pragma unroll
+        for (int q = 0; q < 16; q++) wa[q] = wr[q];
+    }
+    // ALL bodies' operands of this slice are requested up front, coalesced (768 consecutive floats of g_local and of v_posed per body: one
+    // 16-byte load each for threads 0..191), and parked in LDS component-major
+    float *sG = (float *)smem;                                  // [SKA_NBODY][3][SKA_ROW]
+    float *sP = sG + SKA_NBODY * 3 * SKA_ROW;                   // [SKA_NBODY][3][SKA_ROW]
+    {
+        f4 og[SKA_NBODY], op[SKA_NBODY];
+        const int t4 = threadIdx.x;
+#pragma unroll
+        for (int bb = 0; bb < SKA_NBODY; bb++)
+            if (bb < nb && t4 < 192) {
+                og[bb] = *(const f4 *)(o.gl + (size_t)(b0 + bb) * o.row_stride + t4 * 4);
+                op[bb] = *(const f4 *)(o.vp + (size_t)(b0 + bb) * o.row_stride + t4 * 4);
+            }
+#pragma unroll
+        for (int bb = 0; bb < SKA_NBODY; bb++)
+            if (bb < nb && t4 < 192) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = t4 * 4 + e, v = i / 3, comp = i - 3 * v;
+                    const int pos = (bb * 3 + comp) * SKA_ROW + v + 4 * (v >> 6);
+                    sG[pos] = og[bb][e];
+                    sP[pos] = op[bb][e];
+                }
+            }
+    }
+    __syncthreads();
+    PSI_SKA_MARK(0);
+    // my columns: tile nt -> column 16 nt + li = 12 bb + 4 r + s
+    int goff[NT], poff[NT];                                     // float offsets of my (body, r) / (body, s) rows + my 64-vertex run; poff < 0: s == 3
+    f4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int c = min(16 * nt + li, ncol - 1);             // (columns past the last body repeat the last one; they are not stored)
+        const int bb = c / 12, rs = c - 12 * bb, r = rs >> 2, sx = rs & 3;
+        goff[nt] = (bb * 3 + r) * SKA_ROW + lk * 68;
+        poff[nt] = sx < 3 ? (bb * 3 + sx) * SKA_ROW + lk * 68 : -1;
+        acc[nt] = (f4){0, 0, 0, 0};
+    }
+    // (requesting quad q + 1's LDS operands before quad q's MFMAs — a denser MFMA stream of this wave — measured SLOWER, 23.1 against 21.8 us:
+    // the stream wave on the same SIMD then waits longer for the pipe, and the launch ends when the later of the two kinds does)
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        f4 bop[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            const f4 g4 = *(const f4 *)(sG + goff[nt] + 4 * q);
+            const f4 p4 = *(const f4 *)(sP + max(poff[nt], 0) + 4 * q);
+            bop[nt] = poff[nt] >= 0 ? g4 * p4 : g4;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[q][e], bop[nt][e], acc[nt], 0, 0, 0);
+        if (q == 0) PSI_SKA_MARK(1);
+        __builtin_amdgcn_sched_barrier(0);                      // (the scheduler otherwise hoists every quad's LDS reads to the top and spills)
+    }
+    // D[row = 4 lk + e -> joint 16 w + 4 lk + e][col = li -> column 16 nt + li]
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int c = 16 * nt + li;
+        if (c < ncol) {
+            const int bb = c / 12, rs = c - 12 * bb;
+            float *po = o.part + (((size_t)(b0 + bb)) * PSI_JP + w * 16 + lk * 4) * 16 + rs;
+#pragma unroll
+            for (int e = 0; e < 4; e++) po[e * 16] = acc[nt][e];
+        }
+    }
+}
+
+// the same, column-tile count chosen at run time (12 nbody columns)
+__device__ __forceinline__ void skin_bwd_A_dispatch(const PsiSkaSlice &o, int B, int b0, int nbody, psi_f4 *smem)
+{
+    switch ((12 * nbody + 15) >> 4) {
+    case 1: skin_bwd_A_body<1>(o, B, b0, nbody, smem); break;
+    case 2: skin_bwd_A_body<2>(o, B, b0, nbody, smem); break;
+    case 3: skin_bwd_A_body<3>(o, B, b0, nbody, smem); break;
+    case 4: skin_bwd_A_body<4>(o, B, b0, nbody, smem); break;
+    case 5: skin_bwd_A_body<5>(o, B, b0, nbody, smem); break;
+    default: skin_bwd_A_body<SKA_MAXT>(o, B, b0, nbody, smem); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// blend backward (MFMA): g_feat[b][k] = sum_n g_vp[b][n] dirs[k][n]
+// workgroup = 4 waves sharing a 64-row k group and an n-slice; wave w takes n-steps w, w+4, ...; LDS reduce.
+// ------------------------------------------------------------------------------------------------
+// operands of ONE class of columns (the model's 3 V, or the engine's 3 n_c contact columns)
+struct PsiBlendBwdCols {
+    const float *dirs_b;       // [total_steps][Kpad][16]: the matrix in 16-column tiles
+    const float *g_vp;         // [B][row_stride]
+    size_t row_stride;
+    int Kpad, total_steps;
+};
+constexpr int PSI_BLEND_BWD_KT = 4;
+template <int MT>
+constexpr int psi_blend_bwd_smem_f4() { return 4 * PSI_BLEND_BWD_KT * MT * 64; }
+
+// steps [s_begin, s_end) of the class; part: [B][Kpad] of the slice
+template <int MT>
+__device__ __forceinline__ void blend_bwd_body(const PsiBlendBwdCols &o, int B, int s_begin, int s_end, float *__restrict__ part, int kgroup,
+                                               int bgroup, psi_f4 *smem)
+{
+    typedef psi_f4 f4;
+    constexpr int KT = PSI_BLEND_BWD_KT;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int k0 = kgroup * 16 * KT;
+    const int b0 = bgroup * 16 * MT;
+    const int total_steps = o.total_steps;
+    s_end = min(s_end, total_steps);
+    f4 acc[KT][MT];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[kt][t] = (f4){0, 0, 0, 0};
+    const float *grow[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) grow[t] = o.g_vp + (size_t)min(b0 + t * 16 + li, B - 1) * o.row_stride + 4 * lk;
+    const float *drow[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) drow[kt] = o.dirs_b + (size_t)(k0 + kt * 16 + li) * 16 + 4 * lk;   // + step base: a wave-load is 1 KB contiguous
+    // each wave owns steps s_begin+w, +4, ...; PF steps' operands (PF x (MT + KT) 16-byte loads) are issued before the first MFMA group
+    // waits, and the scheduler is fenced so it cannot sink them back next to their uses.  PF = 1: with the skin_bwd_A waves sharing the SIMDs
+    // (one each) a short MFMA burst per round trip serves the LAUNCH best — rocprofv3, B = 32: PF = 1 22.0 us, 2 22.6, 3 23.9 (round 3's
+    // setting, tuned before the two kinds of wave were balanced), 4 25.1; double-buffered (the next step's loads in flight under the MFMAs)
+    // 22.0 at PF = 1 and 29-35 at PF = 2-3: whatever lets the stream wave hold the matrix pipe longer delays the other kind, and the
+    // launch ends with the later of the two
+    constexpr int PF = 1;
+    for (int st0 = s_begin + w; st0 < s_end; st0 += 4 * PF) {
+        f4 ga[PF][MT], db[PF][KT];
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+            const int st = min(st0 + 4 * p, total_steps - 1);
+            const int n0 = st * 16;
+#pragma unroll
+            for (int t = 0; t < MT; t++) ga[p][t] = *(const f4 *)(grow[t] + n0);
+#pragma unroll
+            for (int kt = 0; kt < KT; kt++) db[p][kt] = *(const f4 *)(drow[kt] + (size_t)st * o.Kpad * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+            if (st0 + 4 * p < s_end) {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+                        for (int t = 0; t < MT; t++)
+                            acc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[p][t][e], db[p][kt][e], acc[kt][t], 0, 0, 0);
+            }
+        }
+    }
+    f4 (*red)[KT][MT][64] = (f4 (*)[KT][MT][64])smem;      // [4][KT][MT][64]
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int t = 0; t < MT; t++) red[w][kt][t][lane] = acc[kt][t];
+    __syncthreads();
+    // wave w finishes k-tile w: D[row = lk*4+e -> body][col = li -> k]
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        f4 ov = red[0][w][t][lane] + red[1][w][t][lane] + red[2][w][t][lane] + red[3][w][t][lane];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            int b = b0 + t * 16 + lk * 4 + e;
+            if (b < B) part[(size_t)b * o.Kpad + k0 + w * 16 + li] = ov[e];
+        }
+    }
+}
+
+// Placement of the stream workgroups: workgroup `bid` runs on XCD bid % 8 (observed dispatch order) and every XCD has its own L2, so the
+// k-groups that share an n-slice — and therefore read the same g_vposed columns — are placed on ONE XCD: that slice of g_vposed is
+// fetched from memory once and served to the other k-groups from L2 (it used to be fetched by all 8 XCDs).
+__device__ __forceinline__ void psi_blend_bwd_place(int bid, int kgroups, int nslices, int &kg, int &slice, int &bg)
+{
+    if ((nslices & 7) == 0) {
+        const int xcd = bid & 7, idx = bid >> 3, spx = nslices >> 3;
+        kg = idx % kgroups;
+        const int t = idx / kgroups;
+        slice = xcd + 8 * (t % spx);
+        bg = t / spx;
+    } else {
+        kg = bid % kgroups;
+        const int rest = bid / kgroups;
+        slice = rest % nslices;
+        bg = rest / nslices;
+    }
+}

@@ -139,6 +139,11 @@ struct KdQueryFromMemory {
         const float *qp = xyz1 + (size_t)b * qstride + qrow * 3;
         qx = qp[0]; qy = qp[1]; qz = qp[2];
     }
+    // CONTACT searches: contact_post(o, g) sees the gradient of the query's contact term in lane 0 of its group, contact_finish(b, bx, nbx)
+    // runs once per workgroup with all threads present — a source that produced the query point itself can carry that gradient further back
+    // on the spot (fit.hip: ContactSkinSrc); a source that read the point from memory has nothing to add
+    __device__ __forceinline__ void contact_post(size_t, float, float, float) {}
+    __device__ __forceinline__ void contact_finish(int, int, int) {}
 };
 
 // sum of the per-group contact terms over the workgroup (fixed order) -> *out
@@ -174,8 +179,8 @@ __device__ __forceinline__ int kd_warm_candidate(const KdDev &T, int h, float4 &
 // One round of the search: the workgroup's QPB lane groups answer one query each.  (qx,qy,qz): the group's query (the same values in
 // all LPQ lanes of the group), active: the group has a query, o: its output slot (dist / idx / hint / gq index).  Returns the contact
 // term s / (s + c) of the query in lane 0 of its group (0 elsewhere) when CONTACT.  No barriers inside: groups are independent.
-template <bool CONTACT>
-__device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float qy, float qz, bool active, size_t o, float *__restrict__ dist,
+template <bool CONTACT, class QSrc>
+__device__ __forceinline__ float kd_query_round(const KdDev &T, QSrc &qsrc, float qx, float qy, float qz, bool active, size_t o, float *__restrict__ dist,
                                                 int *__restrict__ idx, float cconst, float gscale, float *__restrict__ gq, int *__restrict__ hint,
                                                 int rows, int *smem_i, int h, const float4 &hp)
 {
@@ -407,9 +412,13 @@ __device__ __forceinline__ float kd_query_round(const KdDev &T, float qx, float 
             float den = sq + cconst;
             fval = sq / den;
             float gg = gscale * (cconst / (2.0f * sq * den * den)) * 2.0f;
-            gq[o * 3 + 0] = gg * (qx - w.x);
-            gq[o * 3 + 1] = gg * (qy - w.y);
-            gq[o * 3 + 2] = gg * (qz - w.z);
+            const float gx = gg * (qx - w.x), gy = gg * (qy - w.y), gz = gg * (qz - w.z);
+            if (gq) {
+                gq[o * 3 + 0] = gx;
+                gq[o * 3 + 1] = gy;
+                gq[o * 3 + 2] = gz;
+            }
+            qsrc.contact_post(o, gx, gy, gz);
         }
     }
     return fval;
@@ -440,8 +449,11 @@ __device__ __forceinline__ void kd_query_body(KdDev T0, QSrc qsrc, int n, float 
     qsrc.point(b, active ? j : 0, c, qx, qy, qz);                // every lane of the group ends up with the same point
     PSI_SSTOP(4);                                                // (dev: differential timing — the query source alone)
     PSI_KD_MARK(0);
-    const float fval = kd_query_round<CONTACT>(T, qx, qy, qz, active, o, dist, idx, cconst, gscale, gq, hint, rows, smem_i, h, hp);
-    if (CONTACT) kd_block_fsum(fval, fpart + (size_t)b * nbx + bx);
+    const float fval = kd_query_round<CONTACT>(T, qsrc, qx, qy, qz, active, o, dist, idx, cconst, gscale, gq, hint, rows, smem_i, h, hp);
+    if (CONTACT) {
+        kd_block_fsum(fval, fpart + (size_t)b * nbx + bx);
+        qsrc.contact_finish(b, bx, nbx);
+    }
 }
 
 static inline size_t kd_lds_bytes(int rows) { return (size_t)QPB * rows * 8; }
