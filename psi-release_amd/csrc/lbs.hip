@@ -6,10 +6,9 @@
 //
 // Data layout in HBM (built once by psi_lbs_create, fp32):
 //   dirs_b [Npad/16][Kpad][16] the same matrix in 16-column tiles (the backward's copy)
-//   dirs  [Npad/64][Kpad][64]  column-tile-major: tile t holds columns 64t..64t+63 of the [Kpad][Npad] matrix whose rows
-//                        0..NB-1 = shapedirs^T and NB..NB+P-1 = posedirs (zero padded; N = 3V).  A workgroup's 64-column
-//                        strip is one contiguous 128 KB run, so the stream is sequential per CU instead of 256-byte
-//                        pieces 126 KB apart.
+//   dirs  [Npad/32][Kpad/4][32][4]  column-tile-major, k-quad interleaved: tile t holds columns 32t..32t+31 of the [Kpad][Npad] matrix
+//                        whose rows 0..NB-1 = shapedirs^T and NB..NB+P-1 = posedirs (zero padded; N = 3V).  A wave's 32-column strip is
+//                        one contiguous 64 KB run read with 16-byte requests (blend_fwd_cols_kernel).
 //                        Shape and pose blendshapes are ONE contraction: v_posed = v_template + feat @ dirs,
 //                        feat[b] = [betas | (R_1..R_{J-1} - I)]  (lbs.py:81 and :94-99 fused; 64 MB streamed once).
 //   WT    [64][Vpad]     skinning weights transposed (coalesced per-vertex reads), zero padded.
@@ -43,9 +42,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-#ifndef PSI_BLEND_FWD_BUFS
-#define PSI_BLEND_FWD_BUFS 2          // operand buffers of blend_fwd (3 measured no faster)
-#endif
 constexpr int JP = PSI_JP;      // padded joint count (one wave)
 constexpr int SKIN_BLK = PSI_SKIN_BLK;
 
@@ -107,203 +103,109 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(LbsDev m, const float *__r
 
 // ------------------------------------------------------------------------------------------------
 // blend forward: v_posed[b][n] = v_template[n] + sum_k feat[b][k] dirs[k][n]      (MFMA f32 16x16x4)
-// workgroup = 4 waves = one 64-column tile; wave w contracts k in [w*Kpad/4, (w+1)*Kpad/4); LDS reduce.
-// B operand: each lane loads 16 B (4 consecutive columns of one dirs row): 4 rows x 256 B per wave-load.
-// MFMA c of a k-step uses element c of that float4, so its 16 output columns are n0 + 4*(lane&15) + c.
+// Column decomposition: a WAVE owns 32 output columns (half a 64-column tile) and contracts ALL of K for them, so there is no cross-wave
+// reduction at all — no LDS, no barriers, no tile boundary at which the four waves of a workgroup wait for each other (the K-split kernel
+// of rounds 1-3 ended every tile with an LDS reduction and two barriers: 3.6 TB/s).  984 waves = one per SIMD on 246 CUs.
+// One wave per SIMD by design (amdgpu_waves_per_eu(1,1)): two co-resident waves of this kernel contend for the SIMD's matrix pipe and
+// measured 30% slower; latency is hidden inside the wave by a rolling register ring FOUR 64-k chunks deep (24 KB per wave in flight beside
+// the chunk being multiplied).  Without the waves_per_eu bound the scheduler would target 8 waves/SIMD, cap the kernel near 40 VGPRs and
+// sink the prefetched loads back next to their MFMAs.
+//   B operand, round 6: 16-BYTE loads.  The forward's copy of the matrix is k-quad interleaved — [32-column tile][Kpad/4][32][4]: the four
+// consecutive k of a quad lie side by side for one column, so a lane's 16 bytes are the B operands of FOUR consecutive MFMA steps of one
+// of its two columns (round 4-5 loaded 8 bytes = two columns of one k per lane: 8-byte accesses run at 0.54-0.70 of the 16-byte rate on
+// gfx950, MI355X_MICROARCH.md, and the kernel sat at 4.2 TB/s = 0.69 of what the same matrix streams at with 16-byte requests).  Lane li
+// owns the logical columns 2 li and 2 li + 1 (ONE 8-byte store per body row); inside a tile they are stored at slots li and li + 16, so
+// the 16 lanes of a k-group request 256 contiguous bytes per instruction.  The k order inside an accumulator is ascending for every
+// (body, column) at every batch size — the same sums, bit for bit, as the 8-byte form.
 // ------------------------------------------------------------------------------------------------
-// One wave per SIMD by design (amdgpu_waves_per_eu(1,1)): two co-resident waves of this kernel contend for the SIMD's
-// matrix pipe and measured 30% slower (gpurun t18: 25.9 vs 19.9 us at B=32).  Latency is hidden inside the wave instead:
-// a rolling double buffer keeps the operands of the NEXT 64-k chunk (16 dirs loads = 16 KB + the A quads) in flight while the
-// current chunk's 32*MT MFMAs issue, across chunk and tile boundaries.  Without the waves_per_eu bound the scheduler would
-// target 8 waves/SIMD, cap the kernel near 40 VGPRs and sink the prefetched loads back next to their MFMAs.
-template <int MT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void blend_fwd_kernel(LbsDev m, const float *__restrict__ feat, int B,
-                                                                                           float *__restrict__ v_posed, int tiles_per_block)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b0 = blockIdx.y * 16 * MT;
-    const int kq = m.Kpad / 4;                  // k range of this wave (Kpad % 256 == 0 -> kq % 64 == 0)
-    const int nch = kq / 64;                    // 64-k chunks per tile for this wave
-    const int li = lane & 15, lk = lane >> 4;
-    const int Bpad = (B + 15) & ~15;
-    const int ntiles = m.Npad / 64;
-    const int tile0 = blockIdx.x * tiles_per_block;
-    const int nt = min(tiles_per_block, ntiles - tile0);
-    const int total = nt * nch;
-    __shared__ f4 red[4][MT][4][64];
-
-    // k order inside a 64-wide chunk: lane group lk owns k = base + 16*lk + s (s = MFMA step 0..15).  feat is stored as
-    // k-quads [Kpad/4][Bpad][4], so the A operands of four consecutive steps are ONE 16-byte load per lane.
-    auto load_chunk = [&](int it, f4 (&q)[16], f4 (&a4)[MT][4]) {
-        const int tile = tile0 + it / nch, ch = it % nch;
-        const int kb = w * kq + 64 * ch + 16 * lk;
-#pragma unroll
-        for (int t = 0; t < MT; t++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) a4[t][j] = *(const f4 *)(feat + ((size_t)(kb / 4 + j) * Bpad + b0 + t * 16 + li) * 4);
-        const float *brow = m.dirs + ((size_t)tile * m.Kpad + kb) * 64 + 4 * li;
-#pragma unroll
-        for (int sidx = 0; sidx < 16; sidx++) q[sidx] = *(const f4 *)(brow + (size_t)sidx * 64);
-    };
-    f4 acc[MT][4];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int t = 0; t < MT; t++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) acc[t][c] = (f4){0, 0, 0, 0};
-    };
-    auto mfma_chunk = [&](const f4 (&q)[16], const f4 (&a4)[MT][4]) {
-#pragma unroll
-        for (int sidx = 0; sidx < 16; sidx++)
-#pragma unroll
-            for (int t = 0; t < MT; t++)
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t][sidx >> 2][sidx & 3], q[sidx][c], acc[t][c], 0, 0, 0);
-    };
-    auto finish_tile = [&](int it) {            // after the last chunk of a tile: 4-way k reduction through LDS, add template, store
-        if ((it % nch) != nch - 1) return;
-        const int n0 = (tile0 + it / nch) * 64;
-#pragma unroll
-        for (int t = 0; t < MT; t++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) red[w][t][c][lane] = acc[t][c];
-        __syncthreads();
-        f4 vt = *(const f4 *)(m.v_template + n0 + 4 * li);
-#pragma unroll
-        for (int t = 0; t < MT; t++) {
-            f4 o = vt;
-#pragma unroll
-            for (int ww = 0; ww < 4; ww++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) o[c] += ((const float *)&red[ww][t][c][lane])[w];   // wave w finishes row lk*4 + w
-            int b = b0 + t * 16 + lk * 4 + w;
-            if (b < B) *(f4 *)(v_posed + (size_t)b * m.Npad + n0 + 4 * li) = o;
-        }
-        __syncthreads();
-        zero_acc();
-    };
-
-#if PSI_BLEND_FWD_BUFS == 3
-    // three operand buffers: the chunk two positions ahead is requested before the current chunk's MFMAs issue
-    f4 qA[16], qB[16], qC[16], aA[MT][4], aB[MT][4], aC[MT][4];
-    zero_acc();
-    load_chunk(0, qA, aA);
-    if (total > 1) load_chunk(1, qB, aB);
-    for (int it = 0; it < total; it += 3) {
-        if (it + 2 < total) load_chunk(it + 2, qC, aC);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_chunk(qA, aA);
-        finish_tile(it);
-        if (it + 1 < total) {
-            if (it + 3 < total) load_chunk(it + 3, qA, aA);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(qB, aB);
-            finish_tile(it + 1);
-        }
-        if (it + 2 < total) {
-            if (it + 4 < total) load_chunk(it + 4, qB, aB);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(qC, aC);
-            finish_tile(it + 2);
-        }
-    }
-#else
-    f4 qA[16], qB[16], aA[MT][4], aB[MT][4];
-    zero_acc();
-    load_chunk(0, qA, aA);
-    for (int it = 0; it < total; it += 2) {
-        if (it + 1 < total) load_chunk(it + 1, qB, aB);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_chunk(qA, aA);
-        finish_tile(it);
-        if (it + 1 < total) {
-            if (it + 2 < total) load_chunk(it + 2, qA, aA);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(qB, aB);
-            finish_tile(it + 1);
-        }
-    }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// blend forward, column decomposition (round 4; the default): a WAVE owns 32 output columns (half a 64-column tile) and contracts ALL of
-// K for them, so there is no cross-wave reduction at all — no LDS, no barriers, no tile boundary at which the four waves of a workgroup
-// wait for each other (the K-split kernel above ends every tile with an LDS reduction and two barriers, and its waves have only two
-// 16 KB chunks in flight: 3.6 TB/s against the 5.2 TB/s the same matrix streams at in the backward).  B operand: each lane loads 8 bytes
-// (2 consecutive columns of one dirs row), 16 rows per 64-k chunk, FOUR chunks deep in a rolling register ring (48 loads = 24 KB per
-// wave in flight beside the chunk being multiplied); MFMA c of a k-step uses element c of that pair, so the 16 output columns of
-// accumulator c are n0 + 2 * (lane & 15) + c.  984 waves = one per SIMD on 246 CUs, the two halves of a tile in one workgroup.
-// The k order inside an accumulator is ascending for every (body, column) at every batch size.
-// ------------------------------------------------------------------------------------------------
-template <int MT>
+// NCH = Kpad / 64 at compile time (8 for SMPL-X): the chunk loop is then STRAIGHT-LINE code.  As a loop, hipcc's wait-count insertion is
+// conservative at the loop header: the first chunk of every trip waited with vmcnt(0) — for ALL outstanding loads, including the chunk
+// requested a few cycles earlier, i.e. the ring was drained and a full memory latency exposed once per trip (found in the ISA, round 6;
+// in straight-line code the waits are exact: vmcnt(48) .. before the first MFMA of a chunk).  NCH = 0: any Kpad, the loop form.
+template <int MT, int NCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void blend_fwd_cols_kernel(LbsDev m, const float *__restrict__ feat, int B,
                                                                                                 float *__restrict__ v_posed)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int gw = blockIdx.x * 4 + w;                   // half-tile of this wave
+    const int gw = blockIdx.x * 4 + w;                   // 32-column tile of this wave
     if (gw >= m.Npad / 32) return;
-    const int tile = gw >> 1, h = gw & 1;
     const int b0 = blockIdx.y * 16 * MT;
     const int li = lane & 15, lk = lane >> 4;
     const int Bpad = (B + 15) & ~15;
-    const int nch = m.Kpad / 64;                         // 64-k chunks (Kpad % 256 == 0)
-    // k order inside a chunk: lane group lk owns k = 64 ch + 16 lk + s (s = MFMA step 0..15); feat is stored as k-quads [Kpad/4][Bpad][4],
-    // so the A operands of four consecutive steps are ONE 16-byte load per lane
-    const float *brow = m.dirs + ((size_t)tile * m.Kpad + 16 * lk) * 64 + 32 * h + 2 * li;
+    const int nch = NCH ? NCH : m.Kpad / 64;             // 64-k chunks (Kpad % 256 == 0)
+    // k order inside a chunk: lane group lk owns k = 64 ch + 16 lk + s (s = MFMA step 0..15) = the quads 16 ch + 4 lk + j, j = 0..3; feat is
+    // stored as k-quads [Kpad/4][Bpad][4], so the A operands of four consecutive steps are ONE 16-byte load per lane as well
+    const float *brow = m.dirs + (size_t)gw * m.dirs_tile + ((size_t)(4 * lk) * 32 + li) * 4;
     const float *arow = feat + ((size_t)(4 * lk) * Bpad + b0 + li) * 4;
-    auto load_chunk = [&](int ch, psi_f2 (&q)[16], f4 (&a4)[MT][4]) {
+    auto load_chunk = [&](int ch, f4 (&q)[4][2], f4 (&a4)[MT][4]) {
 #pragma unroll
         for (int t = 0; t < MT; t++)
 #pragma unroll
             for (int j = 0; j < 4; j++) a4[t][j] = *(const f4 *)(arow + ((size_t)(16 * ch + j) * Bpad + t * 16) * 4);
-        const float *bq = brow + (size_t)ch * 64 * 64;
+        const float *bq = brow + (size_t)ch * 16 * 32 * 4;
 #pragma unroll
-        for (int sidx = 0; sidx < 16; sidx++) q[sidx] = *(const psi_f2 *)(bq + sidx * 64);
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) q[j][c] = *(const f4 *)(bq + (j * 32 + 16 * c) * 4);
     };
     f4 acc[MT][2];
 #pragma unroll
     for (int t = 0; t < MT; t++)
 #pragma unroll
         for (int c = 0; c < 2; c++) acc[t][c] = (f4){0, 0, 0, 0};
-    auto mfma_chunk = [&](const psi_f2 (&q)[16], const f4 (&a4)[MT][4]) {
+    auto mfma_chunk = [&](const f4 (&q)[4][2], const f4 (&a4)[MT][4]) {
 #pragma unroll
         for (int sidx = 0; sidx < 16; sidx++)
 #pragma unroll
             for (int t = 0; t < MT; t++)
 #pragma unroll
                 for (int c = 0; c < 2; c++)
-                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t][sidx >> 2][sidx & 3], q[sidx][c], acc[t][c], 0, 0, 0);
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t][sidx >> 2][sidx & 3], q[sidx >> 2][c][sidx & 3], acc[t][c], 0, 0, 0);
     };
-    psi_f2 q0[16], q1[16], q2[16], q3[16];
-    f4 a0[MT][4], a1[MT][4], a2[MT][4], a3[MT][4];
-    const psi_f2 vt = *(const psi_f2 *)(m.v_template + tile * 64 + 32 * h + 2 * li);
-    load_chunk(0, q0, a0);
-    if (nch > 1) load_chunk(1, q1, a1);
-    if (nch > 2) load_chunk(2, q2, a2);
-    for (int ch = 0; ch < nch; ch += 4) {
-        if (ch + 3 < nch) load_chunk(ch + 3, q3, a3);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_chunk(q0, a0);
-        if (ch + 1 < nch) {
-            if (ch + 4 < nch) load_chunk(ch + 4, q0, a0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(q1, a1);
+    const psi_f2 vt = *(const psi_f2 *)(m.v_template + gw * 32 + 2 * li);
+    if (NCH) {
+        f4 q[4][4][2], a[4][MT][4];
+#pragma unroll
+        for (int ch = 0; ch < 3 && ch < NCH; ch++) {
+            load_chunk(ch, q[ch], a[ch]);
+            __builtin_amdgcn_sched_barrier(0);           // (request order = use order: the scheduler otherwise moves chunk 0's last quad behind chunk 2)
         }
-        if (ch + 2 < nch) {
-            if (ch + 5 < nch) load_chunk(ch + 5, q1, a1);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            if (ch + 3 < NCH) load_chunk(ch + 3, q[(ch + 3) & 3], a[(ch + 3) & 3]);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(q2, a2);
+            mfma_chunk(q[ch & 3], a[ch & 3]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (ch + 3 < nch) {
-            if (ch + 6 < nch) load_chunk(ch + 6, q2, a2);
+    } else {
+        f4 q0[4][2], q1[4][2], q2[4][2], q3[4][2];
+        f4 a0[MT][4], a1[MT][4], a2[MT][4], a3[MT][4];
+        load_chunk(0, q0, a0);
+        if (nch > 1) load_chunk(1, q1, a1);
+        if (nch > 2) load_chunk(2, q2, a2);
+        for (int ch = 0; ch < nch; ch += 4) {
+            if (ch + 3 < nch) load_chunk(ch + 3, q3, a3);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(q3, a3);
+            mfma_chunk(q0, a0);
+            if (ch + 1 < nch) {
+                if (ch + 4 < nch) load_chunk(ch + 4, q0, a0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chunk(q1, a1);
+            }
+            if (ch + 2 < nch) {
+                if (ch + 5 < nch) load_chunk(ch + 5, q1, a1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chunk(q2, a2);
+            }
+            if (ch + 3 < nch) {
+                if (ch + 6 < nch) load_chunk(ch + 6, q2, a2);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chunk(q3, a3);
+            }
         }
     }
     // D[row = 4 lk + e -> body][col = li -> columns 2 li, 2 li + 1]: one 8-byte store per body row
-    float *orow = v_posed + (size_t)tile * 64 + 32 * h + 2 * li;
+    float *orow = v_posed + (size_t)gw * 32 + 2 * li;
 #pragma unroll
     for (int t = 0; t < MT; t++)
 #pragma unroll
@@ -497,8 +399,17 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
         d.n_items = (int)sub_item.size();
     }
     // host staging
-    std::vector<float> dirs((size_t)d.Kpad * d.Npad, 0.0f), dirs_b((size_t)d.Kpad * d.Npad, 0.0f), vt(d.Npad, 0.0f), WT((size_t)JP * d.Vpad, 0.0f);
-    auto dirs_at = [&](int k, int n) -> float & { return dirs[((size_t)(n >> 6) * d.Kpad + k) * 64 + (n & 63)]; };
+    // tile stride of the forward copy: a tile's 32 x Kpad floats + a skew (PSI_DIRS_SKEW floats, default 1088 = 4352 bytes), so that the
+    // 984 waves that walk their tiles at the same pace do not sit on the same memory channels (tiles exactly 64 KB apart do)
+    {
+        const char *sk = getenv("PSI_DIRS_SKEW");
+        d.dirs_tile = d.Kpad * 32 + (sk ? atoi(sk) / 4 * 4 : 1088);
+    }
+    std::vector<float> dirs((size_t)(d.Npad / 32) * d.dirs_tile, 0.0f), dirs_b((size_t)d.Kpad * d.Npad, 0.0f), vt(d.Npad, 0.0f), WT((size_t)JP * d.Vpad, 0.0f);
+    // forward copy: [32-column tile][Kpad/4][slot][4]: k-quad interleaved; logical column 2 l + c of a tile sits in slot l + 16 c (blend_fwd_cols_kernel)
+    auto dirs_at = [&](int k, int n) -> float & {
+        return dirs[(size_t)(n >> 5) * d.dirs_tile + (((size_t)(k >> 2)) * 32 + (((n & 31) >> 1) + 16 * (n & 1))) * 4 + (k & 3)];
+    };
     for (int l = 0; l < NB; l++)
         for (int n = 0; n < d.N; n++) dirs_at(l, n) = h_shapedirs[(size_t)n * NB + l];                  // [V,3,NB] -> row l
     for (int p = 0; p < d.P; p++)
@@ -623,29 +534,15 @@ extern "C" size_t psi_lbs_workspace_floats(const psi_lbs_model *m, int B)
 
 static int lbs_launch_blend(const LbsDev &m, const WsLayout &L, int B, float *ws, hipStream_t st)
 {
-    static const bool ksplit = getenv("PSI_BLEND_FWD") && getenv("PSI_BLEND_FWD")[0] == '0';    // the round-1..3 K-split kernel (A/B)
-    if (!ksplit) {
-        const int bgroups = B > 32 ? psi_cdiv(B, 64) : 1;
-        const dim3 grid(psi_cdiv(m.Npad / 32, 4), bgroups);
-        if (B > 32)
-            hipLaunchKernelGGL(blend_fwd_cols_kernel<4>, grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
-        else if (B > 16)
-            hipLaunchKernelGGL(blend_fwd_cols_kernel<2>, grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
-        else
-            hipLaunchKernelGGL(blend_fwd_cols_kernel<1>, grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed);
-    } else {
-        const int ntiles = m.Npad / 64;
-        const int bgroups = B > 32 ? psi_cdiv(B, 64) : 1;
-        int tpb = psi_cdiv((long)ntiles * bgroups, 256);          // ~one workgroup (1 wave/SIMD) per CU, single round
-        if (tpb < 1) tpb = 1;
-        dim3 grid(psi_cdiv(ntiles, tpb), bgroups);
-        if (B > 32)
-            hipLaunchKernelGGL(blend_fwd_kernel<4>, grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed, tpb);
-        else if (B > 16)
-            hipLaunchKernelGGL(blend_fwd_kernel<2>, grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed, tpb);
-        else
-            hipLaunchKernelGGL(blend_fwd_kernel<1>, grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed, tpb);
-    }
+    const int bgroups = B > 32 ? psi_cdiv(B, 64) : 1;
+    const dim3 grid(psi_cdiv(m.Npad / 32, 4), bgroups);
+    static const bool loop_form = getenv("PSI_BLEND_FWD_LOOP") && getenv("PSI_BLEND_FWD_LOOP")[0] == '1';      // dev A/B: the chunk loop as a loop
+#define PSI_LAUNCH_BLEND(MT_, NCH_) hipLaunchKernelGGL((blend_fwd_cols_kernel<MT_, NCH_>), grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed)
+    const bool k8 = m.Kpad == 512 && !loop_form;              // SMPL-X: 506 feature rows -> 8 chunks
+    if (B > 32) { if (k8) PSI_LAUNCH_BLEND(4, 8); else PSI_LAUNCH_BLEND(4, 0); }
+    else if (B > 16) { if (k8) PSI_LAUNCH_BLEND(2, 8); else PSI_LAUNCH_BLEND(2, 0); }
+    else { if (k8) PSI_LAUNCH_BLEND(1, 8); else PSI_LAUNCH_BLEND(1, 0); }
+#undef PSI_LAUNCH_BLEND
     PSI_CHECK_LAUNCH("blend_fwd_kernel");
     psi_mark("blend_fwd_kernel", st);
     return 0;

@@ -21,6 +21,7 @@ constexpr int PSI_A_TAIL = 16;      // zero transform rows kept behind the LAST 
 
 struct LbsDev {
     int V, J, NB, P, K, Kpad, N, Npad, Vpad, maxlevel, njump;
+    int dirs_tile;                                   // floats between consecutive 32-column tiles of `dirs` (lbs.hip)
     const float *dirs, *dirs_b, *v_template, *WT, *J_t, *J_s;
     const float *WTt;                                // the same weights as [Vpad/64][PSI_JP][64]: a wave's 64 vertices x all joints = one contiguous 16 KB tile
     const float *Wc;                                 // compressed rows [PSI_WNZ][Vpad]: the k-th non-zero weight of each vertex (ascending joint), or nullptr

@@ -182,9 +182,12 @@ __device__ __forceinline__ void blend_bwd_body(const PsiBlendBwdCols &o, int B, 
     // each wave owns steps s_begin+w, +4, ...; PF steps' operands (PF x (MT + KT) 16-byte loads) are issued before the first MFMA group
     // waits, and the scheduler is fenced so it cannot sink them back next to their uses.  PF = 1: with the skin_bwd_A waves sharing the SIMDs
     // (one each) a short MFMA burst per round trip serves the LAUNCH best — rocprofv3, B = 32: PF = 1 22.0 us, 2 22.6, 3 23.9 (round 3's
-    // setting, tuned before the two kinds of wave were balanced), 4 25.1; double-buffered (the next step's loads in flight under the MFMAs)
-    // 22.0 at PF = 1 and 29-35 at PF = 2-3: whatever lets the stream wave hold the matrix pipe longer delays the other kind, and the
-    // launch ends with the later of the two
+    // setting, tuned before the two kinds of wave were balanced), 4 25.1.
+    // Round 6 rebuilt the step loop as STRAIGHT-LINE code (the loop's header carries a vmcnt(0): hipcc's wait-count insertion is conservative
+    // at back edges — that is what stalled blend_fwd, lbs.hip) with the next 1 .. 4 steps' operands in a register ring and counted waits:
+    // 26.0 / 26.1 / 27.8 / 28.0 us against 25.7 for this loop (profiles/r06_ab_bwd_joint_pipeline.txt).  The launch is not waiting for
+    // memory: the two kinds of wave keep each SIMD's matrix pipe busy for 13-16 of its 26 us (608 + 384 fp32 MFMAs of 32 cycles), and
+    // whatever lets the stream wave issue its bursts back to back only moves the wait to the skin_bwd_A wave on the same SIMD.
     constexpr int PF = 1;
     for (int st0 = s_begin + w; st0 < s_end; st0 += 4 * PF) {
         f4 ga[PF][MT], db[PF][KT];
