@@ -9,14 +9,16 @@
   (``resnet.0.weight``, ``resnet.4.0.conv1.weight``, ``resnet.5.0.downsample.0.weight`` ...) and shapes are those of
   SURVEY.md Appendix B, so reference checkpoints (``epoch-*.ckp`` -> ``model_h_state_dict``) load with strict=True.
 
-These are genuine contractions (conv / linear): they run on the matrix cores through PyTorch-ROCm (MIOpen / hipBLASLt);
-``autocast_bf16=True`` wraps the trunk in bf16 autocast (losses stay fp32).  Differences from the reference that do not
+These are genuine contractions (conv / linear): on a GPU they run on the matrix cores through the hand-written kernels of libpsi_hip.so
+(ops.conv2d_split / conv3x3 / bn_act(_t) / maxpool3x3s2(_t) / linear_act(3): csrc/conv_gemm.hip, conv_stem.hip, conv.hip, bnorm.hip,
+linear.hip) in both precisions — the fp32 model (the reference's, cvae.py:427-455) with three-term split products, ``autocast_bf16=True``
+with bf16 products (losses stay fp32).  The ``nn.Module`` calls that remain in the forward methods are what CPU tensors take (the CPU
+tests of the checkpoint layout and the host logic); there is no environment switch back to the vendor libraries — the tests that compare
+against them patch these predicates (tests/library_paths.py).  Differences from the reference that do not
 change arithmetic: the reparameterisation noise is drawn on the model's device (the reference draws it with the CPU
 generator and copies it, net_layers.py:88-92) and can be injected (``eps=``) for reproducible tests.
 """
 from __future__ import annotations
-
-import os
 
 import torch
 from torch import nn
@@ -26,23 +28,25 @@ def _precise(x):
     """The fp32 models (``autocast_bf16=False``: the reference's precision, cvae.py:427-455) on a GPU run their convolutions, BatchNorms,
     max-pool and dense layers on the hand-written kernels of libpsi_hip.so as well: fp32 NHWC maps, three-term split products on the
     bf16 matrix cores with fp32 accumulation (ops.conv2d_split / bn_act_t / maxpool3x3s2_t / linear_act3; csrc/conv_gemm.hip quantifies the
-    arithmetic: 0.6-3.2e-5 of the reference's recorded forward passes).  PSI_HIP_PRECISE=0 keeps the library (MIOpen / hipBLASLt) path."""
-    import os
-    return (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and os.environ.get('PSI_HIP_PRECISE', '1') != '0')
+    arithmetic: 0.6-3.2e-5 of the reference's recorded forward passes)."""
+    return x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
 
 
 def _lin(owner, layer, x, act=None, slope=0.01, residual=None):
     """``act(layer(x)) (+ residual)`` for an nn.Linear: the fp32 model on the GPU -> ops.linear_act3 (any width); the bf16 mode -> ``_linear``."""
     if _precise(x) and not getattr(owner, 'hip_linear', False):
         from .ops import linear_act3
+        if x.dim() != 2:                                      # nn.Linear semantics: any number of leading dimensions
+            r2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
+            return linear_act3(x.reshape(-1, x.shape[-1]), layer.weight, layer.bias, act, slope, r2).reshape(*x.shape[:-1], layer.out_features)
         return linear_act3(x, layer.weight, layer.bias, act, slope, residual)
     if _use_hip_linear(owner, x):
         # the bf16 mode: bias, LeakyReLU and the skip connection are part of the same launch; the 3-, 72-, 75-wide layers (no 16-wide operand
-        # tiles) take the any-width kernel, whose three-term products are at least the library's fp32 precision (PSI_HIP_LINEAR_ODD=0: library)
+        # tiles) take the any-width kernel, whose three-term products are at least the library's fp32 precision
         if layer.in_features % 16 == 0 and layer.out_features % 16 == 0:
             from .ops import linear_act
             return linear_act(x, layer.weight, layer.bias, 'leaky_relu' if act else None, slope, residual=residual)
-        if os.environ.get('PSI_HIP_LINEAR_ODD', '1') != '0' and x.dim() == 2:
+        if x.dim() == 2:
             from .ops import linear_act3
             return linear_act3(x.float(), layer.weight, layer.bias, act, slope, residual)
     y = _linear(owner, layer, x)
@@ -68,10 +72,9 @@ class ResBlock(nn.Module):
             x = linear_act(x0, self.fc1.weight, self.fc1.bias, 'leaky_relu', slope)
             return linear_act(x, self.fc2.weight, self.fc2.bias, 'leaky_relu', slope, residual=x0)      # fc2 + LeakyReLU + skip: one kernel
         if _precise(x0) and not self.hip_linear:
-            from .ops import linear_act3
             slope = self.acfun.negative_slope
-            x = linear_act3(x0, self.fc1.weight, self.fc1.bias, 'leaky_relu', slope)
-            return linear_act3(x, self.fc2.weight, self.fc2.bias, 'leaky_relu', slope, residual=x0)
+            x = _lin(self, self.fc1, x0, 'leaky_relu', slope)
+            return _lin(self, self.fc2, x, 'leaky_relu', slope, residual=x0)
         x = self.acfun(self.fc1(x0))
         x = self.acfun(self.fc2(x))
         return x + x0
@@ -117,30 +120,27 @@ def _precise_trunk(bn, x):
 
 def _conv(conv, x):
     """A trunk convolution.  fp32 model on the GPU: the general implicit-GEMM kernel with three-term split products (ops.conv2d_split).
-    Under bf16 autocast: the hand-written stride-1 3x3 kernel where it applies (ops.conv3x3; PSI_HIP_CONV=0 keeps the library), the general
-    kernel with one-term bf16 products for the rest (7x7 stem, strided 3x3, 1x1 downsample, 128 -> 32 head; PSI_HIP_CONV2=0: the library)."""
-    import os
+    Under bf16 autocast: the hand-written stride-1 3x3 kernel where it applies (ops.conv3x3), the general kernel with one-term bf16
+    products for the rest (7x7 stem, strided 3x3, 1x1 downsample, 128 -> 32 head)."""
     if _precise(x):
         from . import ops
         if ops.conv2d_supported(conv):
             return ops.conv2d_split(x, conv, nterm=3)
         return conv(x)
-    if (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
-            and os.environ.get('PSI_HIP_CONV', '1') != '0'):
+    if x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16:
         from . import ops
         if ops.conv3x3_supported(conv, x):
             return ops.conv3x3(x, conv)
-        if os.environ.get('PSI_HIP_CONV2', '1') != '0' and ops.conv2d_supported(conv):
+        if ops.conv2d_supported(conv):
             return ops.conv2d_split(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), conv, nterm=1, out_bf16=True)
     return conv(x)
 
 
 def _use_hip_bn(bn, x):
-    """The fused BN kernels cover the training-mode trunk under bf16 autocast (PSI_HIP_BN=0 keeps the library path)."""
-    import os
+    """The fused BN kernels cover the training-mode trunk under bf16 autocast."""
     return (bn.training and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
             and bn.affine and bn.track_running_stats and bn.momentum is not None          # what the kernels implement (nn.BatchNorm2d defaults)
-            and bn.num_features in (8, 16, 32, 64, 128, 256) and os.environ.get('PSI_HIP_BN', '1') != '0')
+            and bn.num_features in (8, 16, 32, 64, 128, 256))
 
 
 def run_trunk(trunk, x):
@@ -191,7 +191,7 @@ def load_pretrained_resnet18(trunk, ckpt_path):
 def set_hip_linear(model, on=True):
     """Route the dense layers of ``model`` (ResBlock stacks and the scene-feature ``fc``) through the hand-written bf16 MFMA kernels of
     libpsi_hip.so (ops.linear_act: Linear + bias + LeakyReLU + skip in one launch, fp32 master weights rounded to bf16 on load).
-    Enabled together with ``autocast_bf16``; see ``_use_hip_linear`` for what that means for precision (PSI_HIP_LINEAR=0: off).
+    Enabled together with ``autocast_bf16``; see ``_use_hip_linear`` for what that means for precision.
     Measured on MI355X at batch 128 (train_s2 step): 7.68 -> 7.59 ms with the layers on these kernels; the backward pair (dX, dW + dbias)
     takes 26 us for a 512 x 512 layer against 38 us for the library route (tools/time_linear_bwd.py)."""
     for m in model.modules():
@@ -203,11 +203,8 @@ def _use_hip_linear(module, x):
     """Dense layers of a model built with ``autocast_bf16=True`` run on the hand-written bf16 MFMA kernels (forward AND backward:
     ops.linear_act) — in training and in no_grad mode alike, so a model gives the same numbers in both.  This is a precision choice of
     the bf16 mode: the ResBlock stacks, which sit outside the autocast region of the library path and ran in fp32 there, round their
-    operands to bf16 (fp32 accumulation, fp32 outputs), like the trunk.  PSI_HIP_LINEAR=0 restores the library path."""
-    import os
-    if not getattr(module, 'hip_linear', False) or not x.is_cuda:
-        return False
-    return os.environ.get('PSI_HIP_LINEAR', '1') != '0'
+    operands to bf16 (fp32 accumulation, fp32 outputs), like the trunk."""
+    return bool(getattr(module, 'hip_linear', False)) and x.is_cuda
 
 
 def _linear(owner, layer, x):
@@ -352,8 +349,7 @@ class HumanCVAES2(nn.Module):
     def forward(self, x_body, eps_g, eps_l, x_s, use_eps=False):
         x_g, x_l = x_body[:, :3], x_body[:, 3:]
         z_s_l = None
-        import os
-        if x_s.is_cuda and self.training and os.environ.get('PSI_TRUNK_STREAMS', '1') != '0':
+        if x_s.is_cuda and self.training:
             # The two scene trunks read the same view and meet only after their scene features: the local VAE's trunk runs on a second
             # stream beside the global VAE's (autograd replays each backward on its forward's stream, so the two backward halves overlap
             # too; inside a captured step the two become parallel branches of the graph).  Their many small launches — BN finalize, weight

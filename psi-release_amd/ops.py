@@ -12,7 +12,6 @@ import torch
 from torch import nn
 from torch.autograd import Function
 
-import os
 
 from . import hip
 
@@ -322,16 +321,8 @@ class _LinearAct(Function):
         N = w.shape[0]
         gy = gy.contiguous().float()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        if os.environ.get('PSI_HIP_LINEAR_BWD', '1') == '0':
-            # PSI_HIP_LINEAR_BWD=0: the two backward GEMMs through the library (hipBLASLt) on the same bf16-rounded operands — mask, cast,
-            # two GEMMs, column sum: seven launches.  The default is the hand-written pair below (dX, dW + dbias; LDS-staged transposed
-            # operands): 26 vs 38 us for a 128 x 512 x 512 layer, 42 vs 66 us for the 32768 -> 256 layer (tools/time_linear_bwd.py)
-            g = gy if not ctx.act else torch.where(a_out > 0, gy, gy * ctx.slope)
-            gb16 = g.to(torch.bfloat16)
-            gx = (gb16 @ w.to(torch.bfloat16)).to(xc.dtype) if need_x else None
-            gw = (gb16.t() @ xc.to(torch.bfloat16)).float() if need_w else None
-            gb = g.sum(0) if need_b else None
-            return gx, gw, gb, gy if (ctx.has_res and ctx.needs_input_grad[3]) else None, None, None
+        # (dX, dW + dbias as ONE hand-written launch pair with LDS-staged transposed operands: 26 vs 38 us for a 128 x 512 x 512 layer against the
+        # library route of mask, cast, two GEMMs, column sum — tests/library_paths.py keeps that route for comparison)
         gx = torch.empty(M, K, device=gy.device, dtype=torch.bfloat16 if ctx.xb else torch.float32) if need_x else None
         gw = torch.empty(N, K, device=gy.device) if (need_w or need_b) else None         # gbias is produced by the dW kernel
         gb = torch.empty(N, device=gy.device) if need_b else None
@@ -362,8 +353,9 @@ def _ptr_cl(t):
 
 
 def _bn_mask_from_x():
-    """PSI_HIP_BN_XMASK=0: every ReLU mask of the BatchNorm backward from the stored output y (dev A/B)"""
-    return os.environ.get('PSI_HIP_BN_XMASK', '1') != '0'
+    """True: a BatchNorm + ReLU layer without a skip connection takes its backward's ReLU mask from x and two per-channel numbers instead of
+    reading the stored output (one map less per pass, bit-identical gradients; the tests patch this to False to check exactly that)"""
+    return True
 
 
 class _BNAct(Function):
@@ -497,7 +489,7 @@ class _Conv3x3(Function):
                 dx = torch.ops.aten.convolution_backward(dyc, xc, wb.permute(0, 3, 1, 2), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                          (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            nws = L.psi_conv3x3_wrw_workspace_floats(N, H, W, Cin, Cout) if os.environ.get('PSI_HIP_CONV_WRW', '1') != '0' else 0
+            nws = L.psi_conv3x3_wrw_workspace_floats(N, H, W, Cin, Cout)
             if nws:
                 # hand-written split-K weight gradient (fp32, deterministic summation order)
                 gw4 = torch.empty(Cout, 3, 3, Cin, device=dy.device, dtype=torch.float32)
@@ -544,6 +536,11 @@ def conv2d_supported(conv):
                                                     conv.padding[0])))
 
 
+def _conv2d_prepared_ok(Cin, Cout, KH, KW, stride, pad):
+    """shapes whose weight is split / re-laid out ONCE per layer and step (psi_conv2d_prepare_weight) instead of in every workgroup"""
+    return bool(hip.lib().psi_conv2d_prepared_ok(Cin, Cout, KH, KW, stride, pad))
+
+
 def _conv2d_dgrad_covered(Cin, Cout, KH, KW):
     """shapes whose input gradient the general kernel takes in its transposed-gather form (psi_hip.h: psi_conv2d_input_grad)"""
     return Cin % 32 == 0 and (Cout % 64 == 0 or Cout * KH * KW <= 4096)
@@ -562,7 +559,7 @@ class _Conv2dSplit(Function):
         b = bias.detach().float().contiguous() if bias is not None else None
         L = hip.lib()
         wt = None
-        if L.psi_conv2d_prepared_ok(Cin, Cout, KH, KW, stride, pad) and os.environ.get('PSI_HIP_CONV_PREP', '1') != '0':
+        if _conv2d_prepared_ok(Cin, Cout, KH, KW, stride, pad):
             # the weight's bf16 parts once per layer and step, in the forward's layout and (when x needs a gradient) the input gradient's
             nel = Cout * KH * KW * Cin * (2 if nterm == 3 else 1)
             wf = torch.empty(nel, device=x.device, dtype=torch.bfloat16)
@@ -589,12 +586,6 @@ class _Conv2dSplit(Function):
             dyc = dyc.float()
         L = hip.lib()
         gx = gw = gb = None
-        if os.environ.get('PSI_HIP_CONV2_BWD', '1') == '0':
-            # PSI_HIP_CONV2_BWD=0: both gradients through the library (aten.convolution_backward -> MIOpen) on the saved operands
-            mask = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2])
-            gx, gw, gb = torch.ops.aten.convolution_backward(dyc.to(xc.dtype), xc, weight.detach().to(xc.dtype), [Cout] if has_bias else None,
-                                                             (stride, stride), (pad, pad), (1, 1), False, (0, 0), 1, mask)
-            return gx, gw.float() if gw is not None else None, gb.float() if gb is not None else None, None, None, None, None
         if ctx.needs_input_grad[0]:
             if _conv2d_dgrad_covered(Cin, Cout, KH, KW):
                 gx = torch.empty((N, Cin, H, W), device=dy.device, dtype=xc.dtype, memory_format=torch.channels_last)
@@ -756,11 +747,6 @@ class _LinearAct3(Function):
         xc, w, a_out = ctx.saved_tensors
         gy = gy.contiguous().float()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        if os.environ.get('PSI_HIP_LINEAR3_BWD', '1') == '0':
-            # PSI_HIP_LINEAR3_BWD=0: the two gradient GEMMs through the library (hipBLASLt, fp32) on the saved operands
-            g = gy if not ctx.act else torch.where(a_out > 0, gy, gy * ctx.slope)
-            return (g @ w if need_x else None, g.t() @ xc if need_w else None, g.sum(0) if need_b else None,
-                    gy if (ctx.has_res and ctx.needs_input_grad[3]) else None, None, None)
         M, K = xc.shape
         N = w.shape[0]
         gx = torch.empty(M, K, device=gy.device) if need_x else None

@@ -7,12 +7,17 @@ parameter — checkpoints of either load into the other), same update (the opera
 15.7 M parameters, 440 MB of traffic) it is one or two launches that take the tensors' addresses in their kernel arguments.  The parameters
 of a group are always stepped together, so their ``step`` entries are ONE shared device scalar (every entry of ``state`` refers to it).
 
-The HIP kernel is the only implementation of the GPU path (PSI_HIP_ADAM=0 hands ``step()`` to torch.optim.Adam — dev A/B); parameters
-that are not fp32 GPU tensors (the CPU tests of the training loop) go through torch.optim.Adam."""
+The HIP kernel is the only implementation of the GPU path; parameter groups it does not cover (CPU tensors in the CPU tests of the training
+loop, amsgrad / maximize / tensor learning rates, parameters that are neither contiguous nor channels_last) go through torch.optim.Adam's
+own update on per-parameter step counters.
+
+Checkpoints travel both ways: ``state_dict()`` hands out one ``step`` tensor PER parameter (clones of the shared counter: torch.optim.Adam
+increments every entry it is given, so aliased entries would be counted once per parameter), ``load_state_dict()`` re-unifies the counters
+of a loaded state eagerly (a later graph capture must not meet separate tensors), and moments saved in another memory layout than the
+parameter has now (contiguous moments of a convolution weight the model has since switched to channels_last) are re-laid out at the next step."""
 from __future__ import annotations
 
 import ctypes
-import os
 
 import torch
 
@@ -29,7 +34,7 @@ class Adam(torch.optim.Adam):
 
     # ------------------------------------------------------------------------------------------
     def _hip_ok(self, group):
-        if os.environ.get('PSI_HIP_ADAM', '1') == '0' or not group.get('fused'):
+        if not group.get('fused'):
             return False
         if group.get('amsgrad') or group.get('maximize') or group.get('differentiable'):
             return False
@@ -45,6 +50,30 @@ class Adam(torch.optim.Adam):
         out = torch.empty_like(p)
         out.copy_(t)
         return out
+
+    @staticmethod
+    def _dense(params):
+        return all(p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last) for p in params)
+
+    def unify_steps(self):
+        """Eagerly make the step counters of every group the HIP kernel covers ONE device scalar (what ``step()`` does lazily): call it
+        before capturing ``step()`` into a graph when the state came from elsewhere (``load_state_dict`` does)."""
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return
+        for group in self.param_groups:
+            params = [p for p in group['params'] if p in self.state and torch.is_tensor(self.state[p].get('step'))]
+            if params and self._hip_ok(group) and self._dense(params):
+                self._shared_step(group, params, [self.state[p]['step'] for p in params])
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.unify_steps()
+
+    def state_dict(self):
+        sd = super().state_dict()
+        # one step tensor per parameter (the entries of `state` alias ONE counter; a consumer that increments each entry must not see that)
+        sd['state'] = {k: (dict(v, step=v['step'].clone()) if torch.is_tensor(v.get('step')) else v) for k, v in sd['state'].items()}
+        return sd
 
     def _shared_step(self, group, params, steps):
         """One device scalar for the whole group; parameters that were stepped a different number of times cannot share one -> None."""
@@ -72,15 +101,19 @@ class Adam(torch.optim.Adam):
             self._init_group(group, params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps)
             if not params:
                 continue
-            shared = self._shared_step(group, params, steps) if self._hip_ok(group) else None
-            if shared is None or any(not (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)) for p in params):
+            # (layout checks BEFORE the counters are unified: a group that takes torch's update keeps per-parameter counters)
+            shared = self._shared_step(group, params, steps) if (self._hip_ok(group) and self._dense(params)) else None
+            if shared is None:
                 self._torch_group_step(group, params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps)
                 continue
             n = len(params)
             gs = [self._dense_like(p, g) for p, g in zip(params, grads)]
-            for p, m, v in zip(params, exp_avgs, exp_avg_sqs):
-                if m.stride() != p.stride() or v.stride() != p.stride():
-                    raise hip.PsiHipError('psi Adam: exp_avg / exp_avg_sq are not laid out like their parameter')
+            for i, p in enumerate(params):
+                # moments saved in another layout than the parameter has now (a checkpoint written before the model's convolution weights went
+                # channels_last, a torch.optim.Adam state): re-laid out once, in place of the loaded tensors
+                for key, lst in (('exp_avg', exp_avgs), ('exp_avg_sq', exp_avg_sqs)):
+                    if lst[i].stride() != p.stride():
+                        lst[i] = self.state[p][key] = self._dense_like(p, lst[i])
             arr = ctypes.c_void_p * n
             dev = params[0].device
             tk = self._ticket.get(dev)
@@ -99,6 +132,11 @@ class Adam(torch.optim.Adam):
 
     def _torch_group_step(self, group, params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps):
         from torch.optim.adam import adam
+        if len({s.data_ptr() for s in steps if torch.is_tensor(s)}) < len(steps):
+            # counters that alias one tensor (a state this class stepped before): torch adds 1 to every entry it is given
+            steps = [s.clone() for s in steps]
+            for p, s in zip(params, steps):
+                self.state[p]['step'] = s
         b1, b2 = group['betas']
         adam(params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps, amsgrad=group['amsgrad'], has_complex=False, beta1=b1, beta2=b2,
              lr=group['lr'], weight_decay=group['weight_decay'], eps=group['eps'], maximize=group['maximize'], foreach=group['foreach'],

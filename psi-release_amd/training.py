@@ -4,8 +4,8 @@ Reference: source/train_s1.py:37-338 (HumanCVAES1, one KL term) and source/train
 Same ``trainconfig`` / ``lossconfig`` keys, same ``cal_loss`` signatures and return order, same checkpoint schema
 ``{'epoch', 'model_h_state_dict', 'optimizer_h_state_dict'}`` in ``{save_dir}/epoch-{ep+1:06d}.ckp`` every 10 epochs and
 every 2 h of wall clock, resume from the newest ``epoch-*.ckp`` by mtime (train_s1.py:220-233,303-321), same verbose
-lines.  The body / Chamfer / SDF sub-stack is the HIP operator set (ops.py, body_model.py); the CVAE trunk is PyTorch
-(MIOpen / hipBLASLt matrix-core path, optional bf16 autocast).  GPU only.
+lines.  The body / Chamfer / SDF sub-stack is the HIP operator set (ops.py, body_model.py); the CVAE (models.py) runs on the hand-written
+convolution / BatchNorm / dense kernels in both precisions (fp32 = the reference's; optional bf16 autocast), the optimiser on optim.Adam.  GPU only.
 
 Data parallel (new; the reference is single-GPU): wrap-free — gradients of the model parameters are all-reduced
 (averaged) across ranks after ``backward`` in one flattened bucket per dtype.  Mean-type losses over equal row shards average to the
@@ -42,6 +42,8 @@ class _TrainBase:
         self.scene_model_ckpt = None
         self.fused_decode = True        # body decode (6D rot -> VPoser -> SMPL-X -> camera frame) as ONE HIP op (fitting.BodyDecoder)
         self.use_graph = False          # capture the whole optimiser step (forward, backward, Adam) in one HIP graph
+        self.fused_glue = True          # the [B,75] body-vector glue and the two scene terms of cal_loss as fused HIP ops (ops.cvae_* / scene_losses)
+        self.grad_bucket_mb = 16.0      # data-parallel runs: size of the gradient buckets (dist.GradBuckets)
         self._graphs = {}
         self._fca_t = None
         for key, val in trainconfig.items():
@@ -52,11 +54,6 @@ class _TrainBase:
         if self.device.type != 'cuda':
             raise RuntimeError('TrainOP runs on the GPU (HIP operators); there is no CPU path')
         os.makedirs(self.save_dir, exist_ok=True)        # every rank of a torchrun job constructs TrainOP on the same save_dir
-        # the convolutions that stay with the library (7x7 stem, the strided ones, the 128 -> 32 head): let MIOpen MEASURE its solvers once per
-        # shape instead of taking the heuristic pick (train_s2 step 4.22 -> 4.00 ms; the search runs in the first steps).  The flag is
-        # process-global in PyTorch: it is set for the duration of a training step only (train_step) and restored, so that a trainer in the
-        # process does not change how later convolutions of other components (generation, fitting, tests) pick their solvers
-        self.miopen_find = os.environ.get('PSI_MIOPEN_FIND', '1') != '0'
         n_dim_body = 72 + 3 if self.use_cont_rot else 72
         self.model_h_latentD = 256
         self.model_h = self._make_model(n_dim_body)
@@ -110,7 +107,7 @@ class _TrainBase:
             body_verts_batch = self.body_mesh_model(return_verts=True, body_pose=joint_rot_batch, cam_ext=cam_ext, **body_param_).vertices
         gate = 1.0 if ep > 0.75 * self.epoch else 0.0                           # train_s1.py:171-173,197-199
         if (isinstance(s_grid_sdf_batch, tuple) and len(s_grid_sdf_batch) == 5 and getattr(self, 'use_scene_index', True)
-                and not psi_dist.is_dist() and os.environ.get('PSI_HIP_GLUE', '1') != '0'):
+                and not psi_dist.is_dist() and self.fused_glue):
             # both scene terms and their vertex gradient as one op (ops.scene_losses): 6 launches forward, 2 backward
             sdf_t, sid, gmin_t, gmax_t, scenes = s_grid_sdf_batch
             loss_contact, loss_sdf_pene = ops.scene_losses(body_verts_batch, self._contact_ids(), scenes, sid, sdf_t, gmin_t, gmax_t,
@@ -137,9 +134,8 @@ class _TrainBase:
 
     def _fused_glue(self, xh):
         """The [B,75] body-vector glue of cal_loss as three HIP launches (ops.cvae_target / ops.cvae_losses) instead of ~190 elementwise
-        operators: the 75-D (6D rotation) layout on the GPU; PSI_HIP_GLUE=0 keeps the operator sequence."""
-        return (self.fused_decode and self.use_cont_rot and xh.is_cuda and xh.shape[1] == 72 and not xh.requires_grad
-                and os.environ.get('PSI_HIP_GLUE', '1') != '0')
+        operators: the 75-D (6D rotation) layout on the GPU; ``fused_glue = False`` keeps the operator sequence."""
+        return self.fused_decode and self.use_cont_rot and xh.is_cuda and xh.shape[1] == 72 and not xh.requires_grad and self.fused_glue
 
     def _fca(self, ep):
         if not self.loss_weight_anealing:
@@ -171,14 +167,14 @@ class _TrainBase:
                    self.save_dir + "/epoch-{:06d}".format(ep + 1) + ".ckp")
 
     # ---- data-parallel gradient exchange: buckets that the gradients alias, reduced from autograd hooks while the backward pass is still
-    # running (psi_release_amd/dist.py: GradBuckets; PSI_GRAD_BUCKET_MB sets the bucket size, default 16)
+    # running (psi_release_amd/dist.py: GradBuckets; ``grad_bucket_mb`` sets the bucket size, default 16)
     def _buckets_begin(self):
         """Start of a step's gradient accumulation: zero the gradients.  Data parallel: through the buckets (created on first use)."""
         if not psi_dist.is_dist():
             self.optimizer_h.zero_grad(set_to_none=self.use_graph)
             return
         if getattr(self, '_buckets', None) is None:
-            self._buckets = psi_dist.GradBuckets(self.model_h, float(os.environ.get('PSI_GRAD_BUCKET_MB', '16')))
+            self._buckets = psi_dist.GradBuckets(self.model_h, float(self.grad_bucket_mb))
         self._buckets.begin()
 
     def _buckets_finish(self):
@@ -218,7 +214,7 @@ class _TrainBase:
             self._fca_t = torch.tensor(float(self._fca(ep)), device=self.device)
         self._fca_t.fill_(float(self._fca(ep)))
         st = self._static_batch(d)
-        # warm-up on a side stream (MIOpen find, workspace growth) — on a snapshot, so that it does not train
+        # warm-up on a side stream (workspace growth, RCCL channel setup) — on a snapshot, so that it does not train
         snap_m = copy.deepcopy(self.model_h.state_dict())
         snap_o = copy.deepcopy(self.optimizer_h.state_dict())
         rng = torch.cuda.get_rng_state(self.device)
@@ -283,24 +279,22 @@ class _TrainBase:
 
     def train_step(self, train_data, ep):
         """One optimiser step on one batch (the body of the ``while batch_gen.has_next_batch()`` loop)."""
-        prev = torch.backends.cudnn.benchmark
-        if getattr(self, 'miopen_find', False):
-            torch.backends.cudnn.benchmark = True
-        try:
-            if self.use_graph:
-                return self._train_step_graph(train_data, ep)
-            if psi_dist.is_dist():
-                self._buckets_begin()
-            else:
-                self.optimizer_h.zero_grad()
-            losses = self._losses_from_batch(train_data, ep)
-            loss_h = sum(losses)
-            loss_h.backward()
-            self._buckets_finish()
-            self.optimizer_h.step()
-            return losses
-        finally:
-            torch.backends.cudnn.benchmark = prev
+        if self.use_graph and psi_dist.is_dist() and torch.distributed.get_backend() != 'nccl':
+            # a host-side collective (gloo: the bucket hooks synchronise the stream and wait for the work) cannot be part of a captured step
+            print('[INFO][train] use_graph needs the RCCL backend for data-parallel runs (got %s): running eager steps' % torch.distributed.get_backend())
+            self.use_graph = False
+        if self.use_graph:
+            return self._train_step_graph(train_data, ep)
+        if psi_dist.is_dist():
+            self._buckets_begin()
+        else:
+            self.optimizer_h.zero_grad()
+        losses = self._losses_from_batch(train_data, ep)
+        loss_h = sum(losses)
+        loss_h.backward()
+        self._buckets_finish()
+        self.optimizer_h.step()
+        return losses
 
     def _epoch_validity(self, batch_gen):
         """Data parallel: which of this epoch's batches EVERY rank has (batch_gen_hdf5.py:198-199,211-214 drop a short batch and a batch with a

@@ -1,8 +1,4 @@
 import os
-
-# The trainers switch on MIOpen's measured solver search (training.py: PSI_MIOPEN_FIND).  In a test process that searches every new
-# convolution shape of every later test (suite 2 min -> 5 min on an MI355X) without testing anything of ours: off here.
-os.environ.setdefault('PSI_MIOPEN_FIND', '0')
 import sys
 
 import numpy as np

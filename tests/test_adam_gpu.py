@@ -106,3 +106,76 @@ def test_step_in_a_hip_graph_and_state_dict_round_trip():
     assert back.hip_steps == 1 and float(back.state[cont[0]]['step']) == 4.0
     for a, b in zip(cont, ref):
         assert float((a.detach() - b.detach()).abs().max()) <= 2.0 ** -22 * (float(b.detach().abs().max()) + 1e-3), tuple(a.shape)
+    # ... and the consumer really steps: torch.optim.Adam increments every step entry it is handed, so the psi state_dict must not alias them
+    ps_o = other.param_groups[0]['params']
+    for p, r in zip(ps_o, ref):
+        p.data.copy_(r.detach())
+    _grads(ps_o, 32)
+    other.step()
+    assert all(float(other.state[p]['step']) == 4.0 for p in ps_o)              # 3 + 1, not 3 + (number of aliased entries)
+
+
+def test_state_from_another_layout_and_separate_counters_are_adopted():
+    """A checkpoint written while a convolution weight was contiguous (before the CVAE switched its trunk to channels_last, or by torch.optim.Adam)
+    loaded into a model whose weight is channels_last NOW: the moments are re-laid out at the next step instead of the step failing; separate
+    per-parameter step tensors are unified by load_state_dict itself, so that a graph capture right after a resume works."""
+    src = [torch.nn.Parameter(torch.randn(16, 8, 3, 3, device=DEV)), torch.nn.Parameter(torch.randn(40, device=DEV))]        # contiguous 4-D weight
+    osrc = torch.optim.Adam(src, lr=1e-3, fused=True)
+    _grads(src, 5)
+    src[0].grad = src[0].grad.contiguous()
+    osrc.step()
+    sd = copy.deepcopy(osrc.state_dict())
+    dst = [torch.nn.Parameter(src[0].detach().clone().contiguous(memory_format=torch.channels_last)), torch.nn.Parameter(src[1].detach().clone())]
+    od = psi_optim.Adam(dst, lr=1e-3)
+    od.load_state_dict(sd)
+    assert len({od.state[p]['step'].data_ptr() for p in dst}) == 1                    # unified eagerly
+    assert od.state[dst[0]]['exp_avg'].stride() != dst[0].stride()                   # still in the checkpoint's layout
+    for p, q in zip(dst, src):
+        p.grad = torch.randn_like(p)
+        q.grad = p.grad.detach().clone().contiguous()
+    static = [p.grad for p in dst]
+    od.step()                                                                         # re-lays the moments out, steps on the HIP kernel
+    osrc.step()
+    assert od.hip_steps == 1 and od.state[dst[0]]['exp_avg'].stride() == dst[0].stride()
+    for a, b in zip(dst, src):
+        assert float((a.detach() - b.detach()).abs().max()) <= 2.0 ** -22 * (float(b.detach().abs().max()) + 1e-3)
+    # resume + capture: a second optimiser takes a state with SEPARATE counters and is captured without an eager step in between
+    od2 = psi_optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in dst], lr=1e-3)
+    od2.load_state_dict(copy.deepcopy(osrc.state_dict()))
+    ps2 = od2.param_groups[0]['params']
+    for p, s in zip(ps2, static):
+        p.grad = s.clone()
+    od2.step()                                                                        # (first step re-lays out; then the capture)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        od2.step()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert float(od2.state[ps2[0]]['step']) == 4.0
+
+
+def test_group_outside_the_kernels_coverage_keeps_its_own_counters():
+    """A group with a parameter that is neither contiguous nor channels_last takes torch's update: its counters must stay per-parameter tensors
+    (never the shared alias, which torch would increment once per parameter)."""
+    base = torch.randn(12, 20, device=DEV)
+    ps = [torch.nn.Parameter(base.t()), torch.nn.Parameter(torch.randn(30, device=DEV))]       # a transposed view: not dense in either layout
+    o = psi_optim.Adam(ps, lr=1e-3)
+    for it in range(3):
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        o.step()
+    assert o.hip_steps == 0
+    assert [float(o.state[p]['step']) for p in ps] == [3.0, 3.0]
+    # a state the HIP kernel stepped (aliased counters) continued by torch's update: de-aliased first
+    qs = [torch.nn.Parameter(torch.randn(8, 4, device=DEV)), torch.nn.Parameter(torch.randn(30, device=DEV))]
+    o2 = psi_optim.Adam(qs, lr=1e-3)
+    for p in qs:
+        p.grad = torch.randn_like(p)
+    o2.step()
+    assert o2.hip_steps == 1 and len({o2.state[p]['step'].data_ptr() for p in qs}) == 1
+    o2.param_groups[0]['amsgrad'] = False
+    o2.param_groups[0]['maximize'] = True                                             # outside the kernel's coverage from now on
+    for p in qs:
+        p.grad = torch.randn_like(p)
+    o2.step()
+    assert [float(o2.state[p]['step']) for p in qs] == [2.0, 2.0]

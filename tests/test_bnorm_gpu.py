@@ -1,13 +1,13 @@
 """Fused BatchNorm (+ ReLU, + skip connection) of the scene trunk (csrc/bnorm.hip, ops.bn_act) against a plain PyTorch fp32 reference
 of the same op on the same bf16-rounded inputs: output, running statistics, and every gradient; then the whole trunk of HumanCVAES2
 with the fused kernels against the library path (torchvision BasicBlock semantics, cvae.py:427-435)."""
-import os
 
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
+import library_paths
 from psi_release_amd import models, ops
 
 pytestmark = pytest.mark.gpu
@@ -79,7 +79,7 @@ def test_maxpool3x3s2_equals_torch(shape):
     assert torch.equal(x.grad, xr.grad)
 
 
-def test_trunk_with_fused_bn_is_as_close_to_fp32_as_the_library_path():
+def test_trunk_with_fused_bn_is_as_close_to_fp32_as_the_library_path(monkeypatch):
     """BodyGlobalPoseVAE scene feature (trunk + conv + fc) in training mode, three ways on the same weights and input: fp32 (no
     autocast: the reference's arithmetic, cvae.py:427-455), bf16 autocast with the library BN (MIOpen), bf16 autocast with the fused
     HIP BN.  bf16 activation gradients through nine convolutions make the per-channel sums of the BN parameters noisy in EITHER bf16
@@ -88,19 +88,20 @@ def test_trunk_with_fused_bn_is_as_close_to_fp32_as_the_library_path():
     torch.manual_seed(0)
     xs = torch.randn(8, 2, 128, 128, device=DEV)
     sd, outs = None, {}
-    for mode in ('fp32', 'lib', 'hip'):
-        os.environ['PSI_HIP_BN'] = '1' if mode == 'hip' else '0'
+    def run(mode):
         m = models.BodyGlobalPoseVAE(zdim=32, in_dim=2, num_hidden=256).to(DEV)
         m.autocast_bf16 = mode != 'fp32'
-        if sd is None:
-            sd = {k: v.clone() for k, v in m.state_dict().items()}
         m.load_state_dict(sd)
         m.train()
         z = m._scene_feature(xs)
         z.float().square().mean().backward()
-        outs[mode] = (z.detach().float(), {k: p.grad.detach().float() for k, p in m.named_parameters() if p.grad is not None},
-                      {k: v.detach().float().clone() for k, v in m.state_dict().items() if 'running' in k or 'num_batches' in k})
-    os.environ.pop('PSI_HIP_BN')
+        return (z.detach().float(), {k: p.grad.detach().float() for k, p in m.named_parameters() if p.grad is not None},
+                {k: v.detach().float().clone() for k, v in m.state_dict().items() if 'running' in k or 'num_batches' in k})
+    sd = {k: v.clone() for k, v in models.BodyGlobalPoseVAE(zdim=32, in_dim=2, num_hidden=256).to(DEV).state_dict().items()}
+    outs['fp32'], outs['hip'] = run('fp32'), run('hip')
+    with monkeypatch.context() as mp_:
+        library_paths.bf16_batchnorm_on_the_library(mp_)             # nn.BatchNorm2d under autocast (MIOpen)
+        outs['lib'] = run('lib')
     z32, g32, r32 = outs['fp32']
     dist = lambda a, b: float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
     for mode in ('lib', 'hip'):
@@ -118,7 +119,7 @@ def test_trunk_with_fused_bn_is_as_close_to_fp32_as_the_library_path():
 @pytest.mark.parametrize('shape,f32', [((64, 64, 32, 32), False), ((8, 128, 16, 16), True), ((3, 64, 9, 5), False), ((2, 128, 7, 3), True)])
 def test_relu_mask_recomputed_from_x_equals_the_stored_mask(shape, f32, monkeypatch):
     """BatchNorm + ReLU without a skip connection: the backward recomputes "y > 0" from x (y = relu(fma(x, scale, shift)), rounded as the forward
-    stored it) and reads one map less per pass; against the same backward with the mask taken from the stored y (PSI_HIP_BN_XMASK=0): every
+    stored it) and reads one map less per pass; against the same backward with the mask taken from the stored y (ops._bn_mask_from_x patched): every
     gradient bit for bit — also with inputs placed ON the threshold (outputs that are exactly zero, and the smallest positive ones)."""
     N, C, H, W = shape
     torch.manual_seed(C + H + W)
@@ -127,7 +128,8 @@ def test_relu_mask_recomputed_from_x_equals_the_stored_mask(shape, f32, monkeypa
     g = torch.randn(shape, device=DEV).to(dt).contiguous(memory_format=torch.channels_last)
     got = {}
     for xmask in ('1', '0'):
-        monkeypatch.setenv('PSI_HIP_BN_XMASK', xmask)
+        if xmask == '0':
+            library_paths.bn_relu_mask_from_the_stored_output(monkeypatch)
         torch.manual_seed(2)
         bn = torch.nn.BatchNorm2d(C).to(DEV).train()
         with torch.no_grad():

@@ -116,7 +116,7 @@ def test_cal_loss_is_the_same_with_and_without_the_fused_glue(tmp_path, smplx_da
                                   T(scene.grid_max)[None], ops.SceneSet(T(scene.verts)[None])))
     out = {}
     for glue in ('1', '0'):
-        monkeypatch.setenv('PSI_HIP_GLUE', glue)
+        op.fused_glue = glue == '1'
         _load(op.model_h, seed)
         op.model_h.train()
         op.model_h.zero_grad()

@@ -6,6 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import library_paths
 from conftest import golden, rel_err
 from psi_release_amd import models, ops, synth
 
@@ -33,7 +34,8 @@ def _case(M, N, K, seed, xb=False):
 def test_linear_act_forward_backward(M, N, K, mode, bwd, monkeypatch):
     # bwd='hip': the hand-written dX / dW kernels (fp32 outputs: exact to the rounded-operand reference); 'library' (default): the
     # backward GEMMs go to hipBLASLt in bf16 (bf16 outputs, like the autocast path this replaces)
-    monkeypatch.setenv('PSI_HIP_LINEAR_BWD', '1' if bwd == 'hip' else '0')
+    if bwd == 'library':
+        library_paths.bf16_dense_backward_on_the_library(monkeypatch)
     btol = 2e-5 if bwd == 'hip' else 1e-2
     x, W, b, res, gy = _case(M, N, K, M + N + K)
     act = None if mode == 'plain' else 'leaky_relu'
@@ -62,7 +64,6 @@ def test_linear_act_forward_backward(M, N, K, mode, bwd, monkeypatch):
 
 
 def test_linear_act_bf16_input_and_determinism(monkeypatch):
-    monkeypatch.setenv('PSI_HIP_LINEAR_BWD', '1')
     x, W, b, res, gy = _case(128, 256, 32768, 5, xb=True)
     xt, Wt = x.clone().requires_grad_(), W.clone().requires_grad_()
     y = ops.linear_act(xt, Wt, b)
@@ -91,8 +92,7 @@ def test_cvae_on_hip_linear_matches_reference_golden(stage, monkeypatch):
     inp = synth.make_cvae_inputs(13, 4)
     T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=DEV)
     out = {}
-    for tag, hip_on in (('hip', '1'), ('torch', '0')):
-        monkeypatch.setenv('PSI_HIP_LINEAR', hip_on)
+    def run():
         if stage == 's1':
             m = models.HumanCVAES1(latentD=256, n_dim_body=75, autocast_bf16=True).to(DEV)
             _load(m, 0)
@@ -105,7 +105,11 @@ def test_cvae_on_hip_linear_matches_reference_golden(stage, monkeypatch):
             m.eval()
             with torch.no_grad():
                 o = m(T(inp['x75']), T(inp['eps32']), T(inp['eps32b']), T(inp['xs']), use_eps=True)
-        out[tag] = o[0].float().cpu().numpy()
+        return o[0].float().cpu().numpy()
+    out['hip'] = run()
+    with monkeypatch.context() as mp_:
+        library_paths.bf16_dense_layers_on_the_library(mp_)          # nn.Linear as PyTorch runs it
+        out['torch'] = run()
     ref = g['s1_eval_xrec' if stage == 's1' else 's2_xrec']
     assert rel_err(out['hip'], ref) < 5e-2
     assert rel_err(out['hip'], out['torch']) < 5e-2
@@ -113,14 +117,12 @@ def test_cvae_on_hip_linear_matches_reference_golden(stage, monkeypatch):
 
 
 def test_hip_linear_policy(monkeypatch):
-    """A model built for bf16 takes the hand-written dense kernels in training and in no_grad mode alike (one arithmetic for both);
-    PSI_HIP_LINEAR=0 switches them off."""
+    """A model built for bf16 takes the hand-written dense kernels in training and in no_grad mode alike (one arithmetic for both)."""
     calls = []
     real = ops.linear_act
     monkeypatch.setattr(ops, 'linear_act', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     rb = models.ResBlock(512).to(DEV)
     x = torch.randn(8, 512, device=DEV)
-    monkeypatch.delenv('PSI_HIP_LINEAR', raising=False)
     rb(x)
     assert len(calls) == 0                                                  # not a bf16 model: library path
     models.set_hip_linear(rb, True)
@@ -131,7 +133,7 @@ def test_hip_linear_policy(monkeypatch):
     y.sum().backward()
     assert len(calls) == 4 and rb.fc1.weight.grad is not None and x.grad is not None
     assert torch.equal(y2, y.detach())                                      # one arithmetic for both modes
-    monkeypatch.setenv('PSI_HIP_LINEAR', '0')
+    models.set_hip_linear(rb, False)
     with torch.no_grad():
         rb(x)
     assert len(calls) == 4

@@ -88,3 +88,59 @@ def test_rccl_ranks_equal_the_oracle_on_the_global_batch(tmp_path, smplx_data, v
     else:
         cam = synth.make_cam_ext(9, per * world)
         _check(trace, smplx_data, vposer_sd, scene, bodies, cam, name='rccl_%d_ranks_proxe_32' % world)
+
+
+def _bucket_worker(rank, world, port, tmp):
+    """The NCCL branch of dist.GradBuckets (side-stream all-reduce issued from autograd hooks): one data-parallel step, eager and captured in a
+    torch.cuda.graph (the collectives become branches of the graph), against the gradients of the full batch."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    from psi_release_amd import dist as pd
+    torch.cuda.set_device(rank)
+    dev = torch.device('cuda', rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    def make():
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Conv2d(2, 8, 3, 1, 1), torch.nn.ReLU(), torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 40), torch.nn.LeakyReLU(),
+                                torch.nn.Linear(40, 5)).to(dev)
+        m[0].to(memory_format=torch.channels_last)
+        return m
+    rs = np.random.RandomState(2)
+    n = 4 * world
+    X = torch.tensor(rs.standard_normal((n, 2, 6, 6)), dtype=torch.float32, device=dev)
+    Y = torch.tensor(rs.standard_normal((n, 5)), dtype=torch.float32, device=dev)
+    lo, hi = pd.shard_rows(n, rank, world)
+    full, mine = make(), make()
+    ((full(X) - Y) ** 2).mean().backward()
+    want = [p.grad.clone() for p in full.parameters()]
+    b = pd.GradBuckets(mine, bucket_mb=0.004)
+    ok = b.n_buckets() >= 3
+
+    def step(xs, ys):
+        b.begin()
+        ((mine(xs) - ys) ** 2).mean().backward()
+        b.finish()
+    step(X[lo:hi], Y[lo:hi])                                           # eager: also RCCL's lazy channel setup, which cannot be captured
+    torch.cuda.synchronize()
+    ok = ok and all(float((p.grad - w).abs().max()) < 1e-5 for p, w in zip(mine.parameters(), want))
+    xs, ys = X[lo:hi].clone(), Y[lo:hi].clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step(xs, ys)
+    for p in mine.parameters():
+        p.grad.zero_()                                                 # (the capture did not execute)
+    graph.replay()
+    torch.cuda.synchronize()
+    ok = ok and all(float((p.grad - w).abs().max()) < 1e-5 for p, w in zip(mine.parameters(), want))
+    open(os.path.join(tmp, 'bk%d' % rank), 'w').write('1' if ok else '0')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_over_rccl_eager_and_captured(tmp_path):
+    world = min(N_GPUS, 8)
+    mp.spawn(_bucket_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(open(tmp_path / ('bk%d' % r)).read() == '1' for r in range(world))

@@ -55,12 +55,13 @@ def test_cal_loss_golden(tmp_path, smplx_data, vposer_sd, stage):
         sum(losses).backward()
         got = np.array([float(l) for l in losses])
         ref = g['%s_ep%d_losses' % (stage, ep)]
-        assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), (got, ref)
+        assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), (got, ref)       # BASELINE north_star: losses within 1e-4 of the reference
         params = dict(op.model_h.named_parameters())
         for k in keys:
             gr = params[k].grad.detach().cpu().numpy().reshape(-1)
             rg = g['%s_ep%d_grad_%s' % (stage, ep, k)].reshape(-1)
-            # the first conv sits below 17 train-mode BatchNorm layers at batch 4: MIOpen-vs-CPU summation order is amplified there
+            # the first conv sits below 17 train-mode BatchNorm layers at batch 4: ReLU / max-pool masks of near-zero activations differ between any
+            # two fp32 evaluations (the reference's CPU run included); test_configs2_gpu.py holds the same gradients to an fp64 arbiter instead of a literal bound
             assert rel_err(gr[:rg.size], rg) < (3e-2 if 'resnet.0' in k else 2e-3), k
     # indirect SDF (scene table + ids) gives the same losses as the dense per-sample volumes
     _load(op.model_h, seed)
