@@ -30,6 +30,8 @@
 #ifdef PSI_HEAD_STOPS
 __device__ int psi_dbg_sstop;            // dev: leave the skinning / scene kernels at this point (tools/head_stops.sh)
 #define PSI_SSTOP(k) do { if (psi_dbg_sstop == (k)) return; } while (0)
+__device__ int psi_dbg_pstop;            // dev: end the tail kernel inside the pose-backward stage (PSI_TAIL_STOP = 20 + k)
+#define PSI_PSTOP(k) do { if (psi_dbg_pstop == (k)) asm volatile("s_endpgm"); } while (0)
 #define PSI_TRACE(lo, hi) PsiBlockTrace trace_((lo), (hi))
 // dev (PSI_SKIN_STOP=9): the workgroup timeline of the LAST fwd_scene launch — {start, end} in 10 ns wall-clock ticks, the hardware id
 // words and the kind of workgroup, one record per workgroup (tools/timeline.py draws it)
@@ -673,7 +675,7 @@ struct ContactSkinSrc {
     }
     __device__ __forceinline__ void prepare(int)
     {
-        __shared__ psi_f2 sA_[PSI_JP][6];
+        psi_f2 (*sA_)[6] = psi_transform_stage<1>()[0];           // (shared with the skinning workgroups of the launch: lbs_device.h)
         __shared__ float sCT_[16];
         __shared__ float sTR_[psikd::QPB][9];
 #pragma unroll
@@ -1733,6 +1735,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     {
         int sst = getenv("PSI_SKIN_STOP") ? atoi(getenv("PSI_SKIN_STOP")) : 0;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(psi_dbg_sstop), &sst, sizeof(int));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(psi_dbg_pstop), &f.stop_t, sizeof(int));
     }
 #endif
     if (const char *hcv = getenv("PSI_HEAD_CLUSTER")) {

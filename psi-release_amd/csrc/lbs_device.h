@@ -8,6 +8,9 @@
 #ifndef PSI_SSTOP
 #define PSI_SSTOP(k)
 #endif
+#ifndef PSI_PSTOP
+#define PSI_PSTOP(k)          // dev: end the program inside the pose-backward stage at point k (fit.hip, -DPSI_HEAD_STOPS)
+#endif
 #include <hip/hip_runtime.h>
 
 typedef float psi_f4 __attribute__((ext_vector_type(4)));
@@ -330,6 +333,7 @@ __device__ __forceinline__ void psi_pose_bwd_finish(const LbsDev &m, const PsiPo
     }
     const float *P = pre.P;
     __syncthreads();
+    PSI_PSTOP(21);
     for (int i = j; i < m.n_items * 12; i += nthr) {
         const int it = i / 12, e = i - it * 12;
         const unsigned int d = sItem[it];
@@ -347,6 +351,7 @@ __device__ __forceinline__ void psi_pose_bwd_finish(const LbsDev &m, const PsiPo
         sS[jj][e] = a;
     }
     __syncthreads();
+    PSI_PSTOP(22);
     // local gradients: gR_j = P_R^T gG_j.R, grel_j = P_R^T gG_j.t  (P = parent's G; root: identity)
     float gR[9], grel[3] = {0, 0, 0};
     for (int e = 0; e < 9; e++) gR[e] = 0.0f;
@@ -381,6 +386,7 @@ __device__ __forceinline__ void psi_pose_bwd_finish(const LbsDev &m, const PsiPo
         for (int c = 0; c < 3; c++) sgJ[j][c] = gJ[c];
     }
     __syncthreads();
+    PSI_PSTOP(23);
     // feature gradient (reduced over n-slices): betas part and pose-feature part
     if (g_betas_b) {
         // g_betas[l] = g_feat[l] + sum_q gJ[q] J_s[q][l]: the (joint, axis) range is cut into nthr/NB parts summed through LDS,
@@ -414,6 +420,7 @@ __device__ __forceinline__ void psi_pose_bwd_finish(const LbsDev &m, const PsiPo
             g_betas_b[l] = a;
         }
     }
+    PSI_PSTOP(24);
     if (act && (g_pose_b || g_rot_b)) {
         if (j >= 1)
             for (int e = 0; e < 9; e++) gR[e] += gf9[e];
@@ -577,6 +584,16 @@ __device__ __forceinline__ void psi_st(void *uniform_base, unsigned lane_off, co
 #define PSI_DENSE_UNROLL 11
 #endif
 enum PsiBlendForm { PsiBlendCompact = 0, PsiBlendPipelined = 1 };
+// LDS home of a workgroup's staged joint transforms ([body][joint][6 float pairs]): ONE array per kernel for every user — the skinning
+// workgroups (PsiBlendN::commit, compressed rows) and, in the fused fitting engine's shared launch, the search workgroups that skin their own
+// contact vertex (fit.hip: ContactSkinSrc) are never the same workgroup, and two separate 3 KB arrays put that launch over an occupancy step
+// of its LDS budget (6 -> 5 workgroups per CU: measured in round 6 as +4 us on the skinning workgroups).
+template <int NB>
+__device__ __forceinline__ psi_f2 (*psi_transform_stage())[PSI_JP][6]
+{
+    __shared__ psi_f2 sA[NB][PSI_JP][6];
+    return sA;
+}
 template <int NB>
 struct PsiBlendN {
     psi_f2 st[NB][2];             // this thread's share of the bodies' transforms (J * 6 float pairs over 256 threads, J <= 85)
@@ -607,7 +624,7 @@ struct PsiBlendN {
     }
     __device__ __forceinline__ Staged commit(const LbsDev &m)
     {
-        __shared__ psi_f2 sA[NB][PSI_JP][6];
+        const Staged sA = psi_transform_stage<NB>();
         if (!m.Wc) return sA;                                   // dense rows read the transforms through the scalar cache (blend)
 #pragma unroll
         for (int n = 0; n < NB; n++)

@@ -205,6 +205,34 @@ __device__ __forceinline__ float kd_query_round(const KdDev &T, QSrc &qsrc, floa
     float curd = 0.0f;
     bool have = active;
     PSI_KD_STAT(int nvis = 0; int ngp = 0;)
+#ifndef PSI_KD_SEED_CELLS
+#define PSI_KD_SEED_CELLS 1.5f
+#endif
+    if (have && T.cell_start && !(best * T.ginv * T.ginv <= PSI_KD_SEED_CELLS * PSI_KD_SEED_CELLS)) {
+        // A FAR (or missing) warm candidate — the first iterations of a fitting loop move a body by a tenth of a metre per step, so last
+        // iteration's winner is several cells away and its ball holds hundreds of points (the 30-round scans behind the launch's stragglers,
+        // profiles/r06_timeline_fwd_scene.txt) — is first replaced by ANY point near the query: the two points of the pair record in the
+        // middle of the query's own cell column, z cells [cz - 1, cz + 1] (two dependent loads: the range, one record).  Ordinary candidates,
+        // evaluated with the same expression and compared by the (d, index) key: the result is unchanged, the ball shrinks to about a cell.
+        // An empty neighbourhood changes nothing (a query with no candidate at all keeps best = +inf and walks the tree as before).
+        // Uniform over the lanes of a group (they hold the same query).
+        const float fx = fminf(fmaxf(floorf((qx - T.gorg[0]) * T.ginv), 0.0f), (float)(T.gn[0] - 1));
+        const float fy = fminf(fmaxf(floorf((qy - T.gorg[1]) * T.ginv), 0.0f), (float)(T.gn[1] - 1));
+        const float fz = fminf(fmaxf(floorf((qz - T.gorg[2]) * T.ginv), 0.0f), (float)(T.gn[2] - 1));
+        const int cz0 = max((int)fz - 1, 0), cz1 = min((int)fz + 1, T.gn[2] - 1);
+        const unsigned cbase = (unsigned)((int)fx * T.gn[1] + (int)fy) * (unsigned)T.gn[2];
+        const int p0 = T.cell_start[cbase + cz0], p1 = T.cell_start[cbase + cz1 + 1];
+        if (p1 > p0) {
+            const float4 *rp = (const float4 *)((const char *)T.gpts + ((unsigned)((p0 + p1) >> 2) << 5));
+            const float4 a = rp[0], b = rp[1];                  // {x0,x1,y0,y1} {z0,z1,i0,i1}; a NaN record past the end compares false
+            const float xa = a.x - qx, ya = a.z - qy, za = b.x - qz, xb = a.y - qx, yb = a.w - qy, zb = b.y - qz;
+            const float da = PSI_SQ3(xa, ya, za), db = PSI_SQ3(xb, yb, zb);
+            const kd_key ka = kd_pack(da, __float_as_int(b.z)), kb = kd_pack(db, __float_as_int(b.w));
+            if (da == da && ka < bestk) bestk = ka;
+            if (db == db && kb < bestk) bestk = kb;
+            best = kd_key_d(bestk);
+        }
+    }
     // Warm query (a candidate from the previous iteration is known): the winner can only lie in the ball of radius sqrt(best) around
     // the query, so instead of walking the tree — ~8 DEPENDENT node / leaf loads — every point of the grid cells that ball touches is
     // evaluated: two dependent rounds of independent loads (cell ranges, then points).
