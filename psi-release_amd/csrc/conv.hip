@@ -40,6 +40,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <int CIN, int WPX, int WCO, int TW>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, const float *__restrict__ bias,
@@ -164,6 +165,172 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const __bf16 *__restrict__
                     o[e] = (__bf16)v;
                 }
                 *(bf16x4 *)(yo + co) = o;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same convolution at the fp32 model's precision (round 6): fp32 NHWC map in, fp32 map out, three-term split products.  The input
+// tile WITH ITS HALO is split into hi = bf16(v) / lo = bf16(v - hi) planes on its way into LDS — once per workgroup, for all nine taps and
+// all output channels (the general kernel of conv_gemm.hip re-loads and re-splits its 64-pixel x 64-channel activation chunk for every tap:
+// 1423 vector instructions per wave against 108 MFMAs, profiles/r06_pmc_conv_gemm.txt) — the weights arrive PREPARED
+// (psi_conv2d_prepare_weight: hi parts [Cout][9][Cin], the lo parts Cout * 9 * Cin elements behind them) and go to LDS as they are, a tap
+// at a time, double-buffered.  A product is lo*hi + hi*lo + hi*hi, fp32 accumulate: the arithmetic conv_gemm.hip documents.
+// REV: the taps are walked backwards (w row tap 8 - t): with the weight in the input gradient's layout [Cin][9][Cout] this is dX of the
+// same layer — the forward kernel on dY.
+// Cin = 64: 256 pixels (8 x 32) x 64 output channels per workgroup; two LDS planes of the halo tile (98 KB) + two weight buffers of two
+// planes (37 KB): one workgroup per CU.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int WPX, int WCO, int TW, bool REV>
+__global__ __launch_bounds__(256) void conv3x3s_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+                                                       float *__restrict__ y, int N, int H, int W, int COUT)
+{
+    constexpr int PX = WPX * 64, TH = PX / TW, COT = WCO * 64, P = CIN + 8, HW_ = TW + 2, HH_ = TH + 2, CH = CIN / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 (*Xh)[P] = (__bf16 (*)[P])smem;                                           // [HH_ * HW_][P] hi parts
+    __bf16 (*Xl)[P] = Xh + HH_ * HW_;                                                // ... lo parts
+    __bf16 (*Ws)[2][COT][P] = (__bf16 (*)[2][COT][P])(smem + (size_t)2 * HH_ * HW_ * P * 2);   // [buffer][plane][COT][P]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wp_ = wv % WPX, wc = wv / WPX;
+    const int li = lane & 31, kb = (lane >> 5) * 8;
+    const int tiles_w = W / TW, tiles_h = H / TH;
+    int t = blockIdx.x;
+    const int tx0 = (t % tiles_w) * TW;
+    t /= tiles_w;
+    const int ty0 = (t % tiles_h) * TH, n = t / tiles_h;
+    const int co0 = blockIdx.y * COT;
+    const size_t wplane = (size_t)COUT * 9 * CIN;                 // elements between the hi and the lo parts of the prepared weight
+
+    // ---- weights of one tap, both planes: 2 x COT rows of CIN channels
+    constexpr int WLD = (2 * COT * CH + 255) / 256, PF = 2;
+    u4 wr[PF][WLD];
+    auto load_w = [&](int tap, u4 (&r)[WLD]) {
+        const int tsrc = REV ? 8 - tap : tap;
+#pragma unroll
+        for (int i = 0; i < WLD; i++) {
+            const int idx = threadIdx.x + 256 * i;
+            if (2 * COT * CH % 256 == 0 || idx < 2 * COT * CH) {
+                const int pl = idx / (COT * CH), rem = idx % (COT * CH), row = rem / CH, c = rem % CH;
+                r[i] = *(const u4 *)(wp + (size_t)pl * wplane + ((size_t)(co0 + row) * 9 + tsrc) * CIN + c * 8);
+            }
+        }
+    };
+    auto store_w = [&](int buf, const u4 (&r)[WLD]) {
+#pragma unroll
+        for (int i = 0; i < WLD; i++) {
+            const int idx = threadIdx.x + 256 * i;
+            if (2 * COT * CH % 256 == 0 || idx < 2 * COT * CH) {
+                const int pl = idx / (COT * CH), rem = idx % (COT * CH), row = rem / CH, c = rem % CH;
+                *(u4 *)&Ws[buf][pl][row][c * 8] = r[i];
+            }
+        }
+    };
+#pragma unroll
+    for (int tp = 0; tp < PF; tp++) load_w(tp, wr[tp]);
+    // ---- input tile with halo (zero outside the image): all of a thread's 32-byte pieces are requested before the first one is split and stored
+    constexpr int NPC = HH_ * HW_ * CH, XLD = (NPC + 255) / 256;
+    {
+        f4 xr[XLD][2];
+#pragma unroll
+        for (int i = 0; i < XLD; i++) {
+            const int idx = threadIdx.x + 256 * i;
+            xr[i][0] = xr[i][1] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (idx < NPC) {
+                const int pix = idx / CH, c = idx % CH;
+                const int iy = ty0 - 1 + pix / HW_, ix = tx0 - 1 + pix % HW_;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    const float *src = x + (((size_t)n * H + iy) * W + ix) * CIN + c * 8;
+                    xr[i][0] = *(const f4 *)src;
+                    xr[i][1] = *(const f4 *)(src + 4);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < XLD; i++) {
+            const int idx = threadIdx.x + 256 * i;
+            if (idx < NPC) {
+                bf16x8 hv, lv;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float v = xr[i][e >> 2][e & 3];
+                    const __bf16 hh = (__bf16)v;
+                    hv[e] = hh;
+                    lv[e] = (__bf16)(v - (float)hh);
+                }
+                *(bf16x8 *)&Xh[idx / CH][(idx % CH) * 8] = hv;
+                *(bf16x8 *)&Xl[idx / CH][(idx % CH) * 8] = lv;
+            }
+        }
+    }
+    store_w(0, wr[0]);
+    __syncthreads();
+
+    f16v acc[2][2];                                          // [co tile][pixel tile]
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[a][b][i] = 0.0f;
+    int pix_base[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++) {
+        const int p = wp_ * 64 + pt * 32 + li;
+        pix_base[pt] = (p / TW) * HW_ + (p % TW);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+        const int buf = tap & 1;
+        if (tap + PF < 9) load_w(tap + PF, wr[tap % PF]);
+        const int toff = (tap / 3) * HW_ + (tap % 3);
+#pragma unroll
+        for (int c0 = 0; c0 < CIN; c0 += 16) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) {
+                ah[ct] = *(const bf16x8 *)&Ws[buf][0][wc * 64 + ct * 32 + li][c0 + kb];
+                al[ct] = *(const bf16x8 *)&Ws[buf][1][wc * 64 + ct * 32 + li][c0 + kb];
+            }
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++) {
+                bh[pt] = *(const bf16x8 *)&Xh[pix_base[pt] + toff][c0 + kb];
+                bl[pt] = *(const bf16x8 *)&Xl[pix_base[pt] + toff][c0 + kb];
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                for (int pt = 0; pt < 2; pt++) {
+                    f16v a = acc[ct][pt];
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ct], bh[pt], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ct], bl[pt], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ct], bh[pt], a, 0, 0, 0);
+                    acc[ct][pt] = a;
+                }
+        }
+        if (tap + 1 < 9) store_w(buf ^ 1, wr[(tap + 1) % PF]);
+        __syncthreads();
+    }
+    // ---- epilogue: D[row = co][col = pixel]; lane (li, h) holds rows 8g + 4h + (0..3), g = 0..3, of column li: 16-byte stores
+    const int h = lane >> 5;
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++) {
+        const int p = wp_ * 64 + pt * 32 + li;
+        const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+        float *yo = y + (((size_t)n * H + oy) * W + ox) * COUT + co0 + wc * 64;
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = ct * 32 + 8 * g + 4 * h;
+                f4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float v = acc[ct][pt][4 * g + e];
+                    if (bias) v += bias[co0 + wc * 64 + co + e];
+                    o[e] = v;
+                }
+                *(f4 *)(yo + co) = o;
             }
     }
 }
@@ -294,23 +461,172 @@ __global__ __launch_bounds__(256) void conv3x3_wrw_kernel(const __bf16 *__restri
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same weight gradient at the fp32 model's precision (round 6): fp32 maps in, every operand split into hi = bf16(v), lo = bf16(v - hi)
+// on its way into LDS — ONCE per workgroup and stage, for all nine taps — and a product is lo*hi + hi*lo + hi*hi with fp32 accumulation
+// (conv_gemm.hip documents the arithmetic; the general kernel's weight gradient gives a workgroup one tap, so every element of dY and of
+// X is loaded, split and transposed nine times: 13 161 vector instructions per wave against 439 MFMAs, profiles/r06_pmc_conv_wgrad.txt).
+// Same tile as the bf16 kernel above (64 co x 64 ci, all nine taps, 128-pixel stages, the shifted runs assembled with v_alignbit), two
+// LDS planes per operand (110-119 KB: one workgroup per CU, one wave per SIMD), so the next stage's 20 16-byte loads per thread are
+// requested before the current stage's 216 MFMAs per wave and wait in registers.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned psi_pack_bf16(__bf16 a, __bf16 b)
+{
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+template <int TW>
+__global__ __launch_bounds__(256) void conv3x3_wrw3_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part,
+                                                           int N, int H, int CIN, int COUT, int nsplit)
+{
+    constexpr int TR = 128 / TW, PXP = 128 + 8, RP = TW + 16, XP = (TR + 2) * RP + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 (*dYh)[PXP] = (__bf16 (*)[PXP])smem;                                       // [64 co][128 px], hi parts
+    __bf16 (*dYl)[PXP] = dYh + 64;                                                    // ... lo parts
+    __bf16 (*Xh)[XP] = (__bf16 (*)[XP])(smem + (size_t)2 * 64 * PXP * 2);              // [64 ci][(TR + 2) rows of RP]
+    __bf16 (*Xl)[XP] = Xh + 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ct = wv & 1, it = wv >> 1;
+    const int li = lane & 31, kb = (lane >> 5) * 8, h = lane >> 5;
+    const int split = blockIdx.x, co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+    const int stages_per_img = H / TR, nstage = N * stages_per_img;
+    for (int i = threadIdx.x; i < 2 * 64 * XP / 2; i += 256) ((unsigned *)&Xh[0][0])[i] = 0u;     // the padding columns (both planes) are never written again
+    f16v acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[tp][i] = 0.0f;
+    // item = (pixel pair q, channel piece c of 8 channels): two pixels x two 16-byte halves
+    constexpr int DP = 64, DLD = DP * 8 / 256;
+    constexpr int XPR = (TR + 2) * TW / 2, XIT = XPR * 8, XLD = (XIT + 255) / 256;
+    f4 dv[DLD][2][2], xv[XLD][2][2];
+    auto load_stage = [&](int stg) {
+        const int n = stg / stages_per_img, oy0 = (stg % stages_per_img) * TR;
+#pragma unroll
+        for (int i = 0; i < DLD; i++) {
+            const int idx = threadIdx.x + 256 * i, q = idx % DP, c = idx / DP, px = 2 * q;
+            const float *src = dy + (((size_t)n * H + oy0 + px / TW) * TW + px % TW) * COUT + co0 + c * 8;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                dv[i][u][0] = *(const f4 *)(src + (size_t)u * COUT);
+                dv[i][u][1] = *(const f4 *)(src + (size_t)u * COUT + 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < XLD; i++) {
+            const int idx = threadIdx.x + 256 * i, q = idx % XPR, c = idx / XPR, px = 2 * q;
+            const int iy = oy0 - 1 + px / TW;
+#pragma unroll
+            for (int u = 0; u < 2; u++) xv[i][u][0] = xv[i][u][1] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (idx < XIT && iy >= 0 && iy < H) {
+                const float *src = x + (((size_t)n * H + iy) * TW + px % TW) * CIN + ci0 + c * 8;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    xv[i][u][0] = *(const f4 *)(src + (size_t)u * CIN);
+                    xv[i][u][1] = *(const f4 *)(src + (size_t)u * CIN + 4);
+                }
+            }
+        }
+    };
+    // 8 channels x {pixel, pixel + 1}, fp32 -> one {hi, hi} dword and one {lo, lo} dword per channel row
+    auto scatter = [&](const f4 (&p)[2][2], __bf16 *rowh, __bf16 *rowl, int pitch) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float v0 = p[0][e >> 2][e & 3], v1 = p[1][e >> 2][e & 3];
+            const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+            const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
+            *(unsigned *)(rowh + (size_t)e * pitch) = psi_pack_bf16(h0, h1);
+            *(unsigned *)(rowl + (size_t)e * pitch) = psi_pack_bf16(l0, l1);
+        }
+    };
+    if (split < nstage) load_stage(split);
+    for (int stg = split; stg < nstage; stg += nsplit) {
+        __syncthreads();                                     // previous stage's MFMAs are done with LDS (and the zero fill is visible)
+#pragma unroll
+        for (int i = 0; i < DLD; i++) {
+            const int idx = threadIdx.x + 256 * i, q = idx % DP, c = idx / DP;
+            scatter(dv[i], &dYh[c * 8][2 * q], &dYl[c * 8][2 * q], PXP);
+        }
+#pragma unroll
+        for (int i = 0; i < XLD; i++) {
+            const int idx = threadIdx.x + 256 * i, q = idx % XPR, c = idx / XPR, px = 2 * q;
+            if (idx < XIT) scatter(xv[i], &Xh[c * 8][(px / TW) * RP + 8 + px % TW], &Xl[c * 8][(px / TW) * RP + 8 + px % TW], XP);
+        }
+        __syncthreads();
+        if (stg + nsplit < nstage) load_stage(stg + nsplit);     // in flight during this stage's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k0 = 0; k0 < 128; k0 += 16) {
+            const bf16x8 ah = *(const bf16x8 *)&dYh[ct * 32 + li][k0 + kb];
+            const bf16x8 al = *(const bf16x8 *)&dYl[ct * 32 + li][k0 + kb];
+            const int r = k0 / TW, c0 = k0 % TW;
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++) {
+                const int off = (r + kh) * RP + 8 + c0 + kb;
+                u4 B[2][3];                                   // [plane][kw]: the run of eight pixels starting at ox + kw - 1
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                    const __bf16 *mid = (pl ? &Xl[it * 32 + li][0] : &Xh[it * 32 + li][0]) + off;
+                    const u4 L = *(const u4 *)(mid - 8), M = *(const u4 *)mid, R = *(const u4 *)(mid + 8);
+                    B[pl][0][0] = __builtin_amdgcn_alignbit(M[0], L[3], 16);
+                    B[pl][0][1] = __builtin_amdgcn_alignbit(M[1], M[0], 16);
+                    B[pl][0][2] = __builtin_amdgcn_alignbit(M[2], M[1], 16);
+                    B[pl][0][3] = __builtin_amdgcn_alignbit(M[3], M[2], 16);
+                    B[pl][1] = M;
+                    B[pl][2][0] = B[pl][0][1];
+                    B[pl][2][1] = B[pl][0][2];
+                    B[pl][2][2] = B[pl][0][3];
+                    B[pl][2][3] = __builtin_amdgcn_alignbit(R[0], M[3], 16);
+                }
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, B[0][kw]), bl = __builtin_bit_cast(bf16x8, B[1][kw]);
+                    f16v a = acc[kh * 3 + kw];
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, a, 0, 0, 0);
+                    acc[kh * 3 + kw] = a;
+                }
+            }
+        }
+    }
+    // ---- partial tile: D[row = co][col = ci] per tap -> part[split][co][tap][ci]
+    float *po = part + (size_t)split * COUT * 9 * CIN;
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = co0 + ct * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            po[((size_t)co * 9 + tp) * CIN + ci0 + it * 32 + li] = acc[tp][r];
+        }
+}
+
+// FOUR threads per output (lanes 4 i .. 4 i + 3 take the splits s = 0, 1, 2, 3 (mod 4), eight loads in flight each; combined in lane order
+// with two shuffles): 36 864 outputs of a 64 -> 64 layer were 144 workgroups reading 38 MB of partials — 12.7 us, a third of the weight
+// gradient itself; with four times the threads in flight the same sums take half of that.  Fixed order: deterministic.
 __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(const float *__restrict__ part, int nsplit, long n, float *__restrict__ gw)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = t >> 2;
+    const int s0 = (int)(t & 3);
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    int s = 0;
-    for (; s + 7 < nsplit; s += 8) {                          // eight loads in flight; fixed order
-        float v[8];
+    if (i < n) {
+        int s = s0;
+        for (; s + 28 < nsplit; s += 32) {                       // eight loads in flight; fixed order
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = part[(size_t)(s + u) * n + i];
-        a0 += v[0] + v[4];
-        a1 += v[1] + v[5];
-        a2 += v[2] + v[6];
-        a3 += v[3] + v[7];
+            for (int u = 0; u < 8; u++) v[u] = part[(size_t)(s + 4 * u) * n + i];
+            a0 += v[0] + v[4];
+            a1 += v[1] + v[5];
+            a2 += v[2] + v[6];
+            a3 += v[3] + v[7];
+        }
+        for (; s < nsplit; s += 4) a0 += part[(size_t)s * n + i];
     }
-    for (; s < nsplit; s++) a0 += part[(size_t)s * n + i];
-    gw[i] = (a0 + a1) + (a2 + a3);
+    float r = (a0 + a1) + (a2 + a3);
+    r += __shfl_xor(r, 1, 64);
+    r += __shfl_xor(r, 2, 64);
+    if (i < n && s0 == 0) gw[i] = r;
 }
 
 // weight re-layout for the input gradient: W[co][kh][kw][ci] -> Wt[ci][2-kh][2-kw][co]
@@ -407,7 +723,69 @@ extern "C" int psi_conv3x3_weight_grad(const void *x, const void *dy, int N, int
     PSI_CHECK_LAUNCH("conv3x3_wrw_kernel");
     psi_mark("conv3x3_wrw_kernel", st);
     const long n = (long)Cout * 9 * Cin;
-    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(psi_cdiv(n, 256)), dim3(256), 0, st, ws, S, n, gw);
+    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(psi_cdiv(4 * n, 256)), dim3(256), 0, st, ws, S, n, gw);
     PSI_CHECK_LAUNCH("conv_wrw_reduce_kernel");
+    return 0;
+}
+
+// ---- the fp32 (three-term) weight gradient of the stride-1 3x3 layers: conv_gemm.hip's psi_conv2d_weight_grad routes the shapes this covers here
+int psi_conv3x3_wrw3_ok(int N, int H, int W, int Cin, int Cout)
+{
+    return N > 0 && (W == 16 || W == 32) && H % (128 / W) == 0 && Cin % 64 == 0 && Cout % 64 == 0;
+}
+
+size_t psi_conv3x3_wrw3_workspace_floats(int N, int H, int W, int Cin, int Cout)
+{
+    if (!psi_conv3x3_wrw3_ok(N, H, W, Cin, Cout)) return 0;
+    return (size_t)wrw_splits(N, H, W, Cin, Cout) * Cout * 9 * Cin;
+}
+
+int psi_conv3x3_weight_grad3(const float *x, const float *dy, int N, int H, int W, int Cin, int Cout, float *gw, float *ws, hipStream_t st)
+{
+    PSI_REQUIRE(x && dy && gw && ws && psi_conv3x3_wrw3_ok(N, H, W, Cin, Cout), "shape not covered by the three-term 3x3 weight gradient");
+    const int S = wrw_splits(N, H, W, Cin, Cout);
+    const int TR = 128 / W;
+    const size_t lds = ((size_t)2 * 64 * (128 + 8) + (size_t)2 * 64 * ((TR + 2) * (W + 16) + 8)) * 2;
+    dim3 grid(S, Cout / 64, Cin / 64);
+    if (W == 32) {
+        static std::atomic<unsigned long long> a32{0};
+        PSI_CHECK_HIP(psi_set_max_lds((const void *)conv3x3_wrw3_kernel<32>, lds, a32));
+        hipLaunchKernelGGL(conv3x3_wrw3_kernel<32>, grid, dim3(256), lds, st, x, dy, ws, N, H, Cin, Cout, S);
+    } else {
+        static std::atomic<unsigned long long> a16{0};
+        PSI_CHECK_HIP(psi_set_max_lds((const void *)conv3x3_wrw3_kernel<16>, lds, a16));
+        hipLaunchKernelGGL(conv3x3_wrw3_kernel<16>, grid, dim3(256), lds, st, x, dy, ws, N, H, Cin, Cout, S);
+    }
+    PSI_CHECK_LAUNCH("conv3x3_wrw3_kernel");
+    psi_mark("conv3x3_wrw3_kernel", st);
+    const long n = (long)Cout * 9 * Cin;
+    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(psi_cdiv(4 * n, 256)), dim3(256), 0, st, ws, S, n, gw);
+    PSI_CHECK_LAUNCH("conv_wrw_reduce_kernel");
+    return 0;
+}
+
+// ---- forward / input gradient of the stride-1 3x3 layers at the fp32 model's precision, prepared weights (conv_gemm.hip routes here)
+int psi_conv3x3s_ok(int N, int H, int W, int Cin, int Cout)
+{
+    return N > 0 && Cin == 64 && Cout % 64 == 0 && H % 8 == 0 && W % 32 == 0;
+}
+
+int psi_conv3x3s_forward(const float *x, const void *wp, const float *bias, int N, int H, int W, int Cin, int Cout, float *y, int reversed_taps, hipStream_t st)
+{
+    PSI_REQUIRE(x && wp && y && psi_conv3x3s_ok(N, H, W, Cin, Cout), "shape not covered by the three-term 3x3 kernel");
+    constexpr int CIN = 64, WPX = 4, WCO = 1, TW = 32, PX = WPX * 64, TH = PX / TW, COT = WCO * 64, P = CIN + 8;
+    const size_t lds = ((size_t)2 * (TH + 2) * (TW + 2) * P + (size_t)2 * 2 * COT * P) * 2;
+    dim3 grid((unsigned)(N * (H / TH) * (W / TW)), (unsigned)(Cout / COT));
+    if (reversed_taps) {
+        static std::atomic<unsigned long long> a1{0};
+        PSI_CHECK_HIP(psi_set_max_lds((const void *)conv3x3s_kernel<CIN, WPX, WCO, TW, true>, lds, a1));
+        hipLaunchKernelGGL((conv3x3s_kernel<CIN, WPX, WCO, TW, true>), grid, dim3(256), lds, st, x, (const __bf16 *)wp, bias, y, N, H, W, Cout);
+    } else {
+        static std::atomic<unsigned long long> a0{0};
+        PSI_CHECK_HIP(psi_set_max_lds((const void *)conv3x3s_kernel<CIN, WPX, WCO, TW, false>, lds, a0));
+        hipLaunchKernelGGL((conv3x3s_kernel<CIN, WPX, WCO, TW, false>), grid, dim3(256), lds, st, x, (const __bf16 *)wp, bias, y, N, H, W, Cout);
+    }
+    PSI_CHECK_LAUNCH("conv3x3s_kernel");
+    psi_mark("conv3x3s_kernel", st);
     return 0;
 }

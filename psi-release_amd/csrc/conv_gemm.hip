@@ -670,6 +670,13 @@ extern "C" int psi_conv2d_supported(int Cin, int Cout, int KH, int KW, int strid
 
 // x [N,H,W,Cin] NHWC (x_bf16: bf16, else fp32); w [Cout,KH,KW,Cin] fp32 (a channels_last Conv2d weight); bias [Cout] fp32 or NULL;
 // y [N,OH,OW,Cout] NHWC (y_bf16: bf16, else fp32), OH = (H + 2 pad - KH) / stride + 1.  nterm = 1 | 3 (see the header of this file).
+// PSI_CONV3X3_SPLIT=0 (dev A/B): the stride-1 3x3 layers of the fp32 model stay on the general kernels of this file
+static bool conv3x3_split_route()
+{
+    static const bool on = !(getenv("PSI_CONV3X3_SPLIT") && getenv("PSI_CONV3X3_SPLIT")[0] == '0');
+    return on;
+}
+
 static int conv2d_forward_any(const void *x, int x_bf16, const float *w, int prepared, const float *bias, int N, int H, int W, int Cin, int Cout, int KH,
                               int KW, int stride, int pad, void *y, int y_bf16, int nterm, void *stream)
 {
@@ -683,6 +690,9 @@ static int conv2d_forward_any(const void *x, int x_bf16, const float *w, int pre
         PSI_REQUIRE(!prepared, "the stem's kernels read the fp32 weight");
         return psi_conv_stem_forward(x, x_bf16, w, bias, N, H, W, y, y_bf16, nterm, st);
     }
+    // the stride-1 3x3 layers of the fp32 model with 64 input channels: the halo tile split ONCE per workgroup (conv.hip: conv3x3s_kernel)
+    if (conv3x3_split_route() && prepared && nterm == 3 && !x_bf16 && !y_bf16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && psi_conv3x3s_ok(N, H, W, Cin, Cout))
+        return psi_conv3x3s_forward((const float *)x, (const void *)w, bias, N, H, W, Cin, Cout, (float *)y, 0, st);
 #define PSI_CONV_ARGS x, w, bias, y, N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, st, prepared
     if (nterm == 3) {
         if (x_bf16) return y_bf16 ? launch_bn<3, __bf16, __bf16>(PSI_CONV_ARGS) : launch_bn<3, __bf16, float>(PSI_CONV_ARGS);
@@ -739,6 +749,9 @@ static int conv2d_input_grad_any(const void *dy, int dy_bf16, const float *wt, i
     PSI_REQUIRE(nterm == 1 || nterm == 3, "nterm is 1 or 3");
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     hipStream_t st = (hipStream_t)stream;
+    // (the forward kernel of conv.hip on dY with the taps walked backwards: its "input channels" are Cout)
+    if (conv3x3_split_route() && prepared && nterm == 3 && !dy_bf16 && !dx_bf16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && psi_conv3x3s_ok(N, H, W, Cout, Cin))
+        return psi_conv3x3s_forward((const float *)dy, (const void *)wt, nullptr, N, H, W, Cout, Cin, (float *)dx, 1, st);
     // roles swapped: the kernel's "input" is dY (OH x OW x Cout), its "output" dX (H x W x Cin)
 #define PSI_DG_ARGS dy, wt, nullptr, dx, N, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 1, st, prepared
     if (nterm == 3) {
@@ -770,6 +783,7 @@ extern "C" size_t psi_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin
     const int K = KH * KW * Cin;
     const size_t general = (size_t)wgrad_splits((long)N * OH * OW, K, Cout) * Cout * K;
     if (psi_conv_stem_shape(Cin, Cout, KH, KW, stride, pad)) return std::max(general, psi_conv_stem_wgrad_floats(N, H, W));
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1) return std::max(general, psi_conv3x3_wrw3_workspace_floats(N, H, W, Cin, Cout));
     return general;
 }
 
@@ -785,6 +799,10 @@ extern "C" int psi_conv2d_weight_grad(const void *x, int x_bf16, const void *dy,
     PSI_REQUIRE(OH > 0 && OW > 0, "empty output");
     hipStream_t st = (hipStream_t)stream;
     if (stem_route(Cin, Cout, KH, KW, stride, pad)) return psi_conv_stem_weight_grad(x, x_bf16, dy, dy_bf16, N, H, W, gw, ws, nterm, st);
+    // the stride-1 3x3 layers of the fp32 model (8 of a trunk's 11 convolutions): both operand tiles split ONCE per workgroup for all nine taps
+    // (conv.hip: conv3x3_wrw3_kernel; PSI_CONV3X3_SPLIT=0: the general kernel, dev A/B)
+    if (conv3x3_split_route() && nterm == 3 && !x_bf16 && !dy_bf16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && psi_conv3x3_wrw3_ok(N, H, W, Cin, Cout))
+        return psi_conv3x3_weight_grad3((const float *)x, (const float *)dy, N, H, W, Cin, Cout, gw, ws, st);
     const int K = KH * KW * Cin;
     const int Keff = (Cin % 8) != 0 && Cin * KW <= 16 ? KH * 16 : K;      // (filter-row indexing of a small Cin: conv_wgrad_kernel mode 1)
     const long M = (long)N * OH * OW, nstage = (M + WG_PX - 1) / WG_PX;

@@ -62,3 +62,13 @@ int psi_conv_stem_forward(const void *x, int x_bf16, const float *w, const float
 size_t psi_conv_stem_wgrad_floats(int N, int H, int W);
 int psi_conv_stem_weight_grad(const void *x, int x_bf16, const void *dy, int dy_bf16, int N, int H, int W, float *gw, float *ws, int nterm,
                               hipStream_t st);
+
+// conv.hip: the stride-1 3x3 convolutions of the fp32 model (three-term split products) with the input tile split ONCE per workgroup;
+// conv_gemm.hip's entry points route the shapes these cover here
+int psi_conv3x3_wrw3_ok(int N, int H, int W, int Cin, int Cout);
+size_t psi_conv3x3_wrw3_workspace_floats(int N, int H, int W, int Cin, int Cout);
+int psi_conv3x3_weight_grad3(const float *x, const float *dy, int N, int H, int W, int Cin, int Cout, float *gw, float *ws, hipStream_t st);
+int psi_conv3x3s_ok(int N, int H, int W, int Cin, int Cout);
+// wp: prepared weight parts (psi_conv2d_prepare_weight) — forward layout [Cout][9][Cin]; reversed_taps = 1 with the input gradient's layout
+// [Cin][9][Cout] (and Cin / Cout, x / y in the roles of dY's channels / dX): the input gradient of the same layer
+int psi_conv3x3s_forward(const float *x, const void *wp, const float *bias, int N, int H, int W, int Cin, int Cout, float *y, int reversed_taps, hipStream_t st);
