@@ -30,7 +30,7 @@ released SMPL-X model's 4 non-zeros (the headline keeps the dense random [V, 55]
 The JSON line also carries
   roofline     — the dominant (longest) kernel of the iteration: the bytes the implementation has to MOVE per launch (DESIGN.md section 3;
                  SURVEY 8(d)'s per-unit figure next to it as survey_8d_*) / its average launch duration measured with HIP events on the
-                 launch stream; peak = 8 TB/s HBM3E (MI355X guide); traffic = the PMC bytes of profiles/r05_pmc_traffic.json;
+                 launch stream; peak = 8 TB/s HBM3E (MI355X guide); traffic = the PMC bytes of profiles/r06_pmc_traffic.json;
   cpu_baseline — the oracle (oracle/psi_oracle.py + oracle/chamfer_oracle.c, a CPU port of the reference path,
                  validated against the reference's golden vectors) timed on this box's host cores on a bounded
                  sample of the same workload (rank 0, N=1 only).
@@ -55,7 +55,7 @@ PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 ROOMS = 7                     # fitting_habitat.py:238-241: seven MP3D-R rooms
 LOOP_ITERS = 100              # fitting_proxe.py / fitting_habitat.py: num_iter of the shipped configuration (BASELINE configs[1]: '100-iter loop')
-PMC_FILES = ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json')
+PMC_FILES = ('r06_pmc_traffic.json', 'r05_pmc_traffic.json')
 
 
 def parse(argv=None):
@@ -268,10 +268,13 @@ def kernel_work(args):
                                 'skinning + SDF lookup fused, SURVEY 8(d) accounting: weights + v_posed in, vertices out, 8 corner values + 12 B masked '
                                 'gradient per vertex (round 4 stores only the contact rows of the vertices: `moved_bytes` = what this '
                                 'implementation has to move)'),
-        'fwd_scene_kernel': ('byte', W + B * N * 4.0 + B * V * (12.0 + 32 + 12) + B * nc * (12 + 12 + 8.0) + m * 16.0,
-                             'ONE launch for both scene terms: skinning + SDF lookup (weights + v_posed in, vertices out, 8 gathers + 12 B masked gradient per '
-                             'vertex) and the exact NN search of the contact vertices (posed contact vertex in, gradient + winner out, scene cloud once); the '
-                             'weight rows the search lanes re-read to skin their own query are implementation traffic and not counted'),
+        'fwd_scene_kernel': ('byte', W + B * N * 4.0 + B * V * (12.0 + 32 + 12) + B * nc * (12 + 12 + 8.0) + m * 16.0
+                             + (W + B * V * 12.0 + B * nc * 12.0 + 2 * B * N * 4.0),
+                             'ONE launch for both scene terms AND (round 6) the per-vertex skinning backward: skinning + SDF lookup (weights + v_posed in, '
+                             'vertices out, 8 gathers + 12 B masked gradient per vertex), the exact NN search of the contact vertices (posed contact vertex in, '
+                             'gradient + winner out, scene cloud once), and what SURVEY 8(d) counts for the backward launch it replaces (weights + SDF gradient + '
+                             'contact gradients in, g_local + g_vposed out); the weight rows the search lanes re-read to skin their own query are '
+                             'implementation traffic and not counted'),
         'skin_bwd_v_kernel': ('byte', W + B * V * 12.0 + 2 * B * N * 4.0, 'weights + grad in, g_local + g_vposed out'),
         'skin_bwd_v_grad_kernel': ('byte', W + B * V * 12.0 + B * nc * 12.0 + 2 * B * N * 4.0,
                                    'loss-gradient assembly + skinning backward fused: weights + SDF gradient + contact gradients in, g_local + g_vposed out'),
@@ -292,8 +295,16 @@ def moved_bytes(args, kernel):
     W = J * V * 4.0 if not nnz else nnz * V * 5.0
     if kernel == 'skin_fwd_sdf_kernel':          # vertices: only the n_c contact rows are stored (the search reads them)
         return W + B * N * 4.0 + B * V * (32 + 12.0) + B * nc * 12.0
-    if kernel == 'fwd_scene_kernel':             # shared launch: the search lanes skin their own queries, no vertex is stored
-        return W + B * N * 4.0 + B * V * (32 + 12.0) + B * nc * (12 + 12 + 8.0) + m * 16.0
+    if kernel == 'fwd_scene_kernel':
+        # shared launch, round 6: the search lanes skin their own queries (no vertex is stored), the masked SDF gradient never leaves the lane
+        # (the vertex's backward happens on the spot: g_local + g_vposed out), the weights are read once, the contact slots write their own rows
+        # (g_local, g_vposed, posed vertex: 36 B) next to the 32 B of the query itself
+        return W + B * N * 4.0 + B * V * 32.0 + 2 * B * N * 4.0 + B * nc * (12 + 12 + 8.0 + 36.0) + m * 16.0
+    if kernel == 'bwd_joint_kernel':
+        # + the contact class of rows (round 6): the contact vertices' blend-shape columns gathered once per engine (3 n_c columns of the 506-row
+        # matrix, streamed like the matrix itself), their skinning-weight rows and the slot-ordered gradient rows
+        K = 506
+        return (K * N * 4.0 + B * N * 4.0 + B * K * 4.0 + W + 2 * B * N * 4.0 + B * J * 16 * 4.0) + K * 3 * nc * 4.0 + J * nc * 4.0 + 3 * B * nc * 12.0
     return None
 
 
@@ -310,7 +321,7 @@ def load_rocprof_stats(kernel):
     HIP-event deltas of single launches (the live measurement below) contain the launch gap — about 3 us on this stack — that the
     profiler's begin/end timestamps exclude; the committed summary is quoted next to the live figure so the two can be compared."""
     import csv
-    for f in ('r05_kernel_stats.csv', 'r04_kernel_stats.csv', 'r03_kernel_stats.csv'):
+    for f in ('r06_kernel_stats.csv', 'r05_kernel_stats.csv'):
         p = os.path.join(ROOT, 'profiles', f)
         if not os.path.exists(p):
             continue
@@ -364,8 +375,9 @@ def roofline_from_kernels(args, agg, work):
             roof['bytes_per_launch'] = mb
             roof['achieved'] = round(mb / t_dom * 1e-9, 1)
             roof['frac'] = round(mb / t_dom * 1e-9 / PEAK_HBM_GBS, 4)
-            roof['bytes_note'] = ('`achieved` / `frac` use the bytes this implementation has to move per launch (no [B,V,3] vertex store: the search '
-                                  'lanes skin their own queries); survey_8d_* = the same launch time against SURVEY 8(d) bytes, which count those vertices as an output')
+            roof['bytes_note'] = ('`achieved` / `frac` use the bytes this implementation has to move per launch (fwd_scene: no [B,V,3] vertex store, no '
+                                  'masked-gradient round trip, weights read once; bwd_joint: + the contact class of rows); survey_8d_* = the same launch '
+                                  'time against SURVEY 8(d) bytes of the work the launch does')
         roof['share_of_iteration_time'] = round(agg[dom] / max(sum(agg.values()), 1e-12), 3)
         roof['share_of_iteration_bytes'] = round(w[1] / (131.7e6 + args.batch * 1.76e6), 3) if w[0] == 'byte' else None
         if (args.batch, args.nc, args.m, args.D) == (32, 2048, 32768, 256):

@@ -1,5 +1,7 @@
 """GPU parity of the fitting loop (FittingOP) against the trajectory recorded from the reference's own FittingOP
 (tests/golden/fitting_proxe.npz, made by oracle/make_golden.py) and against the oracle at other settings."""
+import dataclasses
+
 import numpy as np
 import pytest
 import torch
@@ -315,3 +317,38 @@ def test_head_cluster_widths_agree_and_repeat_exactly(smplx_data, vposer_sd, mon
     for hc in (2, 4, 8):
         assert np.abs(short[hc] - short[1]).max() < 1e-4, (hc, np.abs(short[hc] - short[1]).max())
 
+
+
+@pytest.mark.parametrize('B', [3, 32])
+def test_fused_backward_with_duplicate_contact_vertices(smplx_data, vposer_sd, B, monkeypatch):
+    """The skinning backward inside fwd_scene (fit.hip: fused_bwd) on a contact list as cvae.py:99-115 builds it — per part ``list(set(.))``,
+    parts concatenated, so a vertex that two parts list has TWO slots (duplicates kept) — and a slot count that does not fill its last
+    256-slot slice (the padding slots must stay zero rows of the contact class).  Checked: the first-iteration gradient against autograd over
+    the HIP operators (the modular engine), and the reduced joint-transform / blend-shape-feature / translation gradients against the same
+    engine with the per-vertex backward as its own launch (PSI_FIT_FUSED_BWD=0), which adds the two parts per vertex before the contractions."""
+    scene = synth.make_scene(5, 3000, 24, 300)
+    parts = {k: dict(v) for k, v in scene.contact_parts.items()}
+    names = list(parts)
+    shared = parts[names[0]]['verts_ind'][:17]                       # 17 vertices listed by two parts, 5 of them by three
+    parts[names[1]] = dict(parts[names[1]], verts_ind=parts[names[1]]['verts_ind'] + shared)
+    parts[names[4]] = dict(parts[names[4]], verts_ind=parts[names[4]]['verts_ind'] + shared[:5])
+    scene = dataclasses.replace(scene, contact_parts=parts)
+    ids = synth.contact_ids_from_parts(parts)
+    assert len(ids) == 322 and len(set(ids.tolist())) == 300
+    bodies = synth.make_bodies(23, B)
+    bodies['cam_ext'] = synth.make_cam_ext(9, B)
+    g, buf = {}, {}
+    for mode in ('modular', 'fused', 'unfused'):
+        monkeypatch.setenv('PSI_FIT_FUSED_BWD', '0' if mode == 'unfused' else '1')
+        op = make_op(smplx_data, vposer_sd, scene, B, 'modular' if mode == 'modular' else 'fused', num_iter=1, lr=0.05)
+        assert np.array_equal(op.contact_vertex_ids().cpu().numpy(), ids)
+        op.fitting(dict(bodies))
+        g[mode] = (op._fused.buffer('adam_m', (B, 75)) if mode != 'modular' else op.optimizer.state[op.xhr_rec]['exp_avg']).detach().cpu().numpy() * 10
+        if mode != 'modular':
+            buf[mode] = {k: op._fused.buffer(k, s).cpu().numpy() for k, s in (('gA', (B, 64, 16)), ('gfeat', (B, 512)), ('g_transl', (B, 3)))}
+    scale = np.abs(g['modular']).max()
+    assert np.abs(g['fused'] - g['modular']).max() < 1e-5 * scale, np.abs(g['fused'] - g['modular']).max() / scale
+    assert np.abs(g['unfused'] - g['modular']).max() < 1e-5 * scale
+    for k in buf['fused']:
+        ref = buf['unfused'][k]
+        assert np.abs(buf['fused'][k] - ref).max() <= 2e-6 * np.abs(ref).max(), (k, np.abs(buf['fused'][k] - ref).max() / np.abs(ref).max())
