@@ -181,15 +181,17 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const __bf16 *__restrict__
 // Cin = 64: 256 pixels (8 x 32) x 64 output channels per workgroup; two LDS planes of the halo tile (98 KB) + two weight buffers of two
 // planes (37 KB): one workgroup per CU.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int WPX, int WCO, int TW, bool REV>
+template <int CIN, int WPX, int WCO, int TW, int NBUF, bool REV>
 __global__ __launch_bounds__(256) void conv3x3s_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
                                                        float *__restrict__ y, int N, int H, int W, int COUT)
 {
-    constexpr int PX = WPX * 64, TH = PX / TW, COT = WCO * 64, P = CIN + 8, HW_ = TW + 2, HH_ = TH + 2, CH = CIN / 8;
+    // a weight STAGE = the 64 input channels [64 sub, 64 sub + 64) of one tap for the workgroup's COT output channels, both planes; Cin = 64: one
+    // stage per tap in two alternating LDS buffers, Cin = 128: two stages per tap through ONE buffer (two barriers per stage: the LDS budget)
+    constexpr int PX = WPX * 64, TH = PX / TW, COT = WCO * 64, P = CIN + 8, PW = 64 + 8, HW_ = TW + 2, HH_ = TH + 2, CH = CIN / 8, NSUB = CIN / 64, NST = 9 * NSUB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 (*Xh)[P] = (__bf16 (*)[P])smem;                                           // [HH_ * HW_][P] hi parts
     __bf16 (*Xl)[P] = Xh + HH_ * HW_;                                                // ... lo parts
-    __bf16 (*Ws)[2][COT][P] = (__bf16 (*)[2][COT][P])(smem + (size_t)2 * HH_ * HW_ * P * 2);   // [buffer][plane][COT][P]
+    __bf16 (*Ws)[2][COT][PW] = (__bf16 (*)[2][COT][PW])(smem + (size_t)2 * HH_ * HW_ * P * 2);   // [buffer][plane][COT][PW]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wp_ = wv % WPX, wc = wv / WPX;
     const int li = lane & 31, kb = (lane >> 5) * 8;
@@ -201,32 +203,27 @@ __global__ __launch_bounds__(256) void conv3x3s_kernel(const float *__restrict__
     const int co0 = blockIdx.y * COT;
     const size_t wplane = (size_t)COUT * 9 * CIN;                 // elements between the hi and the lo parts of the prepared weight
 
-    // ---- weights of one tap, both planes: 2 x COT rows of CIN channels
-    constexpr int WLD = (2 * COT * CH + 255) / 256, PF = 2;
+    constexpr int WLD = (2 * COT * 8 + 255) / 256, PF = 2;
     u4 wr[PF][WLD];
-    auto load_w = [&](int tap, u4 (&r)[WLD]) {
-        const int tsrc = REV ? 8 - tap : tap;
+    auto load_w = [&](int st, u4 (&r)[WLD]) {
+        const int tap = st / NSUB, sub = st % NSUB, tsrc = REV ? 8 - tap : tap;
 #pragma unroll
         for (int i = 0; i < WLD; i++) {
             const int idx = threadIdx.x + 256 * i;
-            if (2 * COT * CH % 256 == 0 || idx < 2 * COT * CH) {
-                const int pl = idx / (COT * CH), rem = idx % (COT * CH), row = rem / CH, c = rem % CH;
-                r[i] = *(const u4 *)(wp + (size_t)pl * wplane + ((size_t)(co0 + row) * 9 + tsrc) * CIN + c * 8);
-            }
+            const int pl = idx / (COT * 8), rem = idx % (COT * 8), row = rem / 8, c = rem % 8;
+            r[i] = *(const u4 *)(wp + (size_t)pl * wplane + ((size_t)(co0 + row) * 9 + tsrc) * CIN + sub * 64 + c * 8);
         }
     };
     auto store_w = [&](int buf, const u4 (&r)[WLD]) {
 #pragma unroll
         for (int i = 0; i < WLD; i++) {
             const int idx = threadIdx.x + 256 * i;
-            if (2 * COT * CH % 256 == 0 || idx < 2 * COT * CH) {
-                const int pl = idx / (COT * CH), rem = idx % (COT * CH), row = rem / CH, c = rem % CH;
-                *(u4 *)&Ws[buf][pl][row][c * 8] = r[i];
-            }
+            const int pl = idx / (COT * 8), rem = idx % (COT * 8), row = rem / 8, c = rem % 8;
+            *(u4 *)&Ws[buf][pl][row][c * 8] = r[i];
         }
     };
 #pragma unroll
-    for (int tp = 0; tp < PF; tp++) load_w(tp, wr[tp]);
+    for (int st = 0; st < PF; st++) load_w(st, wr[st]);
     // ---- input tile with halo (zero outside the image): all of a thread's 32-byte pieces are requested before the first one is split and stored
     constexpr int NPC = HH_ * HW_ * CH, XLD = (NPC + 255) / 256;
     {
@@ -280,12 +277,12 @@ __global__ __launch_bounds__(256) void conv3x3s_kernel(const float *__restrict__
         pix_base[pt] = (p / TW) * HW_ + (p % TW);
     }
 #pragma unroll
-    for (int tap = 0; tap < 9; tap++) {
-        const int buf = tap & 1;
-        if (tap + PF < 9) load_w(tap + PF, wr[tap % PF]);
+    for (int st = 0; st < NST; st++) {
+        const int buf = NBUF == 2 ? (st & 1) : 0, tap = st / NSUB, sub = st % NSUB;
+        if (st + PF < NST) load_w(st + PF, wr[st % PF]);
         const int toff = (tap / 3) * HW_ + (tap % 3);
 #pragma unroll
-        for (int c0 = 0; c0 < CIN; c0 += 16) {
+        for (int c0 = 0; c0 < 64; c0 += 16) {
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int ct = 0; ct < 2; ct++) {
@@ -294,8 +291,8 @@ __global__ __launch_bounds__(256) void conv3x3s_kernel(const float *__restrict__
             }
 #pragma unroll
             for (int pt = 0; pt < 2; pt++) {
-                bh[pt] = *(const bf16x8 *)&Xh[pix_base[pt] + toff][c0 + kb];
-                bl[pt] = *(const bf16x8 *)&Xl[pix_base[pt] + toff][c0 + kb];
+                bh[pt] = *(const bf16x8 *)&Xh[pix_base[pt] + toff][sub * 64 + c0 + kb];
+                bl[pt] = *(const bf16x8 *)&Xl[pix_base[pt] + toff][sub * 64 + c0 + kb];
             }
 #pragma unroll
             for (int ct = 0; ct < 2; ct++)
@@ -308,8 +305,14 @@ __global__ __launch_bounds__(256) void conv3x3s_kernel(const float *__restrict__
                     acc[ct][pt] = a;
                 }
         }
-        if (tap + 1 < 9) store_w(buf ^ 1, wr[(tap + 1) % PF]);
-        __syncthreads();
+        if (NBUF == 2) {
+            if (st + 1 < NST) store_w(buf ^ 1, wr[(st + 1) % PF]);
+            __syncthreads();
+        } else if (st + 1 < NST) {
+            __syncthreads();                                 // every wave is done with the buffer
+            store_w(0, wr[(st + 1) % PF]);
+            __syncthreads();
+        }
     }
     // ---- epilogue: D[row = co][col = pixel]; lane (li, h) holds rows 8g + 4h + (0..3), g = 0..3, of column li: 16-byte stores
     const int h = lane >> 5;
@@ -767,25 +770,35 @@ int psi_conv3x3_weight_grad3(const float *x, const float *dy, int N, int H, int 
 // ---- forward / input gradient of the stride-1 3x3 layers at the fp32 model's precision, prepared weights (conv_gemm.hip routes here)
 int psi_conv3x3s_ok(int N, int H, int W, int Cin, int Cout)
 {
-    return N > 0 && Cin == 64 && Cout % 64 == 0 && H % 8 == 0 && W % 32 == 0;
+    if (N <= 0 || H % 8) return 0;
+    if (Cin == 64) return Cout % 64 == 0 && W % 32 == 0;
+    if (Cin == 128) return Cout % 128 == 0 && W % 16 == 0;
+    return 0;
+}
+
+template <int CIN, int WPX, int WCO, int TW, int NBUF>
+static int launch_conv3x3s(const float *x, const void *wp, const float *bias, int N, int H, int W, int Cout, float *y, int reversed_taps, hipStream_t st)
+{
+    constexpr int PX = WPX * 64, TH = PX / TW, COT = WCO * 64, P = CIN + 8, PW = 64 + 8;
+    const size_t lds = ((size_t)2 * (TH + 2) * (TW + 2) * P + (size_t)NBUF * 2 * COT * PW) * 2;
+    dim3 grid((unsigned)(N * (H / TH) * (W / TW)), (unsigned)(Cout / COT));
+    if (reversed_taps) {
+        static std::atomic<unsigned long long> a1{0};
+        PSI_CHECK_HIP(psi_set_max_lds((const void *)conv3x3s_kernel<CIN, WPX, WCO, TW, NBUF, true>, lds, a1));
+        hipLaunchKernelGGL((conv3x3s_kernel<CIN, WPX, WCO, TW, NBUF, true>), grid, dim3(256), lds, st, x, (const __bf16 *)wp, bias, y, N, H, W, Cout);
+    } else {
+        static std::atomic<unsigned long long> a0{0};
+        PSI_CHECK_HIP(psi_set_max_lds((const void *)conv3x3s_kernel<CIN, WPX, WCO, TW, NBUF, false>, lds, a0));
+        hipLaunchKernelGGL((conv3x3s_kernel<CIN, WPX, WCO, TW, NBUF, false>), grid, dim3(256), lds, st, x, (const __bf16 *)wp, bias, y, N, H, W, Cout);
+    }
+    PSI_CHECK_LAUNCH("conv3x3s_kernel");
+    psi_mark("conv3x3s_kernel", st);
+    return 0;
 }
 
 int psi_conv3x3s_forward(const float *x, const void *wp, const float *bias, int N, int H, int W, int Cin, int Cout, float *y, int reversed_taps, hipStream_t st)
 {
     PSI_REQUIRE(x && wp && y && psi_conv3x3s_ok(N, H, W, Cin, Cout), "shape not covered by the three-term 3x3 kernel");
-    constexpr int CIN = 64, WPX = 4, WCO = 1, TW = 32, PX = WPX * 64, TH = PX / TW, COT = WCO * 64, P = CIN + 8;
-    const size_t lds = ((size_t)2 * (TH + 2) * (TW + 2) * P + (size_t)2 * 2 * COT * P) * 2;
-    dim3 grid((unsigned)(N * (H / TH) * (W / TW)), (unsigned)(Cout / COT));
-    if (reversed_taps) {
-        static std::atomic<unsigned long long> a1{0};
-        PSI_CHECK_HIP(psi_set_max_lds((const void *)conv3x3s_kernel<CIN, WPX, WCO, TW, true>, lds, a1));
-        hipLaunchKernelGGL((conv3x3s_kernel<CIN, WPX, WCO, TW, true>), grid, dim3(256), lds, st, x, (const __bf16 *)wp, bias, y, N, H, W, Cout);
-    } else {
-        static std::atomic<unsigned long long> a0{0};
-        PSI_CHECK_HIP(psi_set_max_lds((const void *)conv3x3s_kernel<CIN, WPX, WCO, TW, false>, lds, a0));
-        hipLaunchKernelGGL((conv3x3s_kernel<CIN, WPX, WCO, TW, false>), grid, dim3(256), lds, st, x, (const __bf16 *)wp, bias, y, N, H, W, Cout);
-    }
-    PSI_CHECK_LAUNCH("conv3x3s_kernel");
-    psi_mark("conv3x3s_kernel", st);
-    return 0;
+    if (Cin == 64) return launch_conv3x3s<64, 4, 1, 32, 2>(x, wp, bias, N, H, W, Cout, y, reversed_taps, st);
+    return launch_conv3x3s<128, 2, 2, 16, 1>(x, wp, bias, N, H, W, Cout, y, reversed_taps, st);
 }

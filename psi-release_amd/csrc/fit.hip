@@ -1475,8 +1475,6 @@ struct psi_fit_engine {
     bool keep_verts;              // the forward skinning kernel stores the camera-frame vertices (only needed when !self_skin)
     bool scene_skin_first;        // block order inside that launch: skinning + SDF workgroups before the NN-search workgroups
     bool fused_bwd;               // the skinning backward rides on fwd_scene (see fit_bwd_joint_kernel): six launches per iteration, no per-vertex backward launch
-    hipStream_t side;             // data-parallel loop with fused_bwd: statistics + all-reduce run here, beside the joint kernel
-    hipEvent_t ev_fork, ev_join;
     int skin_nb;                  // bodies per workgroup of the forward skinning + SDF kernel (1 or 2: lbs_device.h)
     hipGraph_t graph, graphN, graph2N;     // one iteration / GRAPH_UNROLL iterations / twice that
     hipGraphExec_t graph_exec, graphN_exec, graph2N_exec;
@@ -1929,11 +1927,6 @@ extern "C" void psi_fit_destroy(psi_fit_engine *e)
             (void)hipGraphDestroy(e->g_dp[i]);
         }
     }
-    if (e->side) {
-        (void)hipStreamDestroy(e->side);
-        (void)hipEventDestroy(e->ev_fork);
-        (void)hipEventDestroy(e->ev_join);
-    }
     (void)hipFree(e->blob);
     delete e;
 }
@@ -2063,27 +2056,19 @@ extern "C" int psi_fit_iterate_dp(psi_fit_engine *e, psi_dp_comm *comm, int n_it
     PSI_REQUIRE(psi_dp_world(comm) == e->d.world, "the communicator's size differs from psi_fit_config.world_size");
     hipStream_t st = (hipStream_t)stream;
     float *stats = d_stats ? d_stats : e->stats_local;
-    if (e->fused_bwd && !e->side) {
-        PSI_CHECK_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-        PSI_CHECK_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-        PSI_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-    }
     auto one = [&]() -> int {
         if (e->fused_bwd) {
-            // the global penetration count is needed only where the slices are summed (fit_reduce_kernel): the statistics kernel and the
-            // collective run on a side stream BESIDE the joint kernel (under capture: a fork / join of the graph) instead of between the halves
+            // The global penetration count is needed only where the slices are summed (fit_reduce_kernel), so the statistics come from the joint
+            // kernel's statistics workgroup (no separate launch) and the ONE collective of the iteration sits between the joint kernel and the
+            // reduction: forward -> joint kernel -> ncclAllReduce(stats) -> reduction -> tail, all on one stream / one chain of the graph.
+            // (Round 6 also built the overlapped form — statistics kernel + collective on a side stream BESIDE the joint kernel, a fork / join of
+            // the captured graph: 0.1237 ms per iteration over a 1-rank RCCL group against 0.1102 for the serial chain and 0.1041 single-process
+            // on the same box, profiles/r06_ab_dp_overlap.txt: a cross-stream dependency inside a hipGraph costs ~6 us on this stack, twice,
+            // which is more than the 6-float collective it hides until the all-reduce itself takes longer than that.)
             int rc = fit_forward(e, stats, st, false, false);
-            if (rc) return rc;
-            PSI_CHECK_HIP(hipEventRecord(e->ev_fork, st));
-            PSI_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-            rc = fit_launch_stats(e, stats, e->side);
-            if (!rc) rc = psi_dp_allreduce_sum(comm, stats, 6, e->side);
-            if (rc) return rc;
-            PSI_CHECK_HIP(hipEventRecord(e->ev_join, e->side));
-            rc = fit_backward_joint(e, stats, st, false);
-            if (rc) return rc;
-            PSI_CHECK_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
-            return fit_backward_tail(e, stats, st);
+            if (!rc) rc = fit_backward_joint(e, stats, st, true);
+            if (!rc) rc = psi_dp_allreduce_sum(comm, stats, 6, st);
+            return rc ? rc : fit_backward_tail(e, stats, st);
         }
         int rc = fit_forward(e, stats, st);
         if (!rc) rc = psi_dp_allreduce_sum(comm, stats, 6, st);
