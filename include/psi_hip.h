@@ -189,7 +189,8 @@ int psi_fit_set_problem(psi_fit_engine *engine, const float *d_xhr, const float 
 int psi_fit_forward(psi_fit_engine *engine, float *d_stats, int use_graph, void *stream);
 int psi_fit_backward_step(psi_fit_engine *engine, const float *d_stats, int use_graph, void *stream);
 /* n_iter full iterations on one GPU; use_graph != 0 captures the iteration once (stream must not be the NULL stream)
- * and replays it with hipGraphLaunch — a 10-iteration graph for every full ten, a single-iteration graph for the rest
+ * and replays it with hipGraphLaunch — a 20-iteration graph for every full twenty, a 10-iteration graph for a remaining ten, a
+ * single-iteration graph for the rest
  * (the iteration keeps no host-side state, so the result does not depend on how n_iter is split into calls). */
 int psi_fit_iterate(psi_fit_engine *engine, int n_iter, int use_graph, void *stream);
 /* Copies x [B,75] and the first n_hist rows of the loss-history RING [max_history,4] (row = (adam_step-1) % max_history) =
@@ -218,7 +219,8 @@ int psi_fit_decode_backward(psi_fit_engine *engine, const float *d_grad_verts, f
  * loss normalisers of fitting_proxe.py:105-110,139,155-158 run over the GLOBAL batch through one 6-float all-reduce per iteration.
  * A communicator is created once per process: rank 0 calls psi_dp_unique_id and hands the 128 bytes to every rank (any side channel:
  * torch.distributed's store, MPI, a file), then every rank calls psi_dp_comm_create with its rank — a collective call, made with the
- * rank's GPU current.  psi_fit_iterate_dp runs n_iter iterations of [forward half, ncclAllReduce(stats[0..5]), backward half] on
+ * rank's GPU current.  psi_fit_iterate_dp runs n_iter iterations of [forward kernels + the joint-side backward contraction, which leaves
+ * the rank's LOCAL loss sums in stats; ncclAllReduce(stats[0..5]); the reduction that applies the global penetration count + the tail] on
  * `stream`; with use_graph != 0 as 10-iteration hipGraphs that CONTAIN the RCCL kernel (no host code between iterations).  The engine
  * must have been created with world_size == the communicator's size.  d_stats (device, >= 8 floats, nullable = engine-owned) is the
  * buffer the all-reduce runs in place on.
@@ -246,7 +248,9 @@ int psi_stream_wait(void *stream, int timeout_ms);
 int psi_fit_profile(psi_fit_engine *engine, int n_rep, char *h_names, int name_stride, float *h_ms, int max_stages,
                     int *h_n_stages, void *stream);
 /* Test/diagnostic copy of an engine-owned device buffer by name ("verts" [B,V,3], "g_verts", "pose" [B,165],
- * "g_pose", "g_rot" [B,55,9], "stats" [8], "adam_m"/"adam_v" [B,75]) into d_out (device). */
+ * "g_pose", "g_rot" [B,55,9], "stats" [8], "adam_m"/"adam_v" [B,75]; the backward's intermediates "gA" [B,64,16], "gfeat" [B,Kpad],
+ * "g_transl" [B,3], "gl" / "g_vp" / "v_posed" [B,Npad], and — engines whose per-vertex backward runs inside the scene launch — the
+ * contact class of rows "glc" / "gvpc" / "vpc" [B,3 ncp] in slot order) into d_out (device). */
 int psi_fit_copy_buffer(psi_fit_engine *engine, const char *name, float *d_out, long n_floats, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
