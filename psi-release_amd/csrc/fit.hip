@@ -64,6 +64,7 @@ extern "C" int psi_dbg_timeline(unsigned long long *out, int nblocks)
 #define PSI_SDF_CELLS 1      // the engine's copy of the SDF volume: 1 = cell-major records (two 16-byte gathers per sample), 0 = apron bricks (four 8-byte)
 #endif
 #include "nnindex_device.h"
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1608,8 +1609,11 @@ static int fit_backward_joint(psi_fit_engine *e, float *stats, hipStream_t st, b
     const int n_blend = kgroups * (f.nsn_m + f.nsn_c) * bgroups;
     // bodies per skin_bwd_A workgroup: about one such workgroup per CU beside its stream workgroup
     const int nsl = f.nsv + f.nsv_c;
+    // (AT MOST one: the body groups are whole, so 32 bodies in groups of 6 are 6 groups, not 5.33 — 45 slices x 6 = 270 workgroups put two on
+    // 14 CUs and the launch waited for those: bwd_joint 37.6 us at n_c = 1024 against 28.4 at 2048)
     int nbody = psi_cdiv((long)f.B * nsl, 256);
     if (nbody < 1) nbody = 1;
+    while (nbody < SKA_NBODY && (long)nsl * psi_cdiv(f.B, nbody) > 256) nbody++;
     if (nbody > SKA_NBODY) nbody = SKA_NBODY;
     if (const char *ev = getenv("PSI_SKA_NBODY")) { int v = atoi(ev); if (v >= 1 && v <= SKA_NBODY) nbody = v; }
     const int n_ska = nsl * psi_cdiv(f.B, nbody);
@@ -1792,7 +1796,13 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
         const int SM = Npad / 16, SC = f.ncp3 / 16;
         f.nsv = lv0.nsv;
         f.nsv_c = f.ncp / 256;
-        f.nsn_c = nsn >= 2 ? std::min(nsn - 1, std::max(1, (int)lround((double)nsn * SC / (double)(SM + SC)))) : 0;
+        // column slices of the stream workgroups, split between the two classes so that the LONGEST slice is as short as possible (a
+        // proportional split left a 512-slot contact set with one 96-step slice beside 64-step ones: bwd_joint 42 us instead of 28)
+        f.nsn_c = 0;
+        for (int c = 1, best = INT_MAX; c < nsn; c++) {
+            const int longest = std::max(psi_cdiv(SM, nsn - c), psi_cdiv(SC, c));
+            if (longest < best) { best = longest; f.nsn_c = c; }
+        }
         f.nsn_m = nsn - f.nsn_c;
         f.spm = psi_cdiv(SM, f.nsn_m);
         f.spc = f.nsn_c ? psi_cdiv(SC, f.nsn_c) : 0;
