@@ -72,7 +72,7 @@ WsLayout ws_layout(const LbsDev &m, int B)
     w.nsn = 256 / (m.Kpad / 64) > 0 ? 256 / (m.Kpad / 64) : 1;
     if (w.nsn > m.Npad / 16) w.nsn = m.Npad / 16;
     w.nvb = m.Vpad / SKIN_BLK;
-    w.feat = take((size_t)((B + 15) & ~15) * m.Kpad);        // k-quad layout [Kpad/4][Bpad][4]
+    w.feat = take((size_t)((B + 31) & ~31) * m.Kpad);        // two fp16 parts per entry, MFMA operand order (psi_feat_store, lbs_device.h)
     w.R = take((size_t)B * m.J * 12);           // rows padded to 4 floats
     w.Jl = take((size_t)B * m.J * 3);
     w.G = take((size_t)B * m.J * 12);
@@ -102,117 +102,113 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(LbsDev m, const float *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-// blend forward: v_posed[b][n] = v_template[n] + sum_k feat[b][k] dirs[k][n]      (MFMA f32 16x16x4)
-// Column decomposition: a WAVE owns 32 output columns (half a 64-column tile) and contracts ALL of K for them, so there is no cross-wave
-// reduction at all — no LDS, no barriers, no tile boundary at which the four waves of a workgroup wait for each other (the K-split kernel
-// of rounds 1-3 ended every tile with an LDS reduction and two barriers: 3.6 TB/s).  984 waves = one per SIMD on 246 CUs.
-// One wave per SIMD by design (amdgpu_waves_per_eu(1,1)): two co-resident waves of this kernel contend for the SIMD's matrix pipe and
-// measured 30% slower; latency is hidden inside the wave by a rolling register ring FOUR 64-k chunks deep (24 KB per wave in flight beside
-// the chunk being multiplied).  Without the waves_per_eu bound the scheduler would target 8 waves/SIMD, cap the kernel near 40 VGPRs and
-// sink the prefetched loads back next to their MFMAs.
-//   B operand, round 6: 16-BYTE loads.  The forward's copy of the matrix is k-quad interleaved — [32-column tile][Kpad/4][32][4]: the four
-// consecutive k of a quad lie side by side for one column, so a lane's 16 bytes are the B operands of FOUR consecutive MFMA steps of one
-// of its two columns (round 4-5 loaded 8 bytes = two columns of one k per lane: 8-byte accesses run at 0.54-0.70 of the 16-byte rate on
-// gfx950, MI355X_MICROARCH.md, and the kernel sat at 4.2 TB/s = 0.69 of what the same matrix streams at with 16-byte requests).  Lane li
-// owns the logical columns 2 li and 2 li + 1 (ONE 8-byte store per body row); inside a tile they are stored at slots li and li + 16, so
-// the 16 lanes of a k-group request 256 contiguous bytes per instruction.  The k order inside an accumulator is ascending for every
-// (body, column) at every batch size — the same sums, bit for bit, as the 8-byte form.
+// blend forward: v_posed[b][n] = v_template[n] + sum_k feat[b][k] dirs[k][n]      (v_mfma_f32_32x32x16_f16, three-term split products)
+// Column decomposition: a WAVE owns 32 output columns and contracts ALL of K for them, so there is no cross-wave reduction at all — no
+// LDS, no barriers (the K-split kernel of rounds 1-3 ended every tile with an LDS reduction and two barriers: 3.6 TB/s).  984 waves = one
+// per SIMD on 246 CUs, one wave per SIMD by design (amdgpu_waves_per_eu(1,1)); latency is hidden inside the wave by a rolling register
+// ring FOUR 64-k chunks deep.
+//   Arithmetic (round 6): the fp32 MFMA runs at 1/16 of the fp16 / bf16 rate on gfx950 and kept this launch's matrix pipe busy for 6.6 of
+// its 15 us — with a quarter of the MFMAs the same stream ran 2.2 us faster (profiles/r06_ab_blend_fp16x3.txt).  Both operands are therefore
+// stored as TWO fp16 parts per fp32 value, hi = fp16(x), lo = fp16((x - hi) 2^11) with x = value * (a power of two) — 22 mantissa bits in
+// the same 4 bytes — and a product is hi*hi + (hi*lo + lo*hi) 2^-11, accumulated in fp32 in two accumulators (the dropped lo*lo term and
+// the parts' rounding are 2^-22 relative per product: the accuracy class of a plain fp32 product chain, 3 MFMAs of 32 cycles per 32 x 32 x 16
+// block instead of 16).  The matrix is split once at psi_lbs_create, the feature rows by their producer (psi_feat_store, lbs_device.h).
+//   Layouts: both operands in MFMA operand order, [32-row tile][k-step of 16][part][k half][32 rows][8 k] fp16: a wave's load of one part
+// of one k-step is 1 KB contiguous.  D[row = column n][col = body]: a lane holds, for body (lane & 31), the four 4-column runs
+// n = 8 g + 4 (lane >> 5) + (0..3): 16-byte stores.  The k order inside an accumulator is ascending for every (body, column) at every batch size.
 // ------------------------------------------------------------------------------------------------
 // NCH = Kpad / 64 at compile time (8 for SMPL-X): the chunk loop is then STRAIGHT-LINE code.  As a loop, hipcc's wait-count insertion is
 // conservative at the loop header: the first chunk of every trip waited with vmcnt(0) — for ALL outstanding loads, including the chunk
 // requested a few cycles earlier, i.e. the ring was drained and a full memory latency exposed once per trip (found in the ISA, round 6;
-// in straight-line code the waits are exact: vmcnt(48) .. before the first MFMA of a chunk).  NCH = 0: any Kpad, the loop form.
-template <int MT, int NCH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void blend_fwd_cols_kernel(LbsDev m, const float *__restrict__ feat, int B,
-                                                                                                float *__restrict__ v_posed)
+// in straight-line code the waits are exact).  NCH = 0: any Kpad, the loop form.
+typedef _Float16 psi_h8 __attribute__((ext_vector_type(8)));
+typedef float psi_f16v __attribute__((ext_vector_type(16)));
+typedef unsigned int psi_u4 __attribute__((ext_vector_type(4)));
+template <int MTB, int NCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void blend_fwd_h_kernel(LbsDev m, const float *__restrict__ feat, int B,
+                                                                                             float *__restrict__ v_posed)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int gw = blockIdx.x * 4 + w;                   // 32-column tile of this wave
     if (gw >= m.Npad / 32) return;
-    const int b0 = blockIdx.y * 16 * MT;
-    const int li = lane & 15, lk = lane >> 4;
-    const int Bpad = (B + 15) & ~15;
-    const int nch = NCH ? NCH : m.Kpad / 64;             // 64-k chunks (Kpad % 256 == 0)
-    // k order inside a chunk: lane group lk owns k = 64 ch + 16 lk + s (s = MFMA step 0..15) = the quads 16 ch + 4 lk + j, j = 0..3; feat is
-    // stored as k-quads [Kpad/4][Bpad][4], so the A operands of four consecutive steps are ONE 16-byte load per lane as well
-    const float *brow = m.dirs + (size_t)gw * m.dirs_tile + ((size_t)(4 * lk) * 32 + li) * 4;
-    const float *arow = feat + ((size_t)(4 * lk) * Bpad + b0 + li) * 4;
-    auto load_chunk = [&](int ch, f4 (&q)[4][2], f4 (&a4)[MT][4]) {
+    const int bt0 = blockIdx.y * MTB;                    // first 32-body tile
+    const int li = lane & 31, kh = lane >> 5;
+    const int KS = m.Kpad / 16;
+    const int nch = NCH ? NCH : m.Kpad / 64;             // 64-k chunks = 4 k-steps (Kpad % 256 == 0)
+    const char *dbase = (const char *)m.dirs + (size_t)gw * m.dirs_tile * 4 + (size_t)(kh * 32 + li) * 16;
+    const char *fbase = (const char *)feat + (size_t)bt0 * KS * 2048 + (size_t)(kh * 32 + li) * 16;
+    auto load_chunk = [&](int ch, psi_u4 (&d)[4][2], psi_u4 (&f)[MTB][4][2]) {
 #pragma unroll
-        for (int t = 0; t < MT; t++)
+        for (int s4 = 0; s4 < 4; s4++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) a4[t][j] = *(const f4 *)(arow + ((size_t)(16 * ch + j) * Bpad + t * 16) * 4);
-        const float *bq = brow + (size_t)ch * 16 * 32 * 4;
+            for (int p = 0; p < 2; p++) {
+                d[s4][p] = *(const psi_u4 *)(dbase + (size_t)(ch * 4 + s4) * 2048 + p * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int c = 0; c < 2; c++) q[j][c] = *(const f4 *)(bq + (j * 32 + 16 * c) * 4);
+                for (int t = 0; t < MTB; t++) f[t][s4][p] = *(const psi_u4 *)(fbase + ((size_t)t * KS + ch * 4 + s4) * 2048 + p * 1024);
+            }
     };
-    f4 acc[MT][2];
+    psi_f16v acc[MTB][2];                                // [body tile][hi*hi | hi*lo + lo*hi]
 #pragma unroll
-    for (int t = 0; t < MT; t++)
+    for (int t = 0; t < MTB; t++)
 #pragma unroll
-        for (int c = 0; c < 2; c++) acc[t][c] = (f4){0, 0, 0, 0};
-    auto mfma_chunk = [&](const f4 (&q)[4][2], const f4 (&a4)[MT][4]) {
+        for (int c = 0; c < 2; c++)
 #pragma unroll
-        for (int sidx = 0; sidx < 16; sidx++)
+            for (int i = 0; i < 16; i++) acc[t][c][i] = 0.0f;
+    auto mfma_chunk = [&](const psi_u4 (&d)[4][2], const psi_u4 (&f)[MTB][4][2]) {
 #pragma unroll
-            for (int t = 0; t < MT; t++)
+        for (int s4 = 0; s4 < 4; s4++)
 #pragma unroll
-                for (int c = 0; c < 2; c++)
-                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t][sidx >> 2][sidx & 3], q[sidx >> 2][c][sidx & 3], acc[t][c], 0, 0, 0);
+            for (int t = 0; t < MTB; t++) {
+                const psi_h8 dh = __builtin_bit_cast(psi_h8, d[s4][0]), dl = __builtin_bit_cast(psi_h8, d[s4][1]);
+                const psi_h8 fh = __builtin_bit_cast(psi_h8, f[t][s4][0]), fl = __builtin_bit_cast(psi_h8, f[t][s4][1]);
+                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, fh, acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, fl, acc[t][1], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, fh, acc[t][1], 0, 0, 0);
+            }
     };
-    const psi_f2 vt = *(const psi_f2 *)(m.v_template + gw * 32 + 2 * li);
     if (NCH) {
-        f4 q[4][4][2], a[4][MT][4];
+        psi_u4 d[4][4][2], f[4][MTB][4][2];
 #pragma unroll
         for (int ch = 0; ch < 3 && ch < NCH; ch++) {
-            load_chunk(ch, q[ch], a[ch]);
-            __builtin_amdgcn_sched_barrier(0);           // (request order = use order: the scheduler otherwise moves chunk 0's last quad behind chunk 2)
+            load_chunk(ch, d[ch], f[ch]);
+            __builtin_amdgcn_sched_barrier(0);           // (request order = use order)
         }
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) {
-            if (ch + 3 < NCH) load_chunk(ch + 3, q[(ch + 3) & 3], a[(ch + 3) & 3]);
+            if (ch + 3 < NCH) load_chunk(ch + 3, d[(ch + 3) & 3], f[(ch + 3) & 3]);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(q[ch & 3], a[ch & 3]);
+            mfma_chunk(d[ch & 3], f[ch & 3]);
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
-        f4 q0[4][2], q1[4][2], q2[4][2], q3[4][2];
-        f4 a0[MT][4], a1[MT][4], a2[MT][4], a3[MT][4];
-        load_chunk(0, q0, a0);
-        if (nch > 1) load_chunk(1, q1, a1);
-        if (nch > 2) load_chunk(2, q2, a2);
-        for (int ch = 0; ch < nch; ch += 4) {
-            if (ch + 3 < nch) load_chunk(ch + 3, q3, a3);
+        psi_u4 d0[4][2], d1[4][2], f0[MTB][4][2], f1[MTB][4][2];
+        load_chunk(0, d0, f0);
+        for (int ch = 0; ch < nch; ch += 2) {
+            if (ch + 1 < nch) load_chunk(ch + 1, d1, f1);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(q0, a0);
+            mfma_chunk(d0, f0);
             if (ch + 1 < nch) {
-                if (ch + 4 < nch) load_chunk(ch + 4, q0, a0);
+                if (ch + 2 < nch) load_chunk(ch + 2, d0, f0);
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_chunk(q1, a1);
-            }
-            if (ch + 2 < nch) {
-                if (ch + 5 < nch) load_chunk(ch + 5, q1, a1);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_chunk(q2, a2);
-            }
-            if (ch + 3 < nch) {
-                if (ch + 6 < nch) load_chunk(ch + 6, q2, a2);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_chunk(q3, a3);
+                mfma_chunk(d1, f1);
             }
         }
     }
-    // D[row = 4 lk + e -> body][col = li -> columns 2 li, 2 li + 1]: one 8-byte store per body row
-    float *orow = v_posed + (size_t)gw * 32 + 2 * li;
+    // D[row = 8 g + 4 kh + e -> column][col = li -> body]: four 16-byte stores per body tile
+    const float us = m.dirs_unscale, us2 = m.dirs_unscale * (1.0f / 2048.0f);
 #pragma unroll
-    for (int t = 0; t < MT; t++)
+    for (int g = 0; g < 4; g++) {
+        const int n = gw * 32 + 8 * g + 4 * kh;
+        const f4 vt = *(const f4 *)(m.v_template + n);
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int b = b0 + t * 16 + lk * 4 + e;
-            if (b < B) *(psi_f2 *)(orow + (size_t)b * m.Npad) = (psi_f2){vt.x + acc[t][0][e], vt.y + acc[t][1][e]};
+        for (int t = 0; t < MTB; t++) {
+            const int b = (bt0 + t) * 32 + li;
+            f4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = vt[e] + __builtin_fmaf(acc[t][1][4 * g + e], us2, acc[t][0][4 * g + e] * us);
+            if (b < B) *(f4 *)(v_posed + (size_t)b * m.Npad + n) = o;
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -405,15 +401,34 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
         const char *sk = getenv("PSI_DIRS_SKEW");
         d.dirs_tile = d.Kpad * 32 + (sk ? atoi(sk) / 4 * 4 : 1088);
     }
-    std::vector<float> dirs((size_t)(d.Npad / 32) * d.dirs_tile, 0.0f), dirs_b((size_t)d.Kpad * d.Npad, 0.0f), vt(d.Npad, 0.0f), WT((size_t)JP * d.Vpad, 0.0f);
-    // forward copy: [32-column tile][Kpad/4][slot][4]: k-quad interleaved; logical column 2 l + c of a tile sits in slot l + 16 c (blend_fwd_cols_kernel)
-    auto dirs_at = [&](int k, int n) -> float & {
-        return dirs[(size_t)(n >> 5) * d.dirs_tile + (((size_t)(k >> 2)) * 32 + (((n & 31) >> 1) + 16 * (n & 1))) * 4 + (k & 3)];
-    };
+    std::vector<float> dense((size_t)d.Kpad * d.Npad, 0.0f), dirs((size_t)(d.Npad / 32) * d.dirs_tile, 0.0f), dirs_b((size_t)d.Kpad * d.Npad, 0.0f), vt(d.Npad, 0.0f),
+        WT((size_t)JP * d.Vpad, 0.0f);
+    auto dirs_at = [&](int k, int n) -> float & { return dense[(size_t)k * d.Npad + n]; };
     for (int l = 0; l < NB; l++)
         for (int n = 0; n < d.N; n++) dirs_at(l, n) = h_shapedirs[(size_t)n * NB + l];                  // [V,3,NB] -> row l
     for (int p = 0; p < d.P; p++)
         for (int n = 0; n < d.N; n++) dirs_at(NB + p, n) = h_posedirs[(size_t)p * d.N + n];
+    // forward copy (blend_fwd_h_kernel): every entry as TWO fp16 parts of x = v * scale — hi = fp16(x), lo = fp16((x - hi) * 2^11): 22 mantissa
+    // bits in the same 4 bytes — in MFMA operand order [32-column tile][Kpad/16 k-steps][part][k half][32 columns][8 k].  scale = the power of
+    // two that puts the largest entry into [2^13, 2^14): far from fp16's overflow, and entries down to 1e-9 of the largest stay normal numbers.
+    {
+        float amax = 0.0f;
+        for (float v : dense) amax = std::max(amax, std::fabs(v));
+        int e = 0;
+        if (amax > 0.0f) (void)std::frexp(amax, &e);             // amax = f * 2^e, f in [0.5, 1)
+        const float scale = std::ldexp(1.0f, 14 - e);
+        d.dirs_unscale = 1.0f / (scale * PSI_FEAT_SCALE);
+        _Float16 *dh = reinterpret_cast<_Float16 *>(dirs.data());
+        for (int k = 0; k < d.Kpad; k++)
+            for (int n = 0; n < d.Npad; n++) {
+                const float x = dirs_at(k, n) * scale;
+                const _Float16 hi = (_Float16)x;
+                const _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
+                const size_t o = (size_t)(n >> 5) * d.dirs_tile * 2 + ((size_t)(k >> 4) * 4 + ((k >> 3) & 1)) * 256 + (size_t)(n & 31) * 8 + (k & 7);
+                dh[o] = hi;
+                dh[o + 512] = lo;
+            }
+    }
     // the backward's copy, [Npad/16][Kpad][16]: blend_bwd contracts over n in steps of 16, and with 16-column tiles the 16 rows x 64 B a
     // wave requests per load are ONE contiguous 1 KB (with the forward's 64-column tiles they were sixteen half cache lines)
     for (int k = 0; k < d.Kpad; k++)
@@ -534,13 +549,12 @@ extern "C" size_t psi_lbs_workspace_floats(const psi_lbs_model *m, int B)
 
 static int lbs_launch_blend(const LbsDev &m, const WsLayout &L, int B, float *ws, hipStream_t st)
 {
-    const int bgroups = B > 32 ? psi_cdiv(B, 64) : 1;
+    const int bgroups = B > 32 ? psi_cdiv(B, 64) : 1;           // 32-body tiles per wave: 1, or 2 (every further group re-streams the matrix)
     const dim3 grid(psi_cdiv(m.Npad / 32, 4), bgroups);
     static const bool loop_form = getenv("PSI_BLEND_FWD_LOOP") && getenv("PSI_BLEND_FWD_LOOP")[0] == '1';      // dev A/B: the chunk loop as a loop
-#define PSI_LAUNCH_BLEND(MT_, NCH_) hipLaunchKernelGGL((blend_fwd_cols_kernel<MT_, NCH_>), grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed)
+#define PSI_LAUNCH_BLEND(MT_, NCH_) hipLaunchKernelGGL((blend_fwd_h_kernel<MT_, NCH_>), grid, dim3(256), 0, st, m, ws + L.feat, B, ws + L.v_posed)
     const bool k8 = m.Kpad == 512 && !loop_form;              // SMPL-X: 506 feature rows -> 8 chunks
-    if (B > 32) { if (k8) PSI_LAUNCH_BLEND(4, 8); else PSI_LAUNCH_BLEND(4, 0); }
-    else if (B > 16) { if (k8) PSI_LAUNCH_BLEND(2, 8); else PSI_LAUNCH_BLEND(2, 0); }
+    if (B > 32) { if (k8) PSI_LAUNCH_BLEND(2, 8); else PSI_LAUNCH_BLEND(2, 0); }
     else { if (k8) PSI_LAUNCH_BLEND(1, 8); else PSI_LAUNCH_BLEND(1, 0); }
 #undef PSI_LAUNCH_BLEND
     PSI_CHECK_LAUNCH("blend_fwd_kernel");

@@ -24,7 +24,8 @@ constexpr int PSI_A_TAIL = 16;      // zero transform rows kept behind the LAST 
 
 struct LbsDev {
     int V, J, NB, P, K, Kpad, N, Npad, Vpad, maxlevel, njump;
-    int dirs_tile;                                   // floats between consecutive 32-column tiles of `dirs` (lbs.hip)
+    int dirs_tile;                                   // floats (4-byte units) between consecutive 32-column tiles of `dirs` (lbs.hip)
+    float dirs_unscale;                              // 1 / (scale of the forward copy's fp16 parts x PSI_FEAT_SCALE): a power of two (lbs.hip)
     const float *dirs, *dirs_b, *v_template, *WT, *J_t, *J_s;
     const float *WTt;                                // the same weights as [Vpad/64][PSI_JP][64]: a wave's 64 vertices x all joints = one contiguous 16 KB tile
     const float *Wc;                                 // compressed rows [PSI_WNZ][Vpad]: the k-th non-zero weight of each vertex (ascending joint), or nullptr
@@ -83,15 +84,29 @@ __device__ __forceinline__ void psi_pose_fwd_rest(const LbsDev &m, const float *
     }
 }
 
-// ... and its outputs: the rest joints, the shape entries / zero tail of the blend-shape feature row ([Kpad/4][Bpad][4] k-quads)
+// The blend-shape feature row of body b as blend_fwd's MFMA operand (lbs.hip: three-term fp16 split products at fp32-class accuracy):
+// entry k = v is stored as TWO fp16 parts of x = v * PSI_FEAT_SCALE — hi = fp16(x), lo = fp16((x - hi) * 2^11), 22 mantissa bits
+// together — in v_mfma_f32_32x32x16_f16 operand order: [32-body tile][Kpad/16 k-steps][part][k half][32 bodies][8 k], 2 bytes each.
+// The scale is a power of two (exact); |v| up to 4094 stays finite, |v| below 4e-6 goes subnormal with an ABSOLUTE error below 4e-9.
+constexpr float PSI_FEAT_SCALE = 16.0f;
+__device__ __forceinline__ void psi_feat_store(const LbsDev &m, float *__restrict__ feat, int b, int k, float v)
+{
+    const float x = v * PSI_FEAT_SCALE;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
+    _Float16 *o = (_Float16 *)feat + (((size_t)(b >> 5) * (m.Kpad >> 4) + (k >> 4)) * 4 + ((k >> 3) & 1)) * 256 + (size_t)(b & 31) * 8 + (k & 7);
+    o[0] = hi;
+    o[512] = lo;                                     // the lo part: 2 k halves x 32 bodies x 8 = 512 entries on
+}
+
+// ... and its outputs: the rest joints, the shape entries / zero tail of the blend-shape feature row
 __device__ __forceinline__ void psi_pose_fwd_rest_store(const LbsDev &m, const float *betas_b, int B, int b, const float (*sJ)[3],
                                                         float *__restrict__ feat, float *__restrict__ Jls)
 {
     const int j = threadIdx.x, nthr = blockDim.x;
-    const int Bpad = (B + 15) & ~15;
     for (int q = j; q < m.J * 3; q += nthr) Jls[(size_t)b * m.J * 3 + q] = (&sJ[0][0])[q];
-    for (int l = j; l < m.NB; l += nthr) feat[((size_t)(l >> 2) * Bpad + b) * 4 + (l & 3)] = betas_b[l];
-    for (int l = m.K + j; l < m.Kpad; l += nthr) feat[((size_t)(l >> 2) * Bpad + b) * 4 + (l & 3)] = 0.0f;
+    for (int l = j; l < m.NB; l += nthr) psi_feat_store(m, feat, b, l, betas_b[l]);
+    for (int l = m.K + j; l < m.Kpad; l += nthr) psi_feat_store(m, feat, b, l, 0.0f);
 }
 
 // part 2: Rodrigues, pose feature, kinematic chain, skinning transforms.  sJ must be complete (the first barrier below orders it
@@ -116,7 +131,6 @@ __device__ __forceinline__ void psi_pose_fwd_chain(const LbsDev &m, const float 
                                                    float *__restrict__ joints)
 {
     const int j = threadIdx.x;
-    const int Bpad = (B + 15) & ~15;
     __shared__ float sG[PSI_JP][12];
     __shared__ int sJmp[PSI_NJUMP][PSI_JP];          // the jump rows, so that the round loop below stays a (compact) loop
     const bool act = j < m.J;
@@ -133,7 +147,7 @@ __device__ __forceinline__ void psi_pose_fwd_chain(const LbsDev &m, const float 
         if (j >= 1)
             for (int e = 0; e < 9; e++) {
                 int k = m.NB + (j - 1) * 9 + e;
-                feat[((size_t)(k >> 2) * Bpad + b) * 4 + (k & 3)] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+                psi_feat_store(m, feat, b, k, R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f));
             }
     }
     __syncthreads();

@@ -14,8 +14,8 @@ cp $O/kernel_stats.csv profiles/r06_kernel_stats.csv; python tools/mk_pmc_json.p
 [ -f tools/_variants/stops.so ] && { PSI_HIP_LIB=$GRAFT_REPO_ROOT/tools/_variants/stops.so PSI_SKIN_STOP=9 python tools/timeline.py > $O/timeline_fwd_scene.txt 2>&1; }
 # the blend stream alone in a loop (its 64.5 MB matrix can stay in the 256 MB Infinity Cache) against the same kernel inside the iteration, + L2 counters
 ( cd /tmp; rm -rf /tmp/pb; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o p -- python $GRAFT_REPO_ROOT/tools/time_blend_only.py 32 > /dev/null 2>&1; grep blend_fwd $(find /tmp/pb -name '*kernel_stats.csv' | head -1) > $O/blend_alone_kernel_stats.txt )
-bash tools/pmc2.sh r06l3 "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum FETCH_SIZE" blend_fwd_cols_kernel python $GRAFT_REPO_ROOT/tools/time_blend_only.py 32 > $O/pmc_blend_alone.txt 2>&1
-bash tools/pmc2.sh r06l3 "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum FETCH_SIZE" blend_fwd_cols_kernel python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --secondary 0 > $O/pmc_blend_in_iteration.txt 2>&1
+bash tools/pmc2.sh r06l3 "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum FETCH_SIZE" blend_fwd_h_kernel python $GRAFT_REPO_ROOT/tools/time_blend_only.py 32 > $O/pmc_blend_alone.txt 2>&1
+bash tools/pmc2.sh r06l3 "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum FETCH_SIZE" blend_fwd_h_kernel python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --secondary 0 > $O/pmc_blend_in_iteration.txt 2>&1
 ( time timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_default.json 2> $O/bench_default.err; grep real $O/bench_default.err
 ( PSI_FORCE_DP_PATH=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 ) > $O/bench_dp1_nccl.json 2> $O/bench_dp1_nccl.err
 ( PSI_DIST_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 ) > $O/bench_n2_gloo.json 2> $O/bench_n2_gloo.err

@@ -6,7 +6,7 @@ def rd(c):
     out = {}
     for l in open('gpurun_out/pmc_%s_%s.txt' % (tag, c)).read().splitlines()[1:]:
         k, n, v = l.rsplit(',', 2)
-        k = k.split('<')[0].replace('psi_', '').replace('blend_fwd_cols_kernel', 'blend_fwd_kernel').replace('fit_bwd_joint_kernel', 'bwd_joint_kernel').replace('fit_reduce_kernel', 'reduce_partials_kernel')
+        k = k.split('<')[0].replace('psi_', '').replace('blend_fwd_h_kernel', 'blend_fwd_kernel').replace('fit_bwd_joint_kernel', 'bwd_joint_kernel').replace('fit_reduce_kernel', 'reduce_partials_kernel')
         if k.startswith('skin_fwd_kernel'): k = 'skin_fwd_sdf_kernel' if 'SdfPen' in l else 'skin_fwd_kernel'
         if k.startswith('skin_bwd_v_kernel'): k = 'skin_bwd_v_grad_kernel' if 'FitGrad' in l else 'skin_bwd_v_kernel'
         out[k] = float(v)
