@@ -132,8 +132,11 @@ struct FitDev {
     int fused_bwd, ncp, ncp3;
     float *glc, *gvpc, *vpc;              // [B][ncp3] contact part of g_local / g_vposed, and the posed contact vertices (padding slots stay zero)
     float *gtc_part;                      // [B][nfp][4] translation-gradient partials of the search workgroups (contact part)
+    unsigned *gvbits;                     // [2][64] bit patterns of max |g_vposed| over the penetration / the contact class of rows of this iteration, in 64
+                                          // slots per class (integer atomicMax by their producers, slot = workgroup % 64: no hot address; read and combined by
+                                          // fit_bwd_joint_kernel for the fp16 parts' scale; zeroed by fit_reduce_kernel)
+    const float *dirs_ch;                 // the contact slots' blend-shape columns, one copy per slot, as two fp16 parts per entry in LbsDev::dirs_bh's operand order (12.6 MB at n_c = 2048)
     const float *WTt_c;                   // [ncp/64][PSI_JP][64] skinning weights of the contact slots, tiled per wave like LbsDev::WTt
-    const float *dirs_c;                  // [ncp3/16][Kpad][16] the blend-shape columns of the contact vertices, one copy per slot, in dirs_b's tiles
     float *gA_part, *gfeat_part;          // [nsv + nsv_c][B][JP][16], [nsn_m + nsn_c][B][Kpad] split-contraction partials of both classes
     float *spb;                           // [B] independent-bodies mode: -w_col / N_b (0 when N_b == 0) written by the statistics workgroup
     int nsv, nsv_c, nsn_m, nsn_c, spm, spc;   // slices of the model's vertices / the contact slots (skin_bwd_A), of their columns (blend_bwd) and steps per slice
@@ -500,6 +503,8 @@ struct SdfPenEpilogue {
     float *gl, *gvp, *gtp;
     int Npad, B;
     float gm[2][3], gs[2][3];
+    float gvmax;                  // max |g_vposed entry| this lane has stored (-> gmaxp, one integer atomicMax per workgroup)
+    unsigned *gmaxp;
     // the vertex store of the skinning kernel.  All vertices: [B][V][3] as always.  Contact vertices only (large batches, where the NN search is
     // a launch of its own and reads them): the rows go to their contact SLOT, not to their vertex — the slot list follows the vertex order
     // within a contact part, so the 12-byte pieces of neighbouring lanes are neighbours in memory again (scattered through [B][V][3] they
@@ -565,9 +570,10 @@ struct SdfPenEpilogue {
             lz = psi_dot3(C[2], C[6], C[10], gx, gy, gz);
         }
         psi_st(gl + (size_t)b * Npad, v12, psi_p3{lx, ly, lz});
-        psi_st(gvp + (size_t)b * Npad, v12,
-               psi_p3{psi_dot3(T2[0].x, T2[2].x, T2[4].x, lx, ly, lz), psi_dot3(T2[0].y, T2[2].y, T2[4].y, lx, ly, lz),
-                      psi_dot3(T2[1].x, T2[3].x, T2[5].x, lx, ly, lz)});
+        const float vx = psi_dot3(T2[0].x, T2[2].x, T2[4].x, lx, ly, lz), vy = psi_dot3(T2[0].y, T2[2].y, T2[4].y, lx, ly, lz),
+                    vz = psi_dot3(T2[1].x, T2[3].x, T2[5].x, lx, ly, lz);
+        psi_st(gvp + (size_t)b * Npad, v12, psi_p3{vx, vy, vz});
+        gvmax = fmaxf(gvmax, fmaxf(fabsf(vx), fmaxf(fabsf(vy), fabsf(vz))));
         gs[n][0] = lx; gs[n][1] = ly; gs[n][2] = lz;
     }
     __device__ __forceinline__ void finish(int n, int b, int vblock, int nvb)
@@ -575,18 +581,29 @@ struct SdfPenEpilogue {
         // per workgroup: sum(-sdf) over the penetrating vertices by DPP adds, their count from the lane mask (scalar popcount)
         __shared__ psi_f2 red[PSI_SKIN_BLK / 64];
         __shared__ float red3[PSI_SKIN_BLK / 64][3];
+        __shared__ float redm[PSI_SKIN_BLK / 64];
         const float ws = psi_wave_sum(s[n]);
         const float wc = (float)(int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(neg[n]));
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (psi_f2){ws, wc};
         if (gl) {
             const float sx = psi_wave_sum(gs[n][0]), sy = psi_wave_sum(gs[n][1]), sz = psi_wave_sum(gs[n][2]);
+            float mx = gvmax;
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
             if ((threadIdx.x & 63) == 0) {
                 red3[threadIdx.x >> 6][0] = sx;
                 red3[threadIdx.x >> 6][1] = sy;
                 red3[threadIdx.x >> 6][2] = sz;
+                redm[threadIdx.x >> 6] = mx;
             }
         }
         __syncthreads();
+        if (gl && threadIdx.x == 64) {
+            float mx = redm[0];
+#pragma unroll
+            for (int w = 1; w < PSI_SKIN_BLK / 64; w++) mx = fmaxf(mx, redm[w]);
+            if (mx > 0.0f) atomicMax(gmaxp + (blockIdx.x & 63), __float_as_uint(mx));       // (non-negative floats order like their bit patterns; max is order-independent)
+        }
         if (threadIdx.x == 0) {
             psi_f2 a = red[0];
 #pragma unroll
@@ -605,7 +622,7 @@ struct SdfPenEpilogue {
 static inline SdfPenEpilogue make_sdf_epilogue(const FitDev &f, const PsiSdfGrid &G, bool contact_vertices_only = false, const PsiLbsView *bwd = nullptr)
 {
     SdfPenEpilogue e = {G, f.sdf, f.gmin, f.gmax, f.og, f.penpart, f.D, f.align_corners, f.Vpad, contact_vertices_only ? f.cs_first : nullptr,
-                        {0.0f, 0.0f}, {false, false}, f.cverts, f.cs_ptr, f.cs_idx, f.n_c, nullptr, nullptr, nullptr, 0, f.B, {}, {}};
+                        {0.0f, 0.0f}, {false, false}, f.cverts, f.cs_ptr, f.cs_idx, f.n_c, nullptr, nullptr, nullptr, 0, f.B, {}, {}, 0.0f, f.gvbits};
     if (bwd) {
         e.gl = bwd->gl;
         e.gvp = bwd->g_vp;
@@ -647,6 +664,7 @@ struct ContactSkinSrc {
     // rotation part of the blended transform waits in LDS (each of lanes 0..2 holds one row; held in registers across the search they would
     // cost the launch an occupancy step), the camera is there already
     float (*sTR)[9] = nullptr;    // [QPB][9] row-major rotation part of each query's blended transform
+    float gvm = 0.0f;                     // max |g_vposed entry| of this lane's contact row
     float gs[3] = {0.0f, 0.0f, 0.0f};     // this lane's g_local (lane 0 of a group with a query; 0 elsewhere): summed per workgroup for the translation gradient
     int bq = 0;
     __device__ __forceinline__ void issue(int b, int j)
@@ -731,7 +749,9 @@ struct ContactSkinSrc {
         const size_t row = (size_t)bq * f.ncp3;
         const unsigned off = (unsigned)jslot * 12u;
         psi_st(f.glc + row, off, psi_p3{lx, ly, lz});
-        psi_st(f.gvpc + row, off, psi_p3{psi_dot3(R[0], R[3], R[6], lx, ly, lz), psi_dot3(R[1], R[4], R[7], lx, ly, lz), psi_dot3(R[2], R[5], R[8], lx, ly, lz)});
+        const float vx = psi_dot3(R[0], R[3], R[6], lx, ly, lz), vy = psi_dot3(R[1], R[4], R[7], lx, ly, lz), vz = psi_dot3(R[2], R[5], R[8], lx, ly, lz);
+        psi_st(f.gvpc + row, off, psi_p3{vx, vy, vz});
+        gvm = fmaxf(fabsf(vx), fmaxf(fabsf(vy), fabsf(vz)));
         psi_st(f.vpc + row, off, psi_p3{px, py, pz});
         gs[0] = lx; gs[1] = ly; gs[2] = lz;
     }
@@ -739,13 +759,24 @@ struct ContactSkinSrc {
     {
         if (!f.fused_bwd) return;
         __shared__ float wsum3[psikd::QBLK / 64][3];
+        __shared__ float wmax[psikd::QBLK / 64];
         const float sx = psi_wave_sum(gs[0]), sy = psi_wave_sum(gs[1]), sz = psi_wave_sum(gs[2]);
+        float mx = gvm;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
         if ((threadIdx.x & 63) == 0) {
             wsum3[threadIdx.x >> 6][0] = sx;
             wsum3[threadIdx.x >> 6][1] = sy;
             wsum3[threadIdx.x >> 6][2] = sz;
+            wmax[threadIdx.x >> 6] = mx;
         }
         __syncthreads();
+        if (threadIdx.x == 64) {
+            float m2 = wmax[0];
+#pragma unroll
+            for (int w = 1; w < psikd::QBLK / 64; w++) m2 = fmaxf(m2, wmax[w]);
+            if (m2 > 0.0f) atomicMax(f.gvbits + 64 + (blockIdx.x & 63), __float_as_uint(m2));
+        }
         if (threadIdx.x < 3) {
             float a = 0.0f;
 #pragma unroll
@@ -921,7 +952,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     FitDev f, LbsDev m, const float *__restrict__ g_vp, const float *__restrict__ gl, const float *__restrict__ v_posed, int n_ska, int n_blend,
     int kgroups, int nbody, float *__restrict__ stats)
 {
-    constexpr int SMEM_B = psi_blend_bwd_smem_f4<MT>();
+    constexpr int SMEM_B = psi_blend_bwd_h_smem_f4<(MT + 1) / 2>();
     __shared__ f4 smem[SMEM_B > SKA_SMEM_F4 ? SMEM_B : SKA_SMEM_F4];
     const int bid = blockIdx.x;
     if (bid < n_ska) {
@@ -939,13 +970,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int kg, slice, bg;
         psi_blend_bwd_place(bid - n_ska, kgroups, f.nsn_m + f.nsn_c, kg, slice, bg);
         float *part = f.gfeat_part + (size_t)slice * f.B * m.Kpad;
+        // (the rows' fp16 scale from the class's largest entry of THIS iteration, recorded by fwd_scene_kernel; the matrix's own scale is static)
+        const float dsc_inv = m.dirs_unscale * PSI_FEAT_SCALE;
+        unsigned cbits = f.gvbits[(slice < f.nsn_m ? 0 : 64) + (threadIdx.x & 63)];
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) cbits = max(cbits, (unsigned)__shfl_xor((int)cbits, o2, 64));
         if (slice < f.nsn_m) {
-            const PsiBlendBwdCols o = {m.dirs_b, g_vp, (size_t)m.Npad, m.Kpad, m.Npad / 16};
-            blend_bwd_body<MT>(o, f.B, slice * f.spm, (slice + 1) * f.spm, part, kg, bg, smem);
+            const float gsc = psi_fp16_class_scale(cbits);
+            const PsiBlendBwdColsH o = {m.dirs_bh, g_vp, (size_t)m.Npad, m.Kpad, m.Npad / 16, gsc, dsc_inv / gsc};
+            blend_bwd_h_body<(MT + 1) / 2>(o, f.B, slice * f.spm, (slice + 1) * f.spm, part, kg, bg, smem);
         } else {
             const int c = slice - f.nsn_m;
-            const PsiBlendBwdCols o = {f.dirs_c, f.gvpc, (size_t)f.ncp3, m.Kpad, f.ncp3 / 16};
-            blend_bwd_body<MT>(o, f.B, c * f.spc, (c + 1) * f.spc, part, kg, bg, smem);
+            const float gsc = psi_fp16_class_scale(cbits);
+            const PsiBlendBwdColsH o = {f.dirs_ch, f.gvpc, (size_t)f.ncp3, m.Kpad, f.ncp3 / 16, gsc, dsc_inv / gsc};
+            blend_bwd_h_body<(MT + 1) / 2>(o, f.B, c * f.spc, (c + 1) * f.spc, part, kg, bg, smem);
         }
     } else {
         fit_stats_body(f, stats);
@@ -993,6 +1031,7 @@ __global__ __launch_bounds__(256) void fit_reduce_kernel(FitDev f, PsiLbsView lv
         const float con = psi_sum_slices_split<8>(f.gtc_part + (size_t)b * f.nfp * 4 + cc, (size_t)4, f.nfp, s0);
         if (s0 == 0 && c < 3) f.g_transl[(size_t)b * 3 + c] = __builtin_fmaf(sp, pen, con);
     }
+    if (t >= 64 && t < 192) f.gvbits[t - 64] = 0u;                    // (read by fit_bwd_joint_kernel, the launch before this one: free for the next iteration's producers)
     if (t == 0) {
         const int it = *f.step - 1;
         if (it >= 0) {
@@ -1021,20 +1060,27 @@ __global__ void contact_weight_tiles_kernel(const float *__restrict__ Wct, int n
     const int tile = i / (PSI_JP * 64), j = (i / 64) % PSI_JP, s = tile * 64 + (i & 63);
     WTt_c[i] = s < n_c ? Wct[(size_t)s * PSI_JP + j] : 0.0f;
 }
-__global__ void contact_dirs_kernel(const float *__restrict__ dirs_b, int Kpad, const int *__restrict__ vid, int n_c, int ncp3, float *__restrict__ dirs_c)
+// the contact slots' blend-shape columns as two fp16 parts per entry, in blend_bwd_h_body's operand order (from the model's own fp16 parts)
+__global__ void contact_dirs_h_kernel(const float *__restrict__ dirs_bh, int Kpad, const int *__restrict__ vid, int n_c, int ncp3, float *__restrict__ dirs_ch)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n_all = (size_t)ncp3 * Kpad;
     if (i >= n_all) return;
-    const int n = (int)(i / ((size_t)Kpad * 16)) * 16 + (int)(i & 15), k = (int)((i >> 4) % Kpad);
+    // i enumerates the DESTINATION's fp16 pairs {hi, lo} in (n-step, k-tile, n half, k, n) order
+    const int ne = (int)(i & 7), kr = (int)((i >> 3) & 31), nh = (int)((i >> 8) & 1), KT = Kpad / 32;
+    const int kt = (int)((i >> 9) % KT), s = (int)((i >> 9) / KT);
+    const int n = s * 16 + nh * 8 + ne;
     const int slot = n / 3, comp = n - 3 * slot;
-    float v = 0.0f;
+    _Float16 hi = (_Float16)0.0f, lo = (_Float16)0.0f;
     if (slot < n_c) {
-        const int col = 3 * vid[slot] + comp;
-        v = dirs_b[((size_t)(col >> 4) * Kpad + k) * 16 + (col & 15)];
+        const int sn = 3 * vid[slot] + comp;
+        const size_t so = ((((size_t)(sn >> 4) * KT + kt) * 2) * 2 + ((sn >> 3) & 1)) * 256 + (size_t)kr * 8 + (sn & 7);
+        hi = ((const _Float16 *)dirs_bh)[so];
+        lo = ((const _Float16 *)dirs_bh)[so + 512];
     }
-    dirs_c[i] = v;
+    const size_t o = ((((size_t)s * KT + kt) * 2) * 2 + nh) * 256 + (size_t)kr * 8 + ne;
+    ((_Float16 *)dirs_ch)[o] = hi;
+    ((_Float16 *)dirs_ch)[o + 512] = lo;
 }
-
 // Gradient source of the skinning backward (lbs_device.h): dL/dverts[b][v] = penetration part (global count) + contact
 // part (vertex -> contact slots, CSR), assembled on the fly; workgroup (0,0) records the loss values of the iteration.
 // LOCAL (single process): every workgroup re-derives the global penetration count from the per-workgroup partials (a
@@ -1787,7 +1833,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     f.fused_bwd = e->fused_bwd ? 1 : 0;
     f.ncp = psi_cdiv(f.n_c, 256) * 256;
     f.ncp3 = 3 * f.ncp;
-    size_t o_glc = 0, o_gvpc = 0, o_vpc = 0, o_gtc = 0, o_wttc = 0, o_dirsc = 0, o_gap = 0, o_gfp = 0, o_spb = 0;
+    size_t o_glc = 0, o_gvpc = 0, o_vpc = 0, o_gtc = 0, o_gvb = 0, o_wttc = 0, o_dirsc = 0, o_gap = 0, o_gfp = 0, o_spb = 0;
     {
         // slice counts of the model's own rows: from the LBS workspace layout (offsets only: no memory is touched through this view)
         PsiLbsView lv0;
@@ -1809,7 +1855,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
         if (e->fused_bwd && !f.nsn_c) { e->fused_bwd = false; f.fused_bwd = 0; }
         if (e->fused_bwd) {
             o_glc = take((size_t)B * f.ncp3 * 4); o_gvpc = take((size_t)B * f.ncp3 * 4); o_vpc = take((size_t)B * f.ncp3 * 4);
-            o_gtc = take((size_t)B * f.nfp * 4 * 4); o_wttc = take((size_t)f.ncp * PSI_JP * 4); o_dirsc = take((size_t)f.ncp3 * Kpad * 4);
+            o_gtc = take((size_t)B * f.nfp * 4 * 4); o_gvb = take(512); o_wttc = take((size_t)f.ncp * PSI_JP * 4); o_dirsc = take((size_t)f.ncp3 * Kpad * 4);
             o_gap = take((size_t)(f.nsv + f.nsv_c) * B * PSI_JP * 16 * 4); o_gfp = take((size_t)(f.nsn_m + f.nsn_c) * B * Kpad * 4);
             o_spb = take((size_t)B * 4);
         }
@@ -1860,7 +1906,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
     }
     f.Wct = F(o_wct);
     if (e->fused_bwd) {
-        f.glc = F(o_glc); f.gvpc = F(o_gvpc); f.vpc = F(o_vpc); f.gtc_part = F(o_gtc); f.WTt_c = F(o_wttc); f.dirs_c = F(o_dirsc);
+        f.glc = F(o_glc); f.gvpc = F(o_gvpc); f.vpc = F(o_vpc); f.gtc_part = F(o_gtc); f.WTt_c = F(o_wttc); f.dirs_ch = F(o_dirsc); f.gvbits = (unsigned *)(bl + o_gvb);
         f.gA_part = F(o_gap); f.gfeat_part = F(o_gfp); f.spb = F(o_spb);
     }
     e->scene_skin_first = getenv("PSI_SCENE_ORDER") && getenv("PSI_SCENE_ORDER")[0] == '1';
@@ -1873,8 +1919,8 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
                        f.n_c, J, (float *)f.Wct);
     if (e->fused_bwd) {
         hipLaunchKernelGGL(contact_weight_tiles_kernel, dim3(psi_cdiv((long)f.ncp * PSI_JP, 256)), dim3(256), 0, 0, f.Wct, f.n_c, f.ncp, (float *)f.WTt_c);
-        hipLaunchKernelGGL(contact_dirs_kernel, dim3(psi_cdiv((long)f.ncp3 * e->lv.m.Kpad, 256)), dim3(256), 0, 0, e->lv.m.dirs_b, e->lv.m.Kpad, f.vid,
-                           f.n_c, f.ncp3, (float *)f.dirs_c);
+        hipLaunchKernelGGL(contact_dirs_h_kernel, dim3(psi_cdiv((long)f.ncp3 * e->lv.m.Kpad, 256)), dim3(256), 0, 0, e->lv.m.dirs_bh, e->lv.m.Kpad, f.vid,
+                           f.n_c, f.ncp3, (float *)f.dirs_ch);
     }
     f.sdf_brick = nullptr;
     if (bricks) {

@@ -401,6 +401,7 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
         const char *sk = getenv("PSI_DIRS_SKEW");
         d.dirs_tile = d.Kpad * 32 + (sk ? atoi(sk) / 4 * 4 : 1088);
     }
+    std::vector<float> dirs_bh;
     std::vector<float> dense((size_t)d.Kpad * d.Npad, 0.0f), dirs((size_t)(d.Npad / 32) * d.dirs_tile, 0.0f), dirs_b((size_t)d.Kpad * d.Npad, 0.0f), vt(d.Npad, 0.0f),
         WT((size_t)JP * d.Vpad, 0.0f);
     auto dirs_at = [&](int k, int n) -> float & { return dense[(size_t)k * d.Npad + n]; };
@@ -427,6 +428,19 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
                 const size_t o = (size_t)(n >> 5) * d.dirs_tile * 2 + ((size_t)(k >> 4) * 4 + ((k >> 3) & 1)) * 256 + (size_t)(n & 31) * 8 + (k & 7);
                 dh[o] = hi;
                 dh[o + 512] = lo;
+            }
+        // ... and the same parts in the backward product's operand order, [n-step of 16][Kpad/32][part][n half][32 k][8 n] (blend_bwd_h_body)
+        dirs_bh.assign((size_t)d.Kpad * d.Npad, 0.0f);
+        _Float16 *bh = reinterpret_cast<_Float16 *>(dirs_bh.data());
+        const int KT = d.Kpad / 32;
+        for (int k = 0; k < d.Kpad; k++)
+            for (int n = 0; n < d.Npad; n++) {
+                const float x = dirs_at(k, n) * scale;
+                const _Float16 hi = (_Float16)x;
+                const _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
+                const size_t o = ((((size_t)(n >> 4) * KT + (k >> 5)) * 2) * 2 + ((n >> 3) & 1)) * 256 + (size_t)(k & 31) * 8 + (n & 7);
+                bh[o] = hi;
+                bh[o + 512] = lo;
             }
     }
     // the backward's copy, [Npad/16][Kpad][16]: blend_bwd contracts over n in steps of 16, and with 16-column tiles the 16 rows x 64 B a
@@ -488,14 +502,14 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     // one device blob
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
-    size_t o_dirs = take(dirs.size() * 4), o_dirs_b = take(dirs_b.size() * 4), o_vt = take(vt.size() * 4), o_wt = take(WT.size() * 4), o_wtt = take(WTt.size() * 4), o_jt = take(Jt.size() * 4),
+    size_t o_dirs = take(dirs.size() * 4), o_dirs_b = take(dirs_b.size() * 4), o_dirs_bh = take(dirs_bh.size() * 4), o_vt = take(vt.size() * 4), o_wt = take(WT.size() * 4), o_wtt = take(WTt.size() * 4), o_jt = take(Jt.size() * 4),
            o_js = take(Js.size() * 4), o_wc = take(Wc.size() * 4 + 4), o_wj = take(Wj.size() * 4 + 4), o_par = take(J * 4), o_lvl = take(J * 4), o_cp = take((J + 1) * 4), o_ci = take(cidx.size() * 4),
            o_jump = take(jump.size() * 4), o_sl = take(sub_list.size()), o_si = take(sub_item.size() * 4), o_sf = take(sub_first.size());
     char *blob = nullptr;
     PSI_CHECK_HIP(hipMalloc((void **)&blob, o));
     std::vector<int> par(h_parents, h_parents + J);
     struct { size_t off; const void *src; size_t bytes; } cp[] = {
-        {o_dirs, dirs.data(), dirs.size() * 4}, {o_dirs_b, dirs_b.data(), dirs_b.size() * 4}, {o_vt, vt.data(), vt.size() * 4}, {o_wt, WT.data(), WT.size() * 4}, {o_wtt, WTt.data(), WTt.size() * 4},
+        {o_dirs, dirs.data(), dirs.size() * 4}, {o_dirs_b, dirs_b.data(), dirs_b.size() * 4}, {o_dirs_bh, dirs_bh.data(), dirs_bh.size() * 4}, {o_vt, vt.data(), vt.size() * 4}, {o_wt, WT.data(), WT.size() * 4}, {o_wtt, WTt.data(), WTt.size() * 4},
         {o_jt, Jt.data(), Jt.size() * 4}, {o_js, Js.data(), Js.size() * 4}, {o_wc, Wc.data(), Wc.size() * 4}, {o_wj, Wj.data(), Wj.size() * 4},
         {o_par, par.data(), (size_t)J * 4},
         {o_lvl, level.data(), (size_t)J * 4}, {o_cp, cptr.data(), (size_t)(J + 1) * 4}, {o_ci, cidx.data(), cidx.size() * 4},
@@ -512,6 +526,7 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     }
     d.dirs = (const float *)(blob + o_dirs);
     d.dirs_b = (const float *)(blob + o_dirs_b);
+    d.dirs_bh = (const float *)(blob + o_dirs_bh);
     d.v_template = (const float *)(blob + o_vt);
     d.WT = (const float *)(blob + o_wt);
     d.WTt = (const float *)(blob + o_wtt);

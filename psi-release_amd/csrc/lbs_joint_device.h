@@ -232,6 +232,123 @@ __device__ __forceinline__ void blend_bwd_body(const PsiBlendBwdCols &o, int B, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same product on the fp16 matrix pipe at fp32-class accuracy (round 6; what lbs.hip's blend_fwd_h_kernel does for the forward product):
+// the fp32 MFMA runs at 1/16 of the fp16 rate, and the stream workgroups' 608 fp32 MFMAs per SIMD were what this launch waited for beside its
+// skin_bwd_A waves (with a quarter of them: 25.3 -> 21.2 us, profiles/r06_ab_blend_fp16x3.txt).  The matrix arrives as TWO fp16 parts per
+// entry (hi = fp16(x), lo = fp16((x - hi) 2^11), x = value * a power of two: 22 mantissa bits in the same 4 bytes) in MFMA operand order
+//   dirs_bh [n-step of 16][Kpad/32 k-tiles][part][n half][32 k][8 n]        (a wave's load of one part of one (step, k-tile) is 1 KB contiguous);
+// the gradient rows stay fp32 in memory and are split by the wave that loads them, with the scale 2^s that puts the class's largest entry
+// (an integer atomicMax of its bit pattern by the rows' producers: exact, order-independent) into [2^13, 2^14) — fp16 cannot overflow,
+// entries down to 1e-9 of the largest keep 22 bits, smaller ones an absolute error below 1e-12 of the largest.  A product is
+// hi*hi + (hi*lo + lo*hi) 2^-11 in two fp32 accumulators: 3 MFMAs of 32 cycles per 32 x 32 x 16 block instead of 16.
+// Workgroup = 4 waves sharing a 64-row k group (two 32-row k-tiles) and an n-slice; wave w takes n-steps w, w + 4, ...; LDS reduce.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 psi_h8 __attribute__((ext_vector_type(8)));
+typedef float psi_f16v __attribute__((ext_vector_type(16)));
+typedef unsigned int psi_u4 __attribute__((ext_vector_type(4)));
+struct PsiBlendBwdColsH {
+    const float *dirs_bh;      // the class's columns, two fp16 parts per entry (layout above)
+    const float *g_vp;         // [B][row_stride] fp32
+    size_t row_stride;
+    int Kpad, total_steps;
+    float g_scale;             // 2^s for the rows' fp16 parts
+    float unscale;             // 1 / (matrix scale * g_scale)
+};
+// scale for a class whose largest |entry| has the bit pattern `bits` (0: nothing stored this iteration)
+__device__ __forceinline__ float psi_fp16_class_scale(unsigned bits)
+{
+    int E = (int)((bits >> 23) & 0xffu);                 // largest entry in [2^(E-127), 2^(E-126))
+    if (bits == 0u) E = 140;                             // (any scale: every entry is zero)
+    int se = 267 - E;                                    // biased exponent of 2^(13 - (E - 127))
+    se = se < 27 ? 27 : (se > 227 ? 227 : se);           // |exponent| <= 100: the reciprocal stays a normal number
+    return __uint_as_float((unsigned)se << 23);
+}
+template <int MTB>
+constexpr int psi_blend_bwd_h_smem_f4() { return 4 * 2 * MTB * 4 * 64; }
+
+template <int MTB>
+__device__ __forceinline__ void blend_bwd_h_body(const PsiBlendBwdColsH &o, int B, int s_begin, int s_end, float *__restrict__ part, int kgroup,
+                                                 int bgroup, psi_f4 *smem)
+{
+    typedef psi_f4 f4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int KT = o.Kpad / 32;
+    const int k0 = kgroup * 64;
+    const int b0 = bgroup * 32 * MTB;
+    s_end = min(s_end, o.total_steps);
+    psi_f16v acc[2][MTB][2];                             // [k-tile][body tile][hi*hi | hi*lo + lo*hi]
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+        for (int t = 0; t < MTB; t++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[kt][t][c][i] = 0.0f;
+    const float *grow[MTB];
+#pragma unroll
+    for (int t = 0; t < MTB; t++) grow[t] = o.g_vp + (size_t)min(b0 + t * 32 + li, B - 1) * o.row_stride + 8 * kh;
+    const char *dbase = (const char *)o.dirs_bh + ((size_t)(2 * kgroup) * 2) * 1024 + (size_t)(kh * 32 + li) * 16;
+    const float gsc = o.g_scale;
+    for (int st = s_begin + w; st < s_end; st += 4) {
+        psi_u4 d[2][2];
+        f4 g[MTB][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) d[kt][p] = *(const psi_u4 *)(dbase + ((size_t)st * KT * 2 + (size_t)(kt * 2 + p)) * 1024);
+#pragma unroll
+        for (int t = 0; t < MTB; t++) {
+            g[t][0] = *(const f4 *)(grow[t] + (size_t)st * 16);
+            g[t][1] = *(const f4 *)(grow[t] + (size_t)st * 16 + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < MTB; t++) {
+            psi_h8 gh, gl;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float x = g[t][e >> 2][e & 3] * gsc;
+                const _Float16 hi = (_Float16)x;
+                gh[e] = hi;
+                gl[e] = (_Float16)((x - (float)hi) * 2048.0f);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++) {
+                const psi_h8 dh = __builtin_bit_cast(psi_h8, d[kt][0]), dl = __builtin_bit_cast(psi_h8, d[kt][1]);
+                acc[kt][t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, gh, acc[kt][t][0], 0, 0, 0);
+                acc[kt][t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, gl, acc[kt][t][1], 0, 0, 0);
+                acc[kt][t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, gh, acc[kt][t][1], 0, 0, 0);
+            }
+        }
+    }
+    // D[row = 8 q + 4 kh + e -> k][col = li -> body]: the two accumulators combined, the four waves' sums through LDS, wave w finishes quad q = w
+    f4 (*red)[2][MTB][4][64] = (f4 (*)[2][MTB][4][64])smem;      // [wave][k-tile][body tile][row quad][lane]
+    const float us = o.unscale, us2 = o.unscale * (1.0f / 2048.0f);
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+        for (int t = 0; t < MTB; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = __builtin_fmaf(acc[kt][t][1][4 * q + e], us2, acc[kt][t][0][4 * q + e] * us);
+                red[w][kt][t][q][lane] = v;
+            }
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+        for (int t = 0; t < MTB; t++) {
+            const f4 ov = red[0][kt][t][w][lane] + red[1][kt][t][w][lane] + red[2][kt][t][w][lane] + red[3][kt][t][w][lane];
+            const int b = b0 + t * 32 + li;
+            if (b < B) *(f4 *)(part + (size_t)b * o.Kpad + k0 + kt * 32 + 8 * w + 4 * kh) = ov;
+        }
+}
+
 // Placement of the stream workgroups: workgroup `bid` runs on XCD bid % 8 (observed dispatch order) and every XCD has its own L2, so the
 // k-groups that share an n-slice — and therefore read the same g_vposed columns — are placed on ONE XCD: that slice of g_vposed is
 // fetched from memory once and served to the other k-groups from L2 (it used to be fetched by all 8 XCDs).

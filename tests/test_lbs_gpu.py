@@ -48,6 +48,23 @@ def test_lbs_forward_batch_sizes(layer, oracle_model, B):
     assert rel_err(v.cpu(), vo) < 1e-4
 
 
+@pytest.mark.parametrize('B', [32, 70])
+def test_blend_products_are_in_the_fp32_accuracy_class(layer, smplx_data, oracle_model, B):
+    """blend_fwd multiplies on the fp16 matrix pipe with both operands stored as two fp16 parts per value (22 mantissa bits; lbs.hip).  The
+    result must be as close to an fp64 evaluation of lbs() as the fp32 ORACLE is (K = 4, the arbiter's constant), not merely within 1e-4:
+    large shape parameters and rotations, so the blend offsets are decimetres."""
+    rs = np.random.RandomState(7 + B)
+    betas = (rs.standard_normal((B, 20)) * 2.0).astype(np.float32)
+    pose = (rs.standard_normal((B, 165)) * 0.8).astype(np.float32)
+    v = body_model.lbs(layer.lbs_model, T(betas), T(pose)).cpu().double()
+    m, m64 = oracle_model, O.SMPLXOracle(smplx_data, dtype=torch.float64)
+    with torch.no_grad():
+        v32, _ = O.lbs(C(betas), C(pose), m.v_template, m.shapedirs, m.posedirs, m.J_regressor, m.parents, m.lbs_weights)
+        v64, _ = O.lbs(C(betas).double(), C(pose).double(), m64.v_template, m64.shapedirs, m64.posedirs, m64.J_regressor, m64.parents, m64.lbs_weights)
+    d_prod, d_orc = float((v - v64).abs().max()), float((v32.double() - v64).abs().max())
+    assert d_prod <= 4.0 * d_orc + 1e-7, (d_prod, d_orc)
+
+
 @pytest.mark.parametrize('B,use_cam', [(2, True), (5, False), (32, True), (40, True), (70, False), (131, True)])   # > 32: the 4-tile MFMA variants; >= 128: multi-body skinning
 def test_lbs_backward_vs_autograd(layer, oracle_model, B, use_cam):
     rs = np.random.RandomState(100 + B)
