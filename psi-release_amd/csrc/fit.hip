@@ -132,8 +132,11 @@ struct FitDev {
     int fused_bwd, ncp, ncp3;
     float *glc, *gvpc, *vpc;              // [B][ncp3] contact part of g_local / g_vposed, and the posed contact vertices (padding slots stay zero)
     float *gtc_part;                      // [B][nfp][4] translation-gradient partials of the search workgroups (contact part)
-    unsigned *gvbits;                     // [2][64] bit patterns of max |g_vposed| over the penetration / the contact class of rows of this iteration, in 64
-                                          // slots per class (integer atomicMax by their producers, slot = workgroup % 64: no hot address; read and combined by
+#ifndef PSI_GV_SLOTS
+#define PSI_GV_SLOTS 1024
+#endif
+    unsigned *gvbits;                     // [2][PSI_GV_SLOTS] bit patterns of max |g_vposed| over the penetration / the contact class of rows of this iteration, in
+                                          // slots per class (integer atomicMax by their producers, slot = workgroup % PSI_GV_SLOTS: no hot address; read and combined by
                                           // fit_bwd_joint_kernel for the fp16 parts' scale; zeroed by fit_reduce_kernel)
     const float *dirs_ch;                 // the contact slots' blend-shape columns, one copy per slot, as two fp16 parts per entry in LbsDev::dirs_bh's operand order (12.6 MB at n_c = 2048)
     const float *WTt_c;                   // [ncp/64][PSI_JP][64] skinning weights of the contact slots, tiled per wave like LbsDev::WTt
@@ -602,7 +605,9 @@ struct SdfPenEpilogue {
             float mx = redm[0];
 #pragma unroll
             for (int w = 1; w < PSI_SKIN_BLK / 64; w++) mx = fmaxf(mx, redm[w]);
-            if (mx > 0.0f) atomicMax(gmaxp + (blockIdx.x & 63), __float_as_uint(mx));       // (non-negative floats order like their bit patterns; max is order-independent)
+#ifndef PSI_NO_GVMAX_ATOMIC
+            if (mx > 0.0f) atomicMax(gmaxp + (blockIdx.x & (PSI_GV_SLOTS - 1)), __float_as_uint(mx));
+#endif       // (non-negative floats order like their bit patterns; max is order-independent)
         }
         if (threadIdx.x == 0) {
             psi_f2 a = red[0];
@@ -775,7 +780,9 @@ struct ContactSkinSrc {
             float m2 = wmax[0];
 #pragma unroll
             for (int w = 1; w < psikd::QBLK / 64; w++) m2 = fmaxf(m2, wmax[w]);
-            if (m2 > 0.0f) atomicMax(f.gvbits + 64 + (blockIdx.x & 63), __float_as_uint(m2));
+#ifndef PSI_NO_GVMAX_ATOMIC
+            if (m2 > 0.0f) atomicMax(f.gvbits + PSI_GV_SLOTS + (blockIdx.x & (PSI_GV_SLOTS - 1)), __float_as_uint(m2));
+#endif
         }
         if (threadIdx.x < 3) {
             float a = 0.0f;
@@ -955,6 +962,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int SMEM_B = psi_blend_bwd_h_smem_f4<(MT + 1) / 2>();
     __shared__ f4 smem[SMEM_B > SKA_SMEM_F4 ? SMEM_B : SKA_SMEM_F4];
     const int bid = blockIdx.x;
+#ifdef PSI_HEAD_STOPS
+    PsiBlockTrace trace(11, 11);                         // dev (PSI_SKIN_STOP=11): this launch's workgroup timeline instead of fwd_scene's (tools/timeline_joint.py)
+    trace.kind = bid < n_ska ? (bid % (f.nsv + f.nsv_c) < f.nsv ? 0 : 1) : (bid < n_ska + n_blend ? 2 : 4);
+#endif
     if (bid < n_ska) {
         const int nsl = f.nsv + f.nsv_c, sl = bid % nsl, b0 = (bid / nsl) * nbody;
         float *part = f.gA_part + (size_t)sl * f.B * PSI_JP * 16;
@@ -969,10 +980,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } else if (bid < n_ska + n_blend) {
         int kg, slice, bg;
         psi_blend_bwd_place(bid - n_ska, kgroups, f.nsn_m + f.nsn_c, kg, slice, bg);
+#ifdef PSI_HEAD_STOPS
+        trace.kind = slice < f.nsn_m ? 2 : 3;
+#endif
         float *part = f.gfeat_part + (size_t)slice * f.B * m.Kpad;
         // (the rows' fp16 scale from the class's largest entry of THIS iteration, recorded by fwd_scene_kernel; the matrix's own scale is static)
         const float dsc_inv = m.dirs_unscale * PSI_FEAT_SCALE;
-        unsigned cbits = f.gvbits[(slice < f.nsn_m ? 0 : 64) + (threadIdx.x & 63)];
+        unsigned cbits = 0u;
+#pragma unroll
+        for (int q = 0; q < PSI_GV_SLOTS / 64; q++) cbits = max(cbits, f.gvbits[(slice < f.nsn_m ? 0 : PSI_GV_SLOTS) + q * 64 + (threadIdx.x & 63)]);
 #pragma unroll
         for (int o2 = 32; o2 > 0; o2 >>= 1) cbits = max(cbits, (unsigned)__shfl_xor((int)cbits, o2, 64));
         if (slice < f.nsn_m) {
@@ -1031,7 +1047,7 @@ __global__ __launch_bounds__(256) void fit_reduce_kernel(FitDev f, PsiLbsView lv
         const float con = psi_sum_slices_split<8>(f.gtc_part + (size_t)b * f.nfp * 4 + cc, (size_t)4, f.nfp, s0);
         if (s0 == 0 && c < 3) f.g_transl[(size_t)b * 3 + c] = __builtin_fmaf(sp, pen, con);
     }
-    if (t >= 64 && t < 192) f.gvbits[t - 64] = 0u;                    // (read by fit_bwd_joint_kernel, the launch before this one: free for the next iteration's producers)
+    if (t >= 64 && t < 64 + 2 * PSI_GV_SLOTS) f.gvbits[t - 64] = 0u;         // (read by fit_bwd_joint_kernel, the launch before this one: free for the next iteration's producers)
     if (t == 0) {
         const int it = *f.step - 1;
         if (it >= 0) {
@@ -1855,7 +1871,7 @@ extern "C" int psi_fit_create(psi_fit_engine **out, const psi_lbs_model *lbs, co
         if (e->fused_bwd && !f.nsn_c) { e->fused_bwd = false; f.fused_bwd = 0; }
         if (e->fused_bwd) {
             o_glc = take((size_t)B * f.ncp3 * 4); o_gvpc = take((size_t)B * f.ncp3 * 4); o_vpc = take((size_t)B * f.ncp3 * 4);
-            o_gtc = take((size_t)B * f.nfp * 4 * 4); o_gvb = take(512); o_wttc = take((size_t)f.ncp * PSI_JP * 4); o_dirsc = take((size_t)f.ncp3 * Kpad * 4);
+            o_gtc = take((size_t)B * f.nfp * 4 * 4); o_gvb = take(2 * PSI_GV_SLOTS * 4); o_wttc = take((size_t)f.ncp * PSI_JP * 4); o_dirsc = take((size_t)f.ncp3 * Kpad * 4);
             o_gap = take((size_t)(f.nsv + f.nsv_c) * B * PSI_JP * 16 * 4); o_gfp = take((size_t)(f.nsn_m + f.nsn_c) * B * Kpad * 4);
             o_spb = take((size_t)B * 4);
         }

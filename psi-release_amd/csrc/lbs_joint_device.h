@@ -292,35 +292,49 @@ __device__ __forceinline__ void blend_bwd_h_body(const PsiBlendBwdColsH &o, int 
     for (int t = 0; t < MTB; t++) grow[t] = o.g_vp + (size_t)min(b0 + t * 32 + li, B - 1) * o.row_stride + 8 * kh;
     const char *dbase = (const char *)o.dirs_bh + ((size_t)(2 * kgroup) * 2) * 1024 + (size_t)(kh * 32 + li) * 16;
     const float gsc = o.g_scale;
-    for (int st = s_begin + w; st < s_end; st += 4) {
-        psi_u4 d[2][2];
-        f4 g[MTB][2];
+    // PF steps' operands (PF x (4 + 2 MTB) 16-byte loads per lane) are requested before the first of them is split and multiplied
+#ifndef PSI_BWH_PF
+#define PSI_BWH_PF 1
+#endif
+    constexpr int PF = PSI_BWH_PF;
+    for (int st0 = s_begin + w; st0 < s_end; st0 += 4 * PF) {
+        psi_u4 d[PF][2][2];
+        f4 g[PF][MTB][2];
 #pragma unroll
-        for (int kt = 0; kt < 2; kt++)
+        for (int p = 0; p < PF; p++) {
+            const int st = min(st0 + 4 * p, o.total_steps - 1);
 #pragma unroll
-            for (int p = 0; p < 2; p++) d[kt][p] = *(const psi_u4 *)(dbase + ((size_t)st * KT * 2 + (size_t)(kt * 2 + p)) * 1024);
+            for (int kt = 0; kt < 2; kt++)
 #pragma unroll
-        for (int t = 0; t < MTB; t++) {
-            g[t][0] = *(const f4 *)(grow[t] + (size_t)st * 16);
-            g[t][1] = *(const f4 *)(grow[t] + (size_t)st * 16 + 4);
+                for (int q = 0; q < 2; q++) d[p][kt][q] = *(const psi_u4 *)(dbase + ((size_t)st * KT * 2 + (size_t)(kt * 2 + q)) * 1024);
+#pragma unroll
+            for (int t = 0; t < MTB; t++) {
+                g[p][t][0] = *(const f4 *)(grow[t] + (size_t)st * 16);
+                g[p][t][1] = *(const f4 *)(grow[t] + (size_t)st * 16 + 4);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < MTB; t++) {
-            psi_h8 gh, gl;
+        for (int p = 0; p < PF; p++) {
+            if (st0 + 4 * p < s_end) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const float x = g[t][e >> 2][e & 3] * gsc;
-                const _Float16 hi = (_Float16)x;
-                gh[e] = hi;
-                gl[e] = (_Float16)((x - (float)hi) * 2048.0f);
-            }
+                for (int t = 0; t < MTB; t++) {
+                    psi_h8 gh, gl;
 #pragma unroll
-            for (int kt = 0; kt < 2; kt++) {
-                const psi_h8 dh = __builtin_bit_cast(psi_h8, d[kt][0]), dl = __builtin_bit_cast(psi_h8, d[kt][1]);
-                acc[kt][t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, gh, acc[kt][t][0], 0, 0, 0);
-                acc[kt][t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, gl, acc[kt][t][1], 0, 0, 0);
-                acc[kt][t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, gh, acc[kt][t][1], 0, 0, 0);
+                    for (int e = 0; e < 8; e++) {
+                        const float x = g[p][t][e >> 2][e & 3] * gsc;
+                        const _Float16 hi = (_Float16)x;
+                        gh[e] = hi;
+                        gl[e] = (_Float16)((x - (float)hi) * 2048.0f);
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < 2; kt++) {
+                        const psi_h8 dh = __builtin_bit_cast(psi_h8, d[p][kt][0]), dl = __builtin_bit_cast(psi_h8, d[p][kt][1]);
+                        acc[kt][t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, gh, acc[kt][t][0], 0, 0, 0);
+                        acc[kt][t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, gl, acc[kt][t][1], 0, 0, 0);
+                        acc[kt][t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, gh, acc[kt][t][1], 0, 0, 0);
+                    }
+                }
             }
         }
     }

@@ -352,3 +352,36 @@ def test_fused_backward_with_duplicate_contact_vertices(smplx_data, vposer_sd, B
     for k in buf['fused']:
         ref = buf['unfused'][k]
         assert np.abs(buf['fused'][k] - ref).max() <= 2e-6 * np.abs(ref).max(), (k, np.abs(buf['fused'][k] - ref).max() / np.abs(ref).max())
+
+
+def test_fused_blend_backward_is_in_the_fp32_accuracy_class(smplx_data, vposer_sd):
+    """fit_bwd_joint_kernel multiplies the gradient rows with the blend-shape matrix on the fp16 matrix pipe (two fp16 parts per operand,
+    lbs_joint_device.h: blend_bwd_h_body).  From the engine's own operands (g_vposed of both classes, the global penetration count) the
+    reduced feature gradient is recomputed in fp64 and, for the distance a plain fp32 product has from that, in fp32: the engine must be
+    as close to fp64 as the fp32 product is (K = 4, the arbiter's constant) — not merely within the 1e-4 of the parity bar."""
+    B = 32
+    scene = synth.make_scene(5, 3000, 24, 300)
+    bodies = synth.make_bodies(23, B)
+    bodies['cam_ext'] = synth.make_cam_ext(9, B)
+    op = make_op(smplx_data, vposer_sd, scene, B, 'fused', num_iter=1, lr=0.05)
+    op.fitting(dict(bodies))
+    V, K = 10475, 506
+    ids = op.contact_vertex_ids().cpu().numpy()
+    n_c = len(ids)
+    ncp3 = 3 * ((n_c + 255) // 256 * 256)
+    Npad = 3 * ((V + 255) // 256 * 256)
+    eng = op._fused
+    gvp = eng.buffer('g_vp', (B, Npad)).cpu().numpy()[:, :3 * V]
+    gvpc = eng.buffer('gvpc', (B, ncp3)).cpu().numpy()[:, :3 * n_c]
+    gfeat = eng.buffer('gfeat', (B, 512)).cpu().numpy()[:, :K]
+    stats = eng.buffer('stats', (8,)).cpu().numpy()
+    m = O.SMPLXOracle(smplx_data)
+    D = np.concatenate([m.shapedirs.numpy().reshape(3 * V, -1).T, m.posedirs.numpy()], 0)          # [506][3 V] fp32 values
+    assert D.shape == (K, 3 * V) and stats[4] > 0 and np.abs(gvp).max() > 0 and np.abs(gvpc).max() > 0
+    cols = (3 * ids[:, None] + np.arange(3)[None]).reshape(-1)
+    sp = np.float32(-LOSS['weight_collision']) / np.float32(stats[4])
+    ref = float(sp) * (gvp.astype(np.float64) @ D.T.astype(np.float64)) + gvpc.astype(np.float64) @ D[:, cols].T.astype(np.float64)
+    r32 = sp * (gvp @ D.T) + gvpc @ D[:, cols].T
+    scale = np.abs(ref).max(1, keepdims=True)
+    d_prod, d_f32 = (np.abs(gfeat - ref) / scale).max(), (np.abs(r32 - ref) / scale).max()
+    assert d_prod <= 4.0 * d_f32 + 2e-7, (d_prod, d_f32)
