@@ -258,7 +258,7 @@ def kernel_work(args):
         'nn_partial_kernel': ('flop', 8.0 * B * nc * m, 'brute-force NN: 8 flop per query/target pair, fp32 VALU (no FMA contraction)'),
         'kd_query_kernel': ('byte', B * nc * (12 + 12 + 8) + m * 16.0,
                             'exact NN search (grid ball query / tree walk, latency-bound): queries in, gradients + hints out, scene once'),
-        'blend_fwd_kernel': ('byte', dirs + vt + B * N * 4.0 + B * K * 4.0, 'v_posed = v_t + feat @ dirs: dirs streamed once + feat in + v_posed out'),
+        'blend_fwd_kernel': ('byte', dirs + vt + B * N * 4.0 + B * K * 4.0, 'v_posed = v_t + feat @ dirs: dirs streamed once (two fp16 parts per entry: the same 4 bytes) + feat in + v_posed out'),
         'bwd_joint_kernel': ('byte', dirs + B * N * 4.0 + B * K * 4.0 + W + 2 * B * N * 4.0 + B * J * 16 * 4.0,
                              'blend_bwd (dirs streamed once + g_vposed in + g_feat out) and skin_bwd_A (weights + g_local + v_posed in, joint-transform '
                              'gradients out) as one heterogeneous grid'),
@@ -578,7 +578,7 @@ def bench_fitting(args):
                   'synthetic SMPL-X/VPoser/scene (BASELINE configs[%d])' % (args.batch, args.nc, args.m, args.D, 3 if world >= 8 else 1))
         out = {
             'metric': metric, 'value': round(world / (med / args.steps), 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'dtype_note': 'fp32 storage and arithmetic; the two blend-shape products (v_posed = v_t + feat.dirs and its backward, B <= 128) run on the fp16 matrix pipe as three split products of two fp16 parts per operand (22 mantissa bits, 2^-22 per product): held to the fp32 accuracy class against fp64 by tests/test_lbs_gpu.py and tests/test_fitting_gpu.py (*_accuracy_class)', 'data': 'synthetic',
             'config': {'workload': wl, 'skinning_weight_nnz': args.weight_nnz or 'dense', 'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'engine': args.engine_resolved,
                        'nn': op.nn_mode, 'parallelism': 'dp%d (rows sharded, one 6-float all-reduce per iteration)' % world,
                        'rccl_world_size': rccl_world, 'rccl_ranks_seen': rccl_seen, 'rccl_version': rccl_version, 'dp_launch_mode': dp_modes,

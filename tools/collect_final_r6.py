@@ -8,7 +8,7 @@ cur = {'_doc': 'per-iteration summaries of every arbiter-checked GPU test of the
        'tests': {os.path.basename(f)[:-5]: json.load(open(f)) for f in sorted(glob.glob(O + '/arbiter/*.json'))}}
 json.dump(cur, open(P + '/r06_arbiter.json', 'w'), indent=1)
 for src, dst in (('kernel_stats_sparse_rows.csv', 'r06_kernel_stats_sparse_rows.csv'), ('launch_hist_fwd_scene.txt', 'r06_launch_hist_fwd_scene.txt'),
-                 ('timeline_fwd_scene.txt', 'r06_timeline_fwd_scene.txt'), ('sensitivity.json', 'r06_sensitivity.json')):
+                 ('timeline_fwd_scene.txt', 'r06_timeline_fwd_scene.txt'), ('timeline_bwd_joint.txt', 'r06_timeline_bwd_joint.txt'), ('sensitivity.json', 'r06_sensitivity.json')):
     if os.path.exists(O + '/' + src):
         shutil.copy(O + '/' + src, P + '/' + dst)
 shutil.copy(O + '/kernel_stats.csv', P + '/r06_kernel_stats.csv')

@@ -12,6 +12,7 @@ cp $O/kernel_stats.csv profiles/r06_kernel_stats.csv; python tools/mk_pmc_json.p
 # per-launch distribution of the dominant kernel + workgroup timeline (the -DPSI_HEAD_STOPS variant, when it travelled with the snapshot)
 ( cd /tmp; rm -rf /tmp/kt; rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o p -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 > /dev/null 2>&1; python $GRAFT_REPO_ROOT/tools/launch_hist.py /tmp/kt fwd_scene > $O/launch_hist_fwd_scene.txt 2>&1 )
 [ -f tools/_variants/stops.so ] && { PSI_HIP_LIB=$GRAFT_REPO_ROOT/tools/_variants/stops.so PSI_SKIN_STOP=9 python tools/timeline.py > $O/timeline_fwd_scene.txt 2>&1; }
+[ -f tools/_variants/stops.so ] && { PSI_HIP_LIB=$GRAFT_REPO_ROOT/tools/_variants/stops.so PSI_SKIN_STOP=11 python tools/timeline_joint.py 2>&1 | grep -v '^{' > $O/timeline_bwd_joint.txt; }
 # the blend stream alone in a loop (its 64.5 MB matrix can stay in the 256 MB Infinity Cache) against the same kernel inside the iteration, + L2 counters
 ( cd /tmp; rm -rf /tmp/pb; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o p -- python $GRAFT_REPO_ROOT/tools/time_blend_only.py 32 > /dev/null 2>&1; grep blend_fwd $(find /tmp/pb -name '*kernel_stats.csv' | head -1) > $O/blend_alone_kernel_stats.txt )
 bash tools/pmc2.sh r06l3 "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum FETCH_SIZE" blend_fwd_h_kernel python $GRAFT_REPO_ROOT/tools/time_blend_only.py 32 > $O/pmc_blend_alone.txt 2>&1
