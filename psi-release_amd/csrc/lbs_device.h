@@ -92,7 +92,8 @@ __device__ __forceinline__ void psi_pose_fwd_rest(const LbsDev &m, const float *
 constexpr float PSI_FEAT_SCALE = 16.0f;
 __device__ __forceinline__ void psi_feat_store(const LbsDev &m, float *__restrict__ feat, int b, int k, float v)
 {
-    const float x = v * PSI_FEAT_SCALE;
+    float x = v * PSI_FEAT_SCALE;
+    x = x > 65504.0f ? 65504.0f : (x < -65504.0f ? -65504.0f : x);      // saturates beyond |v| = 4094 instead of producing infinities; a NaN stays a NaN
     const _Float16 hi = (_Float16)x;
     const _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
     _Float16 *o = (_Float16 *)feat + (((size_t)(b >> 5) * (m.Kpad >> 4) + (k >> 4)) * 4 + ((k >> 3) & 1)) * 256 + (size_t)(b & 31) * 8 + (k & 7);
