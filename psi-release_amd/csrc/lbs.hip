@@ -4,13 +4,12 @@
 // whose arithmetic is `lbs` (human_body_prior/body_model/lbs.py:34-118 == smplx 0.1.13 lbs), followed by
 // `+ transl` and PSI's verts_transform (cvae.py:141-149).
 //
-// Data layout in HBM (built once by psi_lbs_create, fp32):
-//   dirs_b [Npad/16][Kpad][16] the same matrix in 16-column tiles (the backward's copy)
-//   dirs  [Npad/32][Kpad/4][32][4]  column-tile-major, k-quad interleaved: tile t holds columns 32t..32t+31 of the [Kpad][Npad] matrix
-//                        whose rows 0..NB-1 = shapedirs^T and NB..NB+P-1 = posedirs (zero padded; N = 3V).  A wave's 32-column strip is
-//                        one contiguous 64 KB run read with 16-byte requests (blend_fwd_cols_kernel).
-//                        Shape and pose blendshapes are ONE contraction: v_posed = v_template + feat @ dirs,
-//                        feat[b] = [betas | (R_1..R_{J-1} - I)]  (lbs.py:81 and :94-99 fused; 64 MB streamed once).
+// Data layout in HBM (built once by psi_lbs_create):
+//   dirs     the [Kpad][Npad] blend-shape matrix — rows 0..NB-1 = shapedirs^T, NB..NB+P-1 = posedirs (zero padded; N = 3V); shape and pose
+//            blendshapes are ONE contraction: v_posed = v_template + feat @ dirs, feat[b] = [betas | (R_1..R_{J-1} - I)] (lbs.py:81 and :94-99
+//            fused) — every entry as TWO fp16 parts (hi, lo: 22 mantissa bits in the fp32 value's 4 bytes) in MFMA operand order
+//            [Npad/32 column tiles][Kpad/16 k-steps][part][k half][32 columns][8 k]: a wave's 32-column strip is one contiguous 64 KB run
+//   dirs_bh  the same parts in the backward product's operand order [Npad/16 n-steps][Kpad/32 k-tiles][part][n half][32 k][8 n]
 //   WT    [64][Vpad]     skinning weights transposed (coalesced per-vertex reads), zero padded.
 //   WTt   [Vpad/64][64][64]  the same weights tiled per wave: [vertex tile][joint][vertex in tile] — the dense skinning blend of a wave
 //                        walks ONE contiguous 16 KB tile, joint after joint (lbs_device.h)
@@ -57,8 +56,9 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // workspace layout (floats)
 // ------------------------------------------------------------------------------------------------
+constexpr int GV_SLOTS = 1024;
 struct WsLayout {
-    size_t feat, R, Jl, G, A, v_posed, gl, g_vp, gA_part, gfeat_part, gt_part, gA, gfeat, total;
+    size_t feat, R, Jl, G, A, v_posed, gl, g_vp, gA_part, gfeat_part, gt_part, gA, gfeat, gvbits, total;
     int nsv, nsn, nvb;
 };
 
@@ -85,6 +85,7 @@ WsLayout ws_layout(const LbsDev &m, int B)
     w.gt_part = take((size_t)w.nvb * B * 4);
     w.gA = take((size_t)B * JP * 16);
     w.gfeat = take((size_t)B * m.Kpad);
+    w.gvbits = take(GV_SLOTS);                  // per-workgroup maxima of |g_vposed| (bit patterns), gv_rowmax_kernel -> bwd_joint_kernel
     w.total = o;
     return w;
 }
@@ -129,9 +130,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                                                              float *__restrict__ v_posed)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int gw = blockIdx.x * 4 + w;                   // 32-column tile of this wave
+    // (body groups of one tile quad on ONE XCD, so that the quad comes from HBM once and from L2 for the other groups, was measured SLOWER — 199 vs 181 us
+    // at B = 512, 52.1 vs 49.4 at 128: at large batches the launch reads more feature rows (every wave all of them: 1 GB at B = 512) than matrix)
+    const int tq = blockIdx.x, y = blockIdx.y;
+    const int gw = tq * 4 + w;                           // 32-column tile of this wave
     if (gw >= m.Npad / 32) return;
-    const int bt0 = blockIdx.y * MTB;                    // first 32-body tile
+    const int bt0 = y * MTB;                             // first 32-body tile
     const int li = lane & 31, kh = lane >> 5;
     const int KS = m.Kpad / 16;
     const int nch = NCH ? NCH : m.Kpad / 64;             // 64-k chunks = 4 k-steps (Kpad % 256 == 0)
@@ -253,13 +257,33 @@ extern "C" int psi_dbg_timeline2(unsigned long long *out, int nblocks)
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psi_dbg_tl2), sizeof(unsigned long long) * 4 * (size_t)(nblocks < 2048 ? nblocks : 2048));
 }
 #endif
+// The largest |entry| of g_vposed [B][Npad] as GV_SLOTS per-workgroup maxima (bit patterns; plain stores: nothing to reset, nothing atomic) — the
+// scale of the rows' fp16 parts in blend_bwd_h_body (lbs_joint_device.h).  The fused fitting engine gets the same number from the kernels
+// that WRITE the rows (fit.hip); here the rows come from psi_skin_bwd_v kernels of several kinds, and one more pass over rows that were
+// written a moment ago costs 2-15 us against the 5-90 us the fp16 matrix pipe saves on the launch behind it.
+__global__ __launch_bounds__(256) void gv_rowmax_kernel(const float *__restrict__ g, size_t n4, unsigned *__restrict__ slots)
+{
+    __shared__ float red[4];
+    float mx = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)GV_SLOTS * 256) {
+        const f4 v = ((const f4 *)g)[i];
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) slots[blockIdx.x] = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
 template <int MT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_joint_kernel(
     LbsDev m, const float *__restrict__ g_vp, const float *__restrict__ gl, const float *__restrict__ v_posed, int B, int steps_per_slice,
-    float *__restrict__ gfeat_part, float *__restrict__ gA_part, int n_blend, int kgroups, int nslices, int nsv, int nbody)
+    float *__restrict__ gfeat_part, float *__restrict__ gA_part, int n_blend, int kgroups, int nslices, int nsv, int nbody,
+    const unsigned *__restrict__ gvbits)
 {
-    // blend_bwd: [4][KT][MT][64] f4; skin_bwd_A: SKA_NBODY bodies' staged operands (2 x 3 component rows each)
-    constexpr int SMEM_B = psi_blend_bwd_smem_f4<MT>();
+    // blend_bwd: [4][2][MTB][4][64] f4; skin_bwd_A: SKA_NBODY bodies' staged operands (2 x 3 component rows each)
+    constexpr int SMEM_B = psi_blend_bwd_h_smem_f4<(MT + 1) / 2>();
     __shared__ f4 smem[SMEM_B > SKA_SMEM_F4 ? SMEM_B : SKA_SMEM_F4];
     // the skin_bwd_A workgroups come FIRST in the grid: a CU serves its workgroups' loads in order, and behind the 72 KB each stream wave
     // requests at once the 100 KB of a skin_bwd_A workgroup arrived after 9.6 us (workgroup timeline) — in front of it they are short
@@ -272,8 +296,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (bid < n_blend) {
         int kg, slice, bg;
         psi_blend_bwd_place(bid, kgroups, nslices, kg, slice, bg);
-        const PsiBlendBwdCols cols = {m.dirs_b, g_vp, (size_t)m.Npad, m.Kpad, m.Npad / 16};
-        blend_bwd_body<MT>(cols, B, slice * steps_per_slice, (slice + 1) * steps_per_slice, gfeat_part + (size_t)slice * B * m.Kpad, kg, bg, smem);
+        // the rows' fp16 scale: the largest |g_vposed| entry of this backward (gv_rowmax_kernel left one maximum per workgroup)
+        unsigned cbits = 0u;
+#pragma unroll
+        for (int q = 0; q < GV_SLOTS / 64; q++) cbits = max(cbits, gvbits[q * 64 + (threadIdx.x & 63)]);
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) cbits = max(cbits, (unsigned)__shfl_xor((int)cbits, o2, 64));
+        const float gsc = psi_fp16_class_scale(cbits);
+        const PsiBlendBwdColsH cols = {m.dirs_bh, g_vp, (size_t)m.Npad, m.Kpad, m.Npad / 16, gsc, m.dirs_unscale * PSI_FEAT_SCALE / gsc};
+        blend_bwd_h_body<(MT + 1) / 2>(cols, B, slice * steps_per_slice, (slice + 1) * steps_per_slice, gfeat_part + (size_t)slice * B * m.Kpad, kg, bg, smem);
     } else {
         const int i = bid - n_blend, vslice = i % nsv;
         // (weights from the wave-tiled copy — the copy skin_bwd_v streamed just before this launch, so most of it is still in L2 / MALL)
@@ -402,7 +433,7 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
         d.dirs_tile = d.Kpad * 32 + (sk ? atoi(sk) / 4 * 4 : 1088);
     }
     std::vector<float> dirs_bh;
-    std::vector<float> dense((size_t)d.Kpad * d.Npad, 0.0f), dirs((size_t)(d.Npad / 32) * d.dirs_tile, 0.0f), dirs_b((size_t)d.Kpad * d.Npad, 0.0f), vt(d.Npad, 0.0f),
+    std::vector<float> dense((size_t)d.Kpad * d.Npad, 0.0f), dirs((size_t)(d.Npad / 32) * d.dirs_tile, 0.0f), vt(d.Npad, 0.0f),
         WT((size_t)JP * d.Vpad, 0.0f);
     auto dirs_at = [&](int k, int n) -> float & { return dense[(size_t)k * d.Npad + n]; };
     for (int l = 0; l < NB; l++)
@@ -443,10 +474,6 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
                 bh[o + 512] = lo;
             }
     }
-    // the backward's copy, [Npad/16][Kpad][16]: blend_bwd contracts over n in steps of 16, and with 16-column tiles the 16 rows x 64 B a
-    // wave requests per load are ONE contiguous 1 KB (with the forward's 64-column tiles they were sixteen half cache lines)
-    for (int k = 0; k < d.Kpad; k++)
-        for (int n = 0; n < d.Npad; n++) dirs_b[((size_t)(n >> 4) * d.Kpad + k) * 16 + (n & 15)] = dirs_at(k, n);
     memcpy(vt.data(), h_v_template, sizeof(float) * d.N);
     std::vector<float> WTt((size_t)JP * d.Vpad, 0.0f);
     for (int v = 0; v < V; v++)
@@ -502,14 +529,14 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
     // one device blob
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
-    size_t o_dirs = take(dirs.size() * 4), o_dirs_b = take(dirs_b.size() * 4), o_dirs_bh = take(dirs_bh.size() * 4), o_vt = take(vt.size() * 4), o_wt = take(WT.size() * 4), o_wtt = take(WTt.size() * 4), o_jt = take(Jt.size() * 4),
+    size_t o_dirs = take(dirs.size() * 4), o_dirs_bh = take(dirs_bh.size() * 4), o_vt = take(vt.size() * 4), o_wt = take(WT.size() * 4), o_wtt = take(WTt.size() * 4), o_jt = take(Jt.size() * 4),
            o_js = take(Js.size() * 4), o_wc = take(Wc.size() * 4 + 4), o_wj = take(Wj.size() * 4 + 4), o_par = take(J * 4), o_lvl = take(J * 4), o_cp = take((J + 1) * 4), o_ci = take(cidx.size() * 4),
            o_jump = take(jump.size() * 4), o_sl = take(sub_list.size()), o_si = take(sub_item.size() * 4), o_sf = take(sub_first.size());
     char *blob = nullptr;
     PSI_CHECK_HIP(hipMalloc((void **)&blob, o));
     std::vector<int> par(h_parents, h_parents + J);
     struct { size_t off; const void *src; size_t bytes; } cp[] = {
-        {o_dirs, dirs.data(), dirs.size() * 4}, {o_dirs_b, dirs_b.data(), dirs_b.size() * 4}, {o_dirs_bh, dirs_bh.data(), dirs_bh.size() * 4}, {o_vt, vt.data(), vt.size() * 4}, {o_wt, WT.data(), WT.size() * 4}, {o_wtt, WTt.data(), WTt.size() * 4},
+        {o_dirs, dirs.data(), dirs.size() * 4}, {o_dirs_bh, dirs_bh.data(), dirs_bh.size() * 4}, {o_vt, vt.data(), vt.size() * 4}, {o_wt, WT.data(), WT.size() * 4}, {o_wtt, WTt.data(), WTt.size() * 4},
         {o_jt, Jt.data(), Jt.size() * 4}, {o_js, Js.data(), Js.size() * 4}, {o_wc, Wc.data(), Wc.size() * 4}, {o_wj, Wj.data(), Wj.size() * 4},
         {o_par, par.data(), (size_t)J * 4},
         {o_lvl, level.data(), (size_t)J * 4}, {o_cp, cptr.data(), (size_t)(J + 1) * 4}, {o_ci, cidx.data(), cidx.size() * 4},
@@ -525,7 +552,6 @@ extern "C" int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, co
         }
     }
     d.dirs = (const float *)(blob + o_dirs);
-    d.dirs_b = (const float *)(blob + o_dirs_b);
     d.dirs_bh = (const float *)(blob + o_dirs_bh);
     d.v_template = (const float *)(blob + o_vt);
     d.WT = (const float *)(blob + o_wt);
@@ -654,9 +680,11 @@ static int lbs_launch_bwd_joint_parts(const LbsDev &m, const WsLayout &L, int B,
     // (Round 4 measured the two halves as two launches of this kernel — stream workgroups, then the skin_bwd_A workgroups: 18.4 us each by
     // rocprofv3 = 36.8 against 27.2 for the heterogeneous grid, profiles/r04_ab_blend_loop.txt.  One grid it stays.)
     const int grid = n_blend + L.nsv * psi_cdiv(B, nbody);
+    hipLaunchKernelGGL(gv_rowmax_kernel, dim3(GV_SLOTS), dim3(256), 0, st, ws + L.g_vp, (size_t)B * m.Npad / 4, (unsigned *)(ws + L.gvbits));
+    PSI_CHECK_LAUNCH("gv_rowmax_kernel");
 #define PSI_LAUNCH_JOINT(MT_)                                                                                                      \
     hipLaunchKernelGGL(bwd_joint_kernel<MT_>, dim3(grid), dim3(256), 0, st, m, ws + L.g_vp, ws + L.gl, ws + L.v_posed, B, steps,     \
-                       ws + L.gfeat_part, ws + L.gA_part, n_blend, kgroups, L.nsn, L.nsv, nbody)
+                       ws + L.gfeat_part, ws + L.gA_part, n_blend, kgroups, L.nsn, L.nsv, nbody, (const unsigned *)(ws + L.gvbits))
     if (mt == 4) PSI_LAUNCH_JOINT(4);
     else if (mt == 2) PSI_LAUNCH_JOINT(2);
     else PSI_LAUNCH_JOINT(1);

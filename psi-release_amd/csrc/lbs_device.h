@@ -26,8 +26,8 @@ struct LbsDev {
     int V, J, NB, P, K, Kpad, N, Npad, Vpad, maxlevel, njump;
     int dirs_tile;                                   // floats (4-byte units) between consecutive 32-column tiles of `dirs` (lbs.hip)
     float dirs_unscale;                              // 1 / (scale of the forward copy's fp16 parts x PSI_FEAT_SCALE): a power of two (lbs.hip)
-    const float *dirs, *dirs_b, *v_template, *WT, *J_t, *J_s;
-    const float *dirs_bh;                            // dirs_b's matrix as two fp16 parts per entry, MFMA operand order (lbs_joint_device.h: blend_bwd_h_body)
+    const float *dirs, *v_template, *WT, *J_t, *J_s; // dirs: the blend-shape matrix as two fp16 parts per entry in blend_fwd's operand order (lbs.hip)
+    const float *dirs_bh;                            // ... and in the backward product's operand order (lbs_joint_device.h: blend_bwd_h_body)
     const float *WTt;                                // the same weights as [Vpad/64][PSI_JP][64]: a wave's 64 vertices x all joints = one contiguous 16 KB tile
     const float *Wc;                                 // compressed rows [PSI_WNZ][Vpad]: the k-th non-zero weight of each vertex (ascending joint), or nullptr
     const unsigned *Wj;                              //                 [PSI_WNZ/4][Vpad]: their joint indices, one byte each (padding: weight 0, joint 0)

@@ -142,98 +142,12 @@ __device__ __forceinline__ void skin_bwd_A_dispatch(const PsiSkaSlice &o, int B,
 
 // ------------------------------------------------------------------------------------------------
 // blend backward (MFMA): g_feat[b][k] = sum_n g_vp[b][n] dirs[k][n]
-// workgroup = 4 waves sharing a 64-row k group and an n-slice; wave w takes n-steps w, w+4, ...; LDS reduce.
-// ------------------------------------------------------------------------------------------------
-// operands of ONE class of columns (the model's 3 V, or the engine's 3 n_c contact columns)
-struct PsiBlendBwdCols {
-    const float *dirs_b;       // [total_steps][Kpad][16]: the matrix in 16-column tiles
-    const float *g_vp;         // [B][row_stride]
-    size_t row_stride;
-    int Kpad, total_steps;
-};
-constexpr int PSI_BLEND_BWD_KT = 4;
-template <int MT>
-constexpr int psi_blend_bwd_smem_f4() { return 4 * PSI_BLEND_BWD_KT * MT * 64; }
-
-// steps [s_begin, s_end) of the class; part: [B][Kpad] of the slice
-template <int MT>
-__device__ __forceinline__ void blend_bwd_body(const PsiBlendBwdCols &o, int B, int s_begin, int s_end, float *__restrict__ part, int kgroup,
-                                               int bgroup, psi_f4 *smem)
-{
-    typedef psi_f4 f4;
-    constexpr int KT = PSI_BLEND_BWD_KT;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int k0 = kgroup * 16 * KT;
-    const int b0 = bgroup * 16 * MT;
-    const int total_steps = o.total_steps;
-    s_end = min(s_end, total_steps);
-    f4 acc[KT][MT];
-#pragma unroll
-    for (int kt = 0; kt < KT; kt++)
-#pragma unroll
-        for (int t = 0; t < MT; t++) acc[kt][t] = (f4){0, 0, 0, 0};
-    const float *grow[MT];
-#pragma unroll
-    for (int t = 0; t < MT; t++) grow[t] = o.g_vp + (size_t)min(b0 + t * 16 + li, B - 1) * o.row_stride + 4 * lk;
-    const float *drow[KT];
-#pragma unroll
-    for (int kt = 0; kt < KT; kt++) drow[kt] = o.dirs_b + (size_t)(k0 + kt * 16 + li) * 16 + 4 * lk;   // + step base: a wave-load is 1 KB contiguous
-    // each wave owns steps s_begin+w, +4, ...; PF steps' operands (PF x (MT + KT) 16-byte loads) are issued before the first MFMA group
-    // waits, and the scheduler is fenced so it cannot sink them back next to their uses.  PF = 1: with the skin_bwd_A waves sharing the SIMDs
-    // (one each) a short MFMA burst per round trip serves the LAUNCH best — rocprofv3, B = 32: PF = 1 22.0 us, 2 22.6, 3 23.9 (round 3's
-    // setting, tuned before the two kinds of wave were balanced), 4 25.1.
-    // Round 6 rebuilt the step loop as STRAIGHT-LINE code (the loop's header carries a vmcnt(0): hipcc's wait-count insertion is conservative
-    // at back edges — that is what stalled blend_fwd, lbs.hip) with the next 1 .. 4 steps' operands in a register ring and counted waits:
-    // 26.0 / 26.1 / 27.8 / 28.0 us against 25.7 for this loop (profiles/r06_ab_bwd_joint_pipeline.txt).  The launch is not waiting for
-    // memory: the two kinds of wave keep each SIMD's matrix pipe busy for 13-16 of its 26 us (608 + 384 fp32 MFMAs of 32 cycles), and
-    // whatever lets the stream wave issue its bursts back to back only moves the wait to the skin_bwd_A wave on the same SIMD.
-    constexpr int PF = 1;
-    for (int st0 = s_begin + w; st0 < s_end; st0 += 4 * PF) {
-        f4 ga[PF][MT], db[PF][KT];
-#pragma unroll
-        for (int p = 0; p < PF; p++) {
-            const int st = min(st0 + 4 * p, total_steps - 1);
-            const int n0 = st * 16;
-#pragma unroll
-            for (int t = 0; t < MT; t++) ga[p][t] = *(const f4 *)(grow[t] + n0);
-#pragma unroll
-            for (int kt = 0; kt < KT; kt++) db[p][kt] = *(const f4 *)(drow[kt] + (size_t)st * o.Kpad * 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int p = 0; p < PF; p++) {
-            if (st0 + 4 * p < s_end) {
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-#pragma unroll
-                    for (int kt = 0; kt < KT; kt++)
-#pragma unroll
-                        for (int t = 0; t < MT; t++)
-                            acc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[p][t][e], db[p][kt][e], acc[kt][t], 0, 0, 0);
-            }
-        }
-    }
-    f4 (*red)[KT][MT][64] = (f4 (*)[KT][MT][64])smem;      // [4][KT][MT][64]
-#pragma unroll
-    for (int kt = 0; kt < KT; kt++)
-#pragma unroll
-        for (int t = 0; t < MT; t++) red[w][kt][t][lane] = acc[kt][t];
-    __syncthreads();
-    // wave w finishes k-tile w: D[row = lk*4+e -> body][col = li -> k]
-#pragma unroll
-    for (int t = 0; t < MT; t++) {
-        f4 ov = red[0][w][t][lane] + red[1][w][t][lane] + red[2][w][t][lane] + red[3][w][t][lane];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            int b = b0 + t * 16 + lk * 4 + e;
-            if (b < B) part[(size_t)b * o.Kpad + k0 + w * 16 + li] = ov[e];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same product on the fp16 matrix pipe at fp32-class accuracy (round 6; what lbs.hip's blend_fwd_h_kernel does for the forward product):
+// Rounds 3-6 ran this product on the fp32 MFMA (v_mfma_f32_16x16x4_f32 over a 16-column-tiled fp32 copy of the matrix; workgroup = 4 waves
+// sharing a 64-row k group and an n-slice, wave w taking n-steps w, w + 4, ..., LDS reduce).  What was learnt on that form and still holds for
+// the one below: ONE step of operands in flight per wave serves the launch best (with the skin_bwd_A waves sharing the SIMDs: 22.0 us at 1
+// step, 22.6 / 23.9 / 25.1 at 2 / 3 / 4), and the step loop as straight-line code with a register ring does not pay
+// (profiles/r06_ab_bwd_joint_pipeline.txt).
+// The product on the fp16 matrix pipe at fp32-class accuracy (round 6; what lbs.hip's blend_fwd_h_kernel does for the forward product):
 // the fp32 MFMA runs at 1/16 of the fp16 rate, and the stream workgroups' 608 fp32 MFMAs per SIMD were what this launch waited for beside its
 // skin_bwd_A waves (with a quarter of them: 25.3 -> 21.2 us, profiles/r06_ab_blend_fp16x3.txt).  The matrix arrives as TWO fp16 parts per
 // entry (hi = fp16(x), lo = fp16((x - hi) 2^11), x = value * a power of two: 22 mantissa bits in the same 4 bytes) in MFMA operand order
