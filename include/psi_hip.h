@@ -131,8 +131,9 @@ int psi_sdf_penetration_stats(const float *sdf_vals, long n, float *stats, void 
  * Arithmetic: fp32 throughout; the blend-shape product v_template + [betas | R - I] . dirs (lbs.py:81,94-99) is formed on the fp16
  * matrix pipe as three split products of two fp16 parts per operand (22 mantissa bits, exact power-of-two scales, fp32 accumulation):
  * 2^-22 relative per product, the accuracy class of an fp32 product chain (tests/test_lbs_gpu.py holds it to fp64 with the margin an
- * fp32 evaluation needs).  |betas| must stay below 4094 (the feature rows' fixed scale).  The fitting engine below forms the matching
- * backward product the same way (batches up to 128); psi_lbs_backward and larger batches use the fp32 matrix instruction.
+ * fp32 evaluation needs).  |betas| beyond 4094 saturate (the feature rows' fixed scale).  The backward product g_feat = g_vposed . dirs^T
+ * is formed the same way, the gradient rows scaled by their largest entry of the call (psi_lbs_backward: a row-maximum pass; the fitting
+ * engine below: recorded by the kernels that write the rows).
  * ------------------------------------------------------------------------------------------- */
 typedef struct psi_lbs_model psi_lbs_model;
 int psi_lbs_create(psi_lbs_model **out, const float *h_v_template, const float *h_shapedirs,
