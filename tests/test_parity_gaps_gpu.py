@@ -163,6 +163,18 @@ def test_fused_iteration_is_run_to_run_bit_identical(smplx_data, vposer_sd):
         assert torch.equal(a, b)
 
 
+def test_full_size_rerun_is_bit_identical_across_processes():
+    """The same property at the BASELINE size and across fresh PROCESSES (fresh device memory, different launch timing): three processes fit the
+    same 32 bodies for 25 iterations (m = 32768, n_c = 2048) and must agree to the last bit — what caught an unreproducible kernel variant in
+    round 6 that the small in-process test above did not (profiles/r06_ab_skin_blend_mfma.txt)."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'check_rerun.py')
+    out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'bit-identical: True' in out.stdout, out.stdout[-500:]
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # train_s2 at batch 128
 # ------------------------------------------------------------------------------------------------------------------
