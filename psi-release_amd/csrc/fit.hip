@@ -893,7 +893,7 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(FitDev f, float *st
 //     SLOT order — a vertex listed by several contact parts simply has several slots;
 //   * fit_bwd_joint_kernel runs the two contractions over BOTH classes of rows in one grid: skin_bwd_A over the model's 41 vertex slices and
 //     the n_c / 256 slot slices (weights: the wave-tiled copies WTt / WTt_c), blend_bwd over the model's columns and the 3 n_c contact
-//     columns (dirs_b / dirs_c: the contact vertices' blend-shape columns gathered once per engine, 12.6 MB at n_c = 2048), the column
+//     columns (dirs_bh / dirs_ch: the contact vertices' blend-shape columns gathered once per engine, 12.6 MB at n_c = 2048), the column
 //     slices sized so that the 256 stream workgroups carry equal shares; one more workgroup produces the iteration's statistics;
 //   * fit_reduce_kernel sums the slices of each class in slice order and combines  sp * (penetration class) + (contact class),
 //     sp = -w_col / N  (per body in the independent-bodies mode).
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(256) void fit_reduce_kernel(FitDev f, PsiLbsView lv
     }
 }
 
-// one-off (psi_fit_create): the contact slots' skinning weights in LbsDev::WTt's wave tiles, and their blend-shape columns in dirs_b's tiles
+// one-off (psi_fit_create): the contact slots' skinning weights in LbsDev::WTt's wave tiles, and their blend-shape columns in dirs_bh's operand order
 __global__ void contact_weight_tiles_kernel(const float *__restrict__ Wct, int n_c, int ncp, float *__restrict__ WTt_c)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
